@@ -1,0 +1,474 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs in the BUILD container only; its outputs are committed).
+
+The reference (trailofbits/reverie, Rust) holds no golden vectors for this path, seeds
+itself from OsRng and cannot be built here, so there is nothing to copy.  This script is
+an INDEPENDENT slow spec model of SURVEY.md Appendix A: one repetition at a time, one
+player at a time, plain Python integers — deliberately not the packed-u64 structure of
+either the reference or oracle/rv_oracle.c — on top of two external primitive
+implementations that exist only in the build container:
+
+  AES-128-CTR : OpenSSL libcrypto (EVP_aes_128_ctr)
+  BLAKE3      : official BLAKE3 1.8.2 C, exported as llvm_blake3_* by libclang-cpp.so
+
+Outputs (tests/golden/):
+  primitives.json     AES-CTR / BLAKE3 / XOF / challenge known answers
+  sharegen.json       packed GF2 shares + Z64 shares for fixed keys (incl. omitted players)
+  proof_<name>.bin    full bincode proof bytes for small circuits with fixed seeds
+  proofs.json         circuit, witness, per-rep digests, comm, challenge for each proof
+
+Reference locations restated (relative to /root/reference/src): crypto/prg.rs:16-37,
+transcript/mod.rs:77-122, generator/{batch,share}.rs, algebra/gf2/{share,recon,domain}.rs,
+algebra/z64/{share,recon,domain}.rs, transcript/prover.rs:57-232,
+interpreter/single.rs:25-157, interpreter/combine.rs:19-219, proof/mod.rs:40-222.
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import struct
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from reverie_amd.ops import (  # noqa: E402  (only the op tuple constructors / constants)
+    B2A, DOM_B2A, DOM_GF2, DOM_SIZEHINT, DOM_Z64, GF2, OP_ADD, OP_ADDCONST, OP_ASSERTZERO, OP_CONST, OP_INPUT, OP_MUL,
+    OP_MULCONST, OP_RANDOM, OP_SUB, OP_SUBCONST, SizeHint, Z64)
+
+M64 = (1 << 64) - 1
+
+# ------------------------------------------------------------------ external primitives
+_crypto = C.CDLL("libcrypto.so.3")
+_crypto.EVP_CIPHER_CTX_new.restype = C.c_void_p
+_crypto.EVP_aes_128_ctr.restype = C.c_void_p
+_b3 = C.CDLL("/opt/rocm/lib/llvm/lib/libclang-cpp.so")
+
+
+def aes_ctr(key: bytes, nbytes: int) -> bytes:
+    ctx = C.c_void_p(_crypto.EVP_CIPHER_CTX_new())
+    assert _crypto.EVP_EncryptInit_ex(ctx, C.c_void_p(_crypto.EVP_aes_128_ctr()), None, key, bytes(16)) == 1
+    out = C.create_string_buffer(nbytes + 32)
+    n = C.c_int()
+    assert _crypto.EVP_EncryptUpdate(ctx, out, C.byref(n), bytes(nbytes), nbytes) == 1
+    _crypto.EVP_CIPHER_CTX_free(ctx)
+    return out.raw[:nbytes]
+
+
+def blake3(data: bytes, n=32, seek=0) -> bytes:
+    h = C.create_string_buffer(4096)
+    _b3.llvm_blake3_hasher_init(h)
+    _b3.llvm_blake3_hasher_update(h, data, C.c_size_t(len(data)))
+    out = C.create_string_buffer(n)
+    _b3.llvm_blake3_hasher_finalize_seek(h, C.c_uint64(seek), out, C.c_size_t(n))
+    return out.raw
+
+
+def rep_seed(r: int) -> bytes:
+    """bench/test seed rule: seed[r] = BLAKE3("rv-seed" || LE32(r))[0..16]"""
+    return blake3(b"rv-seed" + struct.pack("<I", r))[:16]
+
+
+# ------------------------------------------------------------------ spec model, one repetition
+class Rep:
+    def __init__(self, seed: bytes, need_bytes: int):
+        self.seed = seed
+        ks = aes_ctr(seed, 128)
+        self.keys = [ks[16 * p:16 * p + 16] for p in range(8)]  # expand_seed
+        self.ks = [aes_ctr(k, need_bytes) for k in self.keys]
+        self.m2 = 0
+        self.m64 = 0
+        self.on2 = bytearray()
+        self.pre2 = bytearray()
+        self.on64 = bytearray()
+        self.pre64 = bytearray()
+        self.recs2, self.corrs2, self.inputs2 = [], [], []
+        self.recs64, self.corrs64, self.inputs64 = [], [], []
+
+    # A.2 masks
+    def next2(self):
+        m = self.m2
+        self.m2 += 1
+        return [(self.ks[p][m >> 3] >> (7 - (m & 7))) & 1 for p in range(8)]
+
+    def next64(self):
+        m = self.m64
+        self.m64 += 1
+        return [int.from_bytes(self.ks[p][8 * m:8 * m + 8], "little") for p in range(8)]
+
+    # A.5 stream bytes
+    @staticmethod
+    def share_byte(bits):
+        return sum(b << (7 - p) for p, b in enumerate(bits))
+
+    def reconstruct2(self, bits):  # prover.rs:209-213
+        self.on2.append(self.share_byte(bits))
+        self.recs2.append(list(bits))
+        return sum(bits) & 1
+
+    def correction2(self, d):  # prover.rs:215-219
+        self.pre2.append(0xFF if d else 0)
+        self.corrs2.append(d)
+        return d
+
+    def reconstruct64(self, vals):
+        for v in vals:
+            self.on64 += struct.pack("<Q", v)
+        self.recs64.append(list(vals))
+        return sum(vals) & M64
+
+    def correction64(self, d):
+        self.pre64 += struct.pack("<Q", d)
+        self.corrs64.append(d)
+        return d
+
+    def mul2(self, w1, w2):  # single.rs:25-69
+        lab = self.next2()
+        lnew = self.next2()
+        a, b, c = sum(w1[0]) & 1, sum(w2[0]) & 1, sum(lab) & 1
+        delta = self.correction2((a & b) ^ c)
+        s = [(w2[0][p] & w1[1]) ^ (w1[0][p] & w2[1]) ^ lab[p] ^ lnew[p] for p in range(8)]
+        rec = self.reconstruct2(s) ^ delta
+        return (lnew, rec ^ (w1[1] & w2[1]))
+
+    def mul64(self, w1, w2):
+        lab = self.next64()
+        lnew = self.next64()
+        a, b, c = sum(w1[0]) & M64, sum(w2[0]) & M64, sum(lab) & M64
+        delta = self.correction64((a * b - c) & M64)
+        s = [(w2[0][p] * w1[1] + w1[0][p] * w2[1] + lab[p] - lnew[p]) & M64 for p in range(8)]
+        rec = (self.reconstruct64(s) + delta) & M64
+        return (lnew, (rec + w1[1] * w2[1]) & M64)
+
+
+class WitnessInvalid(Exception):
+    pass
+
+
+def run_rep(rep: Rep, ops, wit2, wit64, n64, n2):
+    Z2 = ([0] * 8, 0)
+    w2 = [Z2] * n2
+    w64 = [([0] * 8, 0)] * n64
+    i2 = iter(wit2)
+    i64 = iter(wit64)
+    for (dom, opc, _r, dst, a, b, imm) in ops:
+        if dom == DOM_SIZEHINT:
+            if len(w64) < a:
+                w64 += [([0] * 8, 0)] * (a - len(w64))
+            if len(w2) < b:
+                w2 += [Z2] * (b - len(w2))
+        elif dom == DOM_GF2:
+            c = imm & 1
+            if opc == OP_INPUT:
+                lam = rep.next2()
+                corr = next(i2) ^ (sum(lam) & 1)
+                rep.on2.append(0xFF if corr else 0)
+                rep.inputs2.append(corr)
+                w2[dst] = (lam, corr)
+            elif opc in (OP_ADD, OP_SUB):
+                w2[dst] = ([x ^ y for x, y in zip(w2[a][0], w2[b][0])], w2[a][1] ^ w2[b][1])
+            elif opc == OP_MUL:
+                w2[dst] = rep.mul2(w2[a], w2[b])
+            elif opc in (OP_ADDCONST, OP_SUBCONST):
+                w2[dst] = (w2[a][0], w2[a][1] ^ c)
+            elif opc == OP_MULCONST:
+                w2[dst] = ([x & c for x in w2[a][0]], w2[a][1] & c)
+            elif opc == OP_ASSERTZERO:
+                m = rep.reconstruct2(w2[a][0])
+                if m ^ w2[a][1]:
+                    raise WitnessInvalid()
+            elif opc == OP_RANDOM:
+                w2[dst] = (rep.next2(), 0)
+            elif opc == OP_CONST:
+                w2[dst] = ([0] * 8, c)
+        elif dom == DOM_Z64:
+            c = imm & M64
+            if opc == OP_INPUT:
+                lam = rep.next64()
+                corr = (next(i64) - sum(lam)) & M64
+                rep.on64 += struct.pack("<Q", corr)
+                rep.inputs64.append(corr)
+                w64[dst] = (lam, corr)
+            elif opc == OP_ADD:
+                w64[dst] = ([(x + y) & M64 for x, y in zip(w64[a][0], w64[b][0])], (w64[a][1] + w64[b][1]) & M64)
+            elif opc == OP_SUB:
+                w64[dst] = ([(x - y) & M64 for x, y in zip(w64[a][0], w64[b][0])], (w64[a][1] - w64[b][1]) & M64)
+            elif opc == OP_MUL:
+                w64[dst] = rep.mul64(w64[a], w64[b])
+            elif opc == OP_ADDCONST:
+                w64[dst] = (w64[a][0], (w64[a][1] + c) & M64)
+            elif opc == OP_SUBCONST:
+                w64[dst] = (w64[a][0], (w64[a][1] - c) & M64)
+            elif opc == OP_MULCONST:
+                w64[dst] = ([(x * c) & M64 for x in w64[a][0]], (w64[a][1] * c) & M64)
+            elif opc == OP_ASSERTZERO:
+                m = rep.reconstruct64(w64[a][0])
+                if (m + w64[a][1]) & M64:
+                    raise WitnessInvalid()
+            elif opc == OP_RANDOM:
+                w64[dst] = (rep.next64(), 0)
+            elif opc == OP_CONST:
+                w64[dst] = ([0] * 8, c)
+        elif dom == DOM_B2A:  # combine.rs:132-219 (dst = z64 wire, a = low gf2 wire)
+            aw = [(rep.next2(), 0) for _ in range(64)]
+            zval = sum(((sum(w[0]) & 1) ^ w[1]) << k for k, w in enumerate(aw))
+            mu = rep.next64()
+            kappa = rep.correction64((zval - sum(mu)) & M64)
+            bw = w2[a:a + 64]
+            assert len(bw) == 64
+            xor = lambda u, v: ([x ^ y for x, y in zip(u[0], v[0])], u[1] ^ v[1])  # noqa: E731
+            carry = rep.mul2(aw[0], bw[0])
+            res = [xor(aw[0], bw[0])]
+            for i in range(1, 63):
+                ac = xor(aw[i], carry)
+                bc = xor(bw[i], carry)
+                t = rep.mul2(ac, bc)
+                res.append(xor(ac, bw[i]))
+                carry = xor(t, carry)
+            res.append(xor(carry, xor(aw[63], bw[63])))
+            zrec = 0
+            for k, w in enumerate(res):
+                zrec |= (rep.reconstruct2(w[0]) ^ w[1]) << k
+            w64[dst] = ([(-x) & M64 for x in mu], (zrec - kappa) & M64)
+    return w2, w64
+
+
+def pack_bits(bits):
+    """GF2 proof vectors: 8 items per byte MSB-first, then ALWAYS one more chunk
+    (gf2/share.rs:126-138, gf2/recon.rs:217-229): length = n//8 + 1."""
+    out = bytearray(len(bits) // 8 + 1)
+    for i, b in enumerate(bits):
+        if b:
+            out[i >> 3] |= 0x80 >> (i & 7)
+    return bytes(out)
+
+
+def challenge(comm: bytes):
+    """proof/mod.rs:68-83 + crypto/ro.rs:8-20"""
+    data = b"random-oracle challenge" + b"\x00" + comm
+    omit = {}
+    pos = 0
+    while len(omit) < 40:
+        x = blake3(data, 32, pos)
+        pos += 32
+        rep = int.from_bytes(x[:16], "little") % 256
+        om = int.from_bytes(x[16:], "little") % 8
+        omit[rep] = om
+    return omit
+
+
+def keystream_need(ops):
+    n2 = n64 = 0
+    for (dom, opc, *_rest) in ops:
+        if dom == DOM_GF2:
+            n2 += {OP_INPUT: 1, OP_RANDOM: 1, OP_MUL: 2}.get(opc, 0)
+        elif dom == DOM_Z64:
+            n64 += {OP_INPUT: 1, OP_RANDOM: 1, OP_MUL: 2}.get(opc, 0)
+        elif dom == DOM_B2A:
+            n2 += 64 + 2 * 63
+            n64 += 1
+    return max((n2 + 7) // 8, 8 * n64) + 64
+
+
+def prove(ops, wit2, wit64, wire_counts, seeds):
+    n64, n2 = wire_counts
+    need = keystream_need(ops)
+    reps = []
+    for r in range(256):
+        rep = Rep(seeds[r], need)
+        run_rep(rep, ops, wit2, wit64, n64, n2)
+        reps.append(rep)
+    digests = []
+    hs = []
+    for rep in reps:
+        st = [blake3(bytes(rep.pre2)), blake3(bytes(rep.on2)), blake3(bytes(rep.pre64)), blake3(bytes(rep.on64))]
+        h2 = blake3(st[0] + st[1])
+        h64 = blake3(st[2] + st[3])
+        hs.append(blake3(h2 + h64))
+        digests.append(st)
+    comm = blake3(b"".join(hs))
+    omit = challenge(comm)
+
+    def single(dom):
+        online = b""
+        pre = b""
+        for r, rep in enumerate(reps):
+            if r in omit:
+                o = omit[r]
+                keys = list(rep.keys)
+                keys[o] = bytes(16)
+                if dom == 2:
+                    recs = pack_bits([s[o] for s in rep.recs2])
+                    corrs = pack_bits(rep.corrs2)
+                    inputs = pack_bits(rep.inputs2)
+                else:
+                    recs = b"".join(struct.pack("<Q", s[o]) for s in rep.recs64)
+                    corrs = b"".join(struct.pack("<Q", c) for c in rep.corrs64)
+                    inputs = b"".join(struct.pack("<Q", c) for c in rep.inputs64)
+                online += bytes([o]) + b"".join(keys)
+                for v in (recs, corrs, inputs):
+                    online += struct.pack("<Q", len(v)) + v
+            else:
+                pre += rep.seed + (digests[r][1] if dom == 2 else digests[r][3])
+        return struct.pack("<Q", 40) + online + struct.pack("<Q", 216) + pre
+
+    proof = comm + single(2) + single(64)
+    return proof, hs, digests, comm, omit
+
+
+# ------------------------------------------------------------------ circuits
+def circ_ref_test():
+    """the reference's own end-to-end test circuit (proof/mod.rs:397-427)"""
+    ops = [GF2.Input(1) for _ in range(64)] + [B2A(0, 2), GF2.Input(0), GF2.Input(1), GF2.Mul(2, 0, 1),
+                                                GF2.Add(3, 0, 1), GF2.Mul(2, 2, 3)]
+    return ops, [1] * 128, [0], (128, 128)
+
+
+def circ_gf2_mix():
+    ops = [GF2.Input(i) for i in range(11)]
+    ops += [
+        GF2.Mul(11, 0, 1), GF2.Add(12, 11, 2), GF2.Sub(13, 12, 3), GF2.AddConst(14, 13, 1), GF2.SubConst(15, 14, 0),
+        GF2.MulConst(16, 15, 1), GF2.MulConst(17, 15, 0), GF2.Const(18, 1), GF2.Random(19), GF2.Mul(20, 19, 18),
+        GF2.Mul(21, 16, 4), GF2.Mul(5, 5, 6),  # in-place wire reuse
+        GF2.Add(22, 21, 5), GF2.Mul(23, 22, 22), GF2.Add(24, 23, 22), GF2.AssertZero(24),  # x*x + x == 0
+        GF2.Sub(25, 19, 19), GF2.AssertZero(25), GF2.AssertZero(17),
+        GF2.Input(26), GF2.Mul(27, 26, 7), GF2.Mul(28, 27, 8), GF2.Mul(29, 28, 9), GF2.Mul(30, 29, 10),
+        GF2.Const(31, 0), GF2.Mul(32, 31, 30), GF2.AssertZero(32), GF2.AssertZero(40),  # 40: never written
+    ]
+    wit = [1, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 1]
+    return ops, wit, [], (0, 48)
+
+
+def circ_z64_mix():
+    ops = [Z64.Input(i) for i in range(5)]
+    ops += [
+        Z64.Mul(5, 0, 1), Z64.Add(6, 5, 2), Z64.Sub(7, 6, 3), Z64.AddConst(8, 7, 0xFFFFFFFFFFFFFFFF),
+        Z64.SubConst(9, 8, 12345), Z64.MulConst(10, 9, 0x8000000000000001), Z64.Const(11, 77), Z64.Random(12),
+        Z64.Mul(13, 12, 11), Z64.Sub(14, 12, 12), Z64.AssertZero(14), Z64.Mul(15, 10, 4), Z64.Mul(4, 4, 4),
+    ]
+    wit = [0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFE, 5, 0x123456789ABCDEF0, 3]
+    # make wire 15 - expected == 0 provable: compute expected in the clear
+    v = {}
+    v[5] = (wit[0] * wit[1]) & M64
+    v[6] = (v[5] + wit[2]) & M64
+    v[7] = (v[6] - wit[3]) & M64
+    v[8] = (v[7] + M64) & M64
+    v[9] = (v[8] - 12345) & M64
+    v[10] = (v[9] * 0x8000000000000001) & M64
+    v[15] = (v[10] * wit[4]) & M64
+    ops += [Z64.SubConst(16, 15, v[15]), Z64.AssertZero(16)]
+    return ops, [], wit, (24, 0)
+
+
+def circ_sizehint_mixed():
+    ops = [SizeHint(3, 70), GF2.Input(0), GF2.Input(1), Z64.Input(0)]
+    ops += [GF2.Const(2 + k, (0xDEADBEEF12345678 >> k) & 1) for k in range(64)]
+    ops += [B2A(1, 2), Z64.Add(2, 1, 0), Z64.SubConst(2, 2, (0xDEADBEEF12345678 + 42) & M64), Z64.AssertZero(2),
+            GF2.Mul(66, 0, 1), GF2.AddConst(67, 66, 1), GF2.AssertZero(67)]
+    return ops, [1, 1], [42], (1, 1)  # wire counts deliberately small: SizeHint grows them
+
+
+def circ_empty():
+    return [], [], [], (0, 0)
+
+
+def circ_adder64():
+    """config 1: 64-bit ripple-carry adder, outputs asserted against the clear sum."""
+    A, Bv = 0x0123456789ABCDEF, 0xFEDCBA9876543210
+    ops = [GF2.Input(i) for i in range(128)]
+    wit = [(A >> i) & 1 for i in range(64)] + [(Bv >> i) & 1 for i in range(64)]
+    nxt = 128
+    outs = []
+    carry = None
+    for i in range(64):
+        a, b = i, 64 + i
+        if carry is None:
+            s = nxt; ops.append(GF2.Add(s, a, b)); nxt += 1
+            c = nxt; ops.append(GF2.Mul(c, a, b)); nxt += 1
+        else:
+            ac = nxt; ops.append(GF2.Add(ac, a, carry)); nxt += 1
+            bc = nxt; ops.append(GF2.Add(bc, b, carry)); nxt += 1
+            s = nxt; ops.append(GF2.Add(s, ac, b)); nxt += 1
+            if i < 63:
+                t = nxt; ops.append(GF2.Mul(t, ac, bc)); nxt += 1
+                c = nxt; ops.append(GF2.Add(c, t, carry)); nxt += 1
+        outs.append(s)
+        carry = c
+    total = (A + Bv) & M64
+    for i, s in enumerate(outs):
+        ops.append(GF2.AddConst(nxt, s, (total >> i) & 1))
+        ops.append(GF2.AssertZero(nxt))
+        nxt += 1
+    return ops, wit, [], (0, nxt)
+
+
+CIRCUITS = {
+    "ref_test": circ_ref_test,
+    "gf2_mix": circ_gf2_mix,
+    "z64_mix": circ_z64_mix,
+    "sizehint_mixed": circ_sizehint_mixed,
+    "empty": circ_empty,
+    "adder64": circ_adder64,
+}
+
+
+def main():
+    seeds = [rep_seed(r) for r in range(256)]
+    prim = {
+        "aes_ctr": [{"key": k.hex(), "stream": aes_ctr(k, 80).hex()} for k in
+                    (bytes(16), bytes(range(16)), seeds[0], seeds[255])],
+        "blake3": [{"len": n, "hash": blake3(bytes(i % 251 for i in range(n))).hex(),
+                    "xof_seek7_len131": blake3(bytes(i % 251 for i in range(n)), 131, 7).hex()} for n in
+                   (0, 1, 2, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 2048, 2049, 3072, 3073, 4096, 4097, 5120, 6144,
+                    7168, 8192, 8193, 16384, 31744, 102400)],
+        "rep_seed": {"0": seeds[0].hex(), "1": seeds[1].hex(), "255": seeds[255].hex()},
+        "expand_seed": [{"seed": s.hex(), "keys": aes_ctr(s, 128).hex()} for s in (bytes(16), seeds[3])],
+        "challenge": [],
+    }
+    for comm in (bytes(32), bytes(range(32)), blake3(b"comm")):
+        om = challenge(comm)
+        prim["challenge"].append({"comm": comm.hex(), "omit": [om.get(r, 8) for r in range(256)]})
+    json.dump(prim, open(os.path.join(HERE, "primitives.json"), "w"), indent=1)
+
+    # ---- share generator: one packed group (8 reps x 8 players), with and without omitted players
+    keys = [[blake3(b"key" + bytes([r, p]))[:16] for p in range(8)] for r in range(8)]
+    n = 300
+    ks = [[aes_ctr(keys[r][p], 8 * n + 64) for p in range(8)] for r in range(8)]
+    sg = {"keys": [[k.hex() for k in row] for row in keys], "n": n, "cases": []}
+    for omit in ([8] * 8, [0, 8, 7, 3, 8, 8, 5, 1]):
+        gf2 = []
+        for m in range(n):
+            w = 0
+            for r in range(8):
+                for p in range(8):
+                    if p != omit[r] and (ks[r][p][m >> 3] >> (7 - (m & 7))) & 1:
+                        w |= 1 << (63 - (8 * r + p))
+            gf2.append("%016x" % w)
+        z64 = []
+        for m in range(n):
+            z64.append(["%016x" % (0 if p == omit[r] else int.from_bytes(ks[r][p][8 * m:8 * m + 8], "little"))
+                        for r in range(8) for p in range(8)])
+        h = hashlib.sha256(json.dumps(z64).encode()).hexdigest()
+        sg["cases"].append({"omit": omit, "gf2": gf2, "z64_first4": z64[:4], "z64_last": z64[-1], "z64_sha256_json": h})
+    json.dump(sg, open(os.path.join(HERE, "sharegen.json"), "w"))
+
+    # ---- whole proofs
+    meta = {}
+    for name, fn in CIRCUITS.items():
+        ops, w2, w64, wc = fn()
+        proof, hs, digests, comm, omit = prove(ops, w2, w64, wc, seeds)
+        with open(os.path.join(HERE, f"proof_{name}.bin"), "wb") as f:
+            f.write(proof)
+        meta[name] = {
+            "ops": [list(o) for o in ops], "wit_gf2": w2, "wit_z64": [str(x) for x in w64], "wire_counts": list(wc),
+            "proof_len": len(proof), "proof_blake3": blake3(proof).hex(), "comm": comm.hex(),
+            "omit": [omit.get(r, 8) for r in range(256)],
+            "h": [h.hex() for h in hs[:8]] + [hs[255].hex()],
+            "streams_rep0": [d.hex() for d in digests[0]],
+        }
+        print(name, len(ops), "ops ->", len(proof), "bytes")
+    json.dump(meta, open(os.path.join(HERE, "proofs.json"), "w"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+"""The reference's own tests for this path, re-expressed against the oracle.
+
+  interpreter/single.rs:231-539   gate-value tests with all-zero seeds
+  algebra/mod.rs:210-409          pack/unpack round trips
+  generator/share.rs:76-147       omitted-player share consistency
+  algebra/z64/recon.rs:199-221    wrapping recon arithmetic (via gates)
+  proof/mod.rs:397-427            prove -> verify acceptance
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from reverie_amd.ops import B2A, GF2, Z64, program
+
+ZERO8 = np.zeros((8, 16), np.uint8)
+ONE = 0xFFFFFFFFFFFFFFFF
+M64 = (1 << 64) - 1
+
+
+def gate_gf2(oracle, wit, gate):
+    prog = program([GF2.Input(i) for i in range(len(wit))] + [gate])
+    dst = gate[3]
+    v, _ = oracle.group_wire_values(prog, wit, [], (0, len(prog) + 2), ZERO8, gf2_wire=dst)
+    return v
+
+
+def gate_z64(oracle, wit, gate):
+    prog = program([Z64.Input(i) for i in range(len(wit))] + [gate])
+    dst = gate[3]
+    _, v = oracle.group_wire_values(prog, [], wit, (len(prog) + 2, 0), ZERO8, z64_wire=dst)
+    return v.tolist()
+
+
+def test_mul_gf2(oracle):  # single.rs:231-252
+    g = GF2.Mul(2, 1, 0)
+    assert gate_gf2(oracle, [1, 1], g) == ONE
+    assert gate_gf2(oracle, [1, 0], g) == 0
+    assert gate_gf2(oracle, [0, 0], g) == 0
+
+
+def test_mulc_gf2(oracle):  # single.rs:254-287
+    assert gate_gf2(oracle, [1], GF2.MulConst(1, 0, 1)) == ONE
+    assert gate_gf2(oracle, [0], GF2.MulConst(1, 0, 1)) == 0
+    assert gate_gf2(oracle, [1], GF2.MulConst(1, 0, 0)) == 0
+    assert gate_gf2(oracle, [0], GF2.MulConst(1, 0, 0)) == 0
+
+
+def test_add_sub_addc_gf2(oracle):  # single.rs:289-390
+    for op in (GF2.Add, GF2.Sub):
+        assert gate_gf2(oracle, [1, 1], op(2, 1, 0)) == 0
+        assert gate_gf2(oracle, [1, 0], op(2, 1, 0)) == ONE
+        assert gate_gf2(oracle, [0, 0], op(2, 1, 0)) == 0
+    for op in (GF2.AddConst, GF2.SubConst):
+        assert gate_gf2(oracle, [1], op(1, 0, 1)) == 0
+        assert gate_gf2(oracle, [0], op(1, 0, 1)) == ONE
+        assert gate_gf2(oracle, [1], op(1, 0, 0)) == ONE
+        assert gate_gf2(oracle, [0], op(1, 0, 0)) == 0
+
+
+def test_gates_z64(oracle):  # single.rs:392-539 (incl. wrapping cases)
+    big = M64
+    assert gate_z64(oracle, [3, 5], Z64.Add(2, 1, 0)) == [8] * 8
+    assert gate_z64(oracle, [big, 2], Z64.Add(2, 1, 0)) == [1] * 8
+    assert gate_z64(oracle, [3], Z64.AddConst(1, 0, big)) == [2] * 8
+    assert gate_z64(oracle, [3, 5], Z64.Mul(2, 1, 0)) == [15] * 8
+    assert gate_z64(oracle, [big, big], Z64.Mul(2, 1, 0)) == [1] * 8
+    assert gate_z64(oracle, [1 << 63, 2], Z64.Mul(2, 1, 0)) == [0] * 8
+    assert gate_z64(oracle, [7], Z64.MulConst(1, 0, big)) == [(-7) & M64] * 8
+    assert gate_z64(oracle, [3, 5], Z64.Sub(2, 0, 1)) == [(-2) & M64] * 8
+    assert gate_z64(oracle, [3], Z64.SubConst(1, 0, 5)) == [(-2) & M64] * 8
+
+
+def test_assert_zero(oracle):  # single.rs assert0 test + prover.rs:221-228
+    prog = program([Z64.Input(0), Z64.AssertZero(0)])
+    oracle.group_wire_values(prog, [], [0], (2, 0), ZERO8, z64_wire=0)
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.group_wire_values(prog, [], [5], (2, 0), ZERO8, z64_wire=0)
+    assert e.value.code == 1
+    prog = program([GF2.Input(0), GF2.AssertZero(0)])
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.group_wire_values(prog, [1], [], (0, 2), ZERO8, gf2_wire=0)
+    assert e.value.code == 1
+    with pytest.raises(oracle.OracleError) as e:  # witness too short (prover.rs:190)
+        oracle.group_wire_values(prog, [], [], (0, 2), ZERO8, gf2_wire=0)
+    assert e.value.code == 2
+    with pytest.raises(oracle.OracleError) as e:  # wire out of range (Vec index panic)
+        oracle.group_wire_values(prog, [0], [], (0, 0), ZERO8, gf2_wire=0)
+    assert e.value.code == 3
+
+
+def test_random_values_any_seed(oracle):
+    rng = np.random.default_rng(5)
+    seeds = rng.integers(0, 256, (8, 16), dtype=np.uint8)
+    for a in (0, 1):
+        for b in (0, 1):
+            prog = program([GF2.Input(0), GF2.Input(1), GF2.Mul(2, 0, 1), GF2.Add(3, 2, 0), GF2.Mul(4, 3, 1)])
+            v, _ = oracle.group_wire_values(prog, [a, b], [], (0, 5), seeds, gf2_wire=4)
+            assert v == (ONE if ((a & b) ^ a) & b else 0)
+
+
+LENGTHS = [1, 2, 3, 6, 18, 32, 64, 63, 65, 128, 127]  # algebra/mod.rs:371-409
+
+
+def test_recon_pack_roundtrip(oracle):  # algebra/mod.rs:210-260
+    rng = np.random.default_rng(7)
+    keys = rng.integers(0, 256, (8, 8, 16), dtype=np.uint8)
+    for n in LENGTHS:
+        shares = oracle.sharegen_gf2(keys, [8] * 8, n)
+        recons = np.array([oracle.gf2_reconstruct(int(s)) for s in shares], np.uint64)
+        vecs = oracle.gf2_recon_pack(recons, [1] * 8)
+        assert all(len(v) == n // 8 + 1 for v in vecs)  # always one trailing chunk
+        back = oracle.gf2_recon_unpack(vecs)
+        assert len(back) >= n and (back[:n] == recons).all() and not back[n:].any()
+        sel = [1, 0, 0, 1, 0, 1, 1, 0]
+        part = oracle.gf2_recon_pack(recons, sel)
+        for i in range(8):
+            assert part[i] == (vecs[i] if sel[i] else b"")
+    assert oracle.gf2_recon_pack(recons, [0] * 8) == [b""] * 8
+
+
+def test_share_partial_pack_roundtrip(oracle):  # algebra/mod.rs:262-369
+    rng = np.random.default_rng(8)
+    keys = rng.integers(0, 256, (8, 8, 16), dtype=np.uint8)
+    for n in LENGTHS:
+        shares = oracle.sharegen_gf2(keys, [8] * 8, n)
+        selected = rng.integers(0, 8, 8).tolist()
+        vecs = oracle.gf2_share_pack_selected(shares, selected)
+        assert all(len(v) == n // 8 + 1 for v in vecs)
+        back = oracle.gf2_share_unpack_selected(vecs, selected)
+        keep = 0
+        for i, p in enumerate(selected):
+            keep |= 1 << (63 - (8 * i + p))
+        assert (back[:n] == (shares & np.uint64(keep))).all() and not back[n:].any()
+    none = oracle.gf2_share_pack_selected(shares, [8] * 8)
+    assert none == [b""] * 8
+
+
+def test_share_generator_omit(oracle):  # generator/share.rs:76-147 (+ the Z64 analogue)
+    rng = np.random.default_rng(9)
+    for trial in range(3):
+        keys = rng.integers(0, 256, (8, 8, 16), dtype=np.uint8)
+        n = int(rng.integers(1, 3000))
+        omit = rng.integers(0, 9, 8).tolist()
+        full = oracle.sharegen_gf2(keys, [8] * 8, n)
+        keys2 = keys.copy()
+        keep = 0
+        for i, p in enumerate(omit):
+            if p < 8:
+                keys2[i, p] = 0
+            for q in range(8):
+                if q != p:
+                    keep |= 1 << (63 - (8 * i + q))
+        part = oracle.sharegen_gf2(keys2, omit, n)
+        assert (part == (full & np.uint64(keep))).all()
+        nz = min(n, 300)
+        fz = oracle.sharegen_z64(keys, [8] * 8, nz)
+        pz = oracle.sharegen_z64(keys2, omit, nz)
+        for i, p in enumerate(omit):
+            for q in range(8):
+                if q == p:
+                    assert not pz[:, i, q].any()
+                else:
+                    assert (pz[:, i, q] == fz[:, i, q]).all()
+
+
+def test_sharegen_golden(oracle):
+    sg = json.load(open(os.path.join(GOLDEN, "sharegen.json")))
+    keys = np.array([[list(bytes.fromhex(k)) for k in row] for row in sg["keys"]], np.uint8)
+    import hashlib
+
+    for case in sg["cases"]:
+        out = oracle.sharegen_gf2(keys, case["omit"], sg["n"])
+        assert ["%016x" % int(x) for x in out] == case["gf2"]
+        z = oracle.sharegen_z64(keys, case["omit"], sg["n"])
+        zs = [["%016x" % int(v) for v in row.reshape(-1)] for row in z]
+        assert zs[:4] == case["z64_first4"] and zs[-1] == case["z64_last"]
+        assert hashlib.sha256(json.dumps(zs).encode()).hexdigest() == case["z64_sha256_json"]
+
+
+def test_prover_gf2_mul_prove_verify(oracle):  # proof/mod.rs:397-427, with OS seeds like the reference
+    ops = [GF2.Input(1) for _ in range(64)] + [B2A(0, 2), GF2.Input(0), GF2.Input(1), GF2.Mul(2, 0, 1), GF2.Add(3, 0, 1),
+                                                GF2.Mul(2, 2, 3)]
+    prog = program(ops)
+    seeds = np.frombuffer(os.urandom(4096), np.uint8).reshape(256, 16)
+    pf = oracle.prove(prog, [1] * 128, [0], (128, 128), seeds)
+    assert oracle.verify(prog, (128, 128), pf)
+    bad = bytearray(pf)
+    bad[7] ^= 1  # commitment byte
+    assert not oracle.verify(prog, (128, 128), bytes(bad))
+    # a different circuit must not verify
+    prog2 = program(ops[:-1] + [GF2.Mul(2, 3, 3)])
+    assert not oracle.verify(prog2, (128, 128), pf)
+
+
+def test_bench_circuit_small(oracle, rule_seeds):  # proof/mod.rs:318-395 shape, shortened
+    prog = program([GF2.Input(0), GF2.Input(1)] + [GF2.Mul(2, 0, 1)] * 3000)
+    pf = oracle.prove(prog, [1, 1], [0], (128, 128), rule_seeds)
+    assert oracle.verify(prog, (128, 128), pf)
+    assert len(pf) == 33160 + 40 * (3000 // 8 * 2)  # recons + corrs grow by n/8 bytes each
