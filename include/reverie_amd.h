@@ -1,0 +1,208 @@
+/* reverie_amd — MI355X-native KKW prover/verifier hot path: C-ABI drop-in boundary.
+ *
+ * This header is what a Rust `-sys` shim (or any FFI) binds.  It replaces, at the only
+ * seam where an FFI call is affordable, the reference's
+ *
+ *     Proof::new(circuit, wit_gf2, wit_z64, (z64_wires, gf2_wires)) -> Proof
+ *                                            /root/reference/src/proof/mod.rs:119-222
+ *     Proof::verify(&self, circuit, (z64_wires, gf2_wires)) -> bool
+ *                                            /root/reference/src/proof/mod.rs:224-307
+ *
+ * and everything those two drive: src/generator (AES-CTR share expansion),
+ * src/interpreter over src/algebra's packed GF(2)/Z64 rings, src/transcript, and the
+ * BLAKE3 commitments / random oracle of src/crypto.  Proof bytes are bincode-1.3
+ * compatible with the reference's `Proof`.
+ *
+ * Plain pointers and sizes only; no C++/torch types.  All functions return RV_OK (0) or
+ * an RV_E_* code; nothing aborts the process (the reference panics).
+ * A context is bound to ONE GPU and is thread-compatible: one in-flight call per context.
+ */
+#ifndef REVERIE_AMD_H
+#define REVERIE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- protocol constants: /root/reference/src/lib.rs:17-38 ---- */
+#define RV_PLAYERS 8
+#define RV_PACKED 8
+#define RV_BATCH_SIZE 128
+#define RV_ONLINE_REPS 40
+#define RV_TOTAL_REPS 256
+#define RV_PREPROCESSING_REPS (RV_TOTAL_REPS - RV_ONLINE_REPS)
+#define RV_KEY_SIZE 16  /* src/crypto/prg.rs:9  */
+#define RV_HASH_SIZE 32 /* src/crypto/hash.rs:8 */
+
+/* ---- gate stream ------------------------------------------------------------------
+ * One record per `mcircuit::CombineOperation` (re-exported at src/lib.rs:7; consumed at
+ * src/interpreter/combine.rs:120-132 and src/interpreter/single.rs:106-156).
+ *   domain RV_DOM_GF2 / RV_DOM_Z64 : `Operation<bool>` / `Operation<u64>`, opcode below;
+ *            fields: Input(dst) Random(dst) Add(dst,a,b) AddConst(dst,a,imm) Sub(dst,a,b)
+ *            SubConst(dst,a,imm) Mul(dst,a,b) MulConst(dst,a,imm) AssertZero(a) Const(dst,imm)
+ *            (GF2 constants use bit 0 of imm)
+ *   domain RV_DOM_B2A      : B2A(dst = z64 wire, a = lowest of 64 consecutive gf2 wires)
+ *   domain RV_DOM_SIZEHINT : SizeHint(a = z64 wire count, b = gf2 wire count)
+ */
+typedef struct rv_op {
+    uint8_t domain;
+    uint8_t opcode;
+    uint16_t reserved; /* must be 0 */
+    uint32_t dst;
+    uint32_t a;
+    uint32_t b;
+    uint64_t imm;
+} rv_op; /* 24 bytes */
+
+enum { RV_DOM_GF2 = 0, RV_DOM_Z64 = 1, RV_DOM_B2A = 2, RV_DOM_SIZEHINT = 3 };
+enum {
+    RV_OP_INPUT = 0,
+    RV_OP_RANDOM = 1,
+    RV_OP_ADD = 2,
+    RV_OP_ADDCONST = 3,
+    RV_OP_SUB = 4,
+    RV_OP_SUBCONST = 5,
+    RV_OP_MUL = 6,
+    RV_OP_MULCONST = 7,
+    RV_OP_ASSERTZERO = 8,
+    RV_OP_CONST = 9
+};
+
+/* ---- status codes (reference behaviour in parentheses) ---- */
+enum {
+    RV_OK = 0,
+    RV_E_WITNESS_INVALID = 1, /* (panic, src/transcript/prover.rs:221-228) an AssertZero failed */
+    RV_E_WITNESS_SHORT = 2,   /* (panic "witness is too short", prover.rs:190) */
+    RV_E_WIRE_OOB = 3,        /* (Vec index panic, single.rs:109-155) wire index >= wire count */
+    RV_E_PROOF_MALFORMED = 4, /* (bincode unwrap / assert panics; `omit >= 8` is UB upstream) */
+    RV_E_BAD_OP = 5,          /* unknown domain/opcode or reserved != 0 */
+    RV_E_NOMEM = 6,
+    RV_E_DEVICE = 7, /* no usable gfx950 device / HIP runtime error (see rv_last_error) */
+    RV_E_UNSUPPORTED = 8,
+    RV_E_ARG = 9
+};
+
+typedef struct rv_ctx rv_ctx;         /* one GPU: stream, scratch arena                    */
+typedef struct rv_circuit rv_circuit; /* a gate stream levelised and resident in HBM       */
+typedef struct rv_shard rv_shard;     /* committed repetitions awaiting the challenge      */
+
+const char *rv_strerror(int code);
+/* last HIP/driver error text for this thread ("" if none) */
+const char *rv_last_error(void);
+/* library/ABI version, bumps on any signature change */
+uint32_t rv_abi_version(void);
+
+/* ---- context ---- */
+int rv_ctx_create(int device_ordinal, rv_ctx **out);
+void rv_ctx_destroy(rv_ctx *ctx);
+/* block until all work queued on the context's stream has finished */
+int rv_ctx_sync(rv_ctx *ctx);
+
+/* ---- circuit: the `Arc<Vec<CombineOperation>>` + `wire_counts` arguments of
+ * Proof::new / Proof::verify (proof/mod.rs:119-125,224,232).  Compiling resolves wire
+ * reuse, orders gates into dependency levels, assigns every gate its PRG mask index and
+ * transcript offsets, and uploads the result to HBM; it is reusable across proofs.
+ * Errors that the reference raises while stepping (wire out of range, bad op) are
+ * reported here. */
+int rv_circuit_compile(rv_ctx *ctx, const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
+                       rv_circuit **out);
+void rv_circuit_destroy(rv_circuit *c);
+
+typedef struct rv_circuit_info {
+    uint64_t n_ops;
+    uint64_t gf2_inputs, gf2_muls, gf2_asserts, gf2_linear; /* linear = gates with no transcript output */
+    uint64_t gf2_masks;                                     /* ShareGen::next() calls per repetition       */
+    uint64_t z64_inputs, z64_muls, z64_asserts, z64_linear, z64_masks;
+    uint64_t b2a;
+    uint64_t levels;         /* dependency levels = kernel launches of the interpreter */
+    uint64_t device_bytes;   /* HBM held by the compiled circuit                       */
+    uint64_t scratch_bytes;  /* HBM a full 256-repetition prove needs on top           */
+} rv_circuit_info;
+int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
+
+/* ---- Proof::new -------------------------------------------------------------------
+ * wit_gf2: one byte per GF(2) witness element (0/1), consumed by Input gates in order
+ *          (the reference takes Vec<bool>);  wit_z64: u64 witness elements.
+ * seeds:   256 x 16 bytes, one per repetition (the reference draws them from OsRng,
+ *          proof/mod.rs:131-134).  NULL => drawn from the OS (getrandom).
+ * *proof:  bincode(Proof), allocated by the library, released with rv_free. */
+int rv_prove(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64,
+             size_t n_z64, const uint8_t *seeds, uint8_t **proof, size_t *proof_len);
+
+/* ---- Proof::verify ----------------------------------------------------------------
+ * *ok follows the reference exactly: 0 when a ProofSingle has the wrong number of
+ * repetitions or the recomputed commitment differs, 1 otherwise.  Bytes that cannot be
+ * parsed as a Proof, unequal GF(2) opening lengths inside a verifier group, or an
+ * `omit` value >= 8 return RV_E_PROOF_MALFORMED (the reference panics / is UB). */
+int rv_verify(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, int *ok);
+
+void rv_free(void *p);
+
+/* ---- sharded form (one process per GPU; repetitions [rep_begin, rep_begin+rep_count),
+ * both multiples of 8).  rv_prove == commit(0,256) -> combine -> challenge -> open ->
+ * assemble.  Between commit and open the caller exchanges the 32-byte per-repetition
+ * digests (one all-gather; proof/mod.rs:160-172 is the reference's gather point). */
+int rv_shard_commit(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64,
+                    size_t n_z64, const uint8_t *seeds /* rep_count x 16 */, uint32_t rep_begin, uint32_t rep_count,
+                    rv_shard **out);
+/* device pointer to rep_count x 32 digest bytes (valid until rv_shard_destroy), for RCCL */
+int rv_shard_digests_device(rv_shard *s, void **dptr);
+/* host copy of the same bytes */
+int rv_shard_digests(rv_shard *s, uint8_t *out /* rep_count x 32 */);
+/* Opens the shard's repetitions for the full challenge (omit[256], 8 = preprocessing).
+ * Returns four blobs: the shard's OpenOnline / OpenPreprocessing records, in ascending
+ * repetition order, already in bincode form, for the gf2 and z64 ProofSingle.
+ * Each blob is library-allocated (rv_free). */
+typedef struct rv_shard_parts {
+    uint8_t *gf2_online, *gf2_pre, *z64_online, *z64_pre;
+    size_t gf2_online_len, gf2_pre_len, z64_online_len, z64_pre_len;
+    uint32_t n_online, n_pre;
+} rv_shard_parts;
+int rv_shard_open(rv_shard *s, const uint8_t omit[RV_TOTAL_REPS], rv_shard_parts *parts);
+void rv_shard_destroy(rv_shard *s);
+
+/* Device-resident variant used by bench.py: leaves the shard's four blobs concatenated
+ * in HBM (gf2_online | gf2_pre | z64_online | z64_pre) and returns the device pointer,
+ * valid until the shard is destroyed. */
+int rv_shard_open_device(rv_shard *s, const uint8_t omit[RV_TOTAL_REPS], void **dptr, size_t lens[4]);
+
+/* combine_hashes (proof/mod.rs:102-108): comm = BLAKE3(h[0] || ... || h[255]) */
+int rv_combine_digests(const uint8_t *h /* 256 x 32 */, uint8_t comm[RV_HASH_SIZE]);
+/* challenge_to_opening (proof/mod.rs:74-83): omit[r] in 0..7 for the 40 online reps, else 8 */
+int rv_challenge(const uint8_t comm[RV_HASH_SIZE], uint8_t omit[RV_TOTAL_REPS]);
+/* Concatenates shard parts (ordered by rep_begin) into bincode(Proof) */
+int rv_assemble_proof(const uint8_t comm[RV_HASH_SIZE], const rv_shard_parts *parts, size_t n_parts, uint8_t **proof,
+                      size_t *proof_len);
+/* Verifier side of the sharded form: recomputes the digests of the verifier's
+ * repetition slots [slot_begin, slot_begin+slot_count) (slots 0..39 = online openings in
+ * proof order, 40..255 = preprocessing openings; proof/mod.rs:234-281), multiples of 8. */
+int rv_verify_shard(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, uint32_t slot_begin,
+                    uint32_t slot_count, uint8_t *digests /* slot_count x 32 */);
+/* Final check of Proof::verify (proof/mod.rs:283-306) from all 256 slot digests */
+int rv_verify_finish(const uint8_t *proof, size_t proof_len, const uint8_t *slot_digests /* 256 x 32 */, int *ok);
+
+/* ---- parity-test hooks: each mirrors one reference function so tests can compare the
+ * HIP path with the oracle piecewise ---- */
+/* PRG::new + gen (crypto/prg.rs:16-37) on the GPU: n_keys keys, blocks [first, first+n_blocks) each */
+int rv_hook_prg_blocks(rv_ctx *ctx, const uint8_t *keys, size_t n_keys, uint64_t first_block, size_t n_blocks,
+                       uint8_t *out /* n_keys x n_blocks x 16 */);
+/* expand_seed (transcript/mod.rs:99-106) for n seeds -> n x 8 x 16 key bytes */
+int rv_hook_expand_seed(rv_ctx *ctx, const uint8_t *seeds, size_t n, uint8_t *keys);
+/* ShareGen<GF2>::next() x n for one packed group (generator/share.rs:54-65): keys 8x8x16,
+ * omit[8] (8 = none) -> n packed u64 shares in the reference's bit order */
+int rv_hook_sharegen_gf2(rv_ctx *ctx, const uint8_t *keys, const uint32_t omit[8], size_t n, uint64_t *out);
+/* ShareGen<Z64>::next() x n -> n x 8 x 8 u64 */
+int rv_hook_sharegen_z64(rv_ctx *ctx, const uint8_t *keys, const uint32_t omit[8], size_t n, uint64_t *out);
+/* BLAKE3 of n_streams independent byte strings of equal length len (row-major), on the GPU
+ * tree-hash kernels used for the transcripts (crypto/hash.rs:17-57) */
+int rv_hook_blake3(rv_ctx *ctx, const uint8_t *data, size_t n_streams, size_t len, uint8_t *out /* n x 32 */);
+/* per-stream digests of a committed shard: rep_count x 4 x 32 = H_pre(gf2), H_on(gf2), H_pre(z64), H_on(z64) */
+int rv_hook_shard_stream_digests(rv_shard *s, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REVERIE_AMD_H */

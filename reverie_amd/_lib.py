@@ -1,0 +1,78 @@
+"""ctypes binding of libreverie_amd.so (the C-ABI declared in include/reverie_amd.h).
+
+There is NO CPU fallback: if the HIP library is missing, or no gfx950 device is visible,
+every compute entry point raises.  (The CPU oracle under oracle/ is test infrastructure
+and is never imported from this package.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libreverie_amd.so")
+
+RV_OK = 0
+ERRORS = {
+    1: "WITNESS_INVALID", 2: "WITNESS_SHORT", 3: "WIRE_OOB", 4: "PROOF_MALFORMED", 5: "BAD_OP",
+    6: "NOMEM", 7: "DEVICE", 8: "UNSUPPORTED", 9: "ARG",
+}
+
+
+class ReverieError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        self.name = ERRORS.get(code, "?")
+        super().__init__(f"reverie_amd error {code} ({self.name}){': ' + detail if detail else ''}")
+
+
+class ShardParts(C.Structure):
+    _fields_ = [
+        ("gf2_online", C.c_void_p), ("gf2_pre", C.c_void_p), ("z64_online", C.c_void_p), ("z64_pre", C.c_void_p),
+        ("gf2_online_len", C.c_size_t), ("gf2_pre_len", C.c_size_t), ("z64_online_len", C.c_size_t),
+        ("z64_pre_len", C.c_size_t), ("n_online", C.c_uint32), ("n_pre", C.c_uint32),
+    ]
+
+
+class CircuitInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "n_ops", "gf2_inputs", "gf2_muls", "gf2_asserts", "gf2_linear", "gf2_masks", "z64_inputs", "z64_muls",
+        "z64_asserts", "z64_linear", "z64_masks", "b2a", "levels", "device_bytes", "scratch_bytes")]
+
+
+# every symbol include/reverie_amd.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "rv_strerror", "rv_last_error", "rv_abi_version", "rv_ctx_create", "rv_ctx_destroy", "rv_ctx_sync",
+    "rv_circuit_compile", "rv_circuit_destroy", "rv_circuit_get_info", "rv_prove", "rv_verify", "rv_free",
+    "rv_shard_commit", "rv_shard_digests_device", "rv_shard_digests", "rv_shard_open", "rv_shard_destroy",
+    "rv_shard_open_device", "rv_combine_digests", "rv_challenge", "rv_assemble_proof", "rv_verify_shard",
+    "rv_verify_finish", "rv_hook_prg_blocks", "rv_hook_expand_seed", "rv_hook_sharegen_gf2", "rv_hook_sharegen_z64",
+    "rv_hook_blake3", "rv_hook_shard_stream_digests",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ReverieError(7, f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  "(make -C reverie_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.rv_strerror.restype = C.c_char_p
+        L.rv_last_error.restype = C.c_char_p
+        L.rv_abi_version.restype = C.c_uint32
+        for name in SYMBOLS:
+            fn = getattr(L, name)
+            if name in ("rv_ctx_destroy", "rv_circuit_destroy", "rv_shard_destroy", "rv_free"):
+                fn.restype = None
+            elif name not in ("rv_strerror", "rv_last_error", "rv_abi_version"):
+                fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != RV_OK:
+        raise ReverieError(rc, lib().rv_last_error().decode() if rc in (6, 7) else "")

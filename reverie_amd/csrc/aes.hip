@@ -1,0 +1,248 @@
+// AES-128-CTR share expansion for gfx950 (integer VALU only; no MFMA — this is XOR/AND work).
+//
+// Replaces (all under /root/reference/src/):
+//   crypto/prg.rs:16-37            PRG::new / gen            (AES-128-CTR, BE counter, IV 0)
+//   transcript/mod.rs:99-122       expand_seed               (rep seed -> 8 player keys)
+//   generator/batch.rs:13-40       BatchGen::gen             (one 16-byte batch per player)
+//   generator/share.rs:54-65       ShareGen::next refill
+//   algebra/gf2/domain.rs:66-378   batches_to_shares + the AVX2 movemask transpose
+//
+// Design: the mask generator is BITSLICED with one lane = 32 AES blocks = the 4
+// repetitions x 8 players of one quad word, all at the same CTR block index j.  Register
+// b of the bitsliced state then holds keystream bit b for those 32 (rep, player) slots —
+// which IS the packed share word for mask index 128*j + b (bit 31-(8*i4+p)).  The
+// reference's 64x128 bit transpose (its top CPU cost) disappears: the
+// bitsliced cipher emits the transposed layout natively, and a wavefront stores one
+// 256-byte row per mask index, fully coalesced.
+#include "internal.h"
+
+namespace rv {
+
+__device__ __constant__ uint8_t SBOX_TAB[256] = {
+#include "aes_sbox_table.inc"
+};
+
+// ------------------------------------------------------------------------------------
+// byte-wise AES for the tiny per-shard setup work (256 seeds, 2048 key schedules)
+// ------------------------------------------------------------------------------------
+__device__ inline uint8_t xtime8(uint8_t x) { return (uint8_t)((x << 1) ^ ((x & 0x80) ? 0x1b : 0)); }
+
+__device__ void key_expand(const uint8_t key[16], uint8_t rk[176]) {
+    for (int i = 0; i < 16; i++) rk[i] = key[i];
+    uint8_t rcon = 1;
+    for (int r = 1; r <= 10; r++) {
+        const uint8_t* p = rk + 16 * (r - 1);
+        uint8_t* q = rk + 16 * r;
+        q[0] = p[0] ^ SBOX_TAB[p[13]] ^ rcon;
+        q[1] = p[1] ^ SBOX_TAB[p[14]];
+        q[2] = p[2] ^ SBOX_TAB[p[15]];
+        q[3] = p[3] ^ SBOX_TAB[p[12]];
+        rcon = xtime8(rcon);
+        for (int i = 4; i < 16; i++) q[i] = p[i] ^ q[i - 4];
+    }
+}
+
+__device__ void encrypt_bytes(const uint8_t rk[176], const uint8_t in[16], uint8_t out[16]) {
+    uint8_t s[16], t[16];
+    for (int i = 0; i < 16; i++) s[i] = in[i] ^ rk[i];
+    for (int r = 1; r <= 10; r++) {
+        for (int c = 0; c < 4; c++)
+            for (int row = 0; row < 4; row++) t[4 * c + row] = SBOX_TAB[s[4 * ((c + row) & 3) + row]];
+        if (r < 10) {
+            for (int c = 0; c < 4; c++) {
+                uint8_t a0 = t[4 * c], a1 = t[4 * c + 1], a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+                uint8_t all = a0 ^ a1 ^ a2 ^ a3;
+                s[4 * c + 0] = a0 ^ all ^ xtime8(a0 ^ a1);
+                s[4 * c + 1] = a1 ^ all ^ xtime8(a1 ^ a2);
+                s[4 * c + 2] = a2 ^ all ^ xtime8(a2 ^ a3);
+                s[4 * c + 3] = a3 ^ all ^ xtime8(a3 ^ a0);
+            }
+        } else {
+            for (int i = 0; i < 16; i++) s[i] = t[i];
+        }
+        for (int i = 0; i < 16; i++) s[i] ^= rk[16 * r + i];
+    }
+    for (int i = 0; i < 16; i++) out[i] = s[i];
+}
+
+__device__ inline void ctr_block(uint64_t j, uint8_t b[16]) {
+    for (int i = 0; i < 8; i++) {
+        b[i] = 0;
+        b[8 + i] = (uint8_t)(j >> (56 - 8 * i));
+    }
+}
+
+// expand_seed: keys[r][p] = AES_{seed[r]}(BE128(p))
+__global__ void k_expand_seeds(const uint8_t* __restrict__ seeds, uint32_t n_reps, uint8_t* __restrict__ keys) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_reps * 8) return;
+    uint32_t r = t >> 3, p = t & 7;
+    uint8_t key[16], rk[176], in[16], out[16];
+    for (int i = 0; i < 16; i++) key[i] = seeds[16 * r + i];
+    key_expand(key, rk);
+    ctr_block(p, in);
+    encrypt_bytes(rk, in, out);
+    for (int i = 0; i < 16; i++) keys[16 * t + i] = out[i];
+}
+
+__global__ void k_key_schedule(const uint8_t* __restrict__ keys, uint32_t n_slots, uint8_t* __restrict__ rkbytes) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_slots) return;
+    uint8_t key[16], rk[176];
+    for (int i = 0; i < 16; i++) key[i] = keys[16 * t + i];
+    key_expand(key, rk);
+    for (int i = 0; i < 176; i++) rkbytes[176 * (size_t)t + i] = rk[i];
+}
+
+// rk[(round*128 + 8*byte + bit)*NQ + q] = bit `bit` of round-key byte `byte` of the 32
+// slots of quad q, slot (i4, p) at bit 31 - (8*i4 + p).  Slots are numbered rep*8 + p.
+__global__ void k_bitslice_rk(const uint8_t* __restrict__ rkbytes, uint32_t NQ, uint32_t* __restrict__ rk) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 11u * 128u * NQ) return;
+    uint32_t q = t % NQ, idx = t / NQ;
+    uint32_t byte = idx >> 3, bit = idx & 7;  // byte in 0..175
+    uint32_t w = 0;
+    for (uint32_t s = 0; s < 32; s++) {
+        uint32_t slot = q * 32 + s;
+        w |= (uint32_t)((rkbytes[176 * (size_t)slot + byte] >> bit) & 1) << (31 - s);
+    }
+    rk[t] = w;
+}
+
+// test hook / Z64 path helper: plain CTR blocks, one thread per (key, block)
+__global__ void k_aes_blocks(const uint8_t* __restrict__ rkbytes, uint32_t n_keys, uint64_t first, uint64_t n_blocks,
+                             uint8_t* __restrict__ out) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n_keys * n_blocks) return;
+    uint64_t k = t / n_blocks, b = t % n_blocks;
+    uint8_t rk[176], in[16], o[16];
+    for (int i = 0; i < 176; i++) rk[i] = rkbytes[176 * k + i];
+    ctr_block(first + b, in);
+    encrypt_bytes(rk, in, o);
+    for (int i = 0; i < 16; i++) out[16 * t + i] = o[i];
+}
+
+// ------------------------------------------------------------------------------------
+// bitsliced AES-128: state s[8*i + k] = bit k (0 = LSB) of state byte i, 32 blocks/lane
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void sbox8(uint32_t& b7, uint32_t& b6, uint32_t& b5, uint32_t& b4, uint32_t& b3, uint32_t& b2,
+                                      uint32_t& b1, uint32_t& b0) {
+    const uint32_t U0 = b7, U1 = b6, U2 = b5, U3 = b4, U4 = b3, U5 = b2, U6 = b1, U7 = b0;
+#include "aes_sbox.inc"
+    b7 = S0;
+    b6 = S1;
+    b5 = S2;
+    b4 = S3;
+    b3 = S4;
+    b2 = S5;
+    b1 = S6;
+    b0 = S7;
+}
+
+// SubBytes + ShiftRows: t[new position] = S(s[old position])
+__device__ __forceinline__ void sub_shift(const uint32_t* s, uint32_t* t) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int row = 0; row < 4; row++) {
+            const int src = 8 * (4 * ((c + row) & 3) + row), dst = 8 * (4 * c + row);
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[dst + k] = s[src + k];
+            sbox8(t[dst + 7], t[dst + 6], t[dst + 5], t[dst + 4], t[dst + 3], t[dst + 2], t[dst + 1], t[dst + 0]);
+        }
+    }
+}
+
+// MixColumns + AddRoundKey: s = MC(t) ^ rk
+__device__ __forceinline__ void mix_ark(const uint32_t* t, uint32_t* s, const uint32_t* __restrict__ rk, uint32_t stride) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t* a = t + 32 * c;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t* a0 = a + 8 * r;
+            const uint32_t* a1 = a + 8 * ((r + 1) & 3);
+            const uint32_t* a2 = a + 8 * ((r + 2) & 3);
+            const uint32_t* a3 = a + 8 * ((r + 3) & 3);
+            uint32_t d[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) d[k] = a0[k] ^ a1[k];
+            // xtime(d): y0=d7 y1=d0^d7 y2=d1 y3=d2^d7 y4=d3^d7 y5=d4 y6=d5 y7=d6
+            uint32_t x[8] = {d[7], d[0] ^ d[7], d[1], d[2] ^ d[7], d[3] ^ d[7], d[4], d[5], d[6]};
+            uint32_t* o = s + 32 * c + 8 * r;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o[k] = x[k] ^ a1[k] ^ a2[k] ^ a3[k] ^ rk[(size_t)(32 * c + 8 * r + k) * stride];
+        }
+    }
+}
+
+// One lane: quad q (32 slots), CTR block j.  Writes 128 mask rows.
+__global__ __launch_bounds__(256) void k_aes_gf2_masks(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep,
+                                                       uint32_t NQ, uint64_t first_block, uint64_t n_blocks,
+                                                       uint32_t* __restrict__ masks) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t jl = gid / NQ;
+    const uint32_t q = (uint32_t)(gid % NQ);
+    if (jl >= n_blocks) return;
+    const uint64_t j = first_block + jl;
+    const uint32_t* rkq = rk + q;
+
+    uint32_t s[128], t[128];
+    // round 0: counter block BE128(j) (bytes 8..15 carry j) xor rk[0]
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t cb = 0;
+            if (i >= 8) cb = (uint32_t)0 - (uint32_t)((j >> (8 * (15 - i) + k)) & 1);
+            s[8 * i + k] = rkq[(size_t)(8 * i + k) * NQ] ^ cb;
+        }
+    }
+#pragma unroll 1
+    for (int r = 1; r < 10; r++) {
+        sub_shift(s, t);
+        mix_ark(t, s, rkq + (size_t)r * 128 * NQ, NQ);
+    }
+    sub_shift(s, t);
+    const uint32_t kp = keep ? keep[q] : 0xFFFFFFFFu;
+    const uint32_t* rk10 = rkq + (size_t)10 * 128 * NQ;
+    uint32_t* out = masks + (size_t)jl * 128 * NQ + q;
+    // keystream bit order is MSB-first inside each byte (gf2/domain.rs: share 8i+j <- bit 7-j of byte i)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t v = (t[8 * i + k] ^ rk10[(size_t)(8 * i + k) * NQ]) & kp;
+            out[(size_t)(8 * i + (7 - k)) * NQ] = v;
+        }
+    }
+}
+
+// ---- launchers ----
+void launch_expand_seeds(hipStream_t st, const uint8_t* d_seeds, uint32_t n_reps, uint8_t* d_keys) {
+    uint32_t n = n_reps * 8;
+    hipLaunchKernelGGL(k_expand_seeds, dim3((n + 63) / 64), dim3(64), 0, st, d_seeds, n_reps, d_keys);
+}
+void launch_key_schedule(hipStream_t st, const uint8_t* d_keys, uint32_t n_slots, uint8_t* d_rkbytes) {
+    hipLaunchKernelGGL(k_key_schedule, dim3((n_slots + 63) / 64), dim3(64), 0, st, d_keys, n_slots, d_rkbytes);
+}
+void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, uint32_t* d_rk) {
+    uint32_t n = 11u * 128u * NQ;
+    hipLaunchKernelGGL(k_bitslice_rk, dim3((n + 255) / 256), dim3(256), 0, st, d_rkbytes, NQ, d_rk);
+}
+void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
+                          uint64_t n_blocks, uint32_t* d_masks) {
+    if (!n_blocks) return;
+    uint64_t threads = n_blocks * NQ;
+    hipLaunchKernelGGL(k_aes_gf2_masks, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_rk, d_keep, NQ,
+                       first_block, n_blocks, d_masks);
+}
+void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
+                       uint8_t* d_out) {
+    uint64_t n = (uint64_t)n_keys * n_blocks;
+    if (!n) return;
+    hipLaunchKernelGGL(k_aes_blocks, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_rkbytes, n_keys, first_block,
+                       n_blocks, d_out);
+}
+
+}  // namespace rv

@@ -1,0 +1,931 @@
+// C-ABI implementation (include/reverie_amd.h): contexts, HBM arenas, the prove / verify
+// orchestration of /root/reference/src/proof/mod.rs:119-307 and the host-side Fiat-Shamir
+// pieces (combine_hashes :102-108, challenge_to_opening :74-83, bincode layout :40-66).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/random.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "b3.h"
+#include "compile.h"
+#include "internal.h"
+
+using namespace rv;
+
+// ------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_last_error = buf;
+    return RV_E_DEVICE;
+}
+#define HIPCHK(x)                                                     \
+    do {                                                              \
+        hipError_t e_ = (x);                                          \
+        if (e_ != hipSuccess) return hip_fail(e_, #x, __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* rv_last_error(void) { return g_last_error.c_str(); }
+extern "C" uint32_t rv_abi_version(void) { return 1; }
+
+extern "C" const char* rv_strerror(int code) {
+    switch (code) {
+    case RV_OK: return "ok";
+    case RV_E_WITNESS_INVALID: return "witness is invalid (an AssertZero wire is not zero)";
+    case RV_E_WITNESS_SHORT: return "witness is too short";
+    case RV_E_WIRE_OOB: return "wire index out of range";
+    case RV_E_PROOF_MALFORMED: return "proof bytes are malformed";
+    case RV_E_BAD_OP: return "unknown operation";
+    case RV_E_NOMEM: return "out of memory";
+    case RV_E_DEVICE: return "GPU/HIP error (no usable gfx950 device?)";
+    case RV_E_UNSUPPORTED: return "unsupported";
+    case RV_E_ARG: return "bad argument";
+    }
+    return "unknown error";
+}
+
+// ------------------------------------------------------------------------------------
+// context: one device, one stream, a caching arena (hipMalloc of GB-sized buffers costs
+// milliseconds; proofs over the same circuit reuse the same sizes)
+// ------------------------------------------------------------------------------------
+struct rv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live;
+    size_t cached_bytes = 0;
+
+    int alloc(size_t bytes, void** out) {
+        if (bytes == 0) bytes = 256;
+        bytes = (bytes + 255) & ~(size_t)255;
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
+            *out = it->second;
+            live[*out] = it->first;
+            cached_bytes -= it->first;
+            free_blocks.erase(it);
+            return RV_OK;
+        }
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) {
+            trim();
+            e = hipMalloc(out, bytes);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            g_last_error = "hipMalloc failed";
+            return RV_E_NOMEM;
+        }
+        live[*out] = bytes;
+        return RV_OK;
+    }
+    void release(void* p) {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_blocks.emplace(it->second, p);
+        cached_bytes += it->second;
+        live.erase(it);
+    }
+    void trim() {
+        for (auto& kv : free_blocks) (void)hipFree(kv.second);
+        free_blocks.clear();
+        cached_bytes = 0;
+    }
+};
+
+template <class T>
+static int dalloc(rv_ctx* ctx, size_t count, T** out) {
+    void* p = nullptr;
+    int rc = ctx->alloc(count * sizeof(T), &p);
+    *out = (T*)p;
+    return rc;
+}
+
+extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
+    if (!out) return RV_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        g_last_error = "no HIP device visible: the reverie_amd product path needs an MI355X (gfx950); there is no CPU fallback";
+        return RV_E_DEVICE;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) return RV_E_ARG;
+    HIPCHK(hipSetDevice(device_ordinal));
+    rv_ctx* c = new rv_ctx();
+    c->device = device_ordinal;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete c;
+        return hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
+    }
+    *out = c;
+    return RV_OK;
+}
+
+extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->trim();
+    for (auto& kv : ctx->live) (void)hipFree(kv.first);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int rv_ctx_sync(rv_ctx* ctx) {
+    if (!ctx) return RV_E_ARG;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RV_OK;
+}
+
+extern "C" void rv_free(void* p) { free(p); }
+
+// ------------------------------------------------------------------------------------
+// circuit
+// ------------------------------------------------------------------------------------
+struct rv_circuit {
+    rv_ctx* ctx = nullptr;
+    Compiled cc;  // gates kept on the host too (level table, counts)
+    Gate* d_gates = nullptr;
+    uint32_t* d_rec_rows = nullptr;
+    uint32_t* d_in_rows = nullptr;
+};
+
+static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
+    const size_t NQ = R / 4;
+    const size_t mask_rows = ((cc.n_masks + 127) / 128) * 128;
+    size_t b = 0;
+    b += mask_rows * NQ * 4;
+    b += cc.n_ssa * 2 * NQ * 4;
+    b += (cc.n_on + cc.n_pre) * NQ * 4;
+    b += 4 * b3_stream_scratch_words(std::max(cc.n_on, cc.n_pre), R) * 4;
+    b += (size_t)R * (16 + 128 + 8 * 176) + 11 * 128 * NQ * 4;
+    return b;
+}
+
+extern "C" int rv_circuit_compile(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
+                                  rv_circuit** out) {
+    if (!ctx || !out || (n_ops && !ops)) return RV_E_ARG;
+    *out = nullptr;
+    rv_circuit* c = new rv_circuit();
+    c->ctx = ctx;
+    int rc = compile_ops(ops, n_ops, z64_wires, gf2_wires, c->cc);
+    if (rc) {
+        delete c;
+        return rc;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const Compiled& cc = c->cc;
+    auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+        int r = ctx->alloc(bytes, dst);
+        if (r) return r;
+        if (bytes) HIPCHK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return RV_OK;
+    };
+    if ((rc = up(cc.gates.data(), cc.gates.size() * sizeof(Gate), (void**)&c->d_gates)) ||
+        (rc = up(cc.rec_rows.data(), cc.rec_rows.size() * 4, (void**)&c->d_rec_rows)) ||
+        (rc = up(cc.in_rows.data(), cc.in_rows.size() * 4, (void**)&c->d_in_rows))) {
+        rv_circuit_destroy(c);
+        return rc;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    c->cc.info.device_bytes = cc.gates.size() * sizeof(Gate) + (cc.rec_rows.size() + cc.in_rows.size()) * 4;
+    c->cc.info.scratch_bytes = scratch_bytes_for(cc, RV_TOTAL_REPS);
+    *out = c;
+    return RV_OK;
+}
+
+extern "C" void rv_circuit_destroy(rv_circuit* c) {
+    if (!c) return;
+    c->ctx->release(c->d_gates);
+    c->ctx->release(c->d_rec_rows);
+    c->ctx->release(c->d_in_rows);
+    delete c;
+}
+
+extern "C" int rv_circuit_get_info(const rv_circuit* c, rv_circuit_info* info) {
+    if (!c || !info) return RV_E_ARG;
+    *info = c->cc.info;
+    return RV_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Fiat-Shamir (host): 8 KiB hash + a few XOF blocks
+// ------------------------------------------------------------------------------------
+extern "C" int rv_combine_digests(const uint8_t* h, uint8_t comm[RV_HASH_SIZE]) {
+    if (!h || !comm) return RV_E_ARG;
+    b3::Hasher hs;
+    hs.update(h, RV_TOTAL_REPS * RV_HASH_SIZE);
+    hs.finalize(comm);
+    return RV_OK;
+}
+
+extern "C" int rv_challenge(const uint8_t comm[RV_HASH_SIZE], uint8_t omit[RV_TOTAL_REPS]) {
+    if (!comm || !omit) return RV_E_ARG;
+    static const char CTX[] = "random-oracle challenge";  // proof/mod.rs:18
+    b3::Hasher hs;
+    hs.update(CTX, sizeof CTX - 1);
+    const uint8_t zero = 0;
+    hs.update(&zero, 1);  // crypto/ro.rs:11
+    hs.update(comm, RV_HASH_SIZE);
+    memset(omit, RV_PLAYERS, RV_TOTAL_REPS);
+    int count = 0;
+    uint64_t pos = 0;
+    while (count < RV_ONLINE_REPS) {
+        uint8_t buf[32];
+        hs.xof(pos, buf, 32);
+        pos += 32;
+        const unsigned rep = buf[0];      // u128 LE mod 256
+        const unsigned om = buf[16] & 7;  // u128 LE mod 8
+        if (omit[rep] == RV_PLAYERS) count++;
+        omit[rep] = (uint8_t)om;  // a re-drawn repetition overwrites (HashMap::insert)
+    }
+    return RV_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// shard
+// ------------------------------------------------------------------------------------
+struct rv_shard {
+    rv_ctx* ctx = nullptr;
+    const rv_circuit* c = nullptr;
+    uint32_t rep_begin = 0, R = 0, NQ = 0;
+    uint8_t* d_seeds = nullptr;
+    uint8_t* d_keys = nullptr;
+    uint8_t* d_rkbytes = nullptr;
+    uint32_t* d_rk = nullptr;
+    uint32_t* d_masks = nullptr;
+    uint32_t* d_wires = nullptr;
+    uint32_t* d_on = nullptr;
+    uint32_t* d_pre = nullptr;
+    uint8_t* d_wit = nullptr;
+    uint32_t* d_cv[2] = {nullptr, nullptr};
+    uint32_t* d_dig = nullptr;  // [4][R][8]: pre2, on2, pre64, on64
+    uint8_t* d_h = nullptr;     // [R][32]
+    int* d_err = nullptr;
+    // open
+    uint8_t* d_omit = nullptr;
+    uint64_t* d_offs = nullptr;  // [5][R]
+    uint8_t* d_out = nullptr;
+    std::vector<void*> extra;
+
+    void destroy() {
+        void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk, d_masks, d_wires, d_on, d_pre, d_wit, d_cv[0], d_cv[1],
+                      d_dig,   d_h,    d_err,     d_omit, d_offs, d_out};
+        for (void* p : ps) ctx->release(p);
+        for (void* p : extra) ctx->release(p);
+    }
+};
+
+extern "C" void rv_shard_destroy(rv_shard* s) {
+    if (!s) return;
+    (void)hipStreamSynchronize(s->ctx->stream);
+    s->destroy();
+    delete s;
+}
+
+// key material -> bitsliced round keys, masks
+static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep) {
+    rv_ctx* ctx = s->ctx;
+    const Compiled& cc = s->c->cc;
+    int rc;
+    if ((rc = dalloc(ctx, (size_t)s->R * 8 * 176, &s->d_rkbytes))) return rc;
+    if ((rc = dalloc(ctx, (size_t)11 * 128 * s->NQ, &s->d_rk))) return rc;
+    const uint64_t n_blocks = (cc.n_masks + 127) / 128;
+    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(n_blocks, 1) * 128 * s->NQ, &s->d_masks))) return rc;
+    launch_key_schedule(ctx->stream, s->d_keys, s->R * 8, s->d_rkbytes);
+    launch_bitslice_rk(ctx->stream, s->d_rkbytes, s->NQ, s->d_rk);
+    launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, 0, n_blocks, s->d_masks);
+    return RV_OK;
+}
+
+// interpreter over all levels + transcript digests + joins
+static int shard_run(rv_shard* s, int mode, InterpParams& p) {
+    rv_ctx* ctx = s->ctx;
+    const Compiled& cc = s->c->cc;
+    int rc;
+    if ((rc = dalloc(ctx, (size_t)cc.n_ssa * 2 * s->NQ, &s->d_wires))) return rc;
+    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_on, 1) * s->NQ, &s->d_on))) return rc;
+    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * s->NQ, &s->d_pre))) return rc;
+    if ((rc = dalloc(ctx, 1, &s->d_err))) return rc;
+    const size_t cvw = b3_stream_scratch_words(std::max(cc.n_on, cc.n_pre), s->R);
+    if ((rc = dalloc(ctx, cvw, &s->d_cv[0])) || (rc = dalloc(ctx, cvw, &s->d_cv[1]))) return rc;
+    if ((rc = dalloc(ctx, (size_t)4 * s->R * 8, &s->d_dig))) return rc;
+    if ((rc = dalloc(ctx, (size_t)s->R * 32, &s->d_h))) return rc;
+    HIPCHK(hipMemsetAsync(s->d_err, 0, sizeof(int), ctx->stream));
+    HIPCHK(hipMemsetAsync(s->d_wires, 0, (size_t)2 * s->NQ * 4, ctx->stream));  // SSA 0 = default wire
+    p.NQ = s->NQ;
+    p.wires = s->d_wires;
+    p.masks = s->d_masks;
+    p.on = s->d_on;
+    p.pre = s->d_pre;
+    p.err = s->d_err;
+    const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+    for (size_t l = 0; l < n_levels; l++) launch_interp(ctx->stream, mode, s->c->d_gates, cc.level_start[l], cc.level_start[l + 1], p);
+    uint32_t* dig = s->d_dig;
+    const size_t DW = (size_t)s->R * 8;
+    launch_b3_stream(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
+    launch_b3_stream(ctx->stream, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 1 * DW);
+    // Z64 transcripts (empty for a pure GF(2) circuit: BLAKE3 of the empty string)
+    launch_b3_stream(ctx->stream, s->d_pre, 0, s->NQ, s->d_cv[0], s->d_cv[1], dig + 2 * DW);
+    launch_b3_stream(ctx->stream, s->d_on, 0, s->NQ, s->d_cv[0], s->d_cv[1], dig + 3 * DW);
+    return RV_OK;
+}
+
+static int shard_join(rv_shard* s) {
+    const size_t DW = (size_t)s->R * 8;
+    launch_join(s->ctx->stream, s->d_dig, s->d_dig + DW, s->d_dig + 2 * DW, s->d_dig + 3 * DW, s->R, s->d_h);
+    HIPCHK(hipGetLastError());
+    return RV_OK;
+}
+
+extern "C" int rv_shard_commit(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
+                               size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out) {
+    (void)wit_z64;
+    (void)n_z64;
+    if (!ctx || !c || !out || !seeds) return RV_E_ARG;
+    if (rep_count == 0 || rep_count % 8 || rep_begin % 8 || rep_begin + rep_count > RV_TOTAL_REPS) return RV_E_ARG;
+    *out = nullptr;
+    const Compiled& cc = c->cc;
+    if (n_gf2 < cc.n_in) return RV_E_WITNESS_SHORT;
+    HIPCHK(hipSetDevice(ctx->device));
+    rv_shard* s = new rv_shard();
+    s->ctx = ctx;
+    s->c = c;
+    s->rep_begin = rep_begin;
+    s->R = rep_count;
+    s->NQ = rep_count / 4;
+    int rc = RV_OK;
+    auto fail = [&](int code) {
+        rv_shard_destroy(s);
+        return code;
+    };
+    if ((rc = dalloc(ctx, (size_t)s->R * 16, &s->d_seeds)) || (rc = dalloc(ctx, (size_t)s->R * 128, &s->d_keys)) ||
+        (rc = dalloc(ctx, std::max<size_t>(cc.n_in, 1), &s->d_wit)))
+        return fail(rc);
+    if (hipMemcpyAsync(s->d_seeds, seeds, (size_t)s->R * 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(RV_E_DEVICE);
+    if (cc.n_in && hipMemcpyAsync(s->d_wit, wit_gf2, cc.n_in, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(RV_E_DEVICE);
+    launch_expand_seeds(ctx->stream, s->d_seeds, s->R, s->d_keys);
+    if ((rc = shard_setup_prg(s, nullptr))) return fail(rc);
+    InterpParams p{};
+    p.wit = s->d_wit;
+    if ((rc = shard_run(s, MODE_PROVE, p))) return fail(rc);
+    if ((rc = shard_join(s))) return fail(rc);
+    int err = 0;
+    if (hipMemcpyAsync(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return fail(RV_E_DEVICE);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+        return fail(RV_E_DEVICE);
+    }
+    if (err) return fail(RV_E_WITNESS_INVALID);
+    *out = s;
+    return RV_OK;
+}
+
+extern "C" int rv_shard_digests_device(rv_shard* s, void** dptr) {
+    if (!s || !dptr) return RV_E_ARG;
+    *dptr = s->d_h;
+    return RV_OK;
+}
+
+extern "C" int rv_shard_digests(rv_shard* s, uint8_t* out) {
+    if (!s || !out) return RV_E_ARG;
+    HIPCHK(hipMemcpyAsync(out, s->d_h, (size_t)s->R * 32, hipMemcpyDeviceToHost, s->ctx->stream));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    return RV_OK;
+}
+
+extern "C" int rv_hook_shard_stream_digests(rv_shard* s, uint8_t* out) {
+    if (!s || !out) return RV_E_ARG;
+    std::vector<uint32_t> tmp((size_t)4 * s->R * 8);
+    HIPCHK(hipMemcpyAsync(tmp.data(), s->d_dig, tmp.size() * 4, hipMemcpyDeviceToHost, s->ctx->stream));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    for (uint32_t r = 0; r < s->R; r++)
+        for (int k = 0; k < 4; k++) memcpy(out + ((size_t)r * 4 + k) * 32, &tmp[((size_t)k * s->R + r) * 8], 32);
+    return RV_OK;
+}
+
+// layout of the opened shard in HBM: gf2_online | gf2_pre | z64_online | z64_pre
+struct OpenLayout {
+    uint64_t l2r, l2c, l2i, l64r, l64c, l64i, sz2, sz64;
+    uint32_t n_on, n_pre;
+    size_t len[4], base[4], total;
+};
+
+static OpenLayout open_layout(const Compiled& cc, const uint8_t* omit_local, uint32_t R) {
+    OpenLayout L{};
+    // GF(2) vectors: 8 items per byte, plus the always-present extra chunk
+    L.l2r = cc.n_rec / 8 + 1;
+    L.l2c = cc.n_pre / 8 + 1;
+    L.l2i = cc.n_in / 8 + 1;
+    L.l64r = L.l64c = L.l64i = 0;
+    L.sz2 = 1 + 128 + 24 + L.l2r + L.l2c + L.l2i;
+    L.sz64 = 1 + 128 + 24 + L.l64r + L.l64c + L.l64i;
+    for (uint32_t r = 0; r < R; r++) (omit_local[r] < 8 ? L.n_on : L.n_pre)++;
+    L.len[0] = (size_t)L.n_on * L.sz2;
+    L.len[1] = (size_t)L.n_pre * 48;
+    L.len[2] = (size_t)L.n_on * L.sz64;
+    L.len[3] = (size_t)L.n_pre * 48;
+    size_t off = 0;
+    for (int k = 0; k < 4; k++) {
+        L.base[k] = off;
+        off += L.len[k];
+    }
+    L.total = off;
+    return L;
+}
+
+extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void** dptr, size_t lens[4]) {
+    if (!s || !omit || !dptr || !lens) return RV_E_ARG;
+    rv_ctx* ctx = s->ctx;
+    const Compiled& cc = s->c->cc;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint8_t* om = omit + s->rep_begin;
+    for (uint32_t r = 0; r < s->R; r++)
+        if (om[r] > 8) return RV_E_ARG;
+    const OpenLayout L = open_layout(cc, om, s->R);
+    std::vector<uint64_t> offs((size_t)5 * s->R);  // off2, off64, rec dst, corr dst, in dst
+    uint32_t k_on = 0, k_pre = 0;
+    for (uint32_t r = 0; r < s->R; r++) {
+        if (om[r] < 8) {
+            offs[r] = L.base[0] + (uint64_t)k_on * L.sz2;
+            offs[s->R + r] = L.base[2] + (uint64_t)k_on * L.sz64;
+            offs[2 * s->R + r] = offs[r] + 137;
+            offs[3 * s->R + r] = offs[r] + 145 + L.l2r;
+            offs[4 * s->R + r] = offs[r] + 153 + L.l2r + L.l2c;
+            k_on++;
+        } else {
+            offs[r] = L.base[1] + (uint64_t)k_pre * 48;
+            offs[s->R + r] = L.base[3] + (uint64_t)k_pre * 48;
+            k_pre++;
+        }
+    }
+    int rc;
+    ctx->release(s->d_omit);
+    ctx->release(s->d_offs);
+    ctx->release(s->d_out);
+    s->d_omit = nullptr;
+    s->d_offs = nullptr;
+    s->d_out = nullptr;
+    if ((rc = dalloc(ctx, s->R, &s->d_omit)) || (rc = dalloc(ctx, offs.size(), &s->d_offs)) ||
+        (rc = dalloc(ctx, std::max<size_t>(L.total, 1), &s->d_out)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(s->d_omit, om, s->R, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(s->d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    const size_t DW = (size_t)s->R * 8;
+    launch_open_headers(ctx->stream, s->R, s->d_omit, s->d_seeds, s->d_keys, s->d_dig + 1 * DW, s->d_dig + 3 * DW, s->d_offs,
+                        s->d_offs + s->R, L.l2r, L.l2c, L.l2i, L.l64r, L.l64c, L.l64i, s->d_out);
+    if (L.n_on) {
+        launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, s->d_out);
+        launch_extract_bits(ctx->stream, s->d_pre, nullptr, cc.n_pre, s->NQ, 1, s->d_omit, s->d_offs + 3 * s->R, s->d_out);
+        launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, s->d_out);
+    }
+    HIPCHK(hipGetLastError());
+    // the host vector `offs` must outlive the async copy
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *dptr = s->d_out;
+    for (int k = 0; k < 4; k++) lens[k] = L.len[k];
+    return RV_OK;
+}
+
+extern "C" int rv_shard_open(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], rv_shard_parts* parts) {
+    if (!parts) return RV_E_ARG;
+    memset(parts, 0, sizeof *parts);
+    void* d = nullptr;
+    size_t lens[4];
+    int rc = rv_shard_open_device(s, omit, &d, lens);
+    if (rc) return rc;
+    uint8_t** dst[4] = {&parts->gf2_online, &parts->gf2_pre, &parts->z64_online, &parts->z64_pre};
+    size_t* dl[4] = {&parts->gf2_online_len, &parts->gf2_pre_len, &parts->z64_online_len, &parts->z64_pre_len};
+    size_t off = 0;
+    for (int k = 0; k < 4; k++) {
+        *dst[k] = (uint8_t*)malloc(lens[k] ? lens[k] : 1);
+        if (!*dst[k]) return RV_E_NOMEM;
+        if (lens[k]) HIPCHK(hipMemcpyAsync(*dst[k], (uint8_t*)d + off, lens[k], hipMemcpyDeviceToHost, s->ctx->stream));
+        *dl[k] = lens[k];
+        off += lens[k];
+    }
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    const uint8_t* om = omit + s->rep_begin;
+    for (uint32_t r = 0; r < s->R; r++) (om[r] < 8 ? parts->n_online : parts->n_pre)++;
+    return RV_OK;
+}
+
+static void put_le64(uint8_t* p, uint64_t v) {
+    for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+
+extern "C" int rv_assemble_proof(const uint8_t comm[RV_HASH_SIZE], const rv_shard_parts* parts, size_t n_parts, uint8_t** proof,
+                                 size_t* proof_len) {
+    if (!comm || !parts || !proof || !proof_len) return RV_E_ARG;
+    size_t total = 32 + 4 * 8;
+    uint64_t n_on = 0, n_pre = 0;
+    for (size_t i = 0; i < n_parts; i++) {
+        total += parts[i].gf2_online_len + parts[i].gf2_pre_len + parts[i].z64_online_len + parts[i].z64_pre_len;
+        n_on += parts[i].n_online;
+        n_pre += parts[i].n_pre;
+    }
+    uint8_t* out = (uint8_t*)malloc(total);
+    if (!out) return RV_E_NOMEM;
+    uint8_t* w = out;
+    memcpy(w, comm, 32);
+    w += 32;
+    // Proof { comm, gf2: ProofSingle, z64: ProofSingle }, ProofSingle { online: Vec, preprocessing: Vec }
+    for (int dom = 0; dom < 2; dom++) {
+        put_le64(w, n_on);
+        w += 8;
+        for (size_t i = 0; i < n_parts; i++) {
+            const uint8_t* p = dom == 0 ? parts[i].gf2_online : parts[i].z64_online;
+            const size_t l = dom == 0 ? parts[i].gf2_online_len : parts[i].z64_online_len;
+            if (l) memcpy(w, p, l);
+            w += l;
+        }
+        put_le64(w, n_pre);
+        w += 8;
+        for (size_t i = 0; i < n_parts; i++) {
+            const uint8_t* p = dom == 0 ? parts[i].gf2_pre : parts[i].z64_pre;
+            const size_t l = dom == 0 ? parts[i].gf2_pre_len : parts[i].z64_pre_len;
+            if (l) memcpy(w, p, l);
+            w += l;
+        }
+    }
+    *proof = out;
+    *proof_len = total;
+    return RV_OK;
+}
+
+extern "C" int rv_prove(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
+                        size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len) {
+    if (!ctx || !c || !proof || !proof_len) return RV_E_ARG;
+    *proof = nullptr;
+    *proof_len = 0;
+    uint8_t os_seeds[RV_TOTAL_REPS * RV_KEY_SIZE];
+    if (!seeds) {  // proof/mod.rs:131-134 uses OsRng
+        size_t got = 0;
+        while (got < sizeof os_seeds) {
+            ssize_t n = getrandom(os_seeds + got, sizeof os_seeds - got, 0);
+            if (n <= 0) return RV_E_DEVICE;
+            got += (size_t)n;
+        }
+        seeds = os_seeds;
+    }
+    rv_shard* s = nullptr;
+    int rc = rv_shard_commit(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, 0, RV_TOTAL_REPS, &s);
+    if (rc) return rc;
+    std::vector<uint8_t> h(RV_TOTAL_REPS * 32);
+    uint8_t comm[32], omit[RV_TOTAL_REPS];
+    rv_shard_parts parts{};
+    if (!(rc = rv_shard_digests(s, h.data())) && !(rc = rv_combine_digests(h.data(), comm)) && !(rc = rv_challenge(comm, omit)) &&
+        !(rc = rv_shard_open(s, omit, &parts)))
+        rc = rv_assemble_proof(comm, &parts, 1, proof, proof_len);
+    free(parts.gf2_online);
+    free(parts.gf2_pre);
+    free(parts.z64_online);
+    free(parts.z64_pre);
+    rv_shard_destroy(s);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// proof parsing (bincode 1.3 fixint)
+// ------------------------------------------------------------------------------------
+namespace {
+struct OnRec {
+    uint8_t omit;
+    size_t keys, rec, corr, in;  // offsets into the proof
+    uint64_t n_rec, n_corr, n_in;
+};
+struct PreRec {
+    size_t seed, comm_online;
+};
+struct Single {
+    std::vector<OnRec> on;
+    std::vector<PreRec> pre;
+};
+struct Parsed {
+    Single gf2, z64;
+};
+struct Reader {
+    const uint8_t* p;
+    size_t len, pos = 0;
+    bool bad = false;
+    size_t take(uint64_t n) {
+        if (bad || n > len - pos) {
+            bad = true;
+            return 0;
+        }
+        size_t at = pos;
+        pos += (size_t)n;
+        return at;
+    }
+    uint64_t u64() {
+        size_t at = take(8);
+        if (bad) return 0;
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (uint64_t)p[at + i] << (8 * i);
+        return v;
+    }
+};
+bool parse_single(Reader& r, Single& s) {
+    uint64_t n = r.u64();
+    if (r.bad || n > (r.len - r.pos) / 153 + 1) return false;
+    s.on.resize((size_t)n);
+    for (auto& o : s.on) {
+        size_t at = r.take(1);
+        if (r.bad) return false;
+        o.omit = r.p[at];
+        o.keys = r.take(128);
+        o.n_rec = r.u64();
+        o.rec = r.take(o.n_rec);
+        o.n_corr = r.u64();
+        o.corr = r.take(o.n_corr);
+        o.n_in = r.u64();
+        o.in = r.take(o.n_in);
+        if (r.bad) return false;
+    }
+    n = r.u64();
+    if (r.bad || n > (r.len - r.pos) / 48 + 1) return false;
+    s.pre.resize((size_t)n);
+    for (auto& q : s.pre) {
+        q.seed = r.take(16);
+        q.comm_online = r.take(32);
+        if (r.bad) return false;
+    }
+    return true;
+}
+// returns RV_OK / RV_E_PROOF_MALFORMED; trailing bytes are ignored like bincode::deserialize_from (main.rs:101-103)
+int parse_proof(const uint8_t* proof, size_t len, Parsed& out) {
+    Reader r{proof, len};
+    r.take(32);
+    if (r.bad || !parse_single(r, out.gf2) || !parse_single(r, out.z64)) return RV_E_PROOF_MALFORMED;
+    return RV_OK;
+}
+bool format_ok(const Parsed& p) {  // ProofSingle::check_format, proof/mod.rs:110-114
+    return p.gf2.on.size() == RV_ONLINE_REPS && p.gf2.pre.size() == RV_PREPROCESSING_REPS &&
+           p.z64.on.size() == RV_ONLINE_REPS && p.z64.pre.size() == RV_PREPROCESSING_REPS;
+}
+}  // namespace
+
+extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t slot_begin,
+                               uint32_t slot_count, uint8_t* digests) {
+    if (!ctx || !c || !proof || !digests) return RV_E_ARG;
+    if (slot_count == 0 || slot_count % 8 || slot_begin % 8 || slot_begin + slot_count > RV_TOTAL_REPS) return RV_E_ARG;
+    Parsed P;
+    int rc = parse_proof(proof, proof_len, P);
+    if (rc) return rc;
+    if (!format_ok(P)) return RV_E_PROOF_MALFORMED;  // callers check the format first (rv_verify returns ok=0)
+    const Compiled& cc = c->cc;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t R = slot_count, NQ = R / 4;
+
+    // ---- host-side preparation of the slots (VerifierTranscriptOnline::new, online.rs:25-119;
+    //      VerifierTranscriptPreprocess::new, preprocess.rs:17-43)
+    std::vector<uint8_t> seeds((size_t)R * 16, 0), omit(R, 8);
+    std::vector<uint64_t> src((size_t)6 * R, 0);  // rec off,len ; corr off,len ; in off,len
+    std::vector<uint32_t> keep(NQ, 0xFFFFFFFFu), onm(NQ, 0);
+    for (uint32_t g0 = 0; g0 < R; g0 += 8) {
+        const uint32_t slot0 = slot_begin + g0;
+        if (slot0 < RV_ONLINE_REPS) {
+            const OnRec* o = &P.gf2.on[slot0];
+            const OnRec* z = &P.z64.on[slot0];
+            for (int i = 0; i < 8; i++) {
+                if (o[i].omit >= 8 || z[i].omit >= 8) return RV_E_PROOF_MALFORMED;  // UB upstream (gf2/share.rs:167-199)
+                // Recon::unpack indexes every vector up to the first one's length (gf2/recon.rs:241-259)
+                if (o[i].n_corr < o[0].n_corr || o[i].n_in < o[0].n_in) return RV_E_PROOF_MALFORMED;
+                // Share::unpack_selected asserts equal lengths (gf2/share.rs:157-164)
+                if (o[i].n_rec != o[0].n_rec) return RV_E_PROOF_MALFORMED;
+                const uint32_t r = g0 + i;
+                omit[r] = o[i].omit;
+                src[0 * R + r] = o[i].rec;
+                src[1 * R + r] = o[0].n_rec;
+                src[2 * R + r] = o[i].corr;
+                src[3 * R + r] = o[0].n_corr;
+                src[4 * R + r] = o[i].in;
+                src[5 * R + r] = o[0].n_in;
+                keep[r / 4] &= ~(1u << (31 - 8 * (r % 4) - o[i].omit));  // BatchGen skips the omitted player
+                onm[r / 4] |= 0xFFu << (24 - 8 * (r % 4));
+            }
+        } else {
+            const PreRec* q = &P.gf2.pre[slot0 - RV_ONLINE_REPS];
+            for (int i = 0; i < 8; i++) memcpy(&seeds[(size_t)(g0 + i) * 16], proof + q[i].seed, 16);
+        }
+    }
+
+    rv_shard* s = new rv_shard();
+    s->ctx = ctx;
+    s->c = c;
+    s->rep_begin = slot_begin;
+    s->R = R;
+    s->NQ = NQ;
+    auto fail = [&](int code) {
+        rv_shard_destroy(s);
+        return code;
+    };
+    uint8_t* d_proof = nullptr;
+    uint64_t* d_src = nullptr;
+    uint32_t *d_keep = nullptr, *d_onm = nullptr, *d_sup_in = nullptr, *d_sup_corr = nullptr, *d_sup_rec = nullptr;
+    auto track = [&](void* p) { s->extra.push_back(p); };
+    if ((rc = dalloc(ctx, (size_t)R * 16, &s->d_seeds)) || (rc = dalloc(ctx, (size_t)R * 128, &s->d_keys)) ||
+        (rc = dalloc(ctx, R, &s->d_omit)))
+        return fail(rc);
+    if ((rc = dalloc(ctx, proof_len, &d_proof))) return fail(rc);
+    track(d_proof);
+    if ((rc = dalloc(ctx, src.size(), &d_src))) return fail(rc);
+    track(d_src);
+    if ((rc = dalloc(ctx, NQ, &d_keep))) return fail(rc);
+    track(d_keep);
+    if ((rc = dalloc(ctx, NQ, &d_onm))) return fail(rc);
+    track(d_onm);
+    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_in, 1) * NQ, &d_sup_in))) return fail(rc);
+    track(d_sup_in);
+    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * NQ, &d_sup_corr))) return fail(rc);
+    track(d_sup_corr);
+    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_rec, 1) * NQ, &d_sup_rec))) return fail(rc);
+    track(d_sup_rec);
+#define HC(x)                                 \
+    do {                                      \
+        if ((x) != hipSuccess) {              \
+            hip_fail(hipGetLastError(), #x, __FILE__, __LINE__); \
+            return fail(RV_E_DEVICE);         \
+        }                                     \
+    } while (0)
+    HC(hipMemcpyAsync(s->d_seeds, seeds.data(), seeds.size(), hipMemcpyHostToDevice, ctx->stream));
+    HC(hipMemcpyAsync(s->d_omit, omit.data(), omit.size(), hipMemcpyHostToDevice, ctx->stream));
+    HC(hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, ctx->stream));
+    HC(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HC(hipMemcpyAsync(d_keep, keep.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
+    HC(hipMemcpyAsync(d_onm, onm.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_expand_seeds(ctx->stream, s->d_seeds, R, s->d_keys);
+    // online slots take the opened player keys straight from the proof (online.rs:101-113)
+    for (uint32_t r = 0; r < R; r++)
+        if (omit[r] < 8) HC(hipMemcpyAsync(s->d_keys + (size_t)r * 128, proof + P.gf2.on[slot_begin + r].keys, 128, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = shard_setup_prg(s, d_keep))) return fail(rc);
+    launch_unpack_bits(ctx->stream, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
+    launch_unpack_bits(ctx->stream, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr);
+    launch_unpack_bits(ctx->stream, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec);
+    InterpParams p{};
+    p.on_mask = d_onm;
+    p.sup_in = d_sup_in;
+    p.sup_corr = d_sup_corr;
+    p.sup_rec = d_sup_rec;
+    if ((rc = shard_run(s, MODE_VERIFY, p))) return fail(rc);
+    // preprocessing slots: the online commitment is the one carried by the proof (preprocess.rs:55-57)
+    const size_t DW = (size_t)R * 8;
+    for (uint32_t r = 0; r < R; r++)
+        if (omit[r] >= 8) {
+            const uint32_t k = slot_begin + r - RV_ONLINE_REPS;
+            HC(hipMemcpyAsync(s->d_dig + 1 * DW + (size_t)r * 8, proof + P.gf2.pre[k].comm_online, 32, hipMemcpyHostToDevice, ctx->stream));
+            HC(hipMemcpyAsync(s->d_dig + 3 * DW + (size_t)r * 8, proof + P.z64.pre[k].comm_online, 32, hipMemcpyHostToDevice, ctx->stream));
+        }
+    if ((rc = shard_join(s))) return fail(rc);
+    HC(hipMemcpyAsync(digests, s->d_h, (size_t)R * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HC(hipStreamSynchronize(ctx->stream));
+#undef HC
+    rv_shard_destroy(s);
+    return RV_OK;
+}
+
+extern "C" int rv_verify_finish(const uint8_t* proof, size_t proof_len, const uint8_t* slot_digests, int* ok) {
+    if (!proof || !slot_digests || !ok || proof_len < 32) return RV_E_ARG;
+    uint8_t omit[RV_TOTAL_REPS];
+    rv_challenge(proof, omit);  // proof/mod.rs:290
+    b3::Hasher hs;
+    size_t on = 0, pre = RV_ONLINE_REPS;
+    for (int i = 0; i < RV_TOTAL_REPS; i++) hs.update(slot_digests + 32 * (omit[i] < 8 ? on++ : pre++), 32);
+    uint8_t comm[32];
+    hs.finalize(comm);
+    *ok = memcmp(comm, proof, 32) == 0;
+    return RV_OK;
+}
+
+extern "C" int rv_verify(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, int* ok) {
+    if (!ctx || !c || !proof || !ok) return RV_E_ARG;
+    *ok = 0;
+    Parsed P;
+    int rc = parse_proof(proof, proof_len, P);
+    if (rc) return rc;
+    if (!format_ok(P)) return RV_OK;  // wrong repetition counts: `false`, not an error (proof/mod.rs:225-230)
+    std::vector<uint8_t> dig(RV_TOTAL_REPS * 32);
+    if ((rc = rv_verify_shard(ctx, c, proof, proof_len, 0, RV_TOTAL_REPS, dig.data()))) return rc;
+    return rv_verify_finish(proof, proof_len, dig.data(), ok);
+}
+
+// ------------------------------------------------------------------------------------
+// parity-test hooks
+// ------------------------------------------------------------------------------------
+extern "C" int rv_hook_expand_seed(rv_ctx* ctx, const uint8_t* seeds, size_t n, uint8_t* keys) {
+    if (!ctx || !seeds || !keys || !n) return RV_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    uint8_t *ds = nullptr, *dk = nullptr;
+    int rc;
+    if ((rc = dalloc(ctx, n * 16, &ds)) || (rc = dalloc(ctx, n * 128, &dk))) return rc;
+    HIPCHK(hipMemcpyAsync(ds, seeds, n * 16, hipMemcpyHostToDevice, ctx->stream));
+    launch_expand_seeds(ctx->stream, ds, (uint32_t)n, dk);
+    HIPCHK(hipMemcpyAsync(keys, dk, n * 128, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->release(ds);
+    ctx->release(dk);
+    return RV_OK;
+}
+
+extern "C" int rv_hook_prg_blocks(rv_ctx* ctx, const uint8_t* keys, size_t n_keys, uint64_t first_block, size_t n_blocks,
+                                  uint8_t* out) {
+    if (!ctx || !keys || !out || !n_keys || !n_blocks) return RV_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    uint8_t *dk = nullptr, *drk = nullptr, *dout = nullptr;
+    int rc;
+    if ((rc = dalloc(ctx, n_keys * 16, &dk)) || (rc = dalloc(ctx, n_keys * 176, &drk)) || (rc = dalloc(ctx, n_keys * n_blocks * 16, &dout)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(dk, keys, n_keys * 16, hipMemcpyHostToDevice, ctx->stream));
+    launch_key_schedule(ctx->stream, dk, (uint32_t)n_keys, drk);
+    launch_aes_blocks(ctx->stream, drk, (uint32_t)n_keys, first_block, n_blocks, dout);
+    HIPCHK(hipMemcpyAsync(out, dout, n_keys * n_blocks * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->release(dk);
+    ctx->release(drk);
+    ctx->release(dout);
+    return RV_OK;
+}
+
+extern "C" int rv_hook_sharegen_gf2(rv_ctx* ctx, const uint8_t* keys, const uint32_t omit[8], size_t n, uint64_t* out) {
+    if (!ctx || !keys || !omit || !out || !n) return RV_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t R = 8, NQ = 2;
+    uint8_t *dk = nullptr, *drk = nullptr;
+    uint32_t *d_rk = nullptr, *d_keep = nullptr, *d_masks = nullptr;
+    uint32_t keep[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (uint32_t r = 0; r < 8; r++) {
+        if (omit[r] > 8) return RV_E_ARG;
+        if (omit[r] < 8) keep[r / 4] &= ~(1u << (31 - 8 * (r % 4) - omit[r]));
+    }
+    const uint64_t n_blocks = (n + 127) / 128;
+    int rc;
+    if ((rc = dalloc(ctx, (size_t)R * 128, &dk)) || (rc = dalloc(ctx, (size_t)R * 8 * 176, &drk)) ||
+        (rc = dalloc(ctx, (size_t)11 * 128 * NQ, &d_rk)) || (rc = dalloc(ctx, NQ, &d_keep)) ||
+        (rc = dalloc(ctx, (size_t)n_blocks * 128 * NQ, &d_masks)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(dk, keys, (size_t)R * 128, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_keep, keep, sizeof keep, hipMemcpyHostToDevice, ctx->stream));
+    launch_key_schedule(ctx->stream, dk, R * 8, drk);
+    launch_bitslice_rk(ctx->stream, drk, NQ, d_rk);
+    launch_aes_gf2_masks(ctx->stream, d_rk, d_keep, NQ, 0, n_blocks, d_masks);
+    std::vector<uint32_t> tmp((size_t)n_blocks * 128 * NQ);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d_masks, tmp.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (size_t m = 0; m < n; m++) out[m] = ((uint64_t)tmp[2 * m] << 32) | tmp[2 * m + 1];
+    ctx->release(dk);
+    ctx->release(drk);
+    ctx->release(d_rk);
+    ctx->release(d_keep);
+    ctx->release(d_masks);
+    return RV_OK;
+}
+
+extern "C" int rv_hook_sharegen_z64(rv_ctx* ctx, const uint8_t* keys, const uint32_t omit[8], size_t n, uint64_t* out) {
+    (void)ctx;
+    (void)keys;
+    (void)omit;
+    (void)n;
+    (void)out;
+    return RV_E_UNSUPPORTED;
+}
+
+extern "C" int rv_hook_blake3(rv_ctx* ctx, const uint8_t* data, size_t n_streams, size_t len, uint8_t* out) {
+    if (!ctx || !out || !n_streams || (len && !data)) return RV_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    // lay the streams out in transcript row format: row e, repetition r = stream r
+    const uint32_t R = (uint32_t)((n_streams + 7) / 8 * 8), NQ = R / 4;
+    std::vector<uint32_t> rows((size_t)std::max<size_t>(len, 1) * NQ, 0);
+    for (size_t r = 0; r < n_streams; r++)
+        for (size_t e = 0; e < len; e++) rows[e * NQ + r / 4] |= (uint32_t)data[r * len + e] << (24 - 8 * (r % 4));
+    uint32_t *d_rows = nullptr, *cva = nullptr, *cvb = nullptr, *dig = nullptr;
+    const size_t cvw = b3_stream_scratch_words(len, R);
+    int rc;
+    if ((rc = dalloc(ctx, rows.size(), &d_rows)) || (rc = dalloc(ctx, cvw, &cva)) || (rc = dalloc(ctx, cvw, &cvb)) ||
+        (rc = dalloc(ctx, (size_t)R * 8, &dig)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(d_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_b3_stream(ctx->stream, d_rows, len, NQ, cva, cvb, dig);
+    std::vector<uint32_t> h((size_t)R * 8);
+    HIPCHK(hipMemcpyAsync(h.data(), dig, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    memcpy(out, h.data(), n_streams * 32);
+    ctx->release(d_rows);
+    ctx->release(cva);
+    ctx->release(cvb);
+    ctx->release(dig);
+    return RV_OK;
+}

@@ -1,0 +1,36 @@
+// Gate-stream compiler (host side): turns the reference's sequential instruction list
+// (`for op in circuit { ins.step(op) }`, /root/reference/src/proof/mod.rs:150-152) into a
+// dependency-levelled, SSA-renamed gate array the GPU can execute level by level.
+//
+// Everything that is a pure function of the op list is resolved here, once per circuit:
+//   * wire reuse        -> every write gets a fresh SSA id (id 0 = the all-zero default
+//                          wire a never-written index reads as, interpreter/single.rs:16)
+//   * ShareGen::next()  -> call number `m` per gate (generator/share.rs:54-65 is a pure
+//                          counter over the op list: Input 1, Random 1, Mul 2, in order)
+//   * transcript rows   -> position of each hashed event in the online / preprocessing
+//                          stream (transcript/prover.rs:194,210,216)
+//   * reconstruction / input ordinals for the opening vectors (prover.rs:29-31)
+//   * bounds errors the reference raises while stepping (Vec index panics)
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "internal.h"
+
+namespace rv {
+
+struct Compiled {
+    std::vector<Gate> gates;            // sorted by level, program order inside a level
+    std::vector<uint32_t> level_start;  // gates of level l = [level_start[l], level_start[l+1])
+    std::vector<uint32_t> rec_rows;     // reconstruction ordinal -> online transcript row
+    std::vector<uint32_t> in_rows;      // input ordinal -> online transcript row
+    uint64_t n_ssa = 1;                 // SSA wires incl. the zero wire
+    uint64_t n_masks = 0, n_on = 0, n_pre = 0, n_in = 0, n_rec = 0;
+    rv_circuit_info info{};
+};
+
+// returns RV_OK or RV_E_*
+int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out);
+
+}  // namespace rv

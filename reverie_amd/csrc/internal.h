@@ -1,0 +1,78 @@
+// Internal (non-ABI) declarations shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/reverie_amd.h"
+
+namespace rv {
+
+// ---- HBM data layout -------------------------------------------------------------
+// A shard holds R repetitions (multiple of 8).  Four repetitions x eight players are
+// packed into one 32-bit word ("quad word"): repetition i4 = r % 4 sits in byte i4
+// counted from the most significant byte, player p at bit 31 - (8*i4 + p).  Two
+// consecutive quad words (hi, lo) are exactly the reference's packed u64 share
+// (src/algebra/gf2/share.rs:13-24: bit 63 - (8*rep + player)).
+// A "row" is NQ = R/4 consecutive quad words = one value for every repetition of the
+// shard; with R = 256 a row is 256 bytes = one wavefront-wide coalesced access.
+//   masks  [n_masks][NQ]        fresh PRG masks, index = ShareGen::next() call number
+//   wires  [n_ssa][2][NQ]       {mask row, corr row}; corr is one byte per rep 0x00/0xFF
+//                               (src/algebra/gf2/recon.rs:13-25)
+//   on     [n_on_events][NQ]    online transcript: one byte per rep per event
+//   pre    [n_pre_events][NQ]   preprocessing transcript (corrections), 0x00/0xFF bytes
+
+// compiled gate (device + host)
+struct Gate {
+    uint32_t op;   // GateOp
+    uint32_t dst;  // SSA wire id written
+    uint32_t a, b; // SSA wire ids read
+    uint32_t m;    // first PRG mask index consumed (Input/Random: 1 mask, Mul: 2)
+    uint32_t eo;   // row in the online transcript (Input, Mul, AssertZero)
+    uint32_t ep;   // row in the preprocessing transcript (Mul)
+    uint32_t x;    // Input: witness index; Mul/AssertZero: reconstruction ordinal; *Const: constant
+};
+
+enum GateOp : uint32_t { G_INPUT = 0, G_XOR, G_XORC, G_ANDC, G_MUL, G_ASSERT, G_RANDOM, G_CONST };
+
+enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1 };
+
+struct InterpParams {
+    uint32_t NQ;
+    uint32_t* wires;
+    const uint32_t* masks;
+    uint32_t* on;
+    uint32_t* pre;
+    const uint8_t* wit;       // prover: witness bits, one byte each
+    const uint32_t* on_mask;  // verify: [NQ] 0xFF byte per online-verified rep
+    const uint32_t* sup_in;   // verify: [n_inputs][NQ] supplied masked inputs (smeared)
+    const uint32_t* sup_corr; // verify: [n_mul][NQ] supplied corrections (smeared)
+    const uint32_t* sup_rec;  // verify: [n_rec][NQ] supplied broadcast bit of the omitted player
+    int* err;                 // device flag: RV_E_WITNESS_INVALID
+};
+
+// ---- launchers (implemented in the .hip files) ----
+void launch_expand_seeds(hipStream_t st, const uint8_t* d_seeds, uint32_t n_reps, uint8_t* d_keys /*[n][8][16]*/);
+void launch_key_schedule(hipStream_t st, const uint8_t* d_keys, uint32_t n_slots, uint8_t* d_rkbytes /*[n][176]*/);
+void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, uint32_t* d_rk /*[11][128][NQ]*/);
+void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
+                          uint64_t n_blocks, uint32_t* d_masks);
+void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
+                       uint8_t* d_out);
+void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t hi, const InterpParams& p);
+// BLAKE3 over a row-format transcript: digests[R][8] words
+void launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
+                      uint32_t* d_cv_b, uint32_t* d_digest /*[R][8]*/);
+size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R);
+void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
+                 uint32_t R, uint8_t* d_h /*[R][32]*/);
+void launch_extract_bits(hipStream_t st, const uint32_t* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,
+                         uint32_t NQ, int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
+void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
+                        const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out);
+void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys,
+                         const uint32_t* d_on2, const uint32_t* d_on64, const uint64_t* d_off2, const uint64_t* d_off64,
+                         uint64_t lens2_rec, uint64_t lens2_corr, uint64_t lens2_in, uint64_t lens64_rec, uint64_t lens64_corr,
+                         uint64_t lens64_in, uint8_t* d_out);
+
+}  // namespace rv

@@ -1,0 +1,399 @@
+// Interpreter, transcript hashing and opening kernels for gfx950.
+//
+// Replaces (all under /root/reference/src/):
+//   interpreter/single.rs:25-157      Instance::step / op_mul over the GF(2) ring
+//   algebra/gf2/domain.rs:10-63       Share*Recon, reconstruct (per-byte parity)
+//   transcript/prover.rs:181-232      ProverTranscript::{input,reconstruct,correction,zero_check}
+//   transcript/verifier/online.rs:122-183, verifier/preprocess.rs:46-79
+//   crypto/hash.rs:17-104             BufferedHasher / PackedHasher (per-rep BLAKE3 streams)
+//   transcript/mod.rs:77-96, interpreter/combine.rs:104-118   digest joins
+//   transcript/prover.rs:57-175 + algebra/gf2/{share,recon}.rs Pack/PackSelected  (openings)
+//
+// Lane mapping: one lane = one quad word = 4 repetitions x 8 players (see internal.h);
+// NQ consecutive lanes cover every repetition of the shard for one gate, so a wavefront
+// reads/writes whole 256-byte rows.  Gates of one dependency level are independent and
+// are spread over the grid; levels are separate launches.
+#include "b3.h"
+#include "internal.h"
+
+namespace rv {
+
+// DomainGF2::reconstruct on a quad word: per-byte parity, smeared to 0x00/0xFF
+__device__ __forceinline__ uint32_t recon32(uint32_t t) {
+    t ^= t >> 4;
+    t ^= t >> 2;
+    t ^= t >> 1;
+    t &= 0x01010101u;
+    return (t << 8) - t;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, uint32_t lo, uint32_t hi, InterpParams p) {
+    const uint32_t NQ = p.NQ;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = tid % NQ;
+    const uint32_t worker = tid / NQ;
+    const uint32_t n_workers = (gridDim.x * blockDim.x) / NQ;
+    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[q] : 0u;
+    for (uint32_t gi = lo + worker; gi < hi; gi += n_workers) {
+        const Gate g = gates[gi];
+        uint32_t* wd = p.wires + (size_t)g.dst * 2 * NQ + q;
+        const uint32_t* wa = p.wires + (size_t)g.a * 2 * NQ + q;
+        const uint32_t* wb = p.wires + (size_t)g.b * 2 * NQ + q;
+        switch (g.op) {
+        case G_INPUT: {
+            const uint32_t lam = p.masks[(size_t)g.m * NQ + q];
+            uint32_t corr;
+            if (MODE == MODE_PROVE) {
+                const uint32_t w = p.wit[g.x] ? 0xFFFFFFFFu : 0u;
+                corr = w ^ recon32(lam);
+            } else {
+                corr = p.sup_in[(size_t)g.x * NQ + q] & onm;
+            }
+            p.on[(size_t)g.eo * NQ + q] = corr;
+            wd[0] = lam;
+            wd[NQ] = corr;
+            break;
+        }
+        case G_XOR: {
+            wd[0] = wa[0] ^ wb[0];
+            wd[NQ] = wa[NQ] ^ wb[NQ];
+            break;
+        }
+        case G_XORC: {
+            wd[0] = wa[0];
+            wd[NQ] = wa[NQ] ^ (g.x ? 0xFFFFFFFFu : 0u);
+            break;
+        }
+        case G_ANDC: {
+            const uint32_t c = g.x ? 0xFFFFFFFFu : 0u;
+            wd[0] = wa[0] & c;
+            wd[NQ] = wa[NQ] & c;
+            break;
+        }
+        case G_CONST: {
+            wd[0] = 0;
+            wd[NQ] = g.x ? 0xFFFFFFFFu : 0u;
+            break;
+        }
+        case G_RANDOM: {
+            wd[0] = p.masks[(size_t)g.m * NQ + q];
+            wd[NQ] = 0;
+            break;
+        }
+        case G_MUL: {
+            const uint32_t lx = wa[0], cx = wa[NQ], ly = wb[0], cy = wb[NQ];
+            const uint32_t lab = p.masks[(size_t)g.m * NQ + q];
+            const uint32_t lnew = p.masks[(size_t)(g.m + 1) * NQ + q];
+            const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
+            uint32_t delta = (a & b) ^ c;
+            uint32_t s = (ly & cx) ^ (lx & cy) ^ lab ^ lnew;
+            uint32_t r;
+            if (MODE == MODE_PROVE) {
+                r = recon32(s);
+            } else {
+                // online-verified reps: supplied correction, add the unopened player's broadcast
+                delta = (p.sup_corr[(size_t)g.ep * NQ + q] & onm) | (delta & ~onm);
+                s ^= p.sup_rec[(size_t)g.x * NQ + q];
+                r = recon32(s) & onm;  // preprocessing-verified reps: reconstruct() returns zero
+            }
+            p.pre[(size_t)g.ep * NQ + q] = delta;
+            p.on[(size_t)g.eo * NQ + q] = s;
+            wd[0] = lnew;
+            wd[NQ] = r ^ delta ^ (cx & cy);
+            break;
+        }
+        case G_ASSERT: {
+            uint32_t m = wa[0];
+            if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
+            p.on[(size_t)g.eo * NQ + q] = m;
+            if (MODE == MODE_PROVE) {
+                if ((recon32(m) ^ wa[NQ]) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+            }
+            break;
+        }
+        default:
+            break;
+        }
+    }
+}
+
+void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t hi, const InterpParams& p) {
+    if (hi <= lo) return;
+    const uint64_t want = (uint64_t)(hi - lo) * p.NQ;
+    uint64_t blocks = (want + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (mode == MODE_PROVE)
+        hipLaunchKernelGGL(k_interp<MODE_PROVE>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, hi, p);
+    else
+        hipLaunchKernelGGL(k_interp<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, hi, p);
+}
+
+// ------------------------------------------------------------------------------------
+// BLAKE3 over row-format transcripts.  Thread = (chunk, quad): reads 64 rows per block
+// (coalesced across the quads of a row), de-interleaves the 4 repetitions of its quad
+// word into 4 x 16 message words and runs the 4 compressions back to back.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ,
+                                                   uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t c = tid / NQ;
+    const uint32_t q = (uint32_t)(tid % NQ);
+    if (c >= n_chunks) return;
+    const uint64_t ev0 = c * 1024;
+    const uint64_t len = (n_events - ev0 < 1024) ? (n_events - ev0) : 1024;
+    const uint32_t nblk = len == 0 ? 1 : (uint32_t)((len + 63) / 64);
+    uint32_t cv[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) b3::iv(cv[i]);
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint64_t e0 = ev0 + 64ull * b;
+        const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
+        uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
+        if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
+        uint32_t w[64];
+#pragma unroll
+        for (int e = 0; e < 64; e++) w[e] = (e0 + e < n_events) ? stream[(e0 + e) * NQ + q] : 0u;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; i4++) {
+            uint32_t m[16];
+            const int sh = 24 - 8 * i4;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                m[k] = ((w[4 * k] >> sh) & 0xFFu) | (((w[4 * k + 1] >> sh) & 0xFFu) << 8) |
+                       (((w[4 * k + 2] >> sh) & 0xFFu) << 16) | (((w[4 * k + 3] >> sh) & 0xFFu) << 24);
+            uint32_t o[8];
+            b3::compress<false>(cv[i4], m, c, blen, flags, o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) cv[i4][k] = o[k];
+        }
+    }
+    const uint32_t R = NQ * 4;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; i4++) {
+        uint32_t* dst = cvs + ((size_t)c * R + 4 * q + i4) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[k] = cv[i4][k];
+    }
+}
+
+// one tree level: out[i] = parent(in[2i], in[2i+1]); an odd last node is promoted unchanged
+__global__ void k_b3_parents(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t R, uint32_t* __restrict__ out) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n_out = (n_in + 1) / 2;
+    const uint64_t i = tid / R;
+    const uint32_t r = (uint32_t)(tid % R);
+    if (i >= n_out) return;
+    const uint32_t* l = in + ((size_t)(2 * i) * R + r) * 8;
+    uint32_t o[8];
+    if (2 * i + 1 < n_in) {
+        const uint32_t* rr = in + ((size_t)(2 * i + 1) * R + r) * 8;
+        uint32_t lv[8], rv_[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            lv[k] = l[k];
+            rv_[k] = rr[k];
+        }
+        b3::parent(lv, rv_, n_in == 2 ? b3::ROOT : 0u, o);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[k] = l[k];
+    }
+    uint32_t* d = out + ((size_t)i * R + r) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = o[k];
+}
+
+__global__ void k_copy_words(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < n) out[tid] = in[tid];
+}
+
+size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R) {
+    const uint64_t n_chunks = n_events == 0 ? 1 : (n_events + 1023) / 1024;
+    return (size_t)n_chunks * R * 8;  // per ping-pong buffer
+}
+
+void launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
+                      uint32_t* d_cv_b, uint32_t* d_digest) {
+    const uint32_t R = NQ * 4;
+    uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
+    {
+        const uint64_t threads = n * NQ;
+        hipLaunchKernelGGL(k_b3_chunks, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, n_events, NQ, n,
+                           d_cv_a);
+    }
+    uint32_t* cur = d_cv_a;
+    uint32_t* nxt = d_cv_b;
+    while (n > 1) {
+        const uint64_t n_out = (n + 1) / 2;
+        const uint64_t threads = n_out * R;
+        hipLaunchKernelGGL(k_b3_parents, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, cur, n, R, nxt);
+        uint32_t* t = cur;
+        cur = nxt;
+        nxt = t;
+        n = n_out;
+    }
+    const uint64_t words = (uint64_t)R * 8;
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, cur, d_digest, words);
+}
+
+// Transcript::hash + CombineInstance::hash: h = B3(B3(pre2||on2) || B3(pre64||on64))
+__global__ void k_join(const uint32_t* __restrict__ pre2, const uint32_t* __restrict__ on2, const uint32_t* __restrict__ pre64,
+                       const uint32_t* __restrict__ on64, uint32_t R, uint8_t* __restrict__ h) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    uint32_t m[16], h2[8], h64[8], o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        m[k] = pre2[r * 8 + k];
+        m[8 + k] = on2[r * 8 + k];
+    }
+    b3::hash64(m, h2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        m[k] = pre64[r * 8 + k];
+        m[8 + k] = on64[r * 8 + k];
+    }
+    b3::hash64(m, h64);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        m[k] = h2[k];
+        m[8 + k] = h64[k];
+    }
+    b3::hash64(m, o);
+    uint32_t* d = (uint32_t*)(h + 32 * (size_t)r);
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = o[k];
+}
+
+void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
+                 uint32_t R, uint8_t* d_h) {
+    hipLaunchKernelGGL(k_join, dim3((R + 63) / 64), dim3(64), 0, st, d_pre2, d_on2, d_pre64, d_on64, R, d_h);
+}
+
+// ------------------------------------------------------------------------------------
+// Openings.  kind 0: omitted player's bit of a recorded broadcast share (PackSelected,
+// gf2/share.rs:87-149); kind 1: a 0x00/0xFF recon byte (Pack, gf2/recon.rs:189-239).
+// Items are packed 8 per byte MSB-first; the output vector has n_items/8 + 1 bytes (the
+// reference always emits one more chunk).  Thread = (output byte t, quad q): reads 8 rows,
+// produces the byte for each of its 4 repetitions, stores only for opened ones.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_extract_bits(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows,
+                                                      uint64_t n_items, uint32_t NQ, int kind,
+                                                      const uint8_t* __restrict__ omit /*[R]*/,
+                                                      const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t t = tid / NQ;
+    const uint32_t q = (uint32_t)(tid % NQ);
+    const uint64_t n_bytes = n_items / 8 + 1;
+    if (t >= n_bytes) return;
+    uint32_t om[4];
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        om[i] = omit[4 * q + i];
+        any |= om[i] < 8;
+    }
+    if (!any) return;
+    uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint64_t it = 8 * t + j;
+        if (it < n_items) {
+            const uint64_t row = rows ? rows[it] : it;
+            const uint32_t w = stream[row * NQ + q];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t sh = (kind == 0) ? (31u - 8u * i - (om[i] & 7u)) : (24u - 8u * i);
+                acc[i] |= ((w >> sh) & 1u) << (7 - j);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (om[i] < 8) out[dst_off[4 * q + i] + t] = (uint8_t)acc[i];
+}
+
+void launch_extract_bits(hipStream_t st, const uint32_t* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ,
+                         int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out) {
+    const uint64_t threads = (n_items / 8 + 1) * NQ;
+    hipLaunchKernelGGL(k_extract_bits, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, d_rows, n_items, NQ,
+                       kind, d_omit, d_dst_off, d_out);
+}
+
+// Inverse for the verifier (Pack::unpack / PackSelected::unpack_selected): builds dense
+// rows from the proof's bit vectors.  kind 0: bit placed at the omitted player's position;
+// kind 1: smeared 0x00/0xFF byte.  Reps that are not online-verified, and items beyond a
+// vector's end, read as zero (verifier/online.rs:124,162,170 `unwrap_or_default`).
+__global__ __launch_bounds__(256) void k_unpack_bits(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off,
+                                                     const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit,
+                                                     uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t it = tid / NQ;
+    const uint32_t q = (uint32_t)(tid % NQ);
+    if (it >= n_items) return;
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t r = 4 * q + i;
+        const uint32_t om = omit[r];
+        if (om < 8 && (it >> 3) < src_len[r]) {
+            const uint32_t bit = (blob[src_off[r] + (it >> 3)] >> (7 - (it & 7))) & 1u;
+            if (bit) w |= (kind == 0) ? (1u << (31u - 8u * i - om)) : (0xFFu << (24 - 8 * i));
+        }
+    }
+    rows_out[it * NQ + q] = w;
+}
+
+void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
+                        const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out) {
+    if (!n_items) return;
+    const uint64_t threads = n_items * NQ;
+    hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_blob, d_src_off, d_src_len,
+                       d_omit, n_items, NQ, kind, d_rows_out);
+}
+
+// Fixed-size parts of the openings, one thread per repetition of the shard.
+//   online rep : omit | keys[8][16] with the omitted key zeroed | u64 len | .. | u64 len | .. | u64 len | ..
+//   other rep  : seed[16] | H_on[32]                           (proof/mod.rs:41-53, prover.rs:125-136,167-170)
+// d_off2/d_off64 give each rep's record offset inside the shard's concatenated output.
+__device__ inline void put_u64(uint8_t* p, uint64_t v) {
+    for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+
+__global__ void k_open_headers(uint32_t R, const uint8_t* __restrict__ omit, const uint8_t* __restrict__ seeds,
+                               const uint8_t* __restrict__ keys, const uint32_t* __restrict__ on2,
+                               const uint32_t* __restrict__ on64, const uint64_t* __restrict__ off2,
+                               const uint64_t* __restrict__ off64, uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r,
+                               uint64_t l64c, uint64_t l64i, uint8_t* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const uint32_t om = omit[r];
+    for (int dom = 0; dom < 2; dom++) {
+        uint8_t* o = out + (dom == 0 ? off2[r] : off64[r]);
+        if (om < 8) {
+            const uint64_t lr = dom == 0 ? l2r : l64r, lc = dom == 0 ? l2c : l64c, li = dom == 0 ? l2i : l64i;
+            o[0] = (uint8_t)om;
+            for (int p = 0; p < 8; p++)
+                for (int i = 0; i < 16; i++) o[1 + 16 * p + i] = (p == (int)om) ? 0 : keys[(size_t)r * 128 + 16 * p + i];
+            put_u64(o + 129, lr);
+            put_u64(o + 137 + lr, lc);
+            put_u64(o + 145 + lr + lc, li);
+        } else {
+            const uint32_t* hon = (dom == 0 ? on2 : on64) + (size_t)r * 8;
+            for (int i = 0; i < 16; i++) o[i] = seeds[(size_t)r * 16 + i];
+            for (int k = 0; k < 8; k++)
+                for (int b = 0; b < 4; b++) o[16 + 4 * k + b] = (uint8_t)(hon[k] >> (8 * b));
+        }
+    }
+}
+
+void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys,
+                         const uint32_t* d_on2, const uint32_t* d_on64, const uint64_t* d_off2, const uint64_t* d_off64,
+                         uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i, uint8_t* d_out) {
+    hipLaunchKernelGGL(k_open_headers, dim3((R + 63) / 64), dim3(64), 0, st, R, d_omit, d_seeds, d_keys, d_on2, d_on64, d_off2,
+                       d_off64, l2r, l2c, l2i, l64r, l64c, l64i, d_out);
+}
+
+}  // namespace rv

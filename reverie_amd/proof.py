@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's `Proof` API for this path.
+
+    reference (src/proof/mod.rs)                         here
+    Proof::new(circuit, wit_gf2, wit_z64, (z64, gf2))    Proof.new(circuit, wit_gf2, wit_z64, (z64, gf2))
+    proof.verify(circuit, (z64, gf2)) -> bool            proof.verify(circuit, (z64, gf2)) -> bool
+    bincode::serialize(&proof)                           bytes(proof)     (byte-identical layout)
+    bincode::deserialize(bytes)                          Proof(bytes)
+
+`circuit` is an rv_op array (reverie_amd.ops.program) or an already compiled `Circuit`.
+Everything runs through the C-ABI (include/reverie_amd.h) on the GPU; no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from .ops import OP_DTYPE, TOTAL_REPS, program
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class Context:
+    """One GPU (rv_ctx).  A default context on device 0 (or LOCAL_RANK) is created lazily."""
+
+    _default = None
+
+    def __init__(self, device: int = 0):
+        self.handle = C.c_void_p()
+        _lib.check(_lib.lib().rv_ctx_create(C.c_int(device), C.byref(self.handle)))
+        self.device = device
+
+    @classmethod
+    def default(cls) -> "Context":
+        if cls._default is None:
+            import os
+
+            cls._default = Context(int(os.environ.get("LOCAL_RANK", "0")))
+        return cls._default
+
+    def sync(self):
+        _lib.check(_lib.lib().rv_ctx_sync(self.handle))
+
+    def close(self):
+        if self.handle:
+            _lib.lib().rv_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Circuit:
+    """A gate stream compiled (levelised) and resident in HBM (rv_circuit)."""
+
+    def __init__(self, ops, wire_counts: Tuple[int, int], ctx: Optional[Context] = None):
+        self.ctx = ctx or Context.default()
+        self.ops = program(ops) if len(ops) else np.zeros(0, OP_DTYPE)
+        self.wire_counts = (int(wire_counts[0]), int(wire_counts[1]))  # (z64, gf2), proof/mod.rs:125
+        self.handle = C.c_void_p()
+        _lib.check(_lib.lib().rv_circuit_compile(self.ctx.handle, _ptr(self.ops), C.c_size_t(len(self.ops)),
+                                                 C.c_size_t(self.wire_counts[0]), C.c_size_t(self.wire_counts[1]),
+                                                 C.byref(self.handle)))
+
+    @property
+    def info(self) -> dict:
+        ci = _lib.CircuitInfo()
+        _lib.check(_lib.lib().rv_circuit_get_info(self.handle, C.byref(ci)))
+        return {n: int(getattr(ci, n)) for n, _ in ci._fields_}
+
+    def close(self):
+        if self.handle:
+            _lib.lib().rv_circuit_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _as_circuit(circuit, wire_counts, ctx=None) -> Circuit:
+    if isinstance(circuit, Circuit):
+        if wire_counts is not None and tuple(wire_counts) != circuit.wire_counts:
+            raise ValueError("wire_counts differ from the compiled circuit's")
+        return circuit
+    return Circuit(circuit, wire_counts, ctx)
+
+
+def _witness(wit_gf2, wit_z64):
+    g = np.ascontiguousarray(np.asarray(wit_gf2, dtype=np.uint8))
+    z = np.ascontiguousarray(np.asarray(wit_z64, dtype=np.uint64))
+    return g, z
+
+
+class Proof:
+    def __init__(self, data: bytes):
+        self.data = bytes(data)
+
+    def __bytes__(self):
+        return self.data
+
+    def __len__(self):
+        return len(self.data)
+
+    @property
+    def comm(self) -> bytes:
+        return self.data[:32]
+
+    @staticmethod
+    def new(circuit, wit_gf2: Sequence[int], wit_z64: Sequence[int], wire_counts: Optional[Tuple[int, int]] = None,
+            seeds: Union[None, bytes, np.ndarray] = None, ctx: Optional[Context] = None) -> "Proof":
+        """Proof::new.  `seeds` (256x16 bytes) injects the per-repetition seeds the reference
+        draws from OsRng; None draws them from the OS."""
+        c = _as_circuit(circuit, wire_counts, ctx)
+        g, z = _witness(wit_gf2, wit_z64)
+        s = None
+        if seeds is not None:
+            s = np.ascontiguousarray(np.frombuffer(bytes(seeds), np.uint8) if isinstance(seeds, (bytes, bytearray))
+                                     else np.asarray(seeds, dtype=np.uint8)).reshape(TOTAL_REPS, 16)
+        out = C.c_void_p()
+        n = C.c_size_t()
+        _lib.check(_lib.lib().rv_prove(c.ctx.handle, c.handle, _ptr(g), C.c_size_t(len(g)), _ptr(z), C.c_size_t(len(z)),
+                                       _ptr(s), C.byref(out), C.byref(n)))
+        data = C.string_at(out, n.value)
+        _lib.lib().rv_free(out)
+        return Proof(data)
+
+    def verify(self, circuit, wire_counts: Optional[Tuple[int, int]] = None, ctx: Optional[Context] = None) -> bool:
+        c = _as_circuit(circuit, wire_counts, ctx)
+        ok = C.c_int()
+        buf = (C.c_uint8 * len(self.data)).from_buffer_copy(self.data)
+        _lib.check(_lib.lib().rv_verify(c.ctx.handle, c.handle, buf, C.c_size_t(len(self.data)), C.byref(ok)))
+        return bool(ok.value)
+
+
+# ---- Fiat-Shamir helpers (host) ----
+def combine_digests(h) -> bytes:
+    h = np.ascontiguousarray(np.asarray(h, dtype=np.uint8)).reshape(TOTAL_REPS, 32)
+    out = np.zeros(32, np.uint8)
+    _lib.check(_lib.lib().rv_combine_digests(_ptr(h), _ptr(out)))
+    return out.tobytes()
+
+
+def challenge(comm: bytes) -> np.ndarray:
+    c = np.frombuffer(bytes(comm), np.uint8).copy()
+    out = np.zeros(TOTAL_REPS, np.uint8)
+    _lib.check(_lib.lib().rv_challenge(_ptr(c), _ptr(out)))
+    return out

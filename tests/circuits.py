@@ -1,0 +1,152 @@
+"""Circuit generators shared by tests and bench.py (deterministic)."""
+from __future__ import annotations
+
+import numpy as np
+
+from reverie_amd.ops import (DOM_GF2, GF2, OP_ADD, OP_ADDCONST, OP_ASSERTZERO, OP_DTYPE, OP_INPUT, OP_MUL, program)
+
+M64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & M64
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & M64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+
+
+def _splitmix_array(seed: int, n: int) -> np.ndarray:
+    """n outputs of SplitMix64(seed), vectorised."""
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def layered_gf2(n_in=4096, width=65536, layers=153, p_and=0.5, seed=0x5EED000000000004, fold_to=128):
+    """Config 4: layered random AND/XOR circuit in SSA form.
+
+    n_in Inputs (witness bits from the PRNG); `layers` layers of `width` gates; gate type AND
+    with probability p_and else XOR; operands uniform over the previous layer (layer 0 reads
+    the inputs); tail: XOR-fold the last layer to `fold_to` wires, then AddConst(clear value)
+    + AssertZero on each.  Returns (prog, witness_bits, (z64_wires, gf2_wires), stats).
+    The clear evaluation is done here with numpy so the asserted constants are correct."""
+    n_gates = width * layers
+    r = _splitmix_array(seed, n_in + 3 * n_gates)
+    wit = (r[:n_in] & np.uint64(1)).astype(np.uint8)
+    rr = r[n_in:].reshape(layers, width, 3)
+    if p_and >= 1.0:
+        is_and = np.ones((layers, width), bool)
+    else:
+        thresh = np.uint64(int(p_and * (1 << 32)))
+        is_and = (rr[:, :, 0] & np.uint64(0xFFFFFFFF)) < thresh
+    ops = np.zeros(n_in + n_gates, OP_DTYPE)
+    ops["domain"] = DOM_GF2
+    ops["opcode"][:n_in] = OP_INPUT
+    ops["dst"][:n_in] = np.arange(n_in, dtype=np.uint32)
+    vals = wit.copy()
+    prev_base, prev_n = 0, n_in
+    pos = n_in
+    for l in range(layers):
+        a = (rr[l, :, 1] % np.uint64(prev_n)).astype(np.uint32)
+        b = (rr[l, :, 2] % np.uint64(prev_n)).astype(np.uint32)
+        sl = slice(pos, pos + width)
+        ops["opcode"][sl] = np.where(is_and[l], OP_MUL, OP_ADD)
+        ops["dst"][sl] = np.arange(pos, pos + width, dtype=np.uint32)
+        ops["a"][sl] = prev_base + a
+        ops["b"][sl] = prev_base + b
+        va, vb = vals[a], vals[b]
+        vals = np.where(is_and[l], va & vb, va ^ vb).astype(np.uint8)
+        prev_base, prev_n = pos, width
+        pos += width
+    # tail: XOR-fold to fold_to wires
+    tail = []
+    cur = list(range(prev_base, prev_base + prev_n))
+    cur_vals = vals
+    nxt = pos
+    while len(cur) > fold_to:
+        half = len(cur) // 2
+        lo, hi = cur[:half], cur[half:2 * half]
+        t = np.zeros(half, OP_DTYPE)
+        t["domain"] = DOM_GF2
+        t["opcode"] = OP_ADD
+        t["dst"] = np.arange(nxt, nxt + half, dtype=np.uint32)
+        t["a"] = np.array(lo, np.uint32)
+        t["b"] = np.array(hi, np.uint32)
+        tail.append(t)
+        cur_vals = cur_vals[:half] ^ cur_vals[half:2 * half]
+        cur = list(range(nxt, nxt + half)) + cur[2 * half:]
+        if len(cur) > half:
+            raise ValueError("width must be a power-of-two multiple of fold_to")
+        nxt += half
+    k = len(cur)
+    t = np.zeros(2 * k, OP_DTYPE)
+    t["domain"] = DOM_GF2
+    t["opcode"][0::2] = OP_ADDCONST
+    t["dst"][0::2] = np.arange(nxt, nxt + k, dtype=np.uint32)
+    t["a"][0::2] = np.array(cur, np.uint32)
+    t["imm"][0::2] = cur_vals.astype(np.uint64)
+    t["opcode"][1::2] = OP_ASSERTZERO
+    t["a"][1::2] = np.arange(nxt, nxt + k, dtype=np.uint32)
+    tail.append(t)
+    nxt += k
+    prog = np.concatenate([ops] + tail)
+    stats = {"gates": int(n_gates), "and": int(is_and.sum()), "xor": int(n_gates - is_and.sum()), "inputs": n_in}
+    return np.ascontiguousarray(prog), wit, (0, nxt), stats
+
+
+def random_gf2(rng: np.random.Generator, n_in=12, n_gates=300, n_wires=40, p_assert=0.05):
+    """Random GF(2) program with heavy wire reuse, every op kind, and only valid asserts."""
+    ops = []
+    wit = rng.integers(0, 2, n_in).tolist()
+    val = [None] * n_wires  # clear values (None = depends on a Random gate)
+    defined = [False] * n_wires
+    for i in range(n_in):
+        w = int(rng.integers(0, n_wires))
+        ops.append(GF2.Input(w))
+        val[w] = wit[i]
+        defined[w] = True
+
+    def get(w):
+        return 0 if not defined[w] else val[w]
+
+    for _ in range(n_gates):
+        kind = rng.choice(["mul", "add", "sub", "addc", "subc", "mulc", "const", "random", "assert"],
+                          p=[0.3, 0.2, 0.05, 0.1, 0.05, 0.07, 0.05, 0.05, 0.13])
+        d, a, b = (int(x) for x in rng.integers(0, n_wires, 3))
+        c = int(rng.integers(0, 2))
+        va, vb = get(a), get(b)
+        if kind == "mul":
+            ops.append(GF2.Mul(d, a, b)); nv = None if va is None or vb is None else va & vb
+        elif kind == "add":
+            ops.append(GF2.Add(d, a, b)); nv = None if va is None or vb is None else va ^ vb
+        elif kind == "sub":
+            ops.append(GF2.Sub(d, a, b)); nv = None if va is None or vb is None else va ^ vb
+        elif kind == "addc":
+            ops.append(GF2.AddConst(d, a, c)); nv = None if va is None else va ^ c
+        elif kind == "subc":
+            ops.append(GF2.SubConst(d, a, c)); nv = None if va is None else va ^ c
+        elif kind == "mulc":
+            ops.append(GF2.MulConst(d, a, c)); nv = 0 if c == 0 else va
+        elif kind == "const":
+            ops.append(GF2.Const(d, c)); nv = c
+        elif kind == "random":
+            ops.append(GF2.Random(d)); nv = None
+        else:
+            if va is None or rng.random() > p_assert * 8:
+                continue
+            if va == 1:
+                ops.append(GF2.AddConst(a, a, 1)); val[a] = 0; defined[a] = True
+            ops.append(GF2.AssertZero(a))
+            continue
+        val[d] = nv
+        defined[d] = True
+    return program(ops), wit, (0, n_wires)

@@ -1,0 +1,244 @@
+"""GPU parity tests proper: every call goes through the C-ABI (libreverie_amd.so) on a real
+MI355X and is compared bit-for-bit with the CPU oracle / committed golden vectors."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import circuits
+from conftest import GOLDEN
+from reverie_amd.ops import GF2, OP_DTYPE, program
+
+pytestmark = pytest.mark.gpu
+
+META = json.load(open(os.path.join(GOLDEN, "proofs.json")))
+GF2_ONLY = ["empty", "gf2_mix", "adder64"]
+
+
+@pytest.fixture(scope="module")
+def rv():
+    import reverie_amd
+
+    reverie_amd.Context.default()  # raises loudly if the HIP library or the GPU is missing
+    return reverie_amd
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def load_case(name):
+    m = META[name]
+    prog = program([tuple(o) for o in m["ops"]]) if m["ops"] else np.zeros(0, OP_DTYPE)
+    gold = open(os.path.join(GOLDEN, f"proof_{name}.bin"), "rb").read()
+    return m, prog, m["wit_gf2"], [int(x) for x in m["wit_z64"]], tuple(m["wire_counts"]), gold
+
+
+# ---------------------------------------------------------------- primitives (rows a1, a2, a4, a16)
+def test_prg_blocks(rv, oracle):
+    from reverie_amd import _lib
+
+    rng = np.random.default_rng(1)
+    keys = rng.integers(0, 256, (37, 16), dtype=np.uint8)
+    keys[0] = 0
+    out = np.zeros((37, 9, 16), np.uint8)
+    _lib.check(_lib.lib().rv_hook_prg_blocks(rv.Context.default().handle, _p(keys), C.c_size_t(37), C.c_uint64(5), C.c_size_t(9), _p(out)))
+    blk = C.create_string_buffer(16)
+    for k in range(37):
+        for b in range(9):
+            oracle.lib().rvo_prg_block(keys[k].tobytes(), C.c_uint64(5 + b), blk)
+            assert out[k, b].tobytes() == blk.raw
+    prim = json.load(open(os.path.join(GOLDEN, "primitives.json")))
+    z = np.zeros((1, 2, 16), np.uint8)
+    zk = np.zeros((1, 16), np.uint8)
+    _lib.check(_lib.lib().rv_hook_prg_blocks(rv.Context.default().handle, _p(zk), C.c_size_t(1), C.c_uint64(0), C.c_size_t(2), _p(z)))
+    assert z.tobytes().hex() == prim["aes_ctr"][0]["stream"][:64]
+
+
+def test_expand_seed(rv, oracle, rule_seeds):
+    from reverie_amd import _lib
+
+    keys = np.zeros((256, 8, 16), np.uint8)
+    _lib.check(_lib.lib().rv_hook_expand_seed(rv.Context.default().handle, _p(rule_seeds), C.c_size_t(256), _p(keys)))
+    for r in (0, 1, 17, 255):
+        assert (keys[r] == oracle.expand_seed(rule_seeds[r])).all()
+
+
+def test_sharegen_gf2(rv, oracle):
+    """bitsliced AES-CTR mask generator == ShareGen<GF2>::next() (incl. omitted players)"""
+    from reverie_amd import _lib
+
+    sg = json.load(open(os.path.join(GOLDEN, "sharegen.json")))
+    keys = np.array([[list(bytes.fromhex(k)) for k in row] for row in sg["keys"]], np.uint8)
+    for case in sg["cases"]:
+        out = np.zeros(sg["n"], np.uint64)
+        omit = np.array(case["omit"], np.uint32)
+        _lib.check(_lib.lib().rv_hook_sharegen_gf2(rv.Context.default().handle, _p(keys), _p(omit), C.c_size_t(sg["n"]), _p(out)))
+        assert ["%016x" % int(x) for x in out] == case["gf2"]
+    rng = np.random.default_rng(2)
+    for n in (1, 127, 128, 129, 5000):
+        keys = rng.integers(0, 256, (8, 8, 16), dtype=np.uint8)
+        omit = rng.integers(0, 9, 8).astype(np.uint32)
+        out = np.zeros(n, np.uint64)
+        _lib.check(_lib.lib().rv_hook_sharegen_gf2(rv.Context.default().handle, _p(keys), _p(omit), C.c_size_t(n), _p(out)))
+        assert (out == oracle.sharegen_gf2(keys, omit, n)).all()
+
+
+def test_blake3_streams(rv, oracle):
+    from reverie_amd import _lib
+
+    prim = json.load(open(os.path.join(GOLDEN, "primitives.json")))
+    for kat in prim["blake3"]:
+        n = kat["len"]
+        d = np.frombuffer(bytes(i % 251 for i in range(n)), np.uint8)
+        data = np.ascontiguousarray(np.stack([d, d[::-1]])) if n else np.zeros((2, 0), np.uint8)
+        out = np.zeros((2, 32), np.uint8)
+        _lib.check(_lib.lib().rv_hook_blake3(rv.Context.default().handle, _p(data) if n else None, C.c_size_t(2), C.c_size_t(n), _p(out)))
+        assert out[0].tobytes().hex() == kat["hash"], n
+        buf = C.create_string_buffer(32)
+        oracle.lib().rvo_blake3_hash(data[1].tobytes(), C.c_size_t(n), buf)
+        assert out[1].tobytes() == buf.raw
+    rng = np.random.default_rng(3)
+    for n in (1, 1000, 70001):
+        data = rng.integers(0, 256, (21, n), dtype=np.uint8)
+        out = np.zeros((21, 32), np.uint8)
+        _lib.check(_lib.lib().rv_hook_blake3(rv.Context.default().handle, _p(data), C.c_size_t(21), C.c_size_t(n), _p(out)))
+        buf = C.create_string_buffer(32)
+        for r in range(21):
+            oracle.lib().rvo_blake3_hash(data[r].tobytes(), C.c_size_t(n), buf)
+            assert out[r].tobytes() == buf.raw
+
+
+# ---------------------------------------------------------------- whole proofs
+@pytest.mark.parametrize("name", GF2_ONLY)
+def test_golden_proofs(rv, oracle, rule_seeds, name):
+    m, prog, w2, w64, wc, gold = load_case(name)
+    proof = rv.Proof.new(prog, w2, w64, wc, seeds=rule_seeds)
+    assert bytes(proof) == gold
+    assert proof.verify(prog, wc)
+    assert oracle.verify(prog, wc, bytes(proof))
+    assert rv.Proof(gold).verify(prog, wc)
+
+
+def test_bench_circuit_vs_oracle(rv, oracle, rule_seeds):
+    """the reference's bench circuit (proof/mod.rs:318-354): 2 inputs + N x Mul(2,0,1), wire reuse"""
+    prog = program([GF2.Input(0), GF2.Input(1)] + [GF2.Mul(2, 0, 1)] * 20000)
+    proof = rv.Proof.new(prog, [1, 1], [0], (128, 128), seeds=rule_seeds)
+    assert bytes(proof) == oracle.prove(prog, [1, 1], [0], (128, 128), rule_seeds)
+    assert proof.verify(prog, (128, 128))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_programs_vs_oracle(rv, oracle, seed):
+    rng = np.random.default_rng(100 + seed)
+    prog, wit, wc = circuits.random_gf2(rng, n_in=int(rng.integers(1, 20)), n_gates=int(rng.integers(1, 1500)),
+                                        n_wires=int(rng.integers(3, 60)))
+    seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+    want = oracle.prove(prog, wit, [], wc, seeds)
+    proof = rv.Proof.new(prog, wit, [], wc, seeds=seeds)
+    assert bytes(proof) == want
+    assert proof.verify(prog, wc) and oracle.verify(prog, wc, bytes(proof))
+
+
+def test_layered_circuit_vs_oracle(rv, oracle, rule_seeds):
+    """config-4 generator at a size the oracle finishes in seconds"""
+    prog, wit, wc, st = circuits.layered_gf2(n_in=256, width=2048, layers=12)
+    want = oracle.prove(prog, wit, [], wc, rule_seeds)
+    c = rv.Circuit(prog, wc)
+    proof = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+    assert bytes(proof) == want
+    assert proof.verify(c)
+    info = c.info
+    assert info["gf2_muls"] == st["and"] and info["gf2_inputs"] == 256
+
+
+def test_commit_digests_vs_oracle(rv, oracle, rule_seeds):
+    from reverie_amd import _lib
+
+    prog, wit, wc, _ = circuits.layered_gf2(n_in=64, width=512, layers=5)
+    h, st, comm = oracle.commit(prog, wit, [], wc, rule_seeds)
+    c = rv.Circuit(prog, wc)
+    L = _lib.lib()
+    g = np.asarray(wit, np.uint8)
+    for begin, count in ((0, 256), (64, 32), (248, 8)):
+        sh = C.c_void_p()
+        seeds = np.ascontiguousarray(rule_seeds[begin:begin + count])
+        _lib.check(L.rv_shard_commit(c.ctx.handle, c.handle, _p(g), C.c_size_t(len(g)), None, C.c_size_t(0), _p(seeds),
+                                     C.c_uint32(begin), C.c_uint32(count), C.byref(sh)))
+        out = np.zeros((count, 32), np.uint8)
+        _lib.check(L.rv_shard_digests(sh, _p(out)))
+        sd = np.zeros((count, 4, 32), np.uint8)
+        _lib.check(L.rv_hook_shard_stream_digests(sh, _p(sd)))
+        L.rv_shard_destroy(sh)
+        assert (out == h[begin:begin + count]).all()
+        assert (sd == st[begin:begin + count]).all()
+
+
+# ---------------------------------------------------------------- verifier behaviour
+def test_tamper_and_cross_verify(rv, oracle, rule_seeds):
+    m, prog, w2, w64, wc, gold = load_case("adder64")
+    c = rv.Circuit(prog, wc)
+    rng = np.random.default_rng(3)
+    for pos in rng.integers(0, len(gold), 40):
+        bad = bytearray(gold)
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            want = oracle.verify(prog, wc, bytes(bad))
+            want_err = None
+        except oracle.OracleError as e:
+            want, want_err = None, e.code
+        try:
+            got = rv.Proof(bytes(bad)).verify(c)
+            got_err = None
+        except rv.ReverieError as e:
+            got, got_err = None, e.code
+        assert (got, got_err) == (want, want_err), pos
+
+
+def test_errors(rv, rule_seeds):
+    m, prog, w2, w64, wc, gold = load_case("adder64")
+    bad = list(w2)
+    bad[3] ^= 1
+    with pytest.raises(rv.ReverieError) as e:
+        rv.Proof.new(prog, bad, [], wc, seeds=rule_seeds)
+    assert e.value.code == 1  # invalid witness (prover.rs:221-228 panics)
+    with pytest.raises(rv.ReverieError) as e:
+        rv.Proof.new(prog, w2[:-1], [], wc, seeds=rule_seeds)
+    assert e.value.code == 2  # witness too short
+    with pytest.raises(rv.ReverieError) as e:
+        rv.Circuit(prog, (0, 10))
+    assert e.value.code == 3  # wire out of range
+    with pytest.raises(rv.ReverieError) as e:
+        rv.Proof(gold[:500]).verify(prog, wc)
+    assert e.value.code == 4
+    # wrong repetition count is `false`, not an error (proof/mod.rs:225-230)
+    m, prog, w2, w64, wc, gold = load_case("empty")
+    off = len(gold) - 216 * 48 - 8
+    cut = gold[:off] + (215).to_bytes(8, "little") + gold[off + 8:-48]
+    assert rv.Proof(cut).verify(prog, wc) is False
+
+
+def test_os_seeds_prove_verify(rv, oracle):
+    """seeds=NULL draws from the OS like the reference's OsRng; proof must verify on both sides"""
+    m, prog, w2, w64, wc, gold = load_case("gf2_mix")
+    p1 = rv.Proof.new(prog, w2, w64, wc)
+    p2 = rv.Proof.new(prog, w2, w64, wc)
+    assert bytes(p1) != bytes(p2)
+    assert p1.verify(prog, wc) and oracle.verify(prog, wc, bytes(p2))
+
+
+def test_full_size_properties(rv, rule_seeds):
+    """BASELINE config 4 at full size (10^7 gates): size-independent properties only —
+    prove -> verify accepts, a flipped transcript bit is rejected, proof length is as derived."""
+    prog, wit, wc, st = circuits.layered_gf2()
+    c = rv.Circuit(prog, wc)
+    proof = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+    n_rec = st["and"] + 128
+    expect = 33160 + 40 * ((n_rec // 8) + (st["and"] // 8) + (st["inputs"] // 8))
+    assert len(proof) == expect
+    assert proof.verify(c)
+    bad = bytearray(bytes(proof))
+    bad[len(bad) // 3] ^= 0x10
+    assert not rv.Proof(bytes(bad)).verify(c)
