@@ -101,6 +101,26 @@ void rv_ctx_destroy(rv_ctx *ctx);
 /* block until all work queued on the context's stream has finished */
 int rv_ctx_sync(rv_ctx *ctx);
 
+/* ---- per-phase GPU timing, measured with HIP events on the context's own stream (the
+ * stream every kernel of this library is launched on).  Phases: */
+enum {
+    RV_PH_SETUP = 0,  /* seed expansion, key schedules, round-key bitslicing          */
+    RV_PH_MASKS = 1,  /* k_aes_gf2_masks: bitsliced AES-128-CTR mask generator         */
+    RV_PH_INTERP = 2, /* k_interp: one launch per dependency level                     */
+    RV_PH_HASH = 3,   /* k_b3_chunks + k_b3_parents: transcript BLAKE3                 */
+    RV_PH_JOIN = 4,   /* k_join                                                        */
+    RV_PH_OPEN = 5,   /* k_open_headers + k_extract_bits                               */
+    RV_PH_COUNT = 8
+};
+typedef struct rv_profile {
+    double ms[RV_PH_COUNT];         /* accumulated GPU milliseconds per phase */
+    uint64_t launches[RV_PH_COUNT]; /* kernel launches per phase              */
+    uint64_t calls;                 /* commit / verify_shard calls accumulated */
+} rv_profile;
+/* enable != 0 turns event timing on (adds a few stream events per call); reset != 0 zeroes
+ * the accumulators; out (nullable) receives the current totals. */
+int rv_ctx_profile(rv_ctx *ctx, int enable, int reset, rv_profile *out);
+
 /* ---- circuit: the `Arc<Vec<CombineOperation>>` + `wire_counts` arguments of
  * Proof::new / Proof::verify (proof/mod.rs:119-125,224,232).  Compiling resolves wire
  * reuse, orders gates into dependency levels, assigns every gate its PRG mask index and
@@ -152,6 +172,9 @@ int rv_shard_commit(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, si
 int rv_shard_digests_device(rv_shard *s, void **dptr);
 /* host copy of the same bytes */
 int rv_shard_digests(rv_shard *s, uint8_t *out /* rep_count x 32 */);
+/* device-to-device copy of the same bytes into caller-owned HBM (e.g. a torch tensor that
+ * RCCL will all-gather); complete when the call returns */
+int rv_shard_digests_to_device(rv_shard *s, void *dst_device);
 /* Opens the shard's repetitions for the full challenge (omit[256], 8 = preprocessing).
  * Returns four blobs: the shard's OpenOnline / OpenPreprocessing records, in ascending
  * repetition order, already in bincode form, for the gf2 and z64 ProofSingle.
@@ -168,6 +191,11 @@ void rv_shard_destroy(rv_shard *s);
  * in HBM (gf2_online | gf2_pre | z64_online | z64_pre) and returns the device pointer,
  * valid until the shard is destroyed. */
 int rv_shard_open_device(rv_shard *s, const uint8_t omit[RV_TOTAL_REPS], void **dptr, size_t lens[4]);
+/* Sizes rv_shard_open* will produce for this challenge, without opening */
+int rv_shard_open_size(const rv_shard *s, const uint8_t omit[RV_TOTAL_REPS], size_t lens[4]);
+/* As rv_shard_open_device, but writes the concatenated blobs into caller-owned HBM
+ * (sum of rv_shard_open_size bytes), e.g. a torch tensor handed to RCCL afterwards */
+int rv_shard_open_into(rv_shard *s, const uint8_t omit[RV_TOTAL_REPS], void *dst_device, size_t lens[4]);
 
 /* combine_hashes (proof/mod.rs:102-108): comm = BLAKE3(h[0] || ... || h[255]) */
 int rv_combine_digests(const uint8_t *h /* 256 x 32 */, uint8_t comm[RV_HASH_SIZE]);

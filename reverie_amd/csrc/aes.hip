@@ -153,8 +153,9 @@ __device__ __forceinline__ void sub_shift(const uint32_t* s, uint32_t* t) {
     }
 }
 
-// MixColumns + AddRoundKey: s = MC(t) ^ rk
-__device__ __forceinline__ void mix_ark(const uint32_t* t, uint32_t* s, const uint32_t* __restrict__ rk, uint32_t stride) {
+// MixColumns + AddRoundKey: s = MC(t) ^ rk, round keys read from LDS (stride QW words)
+template <int QW>
+__device__ __forceinline__ void mix_ark(const uint32_t* t, uint32_t* s, const uint32_t* rk) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const uint32_t* a = t + 32 * c;
@@ -171,49 +172,67 @@ __device__ __forceinline__ void mix_ark(const uint32_t* t, uint32_t* s, const ui
             uint32_t x[8] = {d[7], d[0] ^ d[7], d[1], d[2] ^ d[7], d[3] ^ d[7], d[4], d[5], d[6]};
             uint32_t* o = s + 32 * c + 8 * r;
 #pragma unroll
-            for (int k = 0; k < 8; k++) o[k] = x[k] ^ a1[k] ^ a2[k] ^ a3[k] ^ rk[(size_t)(32 * c + 8 * r + k) * stride];
+            for (int k = 0; k < 8; k++) o[k] = x[k] ^ a1[k] ^ a2[k] ^ a3[k] ^ rk[(32 * c + 8 * r + k) * QW];
         }
     }
 }
 
-// One lane: quad q (32 slots), CTR block j.  Writes 128 mask rows.
+// Mask generator.  A workgroup owns QW consecutive quads (QW*32 AES keys) and keeps their
+// 11 bitsliced round keys in LDS (QW*5.5 KiB; 88 KiB at QW=16) for its whole lifetime; its
+// 4 wavefronts then stream CTR blocks: lane = (block sub-index, quad), 64/QW blocks per
+// wavefront per iteration.  Round keys never come from L2 inside the round loop (a first
+// version that read them from global memory was 15x slower: every wavefront of the chip
+// requested the same 256-byte row at the same time and serialised on one L2 channel).
+template <int QW>
 __global__ __launch_bounds__(256) void k_aes_gf2_masks(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep,
                                                        uint32_t NQ, uint64_t first_block, uint64_t n_blocks,
-                                                       uint32_t* __restrict__ masks) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t jl = gid / NQ;
-    const uint32_t q = (uint32_t)(gid % NQ);
-    if (jl >= n_blocks) return;
-    const uint64_t j = first_block + jl;
-    const uint32_t* rkq = rk + q;
-
-    uint32_t s[128], t[128];
-    // round 0: counter block BE128(j) (bytes 8..15 carry j) xor rk[0]
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint32_t cb = 0;
-            if (i >= 8) cb = (uint32_t)0 - (uint32_t)((j >> (8 * (15 - i) + k)) & 1);
-            s[8 * i + k] = rkq[(size_t)(8 * i + k) * NQ] ^ cb;
-        }
-    }
-#pragma unroll 1
-    for (int r = 1; r < 10; r++) {
-        sub_shift(s, t);
-        mix_ark(t, s, rkq + (size_t)r * 128 * NQ, NQ);
-    }
-    sub_shift(s, t);
+                                                       uint32_t blocks_per_wg, uint32_t* __restrict__ masks) {
+    __shared__ uint32_t lds_rk[11 * 128 * QW];
+    constexpr uint32_t JW = 64 / QW;  // CTR blocks per wavefront per iteration
+    const uint32_t n_qg = NQ / QW;
+    const uint32_t qg = blockIdx.x % n_qg;
+    const uint64_t chunk = blockIdx.x / n_qg;
+    // stage this workgroup's round keys: rk[(round*128+idx)*NQ + qg*QW + ql]
+    for (uint32_t i = threadIdx.x; i < 11 * 128 * QW; i += 256) lds_rk[i] = rk[(size_t)(i / QW) * NQ + qg * QW + (i % QW)];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ql = lane % QW, jsub = lane / QW;
+    const uint32_t q = qg * QW + ql;
     const uint32_t kp = keep ? keep[q] : 0xFFFFFFFFu;
-    const uint32_t* rk10 = rkq + (size_t)10 * 128 * NQ;
-    uint32_t* out = masks + (size_t)jl * 128 * NQ + q;
-    // keystream bit order is MSB-first inside each byte (gf2/domain.rs: share 8i+j <- bit 7-j of byte i)
+    const uint32_t* rkl = lds_rk + ql;
+    const uint64_t j_lo = chunk * blocks_per_wg;
+    const uint64_t j_hi = (j_lo + blocks_per_wg < n_blocks) ? j_lo + blocks_per_wg : n_blocks;
+    for (uint64_t jb = j_lo + (uint64_t)wave * JW; jb < j_hi; jb += 4 * JW) {
+        const uint64_t jl = jb + jsub;
+        if (jl >= j_hi) continue;
+        const uint64_t j = first_block + jl;
+        uint32_t s[128], t[128];
+        // round 0: counter block BE128(j) (bytes 8..15 carry j) xor rk[0]
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < 16; i++) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t v = (t[8 * i + k] ^ rk10[(size_t)(8 * i + k) * NQ]) & kp;
-            out[(size_t)(8 * i + (7 - k)) * NQ] = v;
+            for (int k = 0; k < 8; k++) {
+                uint32_t cb = 0;
+                if (i >= 8) cb = (uint32_t)0 - (uint32_t)((j >> (8 * (15 - i) + k)) & 1);
+                s[8 * i + k] = rkl[(8 * i + k) * QW] ^ cb;
+            }
+        }
+#pragma unroll 1
+        for (int r = 1; r < 10; r++) {
+            sub_shift(s, t);
+            mix_ark<QW>(t, s, rkl + r * 128 * QW);
+        }
+        sub_shift(s, t);
+        const uint32_t* rk10 = rkl + 10 * 128 * QW;
+        uint32_t* out = masks + (size_t)jl * 128 * NQ + q;
+        // keystream bit order is MSB-first inside each byte (gf2/domain.rs: share 8i+j <- bit 7-j of byte i)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t v = (t[8 * i + k] ^ rk10[(8 * i + k) * QW]) & kp;
+                out[(size_t)(8 * i + (7 - k)) * NQ] = v;
+            }
         }
     }
 }
@@ -230,12 +249,28 @@ void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, u
     uint32_t n = 11u * 128u * NQ;
     hipLaunchKernelGGL(k_bitslice_rk, dim3((n + 255) / 256), dim3(256), 0, st, d_rkbytes, NQ, d_rk);
 }
+template <int QW>
+static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
+                            uint64_t n_blocks, uint32_t* d_masks) {
+    const uint32_t n_qg = NQ / QW;
+    constexpr uint32_t JW = 64 / QW;
+    // ~4 workgroups per CU in total, each a multiple of one full iteration (4 waves x JW blocks)
+    uint64_t per = (n_blocks * n_qg + 1023) / 1024;
+    per = ((per + 4 * JW - 1) / (4 * JW)) * (4 * JW);
+    const uint64_t chunks = (n_blocks + per - 1) / per;
+    hipLaunchKernelGGL(k_aes_gf2_masks<QW>, dim3((unsigned)(chunks * n_qg)), dim3(256), 0, st, d_rk, d_keep, NQ, first_block,
+                       n_blocks, (uint32_t)per, d_masks);
+}
+
 void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
                           uint64_t n_blocks, uint32_t* d_masks) {
     if (!n_blocks) return;
-    uint64_t threads = n_blocks * NQ;
-    hipLaunchKernelGGL(k_aes_gf2_masks, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_rk, d_keep, NQ,
-                       first_block, n_blocks, d_masks);
+    if (NQ % 16 == 0)
+        launch_masks_qw<16>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
+    else if (NQ % 8 == 0)
+        launch_masks_qw<8>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
+    else
+        launch_masks_qw<2>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
 }
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
                        uint8_t* d_out) {

@@ -61,6 +61,59 @@ struct rv_ctx {
     std::multimap<size_t, void*> free_blocks;
     std::map<void*, size_t> live;
     size_t cached_bytes = 0;
+    // event timing (rv_ctx_profile)
+    bool profiling = false;
+    rv_profile prof{};
+    std::vector<hipEvent_t> ev_pool;
+    struct Mark {
+        int phase;
+        hipEvent_t a, b;
+        uint64_t launches;
+    };
+    std::vector<Mark> marks;
+    int cur_phase = -1;
+    hipEvent_t cur_start = nullptr;
+    uint64_t cur_launches = 0;
+
+    hipEvent_t get_event() {
+        if (!ev_pool.empty()) {
+            hipEvent_t e = ev_pool.back();
+            ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    // phase(p): closes the running phase and opens p (p < 0: just close)
+    void phase(int p) {
+        if (!profiling) return;
+        if (cur_phase >= 0) {
+            hipEvent_t e = get_event();
+            (void)hipEventRecord(e, stream);
+            marks.push_back({cur_phase, cur_start, e, cur_launches});
+        }
+        cur_phase = p;
+        cur_launches = 0;
+        if (p >= 0) {
+            cur_start = get_event();
+            (void)hipEventRecord(cur_start, stream);
+        }
+    }
+    void count(uint64_t n = 1) { cur_launches += n; }
+    // call after a stream sync
+    void collect() {
+        if (!profiling) return;
+        phase(-1);
+        for (auto& m : marks) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, m.a, m.b) == hipSuccess) prof.ms[m.phase] += ms;
+            prof.launches[m.phase] += m.launches;
+            ev_pool.push_back(m.a);
+            ev_pool.push_back(m.b);
+        }
+        marks.clear();
+    }
 
     int alloc(size_t bytes, void** out) {
         if (bytes == 0) bytes = 256;
@@ -149,6 +202,17 @@ extern "C" int rv_ctx_sync(rv_ctx* ctx) {
 }
 
 extern "C" void rv_free(void* p) { free(p); }
+
+extern "C" int rv_ctx_profile(rv_ctx* ctx, int enable, int reset, rv_profile* out) {
+    if (!ctx) return RV_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->collect();
+    if (out) *out = ctx->prof;
+    if (reset) ctx->prof = rv_profile{};
+    ctx->profiling = enable != 0;
+    return RV_OK;
+}
 
 // ------------------------------------------------------------------------------------
 // circuit
@@ -305,7 +369,11 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep) {
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(n_blocks, 1) * 128 * s->NQ, &s->d_masks))) return rc;
     launch_key_schedule(ctx->stream, s->d_keys, s->R * 8, s->d_rkbytes);
     launch_bitslice_rk(ctx->stream, s->d_rkbytes, s->NQ, s->d_rk);
+    ctx->count(2);
+    ctx->phase(RV_PH_MASKS);
     launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, 0, n_blocks, s->d_masks);
+    ctx->count(n_blocks ? 1 : 0);
+    ctx->phase(-1);
     return RV_OK;
 }
 
@@ -331,7 +399,10 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p) {
     p.pre = s->d_pre;
     p.err = s->d_err;
     const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+    ctx->phase(RV_PH_INTERP);
     for (size_t l = 0; l < n_levels; l++) launch_interp(ctx->stream, mode, s->c->d_gates, cc.level_start[l], cc.level_start[l + 1], p);
+    ctx->count(n_levels);
+    ctx->phase(RV_PH_HASH);
     uint32_t* dig = s->d_dig;
     const size_t DW = (size_t)s->R * 8;
     launch_b3_stream(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
@@ -339,12 +410,16 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p) {
     // Z64 transcripts (empty for a pure GF(2) circuit: BLAKE3 of the empty string)
     launch_b3_stream(ctx->stream, s->d_pre, 0, s->NQ, s->d_cv[0], s->d_cv[1], dig + 2 * DW);
     launch_b3_stream(ctx->stream, s->d_on, 0, s->NQ, s->d_cv[0], s->d_cv[1], dig + 3 * DW);
+    ctx->phase(-1);
     return RV_OK;
 }
 
 static int shard_join(rv_shard* s) {
     const size_t DW = (size_t)s->R * 8;
+    s->ctx->phase(RV_PH_JOIN);
+    s->ctx->count();
     launch_join(s->ctx->stream, s->d_dig, s->d_dig + DW, s->d_dig + 2 * DW, s->d_dig + 3 * DW, s->R, s->d_h);
+    s->ctx->phase(-1);
     HIPCHK(hipGetLastError());
     return RV_OK;
 }
@@ -377,6 +452,8 @@ extern "C" int rv_shard_commit(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
         return fail(RV_E_DEVICE);
     if (cc.n_in && hipMemcpyAsync(s->d_wit, wit_gf2, cc.n_in, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(RV_E_DEVICE);
+    ctx->phase(RV_PH_SETUP);
+    ctx->count();
     launch_expand_seeds(ctx->stream, s->d_seeds, s->R, s->d_keys);
     if ((rc = shard_setup_prg(s, nullptr))) return fail(rc);
     InterpParams p{};
@@ -390,6 +467,8 @@ extern "C" int rv_shard_commit(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
         hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
         return fail(RV_E_DEVICE);
     }
+    ctx->collect();
+    ctx->prof.calls++;
     if (err) return fail(RV_E_WITNESS_INVALID);
     *out = s;
     return RV_OK;
@@ -404,6 +483,13 @@ extern "C" int rv_shard_digests_device(rv_shard* s, void** dptr) {
 extern "C" int rv_shard_digests(rv_shard* s, uint8_t* out) {
     if (!s || !out) return RV_E_ARG;
     HIPCHK(hipMemcpyAsync(out, s->d_h, (size_t)s->R * 32, hipMemcpyDeviceToHost, s->ctx->stream));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    return RV_OK;
+}
+
+extern "C" int rv_shard_digests_to_device(rv_shard* s, void* dst_device) {
+    if (!s || !dst_device) return RV_E_ARG;
+    HIPCHK(hipMemcpyAsync(dst_device, s->d_h, (size_t)s->R * 32, hipMemcpyDeviceToDevice, s->ctx->stream));
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     return RV_OK;
 }
@@ -448,7 +534,26 @@ static OpenLayout open_layout(const Compiled& cc, const uint8_t* omit_local, uin
     return L;
 }
 
+extern "C" int rv_shard_open_size(const rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], size_t lens[4]) {
+    if (!s || !omit || !lens) return RV_E_ARG;
+    const OpenLayout L = open_layout(s->c->cc, omit + s->rep_begin, s->R);
+    for (int k = 0; k < 4; k++) lens[k] = L.len[k];
+    return RV_OK;
+}
+
+static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void* dst, void** dptr, size_t lens[4]);
+
 extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void** dptr, size_t lens[4]) {
+    return shard_open_impl(s, omit, nullptr, dptr, lens);
+}
+
+extern "C" int rv_shard_open_into(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void* dst_device, size_t lens[4]) {
+    if (!dst_device) return RV_E_ARG;
+    void* d = nullptr;
+    return shard_open_impl(s, omit, dst_device, &d, lens);
+}
+
+static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void* dst, void** dptr, size_t lens[4]) {
     if (!s || !omit || !dptr || !lens) return RV_E_ARG;
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
@@ -480,23 +585,30 @@ extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REP
     s->d_omit = nullptr;
     s->d_offs = nullptr;
     s->d_out = nullptr;
-    if ((rc = dalloc(ctx, s->R, &s->d_omit)) || (rc = dalloc(ctx, offs.size(), &s->d_offs)) ||
-        (rc = dalloc(ctx, std::max<size_t>(L.total, 1), &s->d_out)))
-        return rc;
+    if ((rc = dalloc(ctx, s->R, &s->d_omit)) || (rc = dalloc(ctx, offs.size(), &s->d_offs))) return rc;
+    uint8_t* d_out = (uint8_t*)dst;
+    if (!d_out) {
+        if ((rc = dalloc(ctx, std::max<size_t>(L.total, 1), &s->d_out))) return rc;
+        d_out = s->d_out;
+    }
     HIPCHK(hipMemcpyAsync(s->d_omit, om, s->R, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(s->d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     const size_t DW = (size_t)s->R * 8;
+    ctx->phase(RV_PH_OPEN);
+    ctx->count(L.n_on ? 4 : 1);
     launch_open_headers(ctx->stream, s->R, s->d_omit, s->d_seeds, s->d_keys, s->d_dig + 1 * DW, s->d_dig + 3 * DW, s->d_offs,
-                        s->d_offs + s->R, L.l2r, L.l2c, L.l2i, L.l64r, L.l64c, L.l64i, s->d_out);
+                        s->d_offs + s->R, L.l2r, L.l2c, L.l2i, L.l64r, L.l64c, L.l64i, d_out);
     if (L.n_on) {
-        launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, s->d_out);
-        launch_extract_bits(ctx->stream, s->d_pre, nullptr, cc.n_pre, s->NQ, 1, s->d_omit, s->d_offs + 3 * s->R, s->d_out);
-        launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, s->d_out);
+        launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
+        launch_extract_bits(ctx->stream, s->d_pre, nullptr, cc.n_pre, s->NQ, 1, s->d_omit, s->d_offs + 3 * s->R, d_out);
+        launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
     }
     HIPCHK(hipGetLastError());
+    ctx->phase(-1);
     // the host vector `offs` must outlive the async copy
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    *dptr = s->d_out;
+    ctx->collect();
+    *dptr = d_out;
     for (int k = 0; k < 4; k++) lens[k] = L.len[k];
     return RV_OK;
 }
@@ -768,11 +880,15 @@ extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
     HC(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HC(hipMemcpyAsync(d_keep, keep.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
     HC(hipMemcpyAsync(d_onm, onm.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->phase(RV_PH_SETUP);
+    ctx->count();
     launch_expand_seeds(ctx->stream, s->d_seeds, R, s->d_keys);
     // online slots take the opened player keys straight from the proof (online.rs:101-113)
     for (uint32_t r = 0; r < R; r++)
         if (omit[r] < 8) HC(hipMemcpyAsync(s->d_keys + (size_t)r * 128, proof + P.gf2.on[slot_begin + r].keys, 128, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = shard_setup_prg(s, d_keep))) return fail(rc);
+    ctx->phase(RV_PH_SETUP);
+    ctx->count(3);
     launch_unpack_bits(ctx->stream, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
     launch_unpack_bits(ctx->stream, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr);
     launch_unpack_bits(ctx->stream, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec);
@@ -793,6 +909,8 @@ extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
     if ((rc = shard_join(s))) return fail(rc);
     HC(hipMemcpyAsync(digests, s->d_h, (size_t)R * 32, hipMemcpyDeviceToHost, ctx->stream));
     HC(hipStreamSynchronize(ctx->stream));
+    ctx->collect();
+    ctx->prof.calls++;
 #undef HC
     rv_shard_destroy(s);
     return RV_OK;
