@@ -249,6 +249,87 @@ void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, u
     uint32_t n = 11u * 128u * NQ;
     hipLaunchKernelGGL(k_bitslice_rk, dim3((n + 255) / 256), dim3(256), 0, st, d_rkbytes, NQ, d_rk);
 }
+// 32x32 bit-matrix transpose (Hacker's Delight 7-3), fully unrolled: registers only
+__device__ __forceinline__ void transpose32(uint32_t* A) {
+    uint32_t m = 0x0000FFFFu;
+#pragma unroll
+    for (int j = 16; j != 0; j >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+            const uint32_t t = (A[k] ^ (A[k + j] >> j)) & m;
+            A[k] ^= t;
+            A[k + j] ^= (t << j);
+        }
+        m ^= (m << (j >> 1));
+    }
+}
+
+// Z64 mask generator (replaces BatchZ64::random + DomainZ64::batches_to_shares,
+// src/algebra/z64/batch.rs:26-29, z64/domain.rs:64-83): the same bitsliced cipher, then the
+// 128 bit-planes of a lane are transposed back to two little-endian u64 per (rep, player)
+// slot.  masks64[(2j+h)*S + slot] with S = NQ*32 slots, slot = rep*8 + player.
+template <int QW>
+__global__ __launch_bounds__(256) void k_aes_z64_masks(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep,
+                                                       uint32_t NQ, uint64_t n_blocks, uint32_t blocks_per_wg,
+                                                       uint64_t* __restrict__ masks64) {
+    __shared__ uint32_t lds_rk[11 * 128 * QW];
+    constexpr uint32_t JW = 64 / QW;
+    const uint32_t n_qg = NQ / QW;
+    const uint32_t qg = blockIdx.x % n_qg;
+    const uint64_t chunk = blockIdx.x / n_qg;
+    for (uint32_t i = threadIdx.x; i < 11 * 128 * QW; i += 256) lds_rk[i] = rk[(size_t)(i / QW) * NQ + qg * QW + (i % QW)];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ql = lane % QW, jsub = lane / QW;
+    const uint32_t q = qg * QW + ql;
+    const uint32_t kp = keep ? keep[q] : 0xFFFFFFFFu;
+    const uint32_t* rkl = lds_rk + ql;
+    const uint64_t S = (uint64_t)NQ * 32;
+    const uint64_t j_lo = chunk * blocks_per_wg;
+    const uint64_t j_hi = (j_lo + blocks_per_wg < n_blocks) ? j_lo + blocks_per_wg : n_blocks;
+    for (uint64_t jb = j_lo + (uint64_t)wave * JW; jb < j_hi; jb += 4 * JW) {
+        const uint64_t j = jb + jsub;
+        if (j >= j_hi) continue;
+        uint32_t s[128], t[128];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t cb = 0;
+                if (i >= 8) cb = (uint32_t)0 - (uint32_t)((j >> (8 * (15 - i) + k)) & 1);
+                s[8 * i + k] = rkl[(8 * i + k) * QW] ^ cb;
+            }
+        }
+#pragma unroll 1
+        for (int r = 1; r < 10; r++) {
+            sub_shift(s, t);
+            mix_ark<QW>(t, s, rkl + r * 128 * QW);
+        }
+        sub_shift(s, t);
+        const uint32_t* rk10 = rkl + 10 * 128 * QW;
+#pragma unroll
+        for (int i = 0; i < 128; i++) t[i] ^= rk10[i * QW];
+        // plane 8*i + k = bit k of keystream byte i; u64 h, bit b  <->  plane 64*h + b
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint32_t lo[32], hi[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                lo[k] = t[64 * h + 31 - k];
+                hi[k] = t[64 * h + 32 + 31 - k];
+            }
+            transpose32(lo);
+            transpose32(hi);
+            uint64_t* out = masks64 + (2 * j + h) * S + (uint64_t)q * 32;
+#pragma unroll
+            for (int sl = 0; sl < 32; sl++) {
+                const uint32_t on = (uint32_t)0 - ((kp >> (31 - sl)) & 1u);  // omitted player's stream stays zero
+                out[sl] = ((uint64_t)(hi[sl] & on) << 32) | (lo[sl] & on);
+            }
+        }
+    }
+}
+
 template <int QW>
 static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
                             uint64_t n_blocks, uint32_t* d_masks) {
@@ -272,6 +353,29 @@ void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* 
     else
         launch_masks_qw<2>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
 }
+template <int QW>
+static void launch_z64_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t n_blocks,
+                          uint64_t* d_masks64) {
+    const uint32_t n_qg = NQ / QW;
+    constexpr uint32_t JW = 64 / QW;
+    uint64_t per = (n_blocks * n_qg + 1023) / 1024;
+    per = ((per + 4 * JW - 1) / (4 * JW)) * (4 * JW);
+    const uint64_t chunks = (n_blocks + per - 1) / per;
+    hipLaunchKernelGGL(k_aes_z64_masks<QW>, dim3((unsigned)(chunks * n_qg)), dim3(256), 0, st, d_rk, d_keep, NQ, n_blocks,
+                       (uint32_t)per, d_masks64);
+}
+
+void launch_aes_z64_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t n_blocks,
+                          uint64_t* d_masks64) {
+    if (!n_blocks) return;
+    if (NQ % 16 == 0)
+        launch_z64_qw<16>(st, d_rk, d_keep, NQ, n_blocks, d_masks64);
+    else if (NQ % 8 == 0)
+        launch_z64_qw<8>(st, d_rk, d_keep, NQ, n_blocks, d_masks64);
+    else
+        launch_z64_qw<2>(st, d_rk, d_keep, NQ, n_blocks, d_masks64);
+}
+
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
                        uint8_t* d_out) {
     uint64_t n = (uint64_t)n_keys * n_blocks;

@@ -223,6 +223,9 @@ struct rv_circuit {
     Gate* d_gates = nullptr;
     uint32_t* d_rec_rows = nullptr;
     uint32_t* d_in_rows = nullptr;
+    Gate64* d_gates64 = nullptr;
+    uint64_t* d_rec_offs64 = nullptr;
+    uint64_t* d_in_offs64 = nullptr;
 };
 
 static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
@@ -234,6 +237,10 @@ static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
     b += (cc.n_on + cc.n_pre) * NQ * 4;
     b += 4 * b3_stream_scratch_words(std::max(cc.n_on, cc.n_pre), R) * 4;
     b += (size_t)R * (16 + 128 + 8 * 176) + 11 * 128 * NQ * 4;
+    // Z64: masks, wires, contiguous transcripts
+    b += ((cc.n_masks64 + 1) / 2 * 2) * (size_t)R * 64;
+    b += cc.n_ssa64 * (size_t)R * 72;
+    b += (cc.on_words64 + cc.pre_words64) * (size_t)R * 8;
     return b;
 }
 
@@ -258,12 +265,16 @@ extern "C" int rv_circuit_compile(rv_ctx* ctx, const rv_op* ops, size_t n_ops, s
     };
     if ((rc = up(cc.gates.data(), cc.gates.size() * sizeof(Gate), (void**)&c->d_gates)) ||
         (rc = up(cc.rec_rows.data(), cc.rec_rows.size() * 4, (void**)&c->d_rec_rows)) ||
-        (rc = up(cc.in_rows.data(), cc.in_rows.size() * 4, (void**)&c->d_in_rows))) {
+        (rc = up(cc.in_rows.data(), cc.in_rows.size() * 4, (void**)&c->d_in_rows)) ||
+        (rc = up(cc.gates64.data(), cc.gates64.size() * sizeof(Gate64), (void**)&c->d_gates64)) ||
+        (rc = up(cc.rec_offs64.data(), cc.rec_offs64.size() * 8, (void**)&c->d_rec_offs64)) ||
+        (rc = up(cc.in_offs64.data(), cc.in_offs64.size() * 8, (void**)&c->d_in_offs64))) {
         rv_circuit_destroy(c);
         return rc;
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    c->cc.info.device_bytes = cc.gates.size() * sizeof(Gate) + (cc.rec_rows.size() + cc.in_rows.size()) * 4;
+    c->cc.info.device_bytes = cc.gates.size() * sizeof(Gate) + (cc.rec_rows.size() + cc.in_rows.size()) * 4 +
+                              cc.gates64.size() * sizeof(Gate64) + (cc.rec_offs64.size() + cc.in_offs64.size()) * 8;
     c->cc.info.scratch_bytes = scratch_bytes_for(cc, RV_TOTAL_REPS);
     *out = c;
     return RV_OK;
@@ -274,6 +285,9 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     c->ctx->release(c->d_gates);
     c->ctx->release(c->d_rec_rows);
     c->ctx->release(c->d_in_rows);
+    c->ctx->release(c->d_gates64);
+    c->ctx->release(c->d_rec_offs64);
+    c->ctx->release(c->d_in_offs64);
     delete c;
 }
 
@@ -333,6 +347,16 @@ struct rv_shard {
     uint32_t* d_on = nullptr;
     uint32_t* d_pre = nullptr;
     uint8_t* d_wit = nullptr;
+    // Z64 domain
+    uint64_t* d_masks64 = nullptr;
+    uint64_t* d_wmask64 = nullptr;
+    uint64_t* d_wcorr64 = nullptr;
+    uint64_t* d_on64 = nullptr;
+    uint64_t* d_pre64 = nullptr;
+    uint64_t* d_wit64 = nullptr;
+    uint8_t* d_keys64 = nullptr;  // verifier only: the z64 openings carry their own key set
+    uint32_t* d_rk64 = nullptr;
+    uint8_t* d_omit64 = nullptr;
     uint32_t* d_cv[2] = {nullptr, nullptr};
     uint32_t* d_dig = nullptr;  // [4][R][8]: pre2, on2, pre64, on64
     uint8_t* d_h = nullptr;     // [R][32]
@@ -344,8 +368,9 @@ struct rv_shard {
     std::vector<void*> extra;
 
     void destroy() {
-        void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk, d_masks, d_wires, d_on, d_pre, d_wit, d_cv[0], d_cv[1],
-                      d_dig,   d_h,    d_err,     d_omit, d_offs, d_out};
+        void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk,    d_masks,  d_wires,   d_on,     d_pre,    d_wit,  d_cv[0],
+                      d_cv[1], d_dig,  d_h,       d_err,   d_omit,   d_offs,    d_out,    d_masks64, d_wmask64,
+                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64};
         for (void* p : ps) ctx->release(p);
         for (void* p : extra) ctx->release(p);
     }
@@ -359,10 +384,17 @@ extern "C" void rv_shard_destroy(rv_shard* s) {
 }
 
 // key material -> bitsliced round keys, masks
-static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep) {
+static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* d_keep64 = nullptr) {
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     int rc;
+    const uint64_t n_blocks64 = (cc.n_masks64 + 1) / 2;
+    if (n_blocks64) {
+        if ((rc = dalloc(ctx, (size_t)n_blocks64 * 2 * s->R * 8, &s->d_masks64))) return rc;
+        if (s->d_keys64) {  // verifier: separate key set for the z64 transcript (reuses d_rkbytes as scratch below)
+            if ((rc = dalloc(ctx, (size_t)11 * 128 * s->NQ, &s->d_rk64))) return rc;
+        }
+    }
     if ((rc = dalloc(ctx, (size_t)s->R * 8 * 176, &s->d_rkbytes))) return rc;
     if ((rc = dalloc(ctx, (size_t)11 * 128 * s->NQ, &s->d_rk))) return rc;
     const uint64_t n_blocks = (cc.n_masks + 127) / 128;
@@ -373,12 +405,22 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep) {
     ctx->phase(RV_PH_MASKS);
     launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, 0, n_blocks, s->d_masks);
     ctx->count(n_blocks ? 1 : 0);
+    if (n_blocks64) {
+        const uint32_t* rk64 = s->d_rk;  // prover: the same seeds feed both domains (proof/mod.rs:131-146)
+        if (s->d_keys64) {
+            launch_key_schedule(ctx->stream, s->d_keys64, s->R * 8, s->d_rkbytes);
+            launch_bitslice_rk(ctx->stream, s->d_rkbytes, s->NQ, s->d_rk64);
+            rk64 = s->d_rk64;
+        }
+        launch_aes_z64_masks(ctx->stream, rk64, s->d_keys64 ? d_keep64 : d_keep, s->NQ, n_blocks64, s->d_masks64);
+        ctx->count(1);
+    }
     ctx->phase(-1);
     return RV_OK;
 }
 
 // interpreter over all levels + transcript digests + joins
-static int shard_run(rv_shard* s, int mode, InterpParams& p) {
+static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64) {
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     int rc;
@@ -386,10 +428,19 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p) {
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_on, 1) * s->NQ, &s->d_on))) return rc;
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * s->NQ, &s->d_pre))) return rc;
     if ((rc = dalloc(ctx, 1, &s->d_err))) return rc;
-    const size_t cvw = b3_stream_scratch_words(std::max(cc.n_on, cc.n_pre), s->R);
+    const size_t cvw = b3_stream_scratch_words(std::max({cc.n_on, cc.n_pre, cc.on_words64 * 8, cc.pre_words64 * 8}), s->R);
     if ((rc = dalloc(ctx, cvw, &s->d_cv[0])) || (rc = dalloc(ctx, cvw, &s->d_cv[1]))) return rc;
     if ((rc = dalloc(ctx, (size_t)4 * s->R * 8, &s->d_dig))) return rc;
     if ((rc = dalloc(ctx, (size_t)s->R * 32, &s->d_h))) return rc;
+    const bool has64 = !cc.gates64.empty();
+    if (has64) {
+        if ((rc = dalloc(ctx, (size_t)cc.n_ssa64 * s->R * 8, &s->d_wmask64))) return rc;
+        if ((rc = dalloc(ctx, (size_t)cc.n_ssa64 * s->R, &s->d_wcorr64))) return rc;
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.on_words64, 1) * s->R, &s->d_on64))) return rc;
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.pre_words64, 1) * s->R, &s->d_pre64))) return rc;
+        HIPCHK(hipMemsetAsync(s->d_wmask64, 0, (size_t)s->R * 64, ctx->stream));
+        HIPCHK(hipMemsetAsync(s->d_wcorr64, 0, (size_t)s->R * 8, ctx->stream));
+    }
     HIPCHK(hipMemsetAsync(s->d_err, 0, sizeof(int), ctx->stream));
     HIPCHK(hipMemsetAsync(s->d_wires, 0, (size_t)2 * s->NQ * 4, ctx->stream));  // SSA 0 = default wire
     p.NQ = s->NQ;
@@ -399,17 +450,37 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p) {
     p.pre = s->d_pre;
     p.err = s->d_err;
     const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+    p64.R = s->R;
+    p64.wmask = s->d_wmask64;
+    p64.wcorr = s->d_wcorr64;
+    p64.masks = s->d_masks64;
+    p64.on = s->d_on64;
+    p64.pre = s->d_pre64;
+    p64.on_words = cc.on_words64;
+    p64.pre_words = cc.pre_words64;
+    p64.wires2 = s->d_wires;
+    p64.masks2 = s->d_masks;
+    p64.NQ = s->NQ;
+    p64.err = s->d_err;
     ctx->phase(RV_PH_INTERP);
-    for (size_t l = 0; l < n_levels; l++) launch_interp(ctx->stream, mode, s->c->d_gates, cc.level_start[l], cc.level_start[l + 1], p);
-    ctx->count(n_levels);
+    for (size_t l = 0; l < n_levels; l++) {
+        if (cc.level_start[l + 1] > cc.level_start[l]) {
+            launch_interp(ctx->stream, mode, s->c->d_gates, cc.level_start[l], cc.level_start[l + 1], p);
+            ctx->count();
+        }
+        if (has64 && cc.level_start64[l + 1] > cc.level_start64[l]) {
+            launch_interp64(ctx->stream, mode, s->c->d_gates64, cc.level_start64[l], cc.level_start64[l + 1], p64);
+            ctx->count();
+        }
+    }
     ctx->phase(RV_PH_HASH);
     uint32_t* dig = s->d_dig;
     const size_t DW = (size_t)s->R * 8;
     launch_b3_stream(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
     launch_b3_stream(ctx->stream, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 1 * DW);
-    // Z64 transcripts (empty for a pure GF(2) circuit: BLAKE3 of the empty string)
-    launch_b3_stream(ctx->stream, s->d_pre, 0, s->NQ, s->d_cv[0], s->d_cv[1], dig + 2 * DW);
-    launch_b3_stream(ctx->stream, s->d_on, 0, s->NQ, s->d_cv[0], s->d_cv[1], dig + 3 * DW);
+    // Z64 transcripts (for a pure GF(2) circuit: BLAKE3 of the empty string)
+    launch_b3_contig(ctx->stream, s->d_pre64, cc.pre_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 2 * DW);
+    launch_b3_contig(ctx->stream, s->d_on64, cc.on_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 3 * DW);
     ctx->phase(-1);
     return RV_OK;
 }
@@ -426,13 +497,11 @@ static int shard_join(rv_shard* s) {
 
 extern "C" int rv_shard_commit(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
                                size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out) {
-    (void)wit_z64;
-    (void)n_z64;
     if (!ctx || !c || !out || !seeds) return RV_E_ARG;
     if (rep_count == 0 || rep_count % 8 || rep_begin % 8 || rep_begin + rep_count > RV_TOTAL_REPS) return RV_E_ARG;
     *out = nullptr;
     const Compiled& cc = c->cc;
-    if (n_gf2 < cc.n_in) return RV_E_WITNESS_SHORT;
+    if (n_gf2 < cc.n_in || n_z64 < cc.n_in64) return RV_E_WITNESS_SHORT;
     HIPCHK(hipSetDevice(ctx->device));
     rv_shard* s = new rv_shard();
     s->ctx = ctx;
@@ -452,13 +521,20 @@ extern "C" int rv_shard_commit(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
         return fail(RV_E_DEVICE);
     if (cc.n_in && hipMemcpyAsync(s->d_wit, wit_gf2, cc.n_in, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(RV_E_DEVICE);
+    if (cc.n_in64) {
+        if ((rc = dalloc(ctx, cc.n_in64, &s->d_wit64))) return fail(rc);
+        if (hipMemcpyAsync(s->d_wit64, wit_z64, cc.n_in64 * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return fail(RV_E_DEVICE);
+    }
     ctx->phase(RV_PH_SETUP);
     ctx->count();
     launch_expand_seeds(ctx->stream, s->d_seeds, s->R, s->d_keys);
     if ((rc = shard_setup_prg(s, nullptr))) return fail(rc);
     InterpParams p{};
     p.wit = s->d_wit;
-    if ((rc = shard_run(s, MODE_PROVE, p))) return fail(rc);
+    Interp64Params p64{};
+    p64.wit = s->d_wit64;
+    if ((rc = shard_run(s, MODE_PROVE, p, p64))) return fail(rc);
     if ((rc = shard_join(s))) return fail(rc);
     int err = 0;
     if (hipMemcpyAsync(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return fail(RV_E_DEVICE);
@@ -517,7 +593,10 @@ static OpenLayout open_layout(const Compiled& cc, const uint8_t* omit_local, uin
     L.l2r = cc.n_rec / 8 + 1;
     L.l2c = cc.n_pre / 8 + 1;
     L.l2i = cc.n_in / 8 + 1;
-    L.l64r = L.l64c = L.l64i = 0;
+    // Z64 vectors: 8 bytes LE per item, no padding (z64/share.rs:42-48, z64/recon.rs:59-65)
+    L.l64r = 8 * cc.n_rec64;
+    L.l64c = 8 * cc.n_corr64;
+    L.l64i = 8 * cc.n_in64;
     L.sz2 = 1 + 128 + 24 + L.l2r + L.l2c + L.l2i;
     L.sz64 = 1 + 128 + 24 + L.l64r + L.l64c + L.l64i;
     for (uint32_t r = 0; r < R; r++) (omit_local[r] < 8 ? L.n_on : L.n_pre)++;
@@ -562,7 +641,7 @@ static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void*
     for (uint32_t r = 0; r < s->R; r++)
         if (om[r] > 8) return RV_E_ARG;
     const OpenLayout L = open_layout(cc, om, s->R);
-    std::vector<uint64_t> offs((size_t)5 * s->R);  // off2, off64, rec dst, corr dst, in dst
+    std::vector<uint64_t> offs((size_t)8 * s->R);  // off2, off64, gf2 rec/corr/in dst, z64 rec/corr/in dst
     uint32_t k_on = 0, k_pre = 0;
     for (uint32_t r = 0; r < s->R; r++) {
         if (om[r] < 8) {
@@ -571,6 +650,9 @@ static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void*
             offs[2 * s->R + r] = offs[r] + 137;
             offs[3 * s->R + r] = offs[r] + 145 + L.l2r;
             offs[4 * s->R + r] = offs[r] + 153 + L.l2r + L.l2c;
+            offs[5 * s->R + r] = offs[s->R + r] + 137;
+            offs[6 * s->R + r] = offs[s->R + r] + 145 + L.l64r;
+            offs[7 * s->R + r] = offs[s->R + r] + 153 + L.l64r + L.l64c;
             k_on++;
         } else {
             offs[r] = L.base[1] + (uint64_t)k_pre * 48;
@@ -602,6 +684,12 @@ static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void*
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
         launch_extract_bits(ctx->stream, s->d_pre, nullptr, cc.n_pre, s->NQ, 1, s->d_omit, s->d_offs + 3 * s->R, d_out);
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
+        launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_rec_offs64, cc.n_rec64, 1, s->R, s->d_omit,
+                         s->d_offs + 5 * s->R, d_out);
+        launch_extract64(ctx->stream, s->d_pre64, cc.pre_words64, nullptr, cc.n_corr64, 0, s->R, s->d_omit, s->d_offs + 6 * s->R,
+                         d_out);
+        launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_in_offs64, cc.n_in64, 0, s->R, s->d_omit,
+                         s->d_offs + 7 * s->R, d_out);
     }
     HIPCHK(hipGetLastError());
     ctx->phase(-1);
@@ -805,9 +893,11 @@ extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
 
     // ---- host-side preparation of the slots (VerifierTranscriptOnline::new, online.rs:25-119;
     //      VerifierTranscriptPreprocess::new, preprocess.rs:17-43)
-    std::vector<uint8_t> seeds((size_t)R * 16, 0), omit(R, 8);
+    std::vector<uint8_t> seeds((size_t)R * 16, 0), omit(R, 8), seeds64((size_t)R * 16, 0), omit64(R, 8);
     std::vector<uint64_t> src((size_t)6 * R, 0);  // rec off,len ; corr off,len ; in off,len
-    std::vector<uint32_t> keep(NQ, 0xFFFFFFFFu), onm(NQ, 0);
+    std::vector<uint64_t> src64((size_t)6 * R, 0);
+    std::vector<uint32_t> keep(NQ, 0xFFFFFFFFu), onm(NQ, 0), keep64(NQ, 0xFFFFFFFFu);
+    const bool has64 = !cc.gates64.empty();
     for (uint32_t g0 = 0; g0 < R; g0 += 8) {
         const uint32_t slot0 = slot_begin + g0;
         if (slot0 < RV_ONLINE_REPS) {
@@ -829,10 +919,24 @@ extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
                 src[5 * R + r] = o[0].n_in;
                 keep[r / 4] &= ~(1u << (31 - 8 * (r % 4) - o[i].omit));  // BatchGen skips the omitted player
                 onm[r / 4] |= 0xFFu << (24 - 8 * (r % 4));
+                // Z64 vectors: length of the group's first record, missing chunks read as zero
+                // (z64/recon.rs:68-108, z64/share.rs:51-91)
+                omit64[r] = z[i].omit;
+                keep64[r / 4] &= ~(1u << (31 - 8 * (r % 4) - z[i].omit));
+                src64[0 * R + r] = z[i].rec;
+                src64[1 * R + r] = std::min(z[i].n_rec, z[0].n_rec / 8 * 8);
+                src64[2 * R + r] = z[i].corr;
+                src64[3 * R + r] = std::min(z[i].n_corr, z[0].n_corr / 8 * 8);
+                src64[4 * R + r] = z[i].in;
+                src64[5 * R + r] = std::min(z[i].n_in, z[0].n_in / 8 * 8);
             }
         } else {
             const PreRec* q = &P.gf2.pre[slot0 - RV_ONLINE_REPS];
-            for (int i = 0; i < 8; i++) memcpy(&seeds[(size_t)(g0 + i) * 16], proof + q[i].seed, 16);
+            const PreRec* q64 = &P.z64.pre[slot0 - RV_ONLINE_REPS];
+            for (int i = 0; i < 8; i++) {
+                memcpy(&seeds[(size_t)(g0 + i) * 16], proof + q[i].seed, 16);
+                memcpy(&seeds64[(size_t)(g0 + i) * 16], proof + q64[i].seed, 16);
+            }
         }
     }
 
@@ -867,6 +971,24 @@ extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
     track(d_sup_corr);
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_rec, 1) * NQ, &d_sup_rec))) return fail(rc);
     track(d_sup_rec);
+    uint64_t *d_src64 = nullptr, *d_sup_in64 = nullptr, *d_sup_corr64 = nullptr, *d_sup_rec64 = nullptr;
+    uint32_t* d_keep64 = nullptr;
+    uint8_t* d_seeds64 = nullptr;
+    if (has64) {
+        if ((rc = dalloc(ctx, (size_t)R * 16, &d_seeds64))) return fail(rc);
+        track(d_seeds64);
+        if ((rc = dalloc(ctx, (size_t)R * 128, &s->d_keys64)) || (rc = dalloc(ctx, R, &s->d_omit64))) return fail(rc);
+        if ((rc = dalloc(ctx, src64.size(), &d_src64))) return fail(rc);
+        track(d_src64);
+        if ((rc = dalloc(ctx, NQ, &d_keep64))) return fail(rc);
+        track(d_keep64);
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_in64, 1) * R, &d_sup_in64))) return fail(rc);
+        track(d_sup_in64);
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_corr64, 1) * R, &d_sup_corr64))) return fail(rc);
+        track(d_sup_corr64);
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_rec64, 1) * R, &d_sup_rec64))) return fail(rc);
+        track(d_sup_rec64);
+    }
 #define HC(x)                                 \
     do {                                      \
         if ((x) != hipSuccess) {              \
@@ -886,18 +1008,39 @@ extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
     // online slots take the opened player keys straight from the proof (online.rs:101-113)
     for (uint32_t r = 0; r < R; r++)
         if (omit[r] < 8) HC(hipMemcpyAsync(s->d_keys + (size_t)r * 128, proof + P.gf2.on[slot_begin + r].keys, 128, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = shard_setup_prg(s, d_keep))) return fail(rc);
+    if (has64) {
+        HC(hipMemcpyAsync(d_seeds64, seeds64.data(), seeds64.size(), hipMemcpyHostToDevice, ctx->stream));
+        HC(hipMemcpyAsync(s->d_omit64, omit64.data(), omit64.size(), hipMemcpyHostToDevice, ctx->stream));
+        HC(hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HC(hipMemcpyAsync(d_keep64, keep64.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
+        launch_expand_seeds(ctx->stream, d_seeds64, R, s->d_keys64);
+        ctx->count();
+        for (uint32_t r = 0; r < R; r++)
+            if (omit64[r] < 8) HC(hipMemcpyAsync(s->d_keys64 + (size_t)r * 128, proof + P.z64.on[slot_begin + r].keys, 128, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((rc = shard_setup_prg(s, d_keep, d_keep64))) return fail(rc);
     ctx->phase(RV_PH_SETUP);
     ctx->count(3);
     launch_unpack_bits(ctx->stream, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
     launch_unpack_bits(ctx->stream, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr);
     launch_unpack_bits(ctx->stream, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec);
+    Interp64Params p64{};
+    if (has64) {
+        launch_unpack64(ctx->stream, d_proof, d_src64 + 4 * R, d_src64 + 5 * R, s->d_omit64, cc.n_in64, R, d_sup_in64);
+        launch_unpack64(ctx->stream, d_proof, d_src64 + 2 * R, d_src64 + 3 * R, s->d_omit64, cc.n_corr64, R, d_sup_corr64);
+        launch_unpack64(ctx->stream, d_proof, d_src64 + 0 * R, d_src64 + 1 * R, s->d_omit64, cc.n_rec64, R, d_sup_rec64);
+        ctx->count(3);
+        p64.omit = s->d_omit64;
+        p64.sup_in = d_sup_in64;
+        p64.sup_corr = d_sup_corr64;
+        p64.sup_rec = d_sup_rec64;
+    }
     InterpParams p{};
     p.on_mask = d_onm;
     p.sup_in = d_sup_in;
     p.sup_corr = d_sup_corr;
     p.sup_rec = d_sup_rec;
-    if ((rc = shard_run(s, MODE_VERIFY, p))) return fail(rc);
+    if ((rc = shard_run(s, MODE_VERIFY, p, p64))) return fail(rc);
     // preprocessing slots: the online commitment is the one carried by the proof (preprocess.rs:55-57)
     const size_t DW = (size_t)R * 8;
     for (uint32_t r = 0; r < R; r++)
@@ -1013,12 +1156,36 @@ extern "C" int rv_hook_sharegen_gf2(rv_ctx* ctx, const uint8_t* keys, const uint
 }
 
 extern "C" int rv_hook_sharegen_z64(rv_ctx* ctx, const uint8_t* keys, const uint32_t omit[8], size_t n, uint64_t* out) {
-    (void)ctx;
-    (void)keys;
-    (void)omit;
-    (void)n;
-    (void)out;
-    return RV_E_UNSUPPORTED;
+    if (!ctx || !keys || !omit || !out || !n) return RV_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint32_t R = 8, NQ = 2;
+    uint8_t *dk = nullptr, *drk = nullptr;
+    uint32_t *d_rk = nullptr, *d_keep = nullptr;
+    uint64_t* d_masks = nullptr;
+    uint32_t keep[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (uint32_t r = 0; r < 8; r++) {
+        if (omit[r] > 8) return RV_E_ARG;
+        if (omit[r] < 8) keep[r / 4] &= ~(1u << (31 - 8 * (r % 4) - omit[r]));
+    }
+    const uint64_t n_blocks = (n + 1) / 2;
+    int rc;
+    if ((rc = dalloc(ctx, (size_t)R * 128, &dk)) || (rc = dalloc(ctx, (size_t)R * 8 * 176, &drk)) ||
+        (rc = dalloc(ctx, (size_t)11 * 128 * NQ, &d_rk)) || (rc = dalloc(ctx, NQ, &d_keep)) ||
+        (rc = dalloc(ctx, (size_t)n_blocks * 2 * R * 8, &d_masks)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(dk, keys, (size_t)R * 128, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_keep, keep, sizeof keep, hipMemcpyHostToDevice, ctx->stream));
+    launch_key_schedule(ctx->stream, dk, R * 8, drk);
+    launch_bitslice_rk(ctx->stream, drk, NQ, d_rk);
+    launch_aes_z64_masks(ctx->stream, d_rk, d_keep, NQ, n_blocks, d_masks);
+    HIPCHK(hipMemcpyAsync(out, d_masks, n * 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->release(dk);
+    ctx->release(drk);
+    ctx->release(d_rk);
+    ctx->release(d_keep);
+    ctx->release(d_masks);
+    return RV_OK;
 }
 
 extern "C" int rv_hook_blake3(rv_ctx* ctx, const uint8_t* data, size_t n_streams, size_t len, uint8_t* out) {

@@ -27,6 +27,13 @@ struct Compiled {
     std::vector<uint32_t> in_rows;      // input ordinal -> online transcript row
     uint64_t n_ssa = 1;                 // SSA wires incl. the zero wire
     uint64_t n_masks = 0, n_on = 0, n_pre = 0, n_in = 0, n_rec = 0;
+    // Z64 domain (gates64 share the level numbering: level l = [level_start64[l], level_start64[l+1]))
+    std::vector<Gate64> gates64;
+    std::vector<uint32_t> level_start64;
+    std::vector<uint64_t> rec_offs64;   // reconstruction ordinal -> word offset in the online transcript
+    std::vector<uint64_t> in_offs64;    // input ordinal -> word offset in the online transcript
+    uint64_t n_ssa64 = 1;
+    uint64_t n_masks64 = 0, on_words64 = 0, pre_words64 = 0, n_in64 = 0, n_rec64 = 0, n_corr64 = 0;
     rv_circuit_info info{};
 };
 

@@ -33,7 +33,52 @@ struct Gate {
     uint32_t x;    // Input: witness index; Mul/AssertZero: reconstruction ordinal; *Const: constant
 };
 
-enum GateOp : uint32_t { G_INPUT = 0, G_XOR, G_XORC, G_ANDC, G_MUL, G_ASSERT, G_RANDOM, G_CONST };
+enum GateOp : uint32_t {
+    G_INPUT = 0, G_XOR, G_XORC, G_ANDC, G_MUL, G_ASSERT, G_RANDOM, G_CONST,
+    G_RECON  // B2A: transcript.reconstruct(mask) + corr, result kept as {mask 0, corr value}
+};
+
+// Z64 ring (src/algebra/z64): one u64 per (repetition, player).
+//   masks64 [n_masks64][R*8] u64   (row m = m-th ShareGen<Z64>::next(), [rep][player])
+//   wmask64 [n_ssa64][R*8]  u64,  wcorr64 [n_ssa64][R] u64
+//   on64 / pre64: per-repetition CONTIGUOUS transcripts [R][n_words] u64 (events have two
+//   sizes, 8 B and 64 B per rep, so a row layout would not have a fixed stride)
+struct Gate64 {
+    uint32_t op;   // Gate64Op
+    uint32_t dst;  // z64 SSA id
+    uint32_t a, b; // z64 SSA ids (B2A: a = first of 64 consecutive gf2 SSA ids holding the revealed sum bits)
+    uint32_t m;    // z64 mask index (Input/Random/B2A: 1, Mul: 2)
+    uint32_t m2;   // B2A: first of the 64 fresh gf2 mask indices
+    uint64_t eo;   // word offset in the per-rep online transcript
+    uint64_t ep;   // word offset in the per-rep preprocessing transcript
+    uint32_t x;    // Input: witness index / input ordinal; Mul, AssertZero: reconstruction ordinal
+    uint32_t xc;   // Mul, B2A: correction ordinal
+    uint64_t imm;  // constants
+};
+
+enum Gate64Op : uint32_t {
+    G64_INPUT = 0, G64_ADD, G64_SUB, G64_ADDC, G64_SUBC, G64_MULC, G64_MUL, G64_ASSERT, G64_RANDOM, G64_CONST, G64_B2A
+};
+
+struct Interp64Params {
+    uint32_t R;
+    uint64_t* wmask;
+    uint64_t* wcorr;
+    const uint64_t* masks;
+    uint64_t* on;        // [R][on_words]
+    uint64_t* pre;       // [R][pre_words]
+    uint64_t on_words, pre_words;
+    const uint64_t* wit;
+    const uint8_t* omit;      // verify: [R] omitted player of online-verified reps, 8 otherwise
+    const uint64_t* sup_in;   // verify: [n_in64][R]
+    const uint64_t* sup_corr; // verify: [n_corr64][R]
+    const uint64_t* sup_rec;  // verify: [n_rec64][R] share of the omitted player
+    // gf2 side, for B2A
+    const uint32_t* wires2;
+    const uint32_t* masks2;
+    uint32_t NQ;
+    int* err;
+};
 
 enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1 };
 
@@ -60,10 +105,22 @@ void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* 
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
                        uint8_t* d_out);
 void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t hi, const InterpParams& p);
+void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t lo, uint32_t hi, const Interp64Params& p);
+// Z64 masks: masks64[m][slot] = LE64(keystream[slot][8m..8m+8)), blocks [first, first+n_blocks) -> masks 2*first..
+void launch_aes_z64_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t n_blocks,
+                          uint64_t* d_masks64);
+// BLAKE3 of R contiguous streams of n_words u64 each -> digests[R][8]
+void launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
+                      uint32_t* d_digest);
+void launch_extract64(hipStream_t st, const uint64_t* d_stream, uint64_t stride_words, const uint64_t* d_offs /*[n_items]*/,
+                      uint64_t n_items, int add_omit, uint32_t R, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
+void launch_unpack64(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
+                     const uint8_t* d_omit, uint64_t n_items, uint32_t R, uint64_t* d_out);
 // BLAKE3 over a row-format transcript: digests[R][8] words
 void launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
                       uint32_t* d_cv_b, uint32_t* d_digest /*[R][8]*/);
 size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R);
+void b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest);
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
                  uint32_t R, uint8_t* d_h /*[R][32]*/);
 void launch_extract_bits(hipStream_t st, const uint32_t* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,

@@ -103,6 +103,17 @@ __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, 
             wd[NQ] = r ^ delta ^ (cx & cy);
             break;
         }
+        case G_RECON: {
+            // B2A's recorded reconstruction (combine.rs:181-183): value = reconstruct(mask) + corr
+            uint32_t m = wa[0];
+            if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
+            p.on[(size_t)g.eo * NQ + q] = m;
+            uint32_t r = recon32(m);
+            if (MODE == MODE_VERIFY) r &= onm;
+            wd[0] = 0;
+            wd[NQ] = r ^ wa[NQ];
+            break;
+        }
         case G_ASSERT: {
             uint32_t m = wa[0];
             if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
@@ -209,6 +220,21 @@ __global__ void k_copy_words(const uint32_t* __restrict__ in, uint32_t* __restri
     if (tid < n) out[tid] = in[tid];
 }
 
+// pairwise tree reduction of n chunk chaining values per repetition, then copy of the roots
+void b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest) {
+    while (n > 1) {
+        const uint64_t n_out = (n + 1) / 2;
+        const uint64_t threads = n_out * R;
+        hipLaunchKernelGGL(k_b3_parents, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, cur, n, R, nxt);
+        uint32_t* t = cur;
+        cur = nxt;
+        nxt = t;
+        n = n_out;
+    }
+    const uint64_t words = (uint64_t)R * 8;
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, cur, d_digest, words);
+}
+
 size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R) {
     const uint64_t n_chunks = n_events == 0 ? 1 : (n_events + 1023) / 1024;
     return (size_t)n_chunks * R * 8;  // per ping-pong buffer
@@ -223,19 +249,7 @@ void launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_event
         hipLaunchKernelGGL(k_b3_chunks, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, n_events, NQ, n,
                            d_cv_a);
     }
-    uint32_t* cur = d_cv_a;
-    uint32_t* nxt = d_cv_b;
-    while (n > 1) {
-        const uint64_t n_out = (n + 1) / 2;
-        const uint64_t threads = n_out * R;
-        hipLaunchKernelGGL(k_b3_parents, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, cur, n, R, nxt);
-        uint32_t* t = cur;
-        cur = nxt;
-        nxt = t;
-        n = n_out;
-    }
-    const uint64_t words = (uint64_t)R * 8;
-    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, cur, d_digest, words);
+    b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);
 }
 
 // Transcript::hash + CombineInstance::hash: h = B3(B3(pre2||on2) || B3(pre64||on64))

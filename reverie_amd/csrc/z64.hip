@@ -1,0 +1,257 @@
+// Z64 ring interpreter, transcript hashing and openings for gfx950.
+//
+// Replaces (all under /root/reference/src/):
+//   algebra/z64/{share,recon,domain}.rs       wrapping u64 arithmetic per (rep, player)
+//   interpreter/single.rs:25-157              Instance::step / op_mul instantiated at Z64
+//   interpreter/combine.rs:19-36,132-219      recon_gf2_to_z64 and the Z64 half of B2A
+//   transcript/{prover,verifier/*}.rs         the same transcript rules as GF(2)
+//
+// Lane mapping: one lane = one (repetition, player) slot, 8 adjacent lanes = one
+// repetition; reconstruct = 3-step shuffle-add inside the 8-lane group.  A gate occupies
+// R*8 lanes (32 wavefronts at R = 256).
+#include "b3.h"
+#include "internal.h"
+
+namespace rv {
+
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, m), hi = __shfl_xor((uint32_t)(v >> 32), m);
+    return ((uint64_t)hi << 32) | lo;
+}
+// DomainZ64::reconstruct (z64/domain.rs:53-61): wrapping sum over the 8 players
+__device__ __forceinline__ uint64_t sum8(uint64_t v) {
+    v += shfl_xor64(v, 1);
+    v += shfl_xor64(v, 2);
+    v += shfl_xor64(v, 4);
+    return v;
+}
+__device__ __forceinline__ uint32_t recon32_(uint32_t t) {
+    t ^= t >> 4;
+    t ^= t >> 2;
+    t ^= t >> 1;
+    t &= 0x01010101u;
+    return (t << 8) - t;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gates, uint32_t lo, uint32_t hi, Interp64Params p) {
+    const uint32_t S = p.R * 8;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t l = tid % S;
+    const uint32_t r = l >> 3, pl = l & 7;
+    const uint32_t worker = tid / S, n_workers = (gridDim.x * blockDim.x) / S;
+    const uint32_t om = (MODE == MODE_VERIFY) ? p.omit[r] : 8u;
+    const bool online = om < 8;  // online-verified repetition (MODE_VERIFY only)
+    for (uint32_t gi = lo + worker; gi < hi; gi += n_workers) {
+        const Gate64 g = gates[gi];
+        uint64_t* dm = p.wmask + (size_t)g.dst * S + l;
+        uint64_t* dc = p.wcorr + (size_t)g.dst * p.R + r;
+        const uint64_t* am = p.wmask + (size_t)g.a * S + l;
+        const uint64_t* ac = p.wcorr + (size_t)g.a * p.R + r;
+        const uint64_t* bm = p.wmask + (size_t)g.b * S + l;
+        const uint64_t* bc = p.wcorr + (size_t)g.b * p.R + r;
+        switch (g.op) {
+        case G64_INPUT: {
+            const uint64_t lam = p.masks[(size_t)g.m * S + l];
+            uint64_t corr;
+            if (MODE == MODE_PROVE)
+                corr = p.wit[g.x] - sum8(lam);
+            else
+                corr = online ? p.sup_in[(size_t)g.x * p.R + r] : 0;
+            *dm = lam;
+            if (pl == 0) {
+                *dc = corr;
+                p.on[(size_t)r * p.on_words + g.eo] = corr;
+            }
+            break;
+        }
+        case G64_ADD:
+            *dm = *am + *bm;
+            if (pl == 0) *dc = *ac + *bc;
+            break;
+        case G64_SUB:
+            *dm = *am - *bm;
+            if (pl == 0) *dc = *ac - *bc;
+            break;
+        case G64_ADDC:
+            *dm = *am;
+            if (pl == 0) *dc = *ac + g.imm;
+            break;
+        case G64_SUBC:
+            *dm = *am;
+            if (pl == 0) *dc = *ac - g.imm;
+            break;
+        case G64_MULC:
+            *dm = *am * g.imm;
+            if (pl == 0) *dc = *ac * g.imm;
+            break;
+        case G64_CONST:
+            *dm = 0;
+            if (pl == 0) *dc = g.imm;
+            break;
+        case G64_RANDOM:
+            *dm = p.masks[(size_t)g.m * S + l];
+            if (pl == 0) *dc = 0;
+            break;
+        case G64_MUL: {
+            const uint64_t lx = *am, cx = *ac, ly = *bm, cy = *bc;
+            const uint64_t lab = p.masks[(size_t)g.m * S + l], lnew = p.masks[(size_t)(g.m + 1) * S + l];
+            const uint64_t a = sum8(lx), b = sum8(ly), c = sum8(lab);
+            uint64_t delta = a * b - c;
+            uint64_t s = ly * cx + lx * cy + lab - lnew;
+            if (MODE == MODE_VERIFY && online) {
+                delta = p.sup_corr[(size_t)g.xc * p.R + r];
+                if (pl == om) s += p.sup_rec[(size_t)g.x * p.R + r];
+            }
+            p.on[(size_t)r * p.on_words + g.eo + pl] = s;
+            uint64_t rec = sum8(s);
+            if (MODE == MODE_VERIFY && !online) rec = 0;
+            *dm = lnew;
+            if (pl == 0) {
+                p.pre[(size_t)r * p.pre_words + g.ep] = delta;
+                *dc = rec + delta + cx * cy;
+            }
+            break;
+        }
+        case G64_ASSERT: {
+            uint64_t m = *am;
+            if (MODE == MODE_VERIFY && online && pl == om) m += p.sup_rec[(size_t)g.x * p.R + r];
+            p.on[(size_t)r * p.on_words + g.eo + pl] = m;
+            if (MODE == MODE_PROVE) {
+                if (sum8(m) + *ac != 0 && pl == 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+            }
+            break;
+        }
+        case G64_B2A: {
+            // random 64-bit value shared bitwise in GF(2): bit k = recon(fresh gf2 mask m2+k)
+            const uint32_t qw = r >> 2, sh = 24 - 8 * (r & 3);
+            uint64_t zval = 0, zrec = 0;
+            for (int k = 0; k < 64; k++) {
+                const uint32_t w = recon32_(p.masks2[(size_t)(g.m2 + k) * p.NQ + qw]);
+                zval |= (uint64_t)((w >> sh) & 1u) << k;
+                const uint32_t v = p.wires2[((size_t)(g.a + k) * 2 + 1) * p.NQ + qw];  // revealed sum bit k
+                zrec |= (uint64_t)((v >> sh) & 1u) << k;
+            }
+            const uint64_t mu = p.masks[(size_t)g.m * S + l];
+            uint64_t kappa = zval - sum8(mu);
+            if (MODE == MODE_VERIFY && online) kappa = p.sup_corr[(size_t)g.xc * p.R + r];
+            *dm = 0 - mu;
+            if (pl == 0) {
+                p.pre[(size_t)r * p.pre_words + g.ep] = kappa;
+                *dc = zrec - kappa;
+            }
+            break;
+        }
+        default:
+            break;
+        }
+    }
+}
+
+void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t lo, uint32_t hi, const Interp64Params& p) {
+    if (hi <= lo) return;
+    const uint64_t S = (uint64_t)p.R * 8;
+    const uint64_t want = (uint64_t)(hi - lo) * S;
+    uint64_t blocks = (want + 255) / 256;
+    const uint64_t cap = ((uint64_t)8192 * 256 / S) * S / 256;  // whole workers only
+    if (blocks > cap) blocks = cap;
+    if (mode == MODE_PROVE)
+        hipLaunchKernelGGL(k_interp64<MODE_PROVE>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, hi, p);
+    else
+        hipLaunchKernelGGL(k_interp64<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, hi, p);
+}
+
+// ---- BLAKE3 over R contiguous little-endian streams: thread = (rep, chunk) ----
+__global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __restrict__ streams, uint64_t n_bytes, uint32_t R,
+                                                          uint64_t n_chunks, uint32_t* __restrict__ cvs) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t c = tid / R;
+    const uint32_t r = (uint32_t)(tid % R);
+    if (c >= n_chunks) return;
+    const uint64_t b0 = c * 1024;
+    const uint64_t len = (n_bytes - b0 < 1024) ? (n_bytes - b0) : 1024;  // multiple of 8
+    const uint32_t nblk = len == 0 ? 1 : (uint32_t)((len + 63) / 64);
+    const uint32_t* src = streams + ((size_t)r * n_bytes + b0) / 4;
+    uint32_t cv[8];
+    b3::iv(cv);
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
+        uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
+        if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
+        uint32_t m[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = (4u * k < blen) ? src[16 * b + k] : 0u;
+        uint32_t o[8];
+        b3::compress<false>(cv, m, c, blen, flags, o);
+#pragma unroll
+        for (int k = 0; k < 8; k++) cv[k] = o[k];
+    }
+    uint32_t* dst = cvs + ((size_t)c * R + r) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[k] = cv[k];
+}
+
+void launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
+                      uint32_t* d_digest) {
+    const uint64_t n_bytes = n_words * 8;
+    uint64_t n = n_bytes == 0 ? 1 : (n_bytes + 1023) / 1024;
+    {
+        const uint64_t threads = n * R;
+        hipLaunchKernelGGL(k_b3_chunks_contig, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                           (const uint32_t*)d_streams, n_bytes, R, n, d_cv_a);
+    }
+    b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);
+}
+
+// ---- openings: 8 bytes LE per item (z64/share.rs:36-49, z64/recon.rs:45-66) ----
+__global__ void k_extract64(const uint64_t* __restrict__ stream, uint64_t stride_words, const uint64_t* __restrict__ offs,
+                            uint64_t n_items, int add_omit, uint32_t R, const uint8_t* __restrict__ omit,
+                            const uint64_t* __restrict__ dst_off, uint8_t* __restrict__ out) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t it = tid % n_items;
+    const uint32_t r = (uint32_t)(tid / n_items);
+    if (r >= R) return;
+    const uint32_t om = omit[r];
+    if (om >= 8) return;
+    const uint64_t off = (offs ? offs[it] : it) + (add_omit ? om : 0);
+    const uint64_t v = stream[(size_t)r * stride_words + off];
+    uint8_t* d = out + dst_off[r] + 8 * it;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = (uint8_t)(v >> (8 * i));
+}
+
+void launch_extract64(hipStream_t st, const uint64_t* d_stream, uint64_t stride_words, const uint64_t* d_offs, uint64_t n_items,
+                      int add_omit, uint32_t R, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out) {
+    if (!n_items) return;
+    const uint64_t threads = n_items * R;
+    hipLaunchKernelGGL(k_extract64, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, stride_words, d_offs,
+                       n_items, add_omit, R, d_omit, d_dst_off, d_out);
+}
+
+// verifier: proof vectors -> dense [item][R] u64; items past a vector's end read as zero
+// (z64/recon.rs:96-104, z64/share.rs:78-88 `unwrap_or([0u8; 8])`)
+__global__ void k_unpack64(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off,
+                           const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t R,
+                           uint64_t* __restrict__ out) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t it = tid / R;
+    const uint32_t r = (uint32_t)(tid % R);
+    if (it >= n_items) return;
+    uint64_t v = 0;
+    if (omit[r] < 8 && (it + 1) * 8 <= src_len[r]) {
+        const uint8_t* s = blob + src_off[r] + 8 * it;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v |= (uint64_t)s[i] << (8 * i);
+    }
+    out[it * R + r] = v;
+}
+
+void launch_unpack64(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
+                     const uint8_t* d_omit, uint64_t n_items, uint32_t R, uint64_t* d_out) {
+    if (!n_items) return;
+    const uint64_t threads = n_items * R;
+    hipLaunchKernelGGL(k_unpack64, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_blob, d_src_off, d_src_len, d_omit,
+                       n_items, R, d_out);
+}
+
+}  // namespace rv

@@ -3,7 +3,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from reverie_amd.ops import (DOM_GF2, GF2, OP_ADD, OP_ADDCONST, OP_ASSERTZERO, OP_DTYPE, OP_INPUT, OP_MUL, program)
+from reverie_amd.ops import (B2A, DOM_GF2, DOM_Z64, GF2, OP_ADD, OP_ADDCONST, OP_ASSERTZERO, OP_DTYPE, OP_INPUT, OP_MUL,
+                             OP_SUBCONST, SizeHint, Z64, program)
 
 M64 = (1 << 64) - 1
 
@@ -150,3 +151,104 @@ def random_gf2(rng: np.random.Generator, n_in=12, n_gates=300, n_wires=40, p_ass
         val[d] = nv
         defined[d] = True
     return program(ops), wit, (0, n_wires)
+
+
+def layered_z64(n_in=1024, width=16384, n_mul=1_000_000, seed=0x5EED000000000005, fold_to=16):
+    """Config 5: layered Z64 circuit, Mul/Add with p=1/2 until n_mul Mul gates, operands
+    uniform over the previous layer, tail SubConst(clear value) + AssertZero on `fold_to` wires."""
+    rng = SplitMix64(seed)
+    wit = [rng.next() for _ in range(n_in)]
+    vals = np.array(wit, dtype=np.uint64)
+    ops = [Z64.Input(i) for i in range(n_in)]
+    prev_base, prev_n = 0, n_in
+    pos = n_in
+    muls = 0
+    gates = 0
+    with np.errstate(over="ignore"):
+        while muls < n_mul:
+            r = _splitmix_array(rng.next(), 3 * width).reshape(width, 3)
+            is_mul = (r[:, 0] & np.uint64(1)).astype(bool)
+            a = (r[:, 1] % np.uint64(prev_n)).astype(np.int64)
+            b = (r[:, 2] % np.uint64(prev_n)).astype(np.int64)
+            left = n_mul - muls
+            cs = np.cumsum(is_mul)
+            w = width if cs[-1] <= left else int(np.searchsorted(cs, left) + 1)
+            for g in range(w):
+                ops.append(Z64.Mul(pos + g, prev_base + int(a[g]), prev_base + int(b[g])) if is_mul[g]
+                           else Z64.Add(pos + g, prev_base + int(a[g]), prev_base + int(b[g])))
+            va, vb = vals[a[:w]], vals[b[:w]]
+            vals = np.where(is_mul[:w], va * vb, va + vb)
+            muls += int(is_mul[:w].sum())
+            gates += w
+            prev_base, prev_n = pos, w
+            pos += w
+    k = min(fold_to, prev_n)
+    for i in range(k):
+        ops.append(Z64.SubConst(pos, prev_base + i, int(vals[i])))
+        ops.append(Z64.AssertZero(pos))
+        pos += 1
+    return program(ops), wit, (pos, 0), {"gates": gates, "mul": muls, "inputs": n_in}
+
+
+def random_mixed(rng: np.random.Generator, n_gates=200):
+    """Random program over both domains with B2A bridges and a SizeHint; asserts only on
+    wires whose clear value is known (values depending on Random gates are never asserted)."""
+    n2, n64 = 90, 12
+    ops = [SizeHint(n64, n2)]
+    w2 = rng.integers(0, 2, 10).tolist()
+    w64 = [int(x) for x in rng.integers(0, 1 << 63, 4, dtype=np.uint64)]
+    v2 = [0] * n2
+    v64 = [0] * n64
+    for i in range(10):
+        ops.append(GF2.Input(i)); v2[i] = w2[i]
+    for i in range(4):
+        ops.append(Z64.Input(i)); v64[i] = w64[i]
+    for _ in range(n_gates):
+        kind = rng.choice(["mul2", "add2", "addc2", "mul64", "add64", "sub64", "mulc64", "addc64", "b2a", "assert2", "assert64",
+                           "rand2", "rand64", "const64"], p=[0.2, 0.15, 0.05, 0.12, 0.08, 0.05, 0.05, 0.05, 0.05, 0.06, 0.06, 0.03, 0.02, 0.03])
+        if kind.endswith("2"):
+            d, a, b = (int(x) for x in rng.integers(0, 16, 3))
+            if kind == "mul2":
+                ops.append(GF2.Mul(d, a, b)); v2[d] = None if v2[a] is None or v2[b] is None else v2[a] & v2[b]
+            elif kind == "add2":
+                ops.append(GF2.Add(d, a, b)); v2[d] = None if v2[a] is None or v2[b] is None else v2[a] ^ v2[b]
+            elif kind == "addc2":
+                ops.append(GF2.AddConst(d, a, 1)); v2[d] = None if v2[a] is None else v2[a] ^ 1
+            elif kind == "rand2":
+                ops.append(GF2.Random(d)); v2[d] = None
+            elif kind == "assert2" and v2[a] is not None:
+                ops.append(GF2.AddConst(80, a, v2[a])); ops.append(GF2.AssertZero(80)); v2[80] = 0
+        else:
+            d, a, b = (int(x) for x in rng.integers(0, n64, 3))
+            c = int(rng.integers(0, 1 << 63, dtype=np.uint64)) * 2 + 1
+            if kind == "mul64":
+                ops.append(Z64.Mul(d, a, b)); v64[d] = None if v64[a] is None or v64[b] is None else (v64[a] * v64[b]) & M64
+            elif kind == "add64":
+                ops.append(Z64.Add(d, a, b)); v64[d] = None if v64[a] is None or v64[b] is None else (v64[a] + v64[b]) & M64
+            elif kind == "sub64":
+                ops.append(Z64.Sub(d, a, b)); v64[d] = None if v64[a] is None or v64[b] is None else (v64[a] - v64[b]) & M64
+            elif kind == "mulc64":
+                ops.append(Z64.MulConst(d, a, c)); v64[d] = None if v64[a] is None else (v64[a] * c) & M64
+            elif kind == "addc64":
+                ops.append(Z64.AddConst(d, a, c)); v64[d] = None if v64[a] is None else (v64[a] + c) & M64
+            elif kind == "const64":
+                ops.append(Z64.Const(d, c)); v64[d] = c
+            elif kind == "rand64":
+                ops.append(Z64.Random(d)); v64[d] = None
+            elif kind == "assert64" and v64[a] is not None:
+                ops.append(Z64.SubConst(n64 - 1, a, v64[a])); ops.append(Z64.AssertZero(n64 - 1)); v64[n64 - 1] = 0
+            elif kind == "b2a":
+                # bits = gf2 wires 16..79: fill them from known wires, then convert
+                val = 0
+                ok = True
+                for k in range(64):
+                    srcw = int(rng.integers(0, 16))
+                    ops.append(GF2.AddConst(16 + k, srcw, int(rng.integers(0, 2))))
+                    bit = None if v2[srcw] is None else v2[srcw] ^ (ops[-1][6] & 1)
+                    v2[16 + k] = bit
+                    if bit is None:
+                        ok = False
+                    else:
+                        val |= bit << k
+                ops.append(B2A(d, 16)); v64[d] = val if ok else None
+    return program(ops), w2, w64, (1, 1)

@@ -14,7 +14,7 @@ from reverie_amd.ops import GF2, OP_DTYPE, program
 pytestmark = pytest.mark.gpu
 
 META = json.load(open(os.path.join(GOLDEN, "proofs.json")))
-GF2_ONLY = ["empty", "gf2_mix", "adder64"]
+ALL_GOLDEN = sorted(META)
 
 
 @pytest.fixture(scope="module")
@@ -86,6 +86,30 @@ def test_sharegen_gf2(rv, oracle):
         assert (out == oracle.sharegen_gf2(keys, omit, n)).all()
 
 
+def test_sharegen_z64(rv, oracle):
+    """bitsliced AES + bit-plane transpose == ShareGen<Z64>::next()"""
+    import hashlib
+
+    from reverie_amd import _lib
+
+    sg = json.load(open(os.path.join(GOLDEN, "sharegen.json")))
+    keys = np.array([[list(bytes.fromhex(k)) for k in row] for row in sg["keys"]], np.uint8)
+    for case in sg["cases"]:
+        out = np.zeros((sg["n"], 8, 8), np.uint64)
+        omit = np.array(case["omit"], np.uint32)
+        _lib.check(_lib.lib().rv_hook_sharegen_z64(rv.Context.default().handle, _p(keys), _p(omit), C.c_size_t(sg["n"]), _p(out)))
+        zs = [["%016x" % int(v) for v in row.reshape(-1)] for row in out]
+        assert zs[:4] == case["z64_first4"] and zs[-1] == case["z64_last"]
+        assert hashlib.sha256(json.dumps(zs).encode()).hexdigest() == case["z64_sha256_json"]
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 3, 1001):
+        keys = rng.integers(0, 256, (8, 8, 16), dtype=np.uint8)
+        omit = rng.integers(0, 9, 8).astype(np.uint32)
+        out = np.zeros((n, 8, 8), np.uint64)
+        _lib.check(_lib.lib().rv_hook_sharegen_z64(rv.Context.default().handle, _p(keys), _p(omit), C.c_size_t(n), _p(out)))
+        assert (out == oracle.sharegen_z64(keys, omit, n)).all()
+
+
 def test_blake3_streams(rv, oracle):
     from reverie_amd import _lib
 
@@ -112,7 +136,7 @@ def test_blake3_streams(rv, oracle):
 
 
 # ---------------------------------------------------------------- whole proofs
-@pytest.mark.parametrize("name", GF2_ONLY)
+@pytest.mark.parametrize("name", ALL_GOLDEN)
 def test_golden_proofs(rv, oracle, rule_seeds, name):
     m, prog, w2, w64, wc, gold = load_case(name)
     proof = rv.Proof.new(prog, w2, w64, wc, seeds=rule_seeds)
@@ -140,6 +164,40 @@ def test_random_programs_vs_oracle(rv, oracle, seed):
     proof = rv.Proof.new(prog, wit, [], wc, seeds=seeds)
     assert bytes(proof) == want
     assert proof.verify(prog, wc) and oracle.verify(prog, wc, bytes(proof))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_mixed_programs_vs_oracle(rv, oracle, seed):
+    """GF(2) + Z64 + B2A + SizeHint, random, every op kind"""
+    rng = np.random.default_rng(500 + seed)
+    prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=int(rng.integers(20, 400)))
+    seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+    want = oracle.prove(prog, w2, w64, wc, seeds)
+    proof = rv.Proof.new(prog, w2, w64, wc, seeds=seeds)
+    assert bytes(proof) == want
+    assert proof.verify(prog, wc) and oracle.verify(prog, wc, bytes(proof))
+    bad = bytearray(want)
+    bad[len(bad) - 216 * 48 - 100] ^= 4  # inside the z64 online openings
+    try:
+        w = oracle.verify(prog, wc, bytes(bad))
+    except oracle.OracleError:
+        w = None
+    try:
+        g = rv.Proof(bytes(bad)).verify(prog, wc)
+    except rv.ReverieError:
+        g = None
+    assert g == w
+
+
+def test_z64_layered_vs_oracle(rv, oracle, rule_seeds):
+    """config-5 generator (Z64 Mul/Add layers) at a size the oracle finishes in seconds"""
+    prog, wit, wc, st = circuits.layered_z64(n_in=64, width=256, n_mul=1500)
+    want = oracle.prove(prog, [], wit, wc, rule_seeds)
+    c = rv.Circuit(prog, wc)
+    proof = rv.Proof.new(c, [], wit, seeds=rule_seeds)
+    assert bytes(proof) == want
+    assert proof.verify(c)
+    assert c.info["z64_muls"] == st["mul"]
 
 
 def test_layered_circuit_vs_oracle(rv, oracle, rule_seeds):
