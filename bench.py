@@ -137,8 +137,10 @@ def main():
         n_masks, n_ssa = info["gf2_masks"], None
         alg = {
             "masks": n_masks * row,  # writes every mask row once
-            "interp": (st["and"] * (32 + 6 * row + 2 * row) + st["xor"] * (32 + 6 * row)),
-            "hash": (info["gf2_muls"] * 2 + info["gf2_inputs"] + info["gf2_asserts"]) * row,
+            # AND: 48 B gate + 4 share rows in + 2 corr-bit rows in + 1 out + online row + pre bits
+            # XOR: 48 B gate + 2 share rows in + 1 out + 3 corr-bit rows
+            "interp": (st["and"] * (48 + 4 * row + 3 * row // 8 + row + row // 8) + st["xor"] * (48 + 3 * row + 3 * row // 8)),
+            "hash": (info["gf2_muls"] + info["gf2_inputs"] + info["gf2_asserts"]) * row + info["gf2_muls"] * row // 8,
         }
         kname = {"masks": "k_aes_gf2_masks", "interp": "k_interp (sum over levels)", "hash": "k_b3_chunks+k_b3_parents"}[dom]
         ach = alg[dom] / (phases[dom] * 1e-3) / 1e9 if phases[dom] > 0 else 0.0

@@ -230,11 +230,10 @@ struct rv_circuit {
 
 static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
     const size_t NQ = R / 4;
-    const size_t mask_rows = ((cc.n_masks + 127) / 128) * 128;
     size_t b = 0;
-    b += mask_rows * NQ * 4;
-    b += cc.n_ssa * 2 * NQ * 4;
-    b += (cc.n_on + cc.n_pre) * NQ * 4;
+    b += cc.n_rows * NQ * 4;
+    b += cc.n_ssa * (NQ / 2);
+    b += cc.n_on * NQ * 4 + cc.n_pre * (NQ / 2);
     b += 4 * b3_stream_scratch_words(std::max(cc.n_on, cc.n_pre), R) * 4;
     b += (size_t)R * (16 + 128 + 8 * 176) + 11 * 128 * NQ * 4;
     // Z64: masks, wires, contiguous transcripts
@@ -342,10 +341,10 @@ struct rv_shard {
     uint8_t* d_keys = nullptr;
     uint8_t* d_rkbytes = nullptr;
     uint32_t* d_rk = nullptr;
-    uint32_t* d_masks = nullptr;
-    uint32_t* d_wires = nullptr;
+    uint32_t* d_masks = nullptr;  // share rows: PRG masks, then computed rows
+    uint8_t* d_wires = nullptr;   // corr bits [n_ssa][NQ/2]
     uint32_t* d_on = nullptr;
-    uint32_t* d_pre = nullptr;
+    uint8_t* d_pre = nullptr;     // [n_pre][NQ/2]
     uint8_t* d_wit = nullptr;
     // Z64 domain
     uint64_t* d_masks64 = nullptr;
@@ -397,8 +396,8 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
     }
     if ((rc = dalloc(ctx, (size_t)s->R * 8 * 176, &s->d_rkbytes))) return rc;
     if ((rc = dalloc(ctx, (size_t)11 * 128 * s->NQ, &s->d_rk))) return rc;
-    const uint64_t n_blocks = (cc.n_masks + 127) / 128;
-    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(n_blocks, 1) * 128 * s->NQ, &s->d_masks))) return rc;
+    const uint64_t n_blocks = cc.n_masks_pad / 128;
+    if ((rc = dalloc(ctx, (size_t)cc.n_rows * s->NQ, &s->d_masks))) return rc;
     launch_key_schedule(ctx->stream, s->d_keys, s->R * 8, s->d_rkbytes);
     launch_bitslice_rk(ctx->stream, s->d_rkbytes, s->NQ, s->d_rk);
     ctx->count(2);
@@ -424,9 +423,9 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     int rc;
-    if ((rc = dalloc(ctx, (size_t)cc.n_ssa * 2 * s->NQ, &s->d_wires))) return rc;
+    if ((rc = dalloc(ctx, (size_t)cc.n_ssa * (s->NQ / 2), &s->d_wires))) return rc;
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_on, 1) * s->NQ, &s->d_on))) return rc;
-    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * s->NQ, &s->d_pre))) return rc;
+    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * (s->NQ / 2), &s->d_pre))) return rc;
     if ((rc = dalloc(ctx, 1, &s->d_err))) return rc;
     const size_t cvw = b3_stream_scratch_words(std::max({cc.n_on, cc.n_pre, cc.on_words64 * 8, cc.pre_words64 * 8}), s->R);
     if ((rc = dalloc(ctx, cvw, &s->d_cv[0])) || (rc = dalloc(ctx, cvw, &s->d_cv[1]))) return rc;
@@ -442,10 +441,11 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
         HIPCHK(hipMemsetAsync(s->d_wcorr64, 0, (size_t)s->R * 8, ctx->stream));
     }
     HIPCHK(hipMemsetAsync(s->d_err, 0, sizeof(int), ctx->stream));
-    HIPCHK(hipMemsetAsync(s->d_wires, 0, (size_t)2 * s->NQ * 4, ctx->stream));  // SSA 0 = default wire
+    HIPCHK(hipMemsetAsync(s->d_wires, 0, (size_t)(s->NQ / 2), ctx->stream));  // SSA 0 = default wire
+    HIPCHK(hipMemsetAsync(s->d_masks + (size_t)cc.n_masks_pad * s->NQ, 0, (size_t)s->NQ * 4, ctx->stream));  // zero row
     p.NQ = s->NQ;
-    p.wires = s->d_wires;
-    p.masks = s->d_masks;
+    p.rows = s->d_masks;
+    p.corr = s->d_wires;
     p.on = s->d_on;
     p.pre = s->d_pre;
     p.err = s->d_err;
@@ -458,14 +458,15 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
     p64.pre = s->d_pre64;
     p64.on_words = cc.on_words64;
     p64.pre_words = cc.pre_words64;
-    p64.wires2 = s->d_wires;
+    p64.corr2 = s->d_wires;
     p64.masks2 = s->d_masks;
     p64.NQ = s->NQ;
     p64.err = s->d_err;
     ctx->phase(RV_PH_INTERP);
     for (size_t l = 0; l < n_levels; l++) {
         if (cc.level_start[l + 1] > cc.level_start[l]) {
-            launch_interp(ctx->stream, mode, s->c->d_gates, cc.level_start[l], cc.level_start[l + 1], p);
+            launch_interp(ctx->stream, mode, s->c->d_gates, cc.level_start[l], cc.level_mul_end[l], cc.level_xor_end[l],
+                          cc.level_start[l + 1], p);
             ctx->count();
         }
         if (has64 && cc.level_start64[l + 1] > cc.level_start64[l]) {
@@ -476,7 +477,7 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
     ctx->phase(RV_PH_HASH);
     uint32_t* dig = s->d_dig;
     const size_t DW = (size_t)s->R * 8;
-    launch_b3_stream(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
+    launch_b3_stream_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
     launch_b3_stream(ctx->stream, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 1 * DW);
     // Z64 transcripts (for a pure GF(2) circuit: BLAKE3 of the empty string)
     launch_b3_contig(ctx->stream, s->d_pre64, cc.pre_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 2 * DW);
@@ -682,7 +683,7 @@ static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void*
                         s->d_offs + s->R, L.l2r, L.l2c, L.l2i, L.l64r, L.l64c, L.l64i, d_out);
     if (L.n_on) {
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
-        launch_extract_bits(ctx->stream, s->d_pre, nullptr, cc.n_pre, s->NQ, 1, s->d_omit, s->d_offs + 3 * s->R, d_out);
+        launch_extract_bits(ctx->stream, s->d_pre, nullptr, cc.n_pre, s->NQ, 2, s->d_omit, s->d_offs + 3 * s->R, d_out);
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
         launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_rec_offs64, cc.n_rec64, 1, s->R, s->d_omit,
                          s->d_offs + 5 * s->R, d_out);

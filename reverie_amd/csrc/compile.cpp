@@ -14,7 +14,9 @@ struct Builder {
     std::vector<Gate> gates;      // program order
     std::vector<uint32_t> level;  // per gate
     std::vector<int32_t> ssa_level;
-    std::vector<uint32_t> cur;  // gf2 wire index -> current SSA id
+    std::vector<uint32_t> ssa_row;  // share row of each SSA wire: PRG mask index, or COMP | computed-row index
+    uint32_t n_comp = 1;            // computed rows; 0 = the all-zero row
+    std::vector<uint32_t> cur;      // gf2 wire index -> current SSA id
     // Z64
     std::vector<Gate64> gates64;
     std::vector<uint32_t> level64;
@@ -23,13 +25,16 @@ struct Builder {
     uint32_t max_level = 0;
     bool any = false;
 
+    static constexpr uint32_t COMP = 0x80000000u;
     explicit Builder(Compiled& o) : out(o) {
         ssa_level.push_back(-1);
+        ssa_row.push_back(COMP | 0);
         ssa_level64.push_back(-1);
     }
 
-    uint32_t new_ssa(int32_t lvl) {
+    uint32_t new_ssa(int32_t lvl, uint32_t row) {
         ssa_level.push_back(lvl);
+        ssa_row.push_back(row);
         return (uint32_t)(ssa_level.size() - 1);
     }
     uint32_t new_ssa64(int32_t lvl) {
@@ -57,8 +62,11 @@ struct Builder {
         g.op = G_XOR;
         g.a = a;
         g.b = b;
+        g.am = ssa_row[a];
+        g.bm = ssa_row[b];
+        g.dm = COMP | n_comp++;
         const int32_t lvl = std::max(ssa_level[a], ssa_level[b]) + 1;
-        g.dst = new_ssa(lvl);
+        g.dst = new_ssa(lvl, g.dm);
         emit(g, (uint32_t)lvl);
         out.info.gf2_linear++;
         return g.dst;
@@ -68,6 +76,8 @@ struct Builder {
         g.op = G_MUL;
         g.a = a;
         g.b = b;
+        g.am = ssa_row[a];
+        g.bm = ssa_row[b];
         g.m = (uint32_t)out.n_masks;
         out.n_masks += 2;
         g.eo = (uint32_t)out.n_on++;
@@ -75,7 +85,7 @@ struct Builder {
         g.x = (uint32_t)out.n_rec++;
         out.rec_rows.push_back(g.eo);
         const int32_t lvl = std::max(ssa_level[a], ssa_level[b]) + 1;
-        g.dst = new_ssa(lvl);
+        g.dst = new_ssa(lvl, g.m + 1);  // the output's mask IS the fresh mask lambda_new
         emit(g, (uint32_t)lvl);
         out.info.gf2_muls++;
         return g.dst;
@@ -84,7 +94,7 @@ struct Builder {
         Gate g{};
         g.op = G_RANDOM;
         g.m = (uint32_t)out.n_masks++;
-        g.dst = new_ssa(0);
+        g.dst = new_ssa(0, g.m);
         emit(g, 0);
         out.info.gf2_linear++;
         return g.dst;
@@ -133,7 +143,7 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 g.eo = (uint32_t)out.n_on++;
                 g.x = (uint32_t)out.n_in++;
                 out.in_rows.push_back(g.eo);
-                g.dst = b.new_ssa(0);
+                g.dst = b.new_ssa(0, g.m);
                 b.cur[op.dst] = g.dst;
                 b.emit(g, 0);
                 info.gf2_inputs++;
@@ -146,7 +156,7 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 if (op.dst >= nw) return RV_E_WIRE_OOB;
                 g.op = G_CONST;
                 g.x = cbit;
-                g.dst = b.new_ssa(0);
+                g.dst = b.new_ssa(0, Builder::COMP | 0);
                 b.cur[op.dst] = g.dst;
                 b.emit(g, 0);
                 info.gf2_linear++;
@@ -167,8 +177,10 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 g.a = b.cur[op.a];
                 g.op = (op.opcode == RV_OP_MULCONST) ? G_ANDC : G_XORC;
                 g.x = cbit;
+                g.am = b.ssa_row[g.a];
                 const int32_t lvl = b.ssa_level[g.a] + 1;
-                g.dst = b.new_ssa(lvl);
+                // the mask is unchanged (AddConst, MulConst 1) or zero (MulConst 0): alias, no copy
+                g.dst = b.new_ssa(lvl, (g.op == G_ANDC && !cbit) ? (Builder::COMP | 0) : g.am);
                 b.cur[op.dst] = g.dst;
                 b.emit(g, (uint32_t)lvl);
                 info.gf2_linear++;
@@ -178,6 +190,7 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 if (op.a >= nw) return RV_E_WIRE_OOB;
                 g.op = G_ASSERT;
                 g.a = b.cur[op.a];
+                g.am = b.ssa_row[g.a];
                 g.eo = (uint32_t)out.n_on++;
                 g.x = (uint32_t)out.n_rec++;
                 out.rec_rows.push_back(g.eo);
@@ -320,11 +333,12 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 Gate r{};
                 r.op = G_RECON;
                 r.a = res[k];
+                r.am = b.ssa_row[r.a];
                 r.eo = (uint32_t)out.n_on++;
                 r.x = (uint32_t)out.n_rec++;
                 out.rec_rows.push_back(r.eo);
                 const int32_t lvl = b.ssa_level[r.a] + 1;
-                r.dst = b.new_ssa(lvl);
+                r.dst = b.new_ssa(lvl, Builder::COMP | 0);
                 if (k == 0) first_out = r.dst;
                 b.emit(r, (uint32_t)lvl);
                 lvl_max = std::max(lvl_max, lvl);
@@ -349,8 +363,40 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
     const uint32_t n_levels = b.any ? b.max_level + 1 : 0;
     sort_by_level(b.gates, b.level, n_levels, out.gates, out.level_start);
     sort_by_level(b.gates64, b.level64, n_levels, out.gates64, out.level_start64);
+    // group each level by kind (gates of one level are independent, so any order is valid):
+    // G_MUL first, then G_XOR, then everything else — lets the kernel run tight per-kind loops
+    out.level_mul_end.assign(n_levels, 0);
+    out.level_xor_end.assign(n_levels, 0);
+    {
+        std::vector<Gate> tmp;
+        for (uint32_t l = 0; l < n_levels; l++) {
+            const uint32_t lo = out.level_start[l], hi = out.level_start[l + 1];
+            tmp.assign(out.gates.begin() + lo, out.gates.begin() + hi);
+            uint32_t w = lo;
+            for (const Gate& g : tmp)
+                if (g.op == G_MUL) out.gates[w++] = g;
+            out.level_mul_end[l] = w;
+            for (const Gate& g : tmp)
+                if (g.op == G_XOR) out.gates[w++] = g;
+            out.level_xor_end[l] = w;
+            for (const Gate& g : tmp)
+                if (g.op != G_MUL && g.op != G_XOR) out.gates[w++] = g;
+        }
+    }
     out.n_ssa = b.ssa_level.size();
     out.n_ssa64 = b.ssa_level64.size();
+    // resolve share rows: PRG masks first (padded to whole AES blocks), computed rows after
+    out.n_masks_pad = (out.n_masks + 127) / 128 * 128;
+    out.n_rows = out.n_masks_pad + b.n_comp;
+    if (out.n_rows > LIM) return RV_E_UNSUPPORTED;
+    auto fix = [&](uint32_t& r) {
+        if (r & Builder::COMP) r = (uint32_t)(out.n_masks_pad + (r & ~Builder::COMP));
+    };
+    for (Gate& g : out.gates) {
+        fix(g.dm);
+        fix(g.am);
+        fix(g.bm);
+    }
     info.gf2_masks = out.n_masks;
     info.z64_masks = out.n_masks64;
     info.levels = n_levels;

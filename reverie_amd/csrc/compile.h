@@ -23,9 +23,13 @@ namespace rv {
 struct Compiled {
     std::vector<Gate> gates;            // sorted by level, program order inside a level
     std::vector<uint32_t> level_start;  // gates of level l = [level_start[l], level_start[l+1])
+    // inside a level gates are grouped by kind: [start, mul_end) G_MUL, [mul_end, xor_end) G_XOR, rest
+    std::vector<uint32_t> level_mul_end, level_xor_end;
     std::vector<uint32_t> rec_rows;     // reconstruction ordinal -> online transcript row
     std::vector<uint32_t> in_rows;      // input ordinal -> online transcript row
     uint64_t n_ssa = 1;                 // SSA wires incl. the zero wire
+    uint64_t n_masks_pad = 0;           // PRG mask rows, padded to whole AES blocks (128)
+    uint64_t n_rows = 1;                // share rows: n_masks_pad + computed rows (first computed = zero row)
     uint64_t n_masks = 0, n_on = 0, n_pre = 0, n_in = 0, n_rec = 0;
     // Z64 domain (gates64 share the level numbering: level l = [level_start64[l], level_start64[l+1]))
     std::vector<Gate64> gates64;

@@ -16,21 +16,31 @@ namespace rv {
 // (src/algebra/gf2/share.rs:13-24: bit 63 - (8*rep + player)).
 // A "row" is NQ = R/4 consecutive quad words = one value for every repetition of the
 // shard; with R = 256 a row is 256 bytes = one wavefront-wide coalesced access.
-//   masks  [n_masks][NQ]        fresh PRG masks, index = ShareGen::next() call number
-//   wires  [n_ssa][2][NQ]       {mask row, corr row}; corr is one byte per rep 0x00/0xFF
-//                               (src/algebra/gf2/recon.rs:13-25)
+//   rows   [n_rows][NQ]         share rows.  Rows [0, n_masks_pad) are the fresh PRG masks
+//                               (index = ShareGen::next() call number, written by the AES
+//                               kernel); the rest are computed wire masks (XOR outputs) with
+//                               row n_masks_pad = the all-zero row.  A wire whose mask IS a
+//                               PRG mask (Input/Random/Mul outputs) or equals another wire's
+//                               (AddConst, MulConst) just points at that row: nothing is copied.
+//   corr   [n_ssa][NQ/2] bytes  wire corrections, ONE BIT per repetition (the reference keeps a
+//                               0x00/0xFF byte, src/algebra/gf2/recon.rs:13-25): quad q owns
+//                               nibble q&1 of byte q/2, nibble bit k <-> repetition 4q + 3 - k
 //   on     [n_on_events][NQ]    online transcript: one byte per rep per event
-//   pre    [n_pre_events][NQ]   preprocessing transcript (corrections), 0x00/0xFF bytes
+//   pre    [n_pre_events][NQ/2] preprocessing transcript (corrections), one bit per rep, same
+//                               nibble layout; expanded to 0x00/0xFF bytes when hashed
 
 // compiled gate (device + host)
 struct Gate {
-    uint32_t op;   // GateOp
-    uint32_t dst;  // SSA wire id written
-    uint32_t a, b; // SSA wire ids read
-    uint32_t m;    // first PRG mask index consumed (Input/Random: 1 mask, Mul: 2)
-    uint32_t eo;   // row in the online transcript (Input, Mul, AssertZero)
-    uint32_t ep;   // row in the preprocessing transcript (Mul)
-    uint32_t x;    // Input: witness index; Mul/AssertZero: reconstruction ordinal; *Const: constant
+    uint32_t op;      // GateOp
+    uint32_t dst;     // SSA wire id written (= its corr row)
+    uint32_t a, b;    // SSA wire ids read
+    uint32_t dm;      // share row written (G_XOR only; other gates alias an existing row)
+    uint32_t am, bm;  // share rows of the operands
+    uint32_t m;       // first PRG mask index consumed (Input/Random: 1 mask, Mul: 2)
+    uint32_t eo;      // row in the online transcript (Input, Mul, AssertZero)
+    uint32_t ep;      // row in the preprocessing transcript (Mul)
+    uint32_t x;       // Input: witness index; Mul/AssertZero: reconstruction ordinal; *Const: constant
+    uint32_t pad;
 };
 
 enum GateOp : uint32_t {
@@ -74,8 +84,8 @@ struct Interp64Params {
     const uint64_t* sup_corr; // verify: [n_corr64][R]
     const uint64_t* sup_rec;  // verify: [n_rec64][R] share of the omitted player
     // gf2 side, for B2A
-    const uint32_t* wires2;
-    const uint32_t* masks2;
+    const uint8_t* corr2;     // compact gf2 corr rows
+    const uint32_t* masks2;   // gf2 share rows (PRG part)
     uint32_t NQ;
     int* err;
 };
@@ -84,10 +94,10 @@ enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1 };
 
 struct InterpParams {
     uint32_t NQ;
-    uint32_t* wires;
-    const uint32_t* masks;
+    uint32_t* rows;           // share rows (PRG masks + computed)
+    uint8_t* corr;            // [n_ssa][NQ/2]
     uint32_t* on;
-    uint32_t* pre;
+    uint8_t* pre;             // [n_pre][NQ/2]
     const uint8_t* wit;       // prover: witness bits, one byte each
     const uint32_t* on_mask;  // verify: [NQ] 0xFF byte per online-verified rep
     const uint32_t* sup_in;   // verify: [n_inputs][NQ] supplied masked inputs (smeared)
@@ -104,7 +114,9 @@ void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* 
                           uint64_t n_blocks, uint32_t* d_masks);
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
                        uint8_t* d_out);
-void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t hi, const InterpParams& p);
+// gates [lo, mul_end) are G_MUL, [mul_end, xor_end) G_XOR, [xor_end, hi) anything else
+void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end, uint32_t hi,
+                   const InterpParams& p);
 void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t lo, uint32_t hi, const Interp64Params& p);
 // Z64 masks: masks64[m][slot] = LE64(keystream[slot][8m..8m+8)), blocks [first, first+n_blocks) -> masks 2*first..
 void launch_aes_z64_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t n_blocks,
@@ -119,11 +131,15 @@ void launch_unpack64(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_sr
 // BLAKE3 over a row-format transcript: digests[R][8] words
 void launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
                       uint32_t* d_cv_b, uint32_t* d_digest /*[R][8]*/);
+// same for a bit-per-rep transcript [n_events][NQ/2] (each bit hashed as a 0x00/0xFF byte)
+void launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
+                           uint32_t* d_cv_b, uint32_t* d_digest);
 size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R);
 void b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest);
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
                  uint32_t R, uint8_t* d_h /*[R][32]*/);
-void launch_extract_bits(hipStream_t st, const uint32_t* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,
+// kind 0: omitted player's bit of a share row; 1: smeared byte of a row; 2: bit-per-rep stream [n][NQ/2]
+void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,
                          uint32_t NQ, int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
 void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
                         const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out);

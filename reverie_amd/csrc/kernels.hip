@@ -27,6 +27,118 @@ __device__ __forceinline__ uint32_t recon32(uint32_t t) {
     return (t << 8) - t;
 }
 
+// corr / preprocessing bits are stored one bit per repetition: nibble bit k <-> byte k of the
+// smeared word (LSB-first), i.e. repetition 4q + 3 - k
+__device__ __forceinline__ uint32_t expand4(uint32_t n) {
+    const uint32_t t = (n | (n << 7) | (n << 14) | (n << 21)) & 0x01010101u;
+    return (t << 8) - t;
+}
+__device__ __forceinline__ uint32_t compress4(uint32_t x) {
+    const uint32_t y = x & 0x08040201u;
+    return (y | (y >> 8) | (y >> 16) | (y >> 24)) & 0xFu;
+}
+__device__ __forceinline__ uint32_t load_bits(const uint8_t* base, size_t row, uint32_t NQ, uint32_t q) {
+    return expand4(((uint32_t)base[row * (NQ >> 1) + (q >> 1)] >> (4 * (q & 1))) & 0xFu);
+}
+// the two quads sharing a byte are adjacent lanes of the same gate
+__device__ __forceinline__ void store_bits(uint8_t* base, size_t row, uint32_t NQ, uint32_t q, uint32_t smeared) {
+    const uint32_t n = compress4(smeared);
+    const uint32_t other = __shfl_xor(n, 1);
+    if (!(q & 1)) base[row * (NQ >> 1) + (q >> 1)] = (uint8_t)(n | (other << 4));
+}
+
+template <int MODE>
+__device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParams& p, uint32_t NQ, uint32_t q, uint32_t onm) {
+    switch (g.op) {
+    case G_INPUT: {
+        const uint32_t lam = p.rows[(size_t)g.m * NQ + q];
+        uint32_t corr;
+        if (MODE == MODE_PROVE) {
+            const uint32_t w = p.wit[g.x] ? 0xFFFFFFFFu : 0u;
+            corr = w ^ recon32(lam);
+        } else {
+            corr = p.sup_in[(size_t)g.x * NQ + q] & onm;
+        }
+        p.on[(size_t)g.eo * NQ + q] = corr;
+        store_bits(p.corr, g.dst, NQ, q, corr);
+        break;
+    }
+    case G_XOR: {
+        p.rows[(size_t)g.dm * NQ + q] = p.rows[(size_t)g.am * NQ + q] ^ p.rows[(size_t)g.bm * NQ + q];
+        // corr bits: plain byte XOR, no expansion needed
+        if (!(q & 1)) {
+            const size_t h = NQ >> 1, o = q >> 1;
+            p.corr[(size_t)g.dst * h + o] = p.corr[(size_t)g.a * h + o] ^ p.corr[(size_t)g.b * h + o];
+        }
+        break;
+    }
+    case G_XORC: {  // mask row aliased at compile time
+        if (!(q & 1)) {
+            const size_t h = NQ >> 1, o = q >> 1;
+            p.corr[(size_t)g.dst * h + o] = p.corr[(size_t)g.a * h + o] ^ (g.x ? 0xFFu : 0u);
+        }
+        break;
+    }
+    case G_ANDC: {
+        if (!(q & 1)) {
+            const size_t h = NQ >> 1, o = q >> 1;
+            p.corr[(size_t)g.dst * h + o] = g.x ? p.corr[(size_t)g.a * h + o] : (uint8_t)0;
+        }
+        break;
+    }
+    case G_CONST: {
+        if (!(q & 1)) p.corr[(size_t)g.dst * (NQ >> 1) + (q >> 1)] = g.x ? 0xFFu : 0u;
+        break;
+    }
+    case G_RANDOM: {
+        if (!(q & 1)) p.corr[(size_t)g.dst * (NQ >> 1) + (q >> 1)] = 0;
+        break;
+    }
+    case G_MUL: {
+        const uint32_t lx = p.rows[(size_t)g.am * NQ + q], ly = p.rows[(size_t)g.bm * NQ + q];
+        const uint32_t lab = p.rows[(size_t)g.m * NQ + q], lnew = p.rows[(size_t)(g.m + 1) * NQ + q];
+        const uint32_t cx = load_bits(p.corr, g.a, NQ, q), cy = load_bits(p.corr, g.b, NQ, q);
+        const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
+        uint32_t delta = (a & b) ^ c;
+        uint32_t s = (ly & cx) ^ (lx & cy) ^ lab ^ lnew;
+        uint32_t r;
+        if (MODE == MODE_PROVE) {
+            r = recon32(s);
+        } else {
+            // online-verified reps: supplied correction, add the unopened player's broadcast
+            delta = (p.sup_corr[(size_t)g.ep * NQ + q] & onm) | (delta & ~onm);
+            s ^= p.sup_rec[(size_t)g.x * NQ + q];
+            r = recon32(s) & onm;  // preprocessing-verified reps: reconstruct() returns zero
+        }
+        p.on[(size_t)g.eo * NQ + q] = s;
+        store_bits(p.pre, g.ep, NQ, q, delta);
+        store_bits(p.corr, g.dst, NQ, q, r ^ delta ^ (cx & cy));
+        break;
+    }
+    case G_RECON: {
+        // B2A's recorded reconstruction (combine.rs:181-183): value = reconstruct(mask) + corr
+        uint32_t m = p.rows[(size_t)g.am * NQ + q];
+        if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
+        p.on[(size_t)g.eo * NQ + q] = m;
+        uint32_t r = recon32(m);
+        if (MODE == MODE_VERIFY) r &= onm;
+        store_bits(p.corr, g.dst, NQ, q, r ^ load_bits(p.corr, g.a, NQ, q));
+        break;
+    }
+    case G_ASSERT: {
+        uint32_t m = p.rows[(size_t)g.am * NQ + q];
+        if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
+        p.on[(size_t)g.eo * NQ + q] = m;
+        if (MODE == MODE_PROVE) {
+            if ((recon32(m) ^ load_bits(p.corr, g.a, NQ, q)) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+        }
+        break;
+    }
+    default:
+        break;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, uint32_t lo, uint32_t hi, InterpParams p) {
     const uint32_t NQ = p.NQ;
@@ -37,100 +149,117 @@ __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, 
     const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[q] : 0u;
     for (uint32_t gi = lo + worker; gi < hi; gi += n_workers) {
         const Gate g = gates[gi];
-        uint32_t* wd = p.wires + (size_t)g.dst * 2 * NQ + q;
-        const uint32_t* wa = p.wires + (size_t)g.a * 2 * NQ + q;
-        const uint32_t* wb = p.wires + (size_t)g.b * 2 * NQ + q;
-        switch (g.op) {
-        case G_INPUT: {
-            const uint32_t lam = p.masks[(size_t)g.m * NQ + q];
-            uint32_t corr;
-            if (MODE == MODE_PROVE) {
-                const uint32_t w = p.wit[g.x] ? 0xFFFFFFFFu : 0u;
-                corr = w ^ recon32(lam);
-            } else {
-                corr = p.sup_in[(size_t)g.x * NQ + q] & onm;
-            }
-            p.on[(size_t)g.eo * NQ + q] = corr;
-            wd[0] = lam;
-            wd[NQ] = corr;
-            break;
-        }
-        case G_XOR: {
-            wd[0] = wa[0] ^ wb[0];
-            wd[NQ] = wa[NQ] ^ wb[NQ];
-            break;
-        }
-        case G_XORC: {
-            wd[0] = wa[0];
-            wd[NQ] = wa[NQ] ^ (g.x ? 0xFFFFFFFFu : 0u);
-            break;
-        }
-        case G_ANDC: {
-            const uint32_t c = g.x ? 0xFFFFFFFFu : 0u;
-            wd[0] = wa[0] & c;
-            wd[NQ] = wa[NQ] & c;
-            break;
-        }
-        case G_CONST: {
-            wd[0] = 0;
-            wd[NQ] = g.x ? 0xFFFFFFFFu : 0u;
-            break;
-        }
-        case G_RANDOM: {
-            wd[0] = p.masks[(size_t)g.m * NQ + q];
-            wd[NQ] = 0;
-            break;
-        }
-        case G_MUL: {
-            const uint32_t lx = wa[0], cx = wa[NQ], ly = wb[0], cy = wb[NQ];
-            const uint32_t lab = p.masks[(size_t)g.m * NQ + q];
-            const uint32_t lnew = p.masks[(size_t)(g.m + 1) * NQ + q];
-            const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
-            uint32_t delta = (a & b) ^ c;
-            uint32_t s = (ly & cx) ^ (lx & cy) ^ lab ^ lnew;
-            uint32_t r;
-            if (MODE == MODE_PROVE) {
-                r = recon32(s);
-            } else {
-                // online-verified reps: supplied correction, add the unopened player's broadcast
-                delta = (p.sup_corr[(size_t)g.ep * NQ + q] & onm) | (delta & ~onm);
-                s ^= p.sup_rec[(size_t)g.x * NQ + q];
-                r = recon32(s) & onm;  // preprocessing-verified reps: reconstruct() returns zero
-            }
-            p.pre[(size_t)g.ep * NQ + q] = delta;
-            p.on[(size_t)g.eo * NQ + q] = s;
-            wd[0] = lnew;
-            wd[NQ] = r ^ delta ^ (cx & cy);
-            break;
-        }
-        case G_RECON: {
-            // B2A's recorded reconstruction (combine.rs:181-183): value = reconstruct(mask) + corr
-            uint32_t m = wa[0];
-            if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
-            p.on[(size_t)g.eo * NQ + q] = m;
-            uint32_t r = recon32(m);
-            if (MODE == MODE_VERIFY) r &= onm;
-            wd[0] = 0;
-            wd[NQ] = r ^ wa[NQ];
-            break;
-        }
-        case G_ASSERT: {
-            uint32_t m = wa[0];
-            if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
-            p.on[(size_t)g.eo * NQ + q] = m;
-            if (MODE == MODE_PROVE) {
-                if ((recon32(m) ^ wa[NQ]) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
-            }
-            break;
-        }
-        default:
-            break;
-        }
+        interp_one_impl<MODE>(g, p, NQ, q, onm);
     }
 }
 
-void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t hi, const InterpParams& p) {
+// Fast path for a full shard (R = 256, NQ = 64): one wavefront = one gate, so the gate record
+// is wave-uniform (scalar loads) and the per-kind ranges run as 4-way unrolled loops that put
+// every operand row of 4 gates in flight before the first use — the generic kernel above is
+// latency-bound on the dependent gate-record -> operand-row chain (2 HBM round trips per gate).
+template <int MODE>
+__device__ __forceinline__ void mul4(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t q, uint32_t onm) {
+    constexpr uint32_t NQ = 64;
+    Gate g[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) g[u] = gates[g0 + u];
+    uint32_t lx[4], ly[4], lab[4], lnew[4], bx[4], by[4], sc[4], sr[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        lx[u] = p.rows[(size_t)g[u].am * NQ + q];
+        ly[u] = p.rows[(size_t)g[u].bm * NQ + q];
+        lab[u] = p.rows[(size_t)g[u].m * NQ + q];
+        lnew[u] = p.rows[(size_t)(g[u].m + 1) * NQ + q];
+        bx[u] = p.corr[(size_t)g[u].a * 32 + (q >> 1)];
+        by[u] = p.corr[(size_t)g[u].b * 32 + (q >> 1)];
+        if (MODE == MODE_VERIFY) {
+            sc[u] = p.sup_corr[(size_t)g[u].ep * NQ + q];
+            sr[u] = p.sup_rec[(size_t)g[u].x * NQ + q];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t cx = expand4((bx[u] >> (4 * (q & 1))) & 0xFu), cy = expand4((by[u] >> (4 * (q & 1))) & 0xFu);
+        const uint32_t a = recon32(lx[u]), b = recon32(ly[u]), c = recon32(lab[u]);
+        uint32_t delta = (a & b) ^ c;
+        uint32_t s = (ly[u] & cx) ^ (lx[u] & cy) ^ lab[u] ^ lnew[u];
+        uint32_t r;
+        if (MODE == MODE_PROVE) {
+            r = recon32(s);
+        } else {
+            delta = (sc[u] & onm) | (delta & ~onm);
+            s ^= sr[u];
+            r = recon32(s) & onm;
+        }
+        p.on[(size_t)g[u].eo * NQ + q] = s;
+        store_bits(p.pre, g[u].ep, NQ, q, delta);
+        store_bits(p.corr, g[u].dst, NQ, q, r ^ delta ^ (cx & cy));
+    }
+}
+
+__device__ __forceinline__ void xor4(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t q) {
+    constexpr uint32_t NQ = 64;
+    Gate g[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) g[u] = gates[g0 + u];
+    uint32_t x[4], y[4], bx[4], by[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        x[u] = p.rows[(size_t)g[u].am * NQ + q];
+        y[u] = p.rows[(size_t)g[u].bm * NQ + q];
+        // 32 corr bytes per wire: lanes 0..31 carry them
+        bx[u] = (q < 32) ? p.corr[(size_t)g[u].a * 32 + q] : 0;
+        by[u] = (q < 32) ? p.corr[(size_t)g[u].b * 32 + q] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        p.rows[(size_t)g[u].dm * NQ + q] = x[u] ^ y[u];
+        if (q < 32) p.corr[(size_t)g[u].dst * 32 + q] = (uint8_t)(bx[u] ^ by[u]);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void interp_one(const Gate& g, const InterpParams& p, uint32_t NQ, uint32_t q, uint32_t onm) {
+    interp_one_impl<MODE>(g, p, NQ, q, onm);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end,
+                                                     uint32_t hi, InterpParams p) {
+    const uint32_t q = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[q] : 0u;
+    // G_MUL range
+    {
+        const uint32_t full = lo + ((mul_end - lo) & ~3u);
+        for (uint32_t g0 = lo + wave * 4; g0 < full; g0 += n_waves * 4) mul4<MODE>(gates, g0, p, q, onm);
+        for (uint32_t gi = full + wave; gi < mul_end; gi += n_waves) interp_one<MODE>(gates[gi], p, 64, q, onm);
+    }
+    // G_XOR range
+    {
+        const uint32_t full = mul_end + ((xor_end - mul_end) & ~3u);
+        for (uint32_t g0 = mul_end + wave * 4; g0 < full; g0 += n_waves * 4) xor4(gates, g0, p, q);
+        for (uint32_t gi = full + wave; gi < xor_end; gi += n_waves) interp_one<MODE>(gates[gi], p, 64, q, onm);
+    }
+    for (uint32_t gi = xor_end + wave; gi < hi; gi += n_waves) interp_one<MODE>(gates[gi], p, 64, q, onm);
+}
+
+void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end, uint32_t hi,
+                   const InterpParams& p) {
     if (hi <= lo) return;
+    if (p.NQ == 64) {
+        // one gate per wavefront per step, 4 gates per unrolled step
+        uint64_t waves = ((uint64_t)(hi - lo) + 3) / 4;
+        uint64_t blocks = (waves + 3) / 4;
+        if (blocks > 4096) blocks = 4096;
+        if (blocks < 1) blocks = 1;
+        if (mode == MODE_PROVE)
+            hipLaunchKernelGGL(k_interp_full<MODE_PROVE>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, mul_end, xor_end, hi, p);
+        else
+            hipLaunchKernelGGL(k_interp_full<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, mul_end, xor_end, hi, p);
+        return;
+    }
     const uint64_t want = (uint64_t)(hi - lo) * p.NQ;
     uint64_t blocks = (want + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -177,6 +306,61 @@ __global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ 
             b3::compress<false>(cv[i4], m, c, blen, flags, o);
 #pragma unroll
             for (int k = 0; k < 8; k++) cv[i4][k] = o[k];
+        }
+    }
+    const uint32_t R = NQ * 4;
+#pragma unroll
+    for (int i4 = 0; i4 < 4; i4++) {
+        uint32_t* dst = cvs + ((size_t)c * R + 4 * q + i4) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[k] = cv[i4][k];
+    }
+}
+
+// Same for a bit-per-rep transcript (the preprocessing stream): every bit is hashed as the
+// 0x00/0xFF byte the reference feeds its hasher (gf2/recon.rs:314-321).
+__global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ,
+                                                        uint64_t n_chunks, uint32_t* __restrict__ cvs) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t c = tid / NQ;
+    const uint32_t q = (uint32_t)(tid % NQ);
+    if (c >= n_chunks) return;
+    const uint64_t ev0 = c * 1024;
+    const uint64_t len = (n_events - ev0 < 1024) ? (n_events - ev0) : 1024;
+    const uint32_t nblk = len == 0 ? 1 : (uint32_t)((len + 63) / 64);
+    const uint32_t h = NQ >> 1, o = q >> 1, sh = 4 * (q & 1);
+    uint32_t cv[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) b3::iv(cv[i]);
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint64_t e0 = ev0 + 64ull * b;
+        const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
+        uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
+        if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
+        // w[k]: the nibbles of events 4k..4k+3 at bits 0,4(unused),... -> build per-rep message words
+        uint32_t m[4][16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            uint32_t nb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t e = e0 + 4 * k + j;
+                nb[j] = (e < n_events) ? (((uint32_t)stream[e * h + o] >> sh) & 0xFu) : 0u;
+            }
+#pragma unroll
+            for (int i4 = 0; i4 < 4; i4++) {
+                const int bit = 3 - i4;  // nibble bit of repetition i4
+                const uint32_t t = ((nb[0] >> bit) & 1u) | (((nb[1] >> bit) & 1u) << 8) | (((nb[2] >> bit) & 1u) << 16) |
+                                   (((nb[3] >> bit) & 1u) << 24);
+                m[i4][k] = (t << 8) - t;
+            }
+        }
+#pragma unroll
+        for (int i4 = 0; i4 < 4; i4++) {
+            uint32_t ov[8];
+            b3::compress<false>(cv[i4], m[i4], c, blen, flags, ov);
+#pragma unroll
+            for (int k = 0; k < 8; k++) cv[i4][k] = ov[k];
         }
     }
     const uint32_t R = NQ * 4;
@@ -252,6 +436,16 @@ void launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_event
     b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);
 }
 
+void launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
+                           uint32_t* d_cv_b, uint32_t* d_digest) {
+    const uint32_t R = NQ * 4;
+    const uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
+    const uint64_t threads = n * NQ;
+    hipLaunchKernelGGL(k_b3_chunks_bits, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, n_events, NQ, n,
+                       d_cv_a);
+    b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);
+}
+
 // Transcript::hash + CombineInstance::hash: h = B3(B3(pre2||on2) || B3(pre64||on64))
 __global__ void k_join(const uint32_t* __restrict__ pre2, const uint32_t* __restrict__ on2, const uint32_t* __restrict__ pre64,
                        const uint32_t* __restrict__ on64, uint32_t R, uint8_t* __restrict__ h) {
@@ -293,7 +487,7 @@ void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, 
 // reference always emits one more chunk).  Thread = (output byte t, quad q): reads 8 rows,
 // produces the byte for each of its 4 repetitions, stores only for opened ones.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_extract_bits(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows,
+__global__ __launch_bounds__(256) void k_extract_bits(const void* __restrict__ stream_, const uint32_t* __restrict__ rows,
                                                       uint64_t n_items, uint32_t NQ, int kind,
                                                       const uint8_t* __restrict__ omit /*[R]*/,
                                                       const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out) {
@@ -311,11 +505,19 @@ __global__ __launch_bounds__(256) void k_extract_bits(const uint32_t* __restrict
     }
     if (!any) return;
     uint32_t acc[4] = {0, 0, 0, 0};
+    const uint32_t* stream = (const uint32_t*)stream_;
+    const uint8_t* bits = (const uint8_t*)stream_;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const uint64_t it = 8 * t + j;
         if (it < n_items) {
             const uint64_t row = rows ? rows[it] : it;
+            if (kind == 2) {
+                const uint32_t nb = ((uint32_t)bits[row * (NQ >> 1) + (q >> 1)] >> (4 * (q & 1))) & 0xFu;
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] |= ((nb >> (3 - i)) & 1u) << (7 - j);
+                continue;
+            }
             const uint32_t w = stream[row * NQ + q];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -329,7 +531,7 @@ __global__ __launch_bounds__(256) void k_extract_bits(const uint32_t* __restrict
         if (om[i] < 8) out[dst_off[4 * q + i] + t] = (uint8_t)acc[i];
 }
 
-void launch_extract_bits(hipStream_t st, const uint32_t* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ,
+void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ,
                          int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out) {
     const uint64_t threads = (n_items / 8 + 1) * NQ;
     hipLaunchKernelGGL(k_extract_bits, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, d_rows, n_items, NQ,

@@ -129,8 +129,9 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
             for (int k = 0; k < 64; k++) {
                 const uint32_t w = recon32_(p.masks2[(size_t)(g.m2 + k) * p.NQ + qw]);
                 zval |= (uint64_t)((w >> sh) & 1u) << k;
-                const uint32_t v = p.wires2[((size_t)(g.a + k) * 2 + 1) * p.NQ + qw];  // revealed sum bit k
-                zrec |= (uint64_t)((v >> sh) & 1u) << k;
+                // revealed sum bit k: bit-per-rep corr row of the k-th G_RECON output
+                const uint32_t v = p.corr2[(size_t)(g.a + k) * (p.NQ >> 1) + (qw >> 1)];
+                zrec |= (uint64_t)((v >> (4 * (qw & 1) + 3 - (r & 3))) & 1u) << k;
             }
             const uint64_t mu = p.masks[(size_t)g.m * S + l];
             uint64_t kappa = zval - sum8(mu);
