@@ -125,6 +125,8 @@ __global__ void k_aes_blocks(const uint8_t* __restrict__ rkbytes, uint32_t n_key
 // ------------------------------------------------------------------------------------
 // bitsliced AES-128: state s[8*i + k] = bit k (0 = LSB) of state byte i, 32 blocks/lane
 // ------------------------------------------------------------------------------------
+#define XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+
 __device__ __forceinline__ void sbox8(uint32_t& b7, uint32_t& b6, uint32_t& b5, uint32_t& b4, uint32_t& b3, uint32_t& b2,
                                       uint32_t& b1, uint32_t& b0) {
     const uint32_t U0 = b7, U1 = b6, U2 = b5, U3 = b4, U4 = b3, U5 = b2, U6 = b1, U7 = b0;
@@ -177,6 +179,66 @@ __device__ __forceinline__ void mix_ark(const uint32_t* t, uint32_t* s, const ui
     }
 }
 
+// One full middle round, column by column: n = MixColumns(ShiftRows(SubBytes(s))) ^ rk.
+// Output column c only needs the four S-box outputs it consumes, so at most one column of
+// temporaries (32 registers) is live beside the old and the new state: this is what lets the
+// kernel fit 2 wavefronts per SIMD (<= 256 registers) without scratch spills.
+template <int QW>
+__device__ __forceinline__ void round_cols(const uint32_t* s, uint32_t* n, const uint32_t* rk) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint32_t col[32];
+#pragma unroll
+        for (int row = 0; row < 4; row++) {
+            const int src = 8 * (4 * ((c + row) & 3) + row);
+#pragma unroll
+            for (int k = 0; k < 8; k++) col[8 * row + k] = s[src + k];
+            sbox8(col[8 * row + 7], col[8 * row + 6], col[8 * row + 5], col[8 * row + 4], col[8 * row + 3], col[8 * row + 2],
+                  col[8 * row + 1], col[8 * row + 0]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t* a0 = col + 8 * r;
+            const uint32_t* a1 = col + 8 * ((r + 1) & 3);
+            const uint32_t* a2 = col + 8 * ((r + 2) & 3);
+            const uint32_t* a3 = col + 8 * ((r + 3) & 3);
+            uint32_t d[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) d[k] = a0[k] ^ a1[k];
+            // out = xtime(d) ^ a1 ^ a2 ^ a3 ^ rk with xtime(d) = {d7, d0^d7, d1, d2^d7, d3^d7, d4, d5, d6},
+            // written as 3-input XORs (v_bitop3_b32 0x96): 27 ops per byte instead of 43
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t rkv = rk[(32 * c + 8 * r + k) * QW];
+                const uint32_t lo = d[(k + 7) & 7];  // d[k-1], d[7] for k = 0
+                uint32_t v;
+                if (k == 1 || k == 3 || k == 4)
+                    v = XOR3(XOR3(lo, d[7], a1[k]), a2[k], a3[k]) ^ rkv;
+                else
+                    v = XOR3(XOR3(lo, a1[k], a2[k]), a3[k], rkv);
+                n[32 * c + 8 * r + k] = v;
+            }
+        }
+        // keep the scheduler from hoisting the next columns' LDS reads / S-boxes up here (that is
+        // what blew the register budget: 128 round-key words in flight at once)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// rounds 1..9 on s (result back in s), two rounds per loop trip so no register shuffling is
+// needed at the back edge; t is the ping-pong buffer
+template <int QW>
+__device__ __forceinline__ void middle_rounds(uint32_t* s, uint32_t* t, const uint32_t* rkl) {
+#pragma unroll 1
+    for (int r = 1; r < 9; r += 2) {
+        round_cols<QW>(s, t, rkl + r * 128 * QW);
+        round_cols<QW>(t, s, rkl + (r + 1) * 128 * QW);
+    }
+    round_cols<QW>(s, t, rkl + 9 * 128 * QW);
+#pragma unroll
+    for (int i = 0; i < 128; i++) s[i] = t[i];
+}
+
 // Mask generator.  A workgroup owns QW consecutive quads (QW*32 AES keys) and keeps their
 // 11 bitsliced round keys in LDS (QW*5.5 KiB; 88 KiB at QW=16) for its whole lifetime; its
 // 4 wavefronts then stream CTR blocks: lane = (block sub-index, quad), 64/QW blocks per
@@ -184,7 +246,7 @@ __device__ __forceinline__ void mix_ark(const uint32_t* t, uint32_t* s, const ui
 // version that read them from global memory was 15x slower: every wavefront of the chip
 // requested the same 256-byte row at the same time and serialised on one L2 channel).
 template <int QW>
-__global__ __launch_bounds__(256) void k_aes_gf2_masks(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep,
+__global__ __launch_bounds__(512, 2) void k_aes_gf2_masks(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep,
                                                        uint32_t NQ, uint64_t first_block, uint64_t n_blocks,
                                                        uint32_t blocks_per_wg, uint32_t* __restrict__ masks) {
     __shared__ uint32_t lds_rk[11 * 128 * QW];
@@ -193,7 +255,7 @@ __global__ __launch_bounds__(256) void k_aes_gf2_masks(const uint32_t* __restric
     const uint32_t qg = blockIdx.x % n_qg;
     const uint64_t chunk = blockIdx.x / n_qg;
     // stage this workgroup's round keys: rk[(round*128+idx)*NQ + qg*QW + ql]
-    for (uint32_t i = threadIdx.x; i < 11 * 128 * QW; i += 256) lds_rk[i] = rk[(size_t)(i / QW) * NQ + qg * QW + (i % QW)];
+    for (uint32_t i = threadIdx.x; i < 11 * 128 * QW; i += 512) lds_rk[i] = rk[(size_t)(i / QW) * NQ + qg * QW + (i % QW)];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ql = lane % QW, jsub = lane / QW;
@@ -202,7 +264,7 @@ __global__ __launch_bounds__(256) void k_aes_gf2_masks(const uint32_t* __restric
     const uint32_t* rkl = lds_rk + ql;
     const uint64_t j_lo = chunk * blocks_per_wg;
     const uint64_t j_hi = (j_lo + blocks_per_wg < n_blocks) ? j_lo + blocks_per_wg : n_blocks;
-    for (uint64_t jb = j_lo + (uint64_t)wave * JW; jb < j_hi; jb += 4 * JW) {
+    for (uint64_t jb = j_lo + (uint64_t)wave * JW; jb < j_hi; jb += 8 * JW) {
         const uint64_t jl = jb + jsub;
         if (jl >= j_hi) continue;
         const uint64_t j = first_block + jl;
@@ -217,11 +279,7 @@ __global__ __launch_bounds__(256) void k_aes_gf2_masks(const uint32_t* __restric
                 s[8 * i + k] = rkl[(8 * i + k) * QW] ^ cb;
             }
         }
-#pragma unroll 1
-        for (int r = 1; r < 10; r++) {
-            sub_shift(s, t);
-            mix_ark<QW>(t, s, rkl + r * 128 * QW);
-        }
+        middle_rounds<QW>(s, t, rkl);
         sub_shift(s, t);
         const uint32_t* rk10 = rkl + 10 * 128 * QW;
         uint32_t* out = masks + (size_t)jl * 128 * NQ + q;
@@ -300,11 +358,7 @@ __global__ __launch_bounds__(256) void k_aes_z64_masks(const uint32_t* __restric
                 s[8 * i + k] = rkl[(8 * i + k) * QW] ^ cb;
             }
         }
-#pragma unroll 1
-        for (int r = 1; r < 10; r++) {
-            sub_shift(s, t);
-            mix_ark<QW>(t, s, rkl + r * 128 * QW);
-        }
+        middle_rounds<QW>(s, t, rkl);
         sub_shift(s, t);
         const uint32_t* rk10 = rkl + 10 * 128 * QW;
 #pragma unroll
@@ -336,10 +390,10 @@ static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t
     const uint32_t n_qg = NQ / QW;
     constexpr uint32_t JW = 64 / QW;
     // ~4 workgroups per CU in total, each a multiple of one full iteration (4 waves x JW blocks)
-    uint64_t per = (n_blocks * n_qg + 1023) / 1024;
-    per = ((per + 4 * JW - 1) / (4 * JW)) * (4 * JW);
+    uint64_t per = (n_blocks * n_qg + 511) / 512;
+    per = ((per + 8 * JW - 1) / (8 * JW)) * (8 * JW);
     const uint64_t chunks = (n_blocks + per - 1) / per;
-    hipLaunchKernelGGL(k_aes_gf2_masks<QW>, dim3((unsigned)(chunks * n_qg)), dim3(256), 0, st, d_rk, d_keep, NQ, first_block,
+    hipLaunchKernelGGL(k_aes_gf2_masks<QW>, dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_rk, d_keep, NQ, first_block,
                        n_blocks, (uint32_t)per, d_masks);
 }
 

@@ -167,24 +167,120 @@ def evaluate(x):
     return sum(env[f"S{i}"] << (7 - i) for i in range(8))
 
 
+def parse():
+    """-> list of (dst, op, x, y, neg_y) in order"""
+    gates = []
+    for line in CIRCUIT.strip().splitlines():
+        lhs, rhs = [t.strip() for t in line.split("=")]
+        m = re.match(r"(\w+) ([\^&]) (~?)(\w+)", rhs)
+        gates.append((lhs, m.group(2), m.group(1), m.group(4), bool(m.group(3))))
+    return gates
+
+
+def lut3_synthesis():
+    """Greedy packing of the 2-input XOR/AND/XNOR netlist into <=3-input LUTs (gfx950 has
+    v_bitop3_b32: any 3-input boolean function in one VALU op).  A gate is inlined into its
+    consumer when it has fan-out 1 and the merged node still has <= 3 distinct inputs."""
+    nodes = {}  # name -> (inputs tuple, fn(dict)->bit)
+    order = []
+    for dst, op, x, y, neg in parse():
+        if op == "^":
+            fn = (lambda x, y, neg: lambda env: env[x] ^ env[y] ^ (1 if neg else 0))(x, y, neg)
+        else:
+            fn = (lambda x, y: lambda env: env[x] & env[y])(x, y)
+        nodes[dst] = ((x, y), fn)
+        order.append(dst)
+    outputs = {f"S{i}" for i in range(8)}
+
+    def fanout():
+        fo = {}
+        for n, (ins, _) in nodes.items():
+            for i in set(ins):
+                fo[i] = fo.get(i, 0) + 1
+        return fo
+
+    def compose(fn, wfn, w):
+        def f(env):
+            e = dict(env)
+            e[w] = wfn(env)
+            return fn(e)
+        return f
+
+    # rule: a gate disappears if EVERY consumer can absorb it and stay within 3 inputs
+    changed = True
+    while changed:
+        changed = False
+        for w in list(order):
+            if w not in nodes or w in outputs:
+                continue
+            wins, wfn = nodes[w]
+            cons = [n for n in order if n in nodes and w in nodes[n][0]]
+            if not cons:
+                continue
+            merged = {}
+            ok = True
+            for n in cons:
+                ins, fn = nodes[n]
+                union = tuple(dict.fromkeys([i for i in ins if i != w] + list(wins)))
+                if len(union) > 3:
+                    ok = False
+                    break
+                merged[n] = (union, compose(fn, wfn, w))
+            if ok:
+                nodes.update(merged)
+                del nodes[w]
+                changed = True
+    final = [n for n in order if n in nodes]
+    luts = []
+    for n in final:
+        ins, fn = nodes[n]
+        ins = tuple(ins)
+        tt = 0
+        for idx in range(1 << len(ins)):
+            env = {name: (idx >> (len(ins) - 1 - k)) & 1 for k, name in enumerate(ins)}
+            if fn(env):
+                tt |= 1 << idx
+        luts.append((n, ins, tt))
+    return luts
+
+
+def eval_luts(luts, x):
+    env = {f"U{i}": (x >> (7 - i)) & 1 for i in range(8)}
+    for n, ins, tt in luts:
+        idx = 0
+        for name in ins:
+            idx = (idx << 1) | env[name]
+        env[n] = (tt >> idx) & 1
+    return sum(env[f"S{i}"] << (7 - i) for i in range(8))
+
+
 def main():
     for x in range(256):
         assert evaluate(x) == sbox_def(x), f"S-box circuit wrong at {x:#x}"
     lines = CIRCUIT.strip().splitlines()
     n_and = sum("&" in l for l in lines)
+    luts = lut3_synthesis()
+    for x in range(256):
+        assert eval_luts(luts, x) == sbox_def(x), f"LUT3 netlist wrong at {x:#x}"
+    n3 = sum(len(ins) == 3 for _, ins, _ in luts)
     out = ["// GENERATED by gen/gen_sbox.py — exhaustively verified against the FIPS-197 S-box definition.",
-           f"// {len(lines)} gates ({n_and} AND). U0/S0 = most significant bit.",
-           "// Included inside aes_sbox(uint32_t &U0..&U7) -> results written back to U0..U7."]
-    for l in lines:
-        lhs, rhs = [s.strip() for s in l.split("=")]
-        out.append(f"const uint32_t {lhs} = {rhs};")
+           f"// {len(lines)}-gate Boyar-Peralta style circuit ({n_and} AND) packed into {len(luts)} ops, {n3} of them",
+           "// 3-input v_bitop3_b32 LUTs (truth-table index = (S0<<2)|(S1<<1)|S2). U0/S0 = most significant bit.",
+           "// Included inside sbox8(): inputs U0..U7, results S0..S7."]
+    for n, ins, tt in luts:
+        if len(ins) == 3:
+            out.append(f"const uint32_t {n} = __builtin_amdgcn_bitop3_b32({ins[0]}, {ins[1]}, {ins[2]}, 0x{tt:02x});")
+        else:
+            a_, b_ = ins
+            expr = {0x6: f"{a_} ^ {b_}", 0x8: f"{a_} & {b_}", 0x9: f"~({a_} ^ {b_})"}[tt]
+            out.append(f"const uint32_t {n} = {expr};")
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aes_sbox.inc")
     open(path, "w").write("\n".join(out) + "\n")
     tab = ", ".join("0x%02x" % sbox_def(x) for x in range(256))
     tpath = os.path.join(os.path.dirname(path), "aes_sbox_table.inc")
     open(tpath, "w").write("// GENERATED by gen/gen_sbox.py from the FIPS-197 S-box definition (used only by the tiny\n"
                            "// key-schedule / seed-expansion kernels; the mask generator uses the bitsliced circuit).\n" + tab + "\n")
-    print("verified 256/256;", len(lines), "gates,", n_and, "AND ->", path)
+    print("verified 256/256;", len(lines), "gates,", n_and, "AND ->", len(luts), "LUT ops (", n3, "three-input ) ->", path)
 
 
 if __name__ == "__main__":
