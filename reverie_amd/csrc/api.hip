@@ -683,7 +683,16 @@ static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void*
                         s->d_offs + s->R, L.l2r, L.l2c, L.l2i, L.l64r, L.l64c, L.l64i, d_out);
     if (L.n_on) {
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
-        launch_extract_bits(ctx->stream, s->d_pre, nullptr, cc.n_pre, s->NQ, 2, s->d_omit, s->d_offs + 3 * s->R, d_out);
+        {
+            OnlineList ol{};
+            for (uint32_t r = 0; r < s->R; r++)
+                if (om[r] < 8 && ol.n < RV_ONLINE_REPS) {
+                    ol.rep[ol.n] = r;
+                    ol.dst[ol.n] = offs[3 * s->R + r];
+                    ol.n++;
+                }
+            launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, ol, d_out);
+        }
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
         launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_rec_offs64, cc.n_rec64, 1, s->R, s->d_omit,
                          s->d_offs + 5 * s->R, d_out);

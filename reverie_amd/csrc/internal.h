@@ -138,6 +138,15 @@ size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R);
 void b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest);
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
                  uint32_t R, uint8_t* d_h /*[R][32]*/);
+// the (at most 40) opened repetitions of a shard with the output offset of one of their vectors;
+// passed by value so the kernel reads it from the kernel-argument segment (scalar loads)
+struct OnlineList {
+    uint32_t n;
+    uint32_t rep[RV_ONLINE_REPS];
+    uint64_t dst[RV_ONLINE_REPS];
+};
+void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint32_t NQ, const OnlineList& ol,
+                              uint8_t* d_out);
 // kind 0: omitted player's bit of a share row; 1: smeared byte of a row; 2: bit-per-rep stream [n][NQ/2]
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,
                          uint32_t NQ, int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);

@@ -337,21 +337,20 @@ __global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restric
         const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
         uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
         if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
-        // w[k]: the nibbles of events 4k..4k+3 at bits 0,4(unused),... -> build per-rep message words
+        // P = the nibbles of events 4k..4k+3, one per byte; repetition i4 owns nibble bit 3-i4
         uint32_t m[4][16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            uint32_t nb[4];
+            uint32_t P = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint64_t e = e0 + 4 * k + j;
-                nb[j] = (e < n_events) ? (((uint32_t)stream[e * h + o] >> sh) & 0xFu) : 0u;
+                const uint32_t nb = (e < n_events) ? (uint32_t)stream[e * h + o] : 0u;
+                P |= ((nb >> sh) & 0xFu) << (8 * j);
             }
 #pragma unroll
             for (int i4 = 0; i4 < 4; i4++) {
-                const int bit = 3 - i4;  // nibble bit of repetition i4
-                const uint32_t t = ((nb[0] >> bit) & 1u) | (((nb[1] >> bit) & 1u) << 8) | (((nb[2] >> bit) & 1u) << 16) |
-                                   (((nb[3] >> bit) & 1u) << 24);
+                const uint32_t t = (P >> (3 - i4)) & 0x01010101u;
                 m[i4][k] = (t << 8) - t;
             }
         }
@@ -507,28 +506,87 @@ __global__ __launch_bounds__(256) void k_extract_bits(const void* __restrict__ s
     uint32_t acc[4] = {0, 0, 0, 0};
     const uint32_t* stream = (const uint32_t*)stream_;
     const uint8_t* bits = (const uint8_t*)stream_;
+    // all 8 row indices first, then all 8 rows: two memory round trips per thread instead of 16
+    uint64_t row[8];
+    uint32_t w[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const uint64_t it = 8 * t + j;
-        if (it < n_items) {
-            const uint64_t row = rows ? rows[it] : it;
-            if (kind == 2) {
-                const uint32_t nb = ((uint32_t)bits[row * (NQ >> 1) + (q >> 1)] >> (4 * (q & 1))) & 0xFu;
+        uint64_t it = 8 * t + j;
+        if (it >= n_items) it = n_items ? n_items - 1 : 0;
+        row[j] = rows ? rows[it] : it;
+    }
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc[i] |= ((nb >> (3 - i)) & 1u) << (7 - j);
-                continue;
-            }
-            const uint32_t w = stream[row * NQ + q];
+    for (int j = 0; j < 8; j++) {
+        if (kind == 2)
+            w[j] = n_items ? (((uint32_t)bits[row[j] * (NQ >> 1) + (q >> 1)] >> (4 * (q & 1))) & 0xFu) : 0u;
+        else
+            w[j] = n_items ? stream[row[j] * NQ + q] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (8 * t + j < n_items) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t sh = (kind == 0) ? (31u - 8u * i - (om[i] & 7u)) : (24u - 8u * i);
-                acc[i] |= ((w >> sh) & 1u) << (7 - j);
+                uint32_t bit;
+                if (kind == 2)
+                    bit = (w[j] >> (3 - i)) & 1u;
+                else
+                    bit = (w[j] >> ((kind == 0) ? (31u - 8u * i - (om[i] & 7u)) : (24u - 8u * i))) & 1u;
+                acc[i] |= bit << (7 - j);
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (om[i] < 8) out[dst_off[4 * q + i] + t] = (uint8_t)acc[i];
+}
+
+// Bit-per-rep source (the preprocessing stream): lane = event row, so a wavefront covers 64
+// consecutive events; for every opened repetition one ballot yields its 64 bits = 8 output
+// bytes (bit-reversed + byte-swapped into the MSB-first packing).  n_bytes includes the
+// always-present extra chunk.
+__global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ,
+                                                           OnlineList ol, uint8_t* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_bytes = n_items / 8 + 1;
+    const uint64_t e = wave * 64 + lane;
+    if (wave * 8 >= n_bytes) return;
+    const uint32_t h = NQ >> 1;  // bytes per row
+    // the lane's whole row once (h <= 32 bytes), then every opened repetition from registers
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (e < n_items) {
+        const uint8_t* rowp = bits + e * h;
+        if (h == 32) {
+            const uint4 lo = *(const uint4*)rowp, hi = *(const uint4*)(rowp + 16);
+            w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
+            w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+        } else {
+            for (uint32_t i = 0; i < h; i++) w[i >> 2] |= (uint32_t)rowp[i] << (8 * (i & 3));
+        }
+    }
+    const bool writer = lane < 8 && wave * 8 + lane < n_bytes;
+#pragma unroll
+    for (int k = 0; k < RV_ONLINE_REPS; k++) {
+        if (k >= (int)ol.n) break;
+        const uint32_t r = ol.rep[k];  // kernel-argument data: scalar, no dependent global load
+        const uint32_t wi = r >> 5, rr = r & 31;
+        const uint32_t pos = 8 * ((rr >> 3) & 3) + 4 * ((rr >> 2) & 1) + 3 - (rr & 3);
+        // wave-uniform word select without dynamic register indexing
+        uint32_t word = w[0];
+#pragma unroll
+        for (int i = 1; i < 8; i++) word = (wi == (uint32_t)i) ? w[i] : word;
+        const unsigned long long bal = __ballot((word >> pos) & 1u);
+        const unsigned long long rev = __brevll(bal);  // event 64w+8t+j -> bit 63-8t-j
+        if (writer) out[ol.dst[k] + wave * 8 + lane] = (uint8_t)(rev >> (56 - 8 * lane));
+    }
+}
+
+void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint32_t NQ, const OnlineList& ol,
+                              uint8_t* d_out) {
+    if (!ol.n) return;
+    const uint64_t waves = (n_items / 8 + 1 + 7) / 8;
+    hipLaunchKernelGGL(k_extract_from_bits, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, d_bits, n_items, NQ, ol, d_out);
 }
 
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ,
