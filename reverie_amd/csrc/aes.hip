@@ -14,6 +14,8 @@
 // reference's 64x128 bit transpose (its top CPU cost) disappears: the
 // bitsliced cipher emits the transposed layout natively, and a wavefront stores one
 // 256-byte row per mask index, fully coalesced.
+#include <stdlib.h>
+
 #include "internal.h"
 
 namespace rv {
@@ -390,7 +392,13 @@ static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t
     const uint32_t n_qg = NQ / QW;
     constexpr uint32_t JW = 64 / QW;
     // ~4 workgroups per CU in total, each a multiple of one full iteration (4 waves x JW blocks)
-    uint64_t per = (n_blocks * n_qg + 511) / 512;
+    // target workgroup count (each takes a whole CU: 88 KiB LDS, 512 x 256 registers).  Fewer than
+    // the chip's 256 CUs leaves room for the interpreter stream to run concurrently.
+    static const uint64_t target_wgs = [] {
+        const char* e = getenv("RV_AES_WGS");
+        return (uint64_t)(e ? atoi(e) : 512);
+    }();
+    uint64_t per = (n_blocks * n_qg + target_wgs - 1) / target_wgs;
     per = ((per + 8 * JW - 1) / (8 * JW)) * (8 * JW);
     const uint64_t chunks = (n_blocks + per - 1) / per;
     hipLaunchKernelGGL(k_aes_gf2_masks<QW>, dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_rk, d_keep, NQ, first_block,

@@ -57,7 +57,19 @@ extern "C" const char* rv_strerror(int code) {
 // ------------------------------------------------------------------------------------
 struct rv_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // setup, AES masks, hashing, openings (VALU-heavy work)
+    hipStream_t stream2 = nullptr;  // the interpreter (HBM-bound), pipelined against the mask generator
+    std::vector<hipEvent_t> sync_pool;
+    hipEvent_t get_sync_event() {
+        if (!sync_pool.empty()) {
+            hipEvent_t e = sync_pool.back();
+            sync_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        return e;
+    }
     std::multimap<size_t, void*> free_blocks;
     std::map<void*, size_t> live;
     size_t cached_bytes = 0;
@@ -73,6 +85,7 @@ struct rv_ctx {
     std::vector<Mark> marks;
     int cur_phase = -1;
     hipEvent_t cur_start = nullptr;
+    hipStream_t cur_stream = nullptr;
     uint64_t cur_launches = 0;
 
     hipEvent_t get_event() {
@@ -85,19 +98,21 @@ struct rv_ctx {
         (void)hipEventCreate(&e);
         return e;
     }
-    // phase(p): closes the running phase and opens p (p < 0: just close)
-    void phase(int p) {
+    // phase(p): closes the running phase and opens p (p < 0: just close); both events of a
+    // phase are recorded on the stream its kernels run on
+    void phase(int p, hipStream_t st = nullptr) {
         if (!profiling) return;
         if (cur_phase >= 0) {
             hipEvent_t e = get_event();
-            (void)hipEventRecord(e, stream);
+            (void)hipEventRecord(e, cur_stream);
             marks.push_back({cur_phase, cur_start, e, cur_launches});
         }
         cur_phase = p;
         cur_launches = 0;
         if (p >= 0) {
+            cur_stream = st ? st : stream;
             cur_start = get_event();
-            (void)hipEventRecord(cur_start, stream);
+            (void)hipEventRecord(cur_start, cur_stream);
         }
     }
     void count(uint64_t n = 1) { cur_launches += n; }
@@ -177,6 +192,7 @@ extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
     rv_ctx* c = new rv_ctx();
     c->device = device_ordinal;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete c;
         return hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
@@ -189,9 +205,11 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
     ctx->trim();
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
 }
 
@@ -365,8 +383,19 @@ struct rv_shard {
     uint64_t* d_offs = nullptr;  // [5][R]
     uint8_t* d_out = nullptr;
     std::vector<void*> extra;
+    // pipelining: the gf2 mask generator runs in chunks on ctx->stream; the interpreter (on
+    // ctx->stream2) waits for the chunk a level needs
+    std::vector<std::pair<uint64_t, hipEvent_t>> mask_chunks;  // (AES blocks complete, event)
+    hipEvent_t ev_setup = nullptr;
+    std::vector<hipEvent_t> misc_events;
 
     void destroy() {
+        for (auto& c : mask_chunks) ctx->sync_pool.push_back(c.second);
+        mask_chunks.clear();
+        for (hipEvent_t e : misc_events) ctx->sync_pool.push_back(e);
+        misc_events.clear();
+        if (ev_setup) ctx->sync_pool.push_back(ev_setup);
+        ev_setup = nullptr;
         void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk,    d_masks,  d_wires,   d_on,     d_pre,    d_wit,  d_cv[0],
                       d_cv[1], d_dig,  d_h,       d_err,   d_omit,   d_offs,    d_out,    d_masks64, d_wmask64,
                       d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64};
@@ -402,8 +431,6 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
     launch_bitslice_rk(ctx->stream, s->d_rkbytes, s->NQ, s->d_rk);
     ctx->count(2);
     ctx->phase(RV_PH_MASKS);
-    launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, 0, n_blocks, s->d_masks);
-    ctx->count(n_blocks ? 1 : 0);
     if (n_blocks64) {
         const uint32_t* rk64 = s->d_rk;  // prover: the same seeds feed both domains (proof/mod.rs:131-146)
         if (s->d_keys64) {
@@ -413,6 +440,21 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
         }
         launch_aes_z64_masks(ctx->stream, rk64, s->d_keys64 ? d_keep64 : d_keep, s->NQ, n_blocks64, s->d_masks64);
         ctx->count(1);
+    }
+    // everything the interpreter reads besides gf2 masks is queued on `stream` before this point
+    s->ev_setup = ctx->get_sync_event();
+    HIPCHK(hipEventRecord(s->ev_setup, ctx->stream));
+    // gf2 masks in chunks, one event each (the interpreter starts as soon as its first levels' masks exist)
+    {
+        const uint64_t target = std::max<uint64_t>((n_blocks + 11) / 12, 2048);
+        for (uint64_t b0 = 0; b0 < n_blocks; b0 += target) {
+            const uint64_t nb = std::min(target, n_blocks - b0);
+            launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, b0, nb, s->d_masks + (size_t)b0 * 128 * s->NQ);
+            ctx->count();
+            hipEvent_t e = ctx->get_sync_event();
+            HIPCHK(hipEventRecord(e, ctx->stream));
+            s->mask_chunks.emplace_back(b0 + nb, e);
+        }
     }
     ctx->phase(-1);
     return RV_OK;
@@ -437,12 +479,14 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
         if ((rc = dalloc(ctx, (size_t)cc.n_ssa64 * s->R, &s->d_wcorr64))) return rc;
         if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.on_words64, 1) * s->R, &s->d_on64))) return rc;
         if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.pre_words64, 1) * s->R, &s->d_pre64))) return rc;
-        HIPCHK(hipMemsetAsync(s->d_wmask64, 0, (size_t)s->R * 64, ctx->stream));
-        HIPCHK(hipMemsetAsync(s->d_wcorr64, 0, (size_t)s->R * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(s->d_wmask64, 0, (size_t)s->R * 64, ctx->stream2));
+        HIPCHK(hipMemsetAsync(s->d_wcorr64, 0, (size_t)s->R * 8, ctx->stream2));
     }
-    HIPCHK(hipMemsetAsync(s->d_err, 0, sizeof(int), ctx->stream));
-    HIPCHK(hipMemsetAsync(s->d_wires, 0, (size_t)(s->NQ / 2), ctx->stream));  // SSA 0 = default wire
-    HIPCHK(hipMemsetAsync(s->d_masks + (size_t)cc.n_masks_pad * s->NQ, 0, (size_t)s->NQ * 4, ctx->stream));  // zero row
+    hipStream_t sb = ctx->stream2;
+    if (s->ev_setup) HIPCHK(hipStreamWaitEvent(sb, s->ev_setup, 0));
+    HIPCHK(hipMemsetAsync(s->d_err, 0, sizeof(int), sb));
+    HIPCHK(hipMemsetAsync(s->d_wires, 0, (size_t)(s->NQ / 2), sb));  // SSA 0 = default wire
+    HIPCHK(hipMemsetAsync(s->d_masks + (size_t)cc.n_masks_pad * s->NQ, 0, (size_t)s->NQ * 4, sb));  // zero row
     p.NQ = s->NQ;
     p.rows = s->d_masks;
     p.corr = s->d_wires;
@@ -462,17 +506,29 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
     p64.masks2 = s->d_masks;
     p64.NQ = s->NQ;
     p64.err = s->d_err;
-    ctx->phase(RV_PH_INTERP);
+    ctx->phase(RV_PH_INTERP, sb);
+    size_t waited = 0;  // mask chunks already waited for
     for (size_t l = 0; l < n_levels; l++) {
+        while (waited < s->mask_chunks.size() &&
+               (waited == 0 ? 0 : s->mask_chunks[waited - 1].first) < cc.level_need_blocks[l]) {
+            HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
+            waited++;
+        }
         if (cc.level_start[l + 1] > cc.level_start[l]) {
-            launch_interp(ctx->stream, mode, s->c->d_gates, cc.level_start[l], cc.level_mul_end[l], cc.level_xor_end[l],
+            launch_interp(sb, mode, s->c->d_gates, cc.level_start[l], cc.level_mul_end[l], cc.level_xor_end[l],
                           cc.level_start[l + 1], p);
             ctx->count();
         }
         if (has64 && cc.level_start64[l + 1] > cc.level_start64[l]) {
-            launch_interp64(ctx->stream, mode, s->c->d_gates64, cc.level_start64[l], cc.level_start64[l + 1], p64);
+            launch_interp64(sb, mode, s->c->d_gates64, cc.level_start64[l], cc.level_start64[l + 1], p64);
             ctx->count();
         }
+    }
+    {
+        hipEvent_t done = ctx->get_sync_event();
+        HIPCHK(hipEventRecord(done, sb));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, done, 0));
+        s->misc_events.push_back(done);
     }
     ctx->phase(RV_PH_HASH);
     uint32_t* dig = s->d_dig;
@@ -1028,7 +1084,6 @@ extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
         for (uint32_t r = 0; r < R; r++)
             if (omit64[r] < 8) HC(hipMemcpyAsync(s->d_keys64 + (size_t)r * 128, proof + P.z64.on[slot_begin + r].keys, 128, hipMemcpyHostToDevice, ctx->stream));
     }
-    if ((rc = shard_setup_prg(s, d_keep, d_keep64))) return fail(rc);
     ctx->phase(RV_PH_SETUP);
     ctx->count(3);
     launch_unpack_bits(ctx->stream, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
@@ -1045,6 +1100,9 @@ extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
         p64.sup_corr = d_sup_corr64;
         p64.sup_rec = d_sup_rec64;
     }
+    // the supplied-value rows above are queued before the mask chunks so the interpreter stream only
+    // has to wait for the setup event, not for the whole mask generator
+    if ((rc = shard_setup_prg(s, d_keep, d_keep64))) return fail(rc);
     InterpParams p{};
     p.on_mask = d_onm;
     p.sup_in = d_sup_in;

@@ -383,6 +383,40 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 if (g.op != G_MUL && g.op != G_XOR) out.gates[w++] = g;
         }
     }
+    // pipelining tables
+    out.level_need_blocks.assign(n_levels, 0);
+    out.level_done_on.assign(n_levels, 0);
+    {
+        std::vector<uint32_t> row_level(out.n_on, 0);
+        for (uint32_t l = 0; l < n_levels; l++) {
+            uint32_t need = l ? out.level_need_blocks[l - 1] : 0;
+            for (uint32_t i = out.level_start[l]; i < out.level_start[l + 1]; i++) {
+                const Gate& g = out.gates[i];
+                uint32_t last = 0;
+                bool uses = true;
+                if (g.op == G_MUL)
+                    last = g.m + 1;
+                else if (g.op == G_INPUT || g.op == G_RANDOM)
+                    last = g.m;
+                else
+                    uses = false;
+                if (uses) need = std::max(need, last / 128 + 1);
+                if (g.op == G_MUL || g.op == G_INPUT || g.op == G_ASSERT || g.op == G_RECON) row_level[g.eo] = l;
+            }
+            out.level_need_blocks[l] = need;
+        }
+        // aliased PRG rows are read by later levels too, but a row a gate reads through am/bm was
+        // consumed as a fresh mask by an EARLIER level's gate, so the prefix maximum covers it
+        uint64_t e = 0;
+        uint32_t run = 0;
+        for (uint32_t l = 0; l < n_levels; l++) {
+            while (e < out.n_on && std::max(run, row_level[e]) <= l) {
+                run = std::max(run, row_level[e]);
+                e++;
+            }
+            out.level_done_on[l] = (uint32_t)e;
+        }
+    }
     out.n_ssa = b.ssa_level.size();
     out.n_ssa64 = b.ssa_level64.size();
     // resolve share rows: PRG masks first (padded to whole AES blocks), computed rows after

@@ -25,6 +25,9 @@ struct Compiled {
     std::vector<uint32_t> level_start;  // gates of level l = [level_start[l], level_start[l+1])
     // inside a level gates are grouped by kind: [start, mul_end) G_MUL, [mul_end, xor_end) G_XOR, rest
     std::vector<uint32_t> level_mul_end, level_xor_end;
+    // pipelining aids (both monotone in l):
+    std::vector<uint32_t> level_need_blocks;  // AES blocks (128 masks) that levels 0..l read
+    std::vector<uint32_t> level_done_on;      // leading online-transcript rows complete once level l has run
     std::vector<uint32_t> rec_rows;     // reconstruction ordinal -> online transcript row
     std::vector<uint32_t> in_rows;      // input ordinal -> online transcript row
     uint64_t n_ssa = 1;                 // SSA wires incl. the zero wire
