@@ -212,6 +212,25 @@ int rv_verify_shard(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size
 /* Final check of Proof::verify (proof/mod.rs:283-306) from all 256 slot digests */
 int rv_verify_finish(const uint8_t *proof, size_t proof_len, const uint8_t *slot_digests /* 256 x 32 */, int *ok);
 
+/* ---- Bristol front end (host only, no GPU) ---------------------------------------------
+ * The reference's README promises Bristol-format circuits; the parser itself lives in the
+ * un-vendored `mcircuit` crate.  This turns Bristol text into the rv_op stream:
+ *   wires 0..n_in-1            -> GF2 Input(w), in wire order (= witness order)
+ *   XOR -> Add, AND -> Mul, INV / NOT -> AddConst(.., 1), EQW -> AddConst(.., 0), EQ -> Const,
+ *   MAND -> one Mul per lane
+ *   if expected_outputs != NULL: for each output wire (the last n_out wires, in order)
+ *   AddConst(tmp, w, expected) + AssertZero(tmp)  — the statement "the circuit maps the witness
+ *   to these outputs" (SURVEY §8d configs 1-3).
+ * format: 0 = auto, 1 = Bristol Fashion ("ngates nwires / niv n.. / nov n.."), 2 = old Bristol
+ * ("ngates nwires / n1 n2 n3").  ops is library-allocated (rv_free). */
+typedef struct rv_bristol_info {
+    uint64_t n_gates, n_wires, n_inputs, n_outputs;
+    uint64_t n_and, n_xor, n_inv, n_other;
+    uint64_t gf2_wires; /* wire count to pass to rv_circuit_compile (includes assertion temporaries) */
+} rv_bristol_info;
+int rv_bristol_parse(const char *text, size_t len, int format, const uint8_t *expected_outputs, rv_op **ops, size_t *n_ops,
+                     rv_bristol_info *info);
+
 /* ---- parity-test hooks: each mirrors one reference function so tests can compare the
  * HIP path with the oracle piecewise ---- */
 /* PRG::new + gen (crypto/prg.rs:16-37) on the GPU: n_keys keys, blocks [first, first+n_blocks) each */

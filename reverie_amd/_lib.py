@@ -40,6 +40,11 @@ class CircuitInfo(C.Structure):
         "z64_asserts", "z64_linear", "z64_masks", "b2a", "levels", "device_bytes", "scratch_bytes")]
 
 
+class BristolInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_gates", "n_wires", "n_inputs", "n_outputs", "n_and", "n_xor", "n_inv",
+                                          "n_other", "gf2_wires")]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("calls", C.c_uint64)]
 
@@ -54,7 +59,7 @@ SYMBOLS = [
     "rv_shard_commit", "rv_shard_digests_device", "rv_shard_digests", "rv_shard_open", "rv_shard_destroy",
     "rv_shard_open_device", "rv_combine_digests", "rv_challenge", "rv_assemble_proof", "rv_verify_shard",
     "rv_verify_finish", "rv_hook_prg_blocks", "rv_hook_expand_seed", "rv_hook_sharegen_gf2", "rv_hook_sharegen_z64",
-    "rv_hook_blake3", "rv_hook_shard_stream_digests", "rv_ctx_profile", "rv_shard_digests_to_device", "rv_shard_open_size", "rv_shard_open_into",
+    "rv_hook_blake3", "rv_hook_shard_stream_digests", "rv_ctx_profile", "rv_shard_digests_to_device", "rv_shard_open_size", "rv_shard_open_into", "rv_bristol_parse",
 ]
 
 _lib = None
