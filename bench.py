@@ -142,13 +142,23 @@ def main():
             "interp": (st["and"] * (48 + 4 * row + 3 * row // 8 + row + row // 8) + st["xor"] * (48 + 3 * row + 3 * row // 8)),
             "hash": (info["gf2_muls"] + info["gf2_inputs"] + info["gf2_asserts"]) * row + info["gf2_muls"] * row // 8,
         }
-        kname = {"masks": "k_aes_gf2_masks", "interp": "k_interp (sum over levels)", "hash": "k_b3_chunks+k_b3_parents"}[dom]
+        kname = {"masks": "k_aes_gf2_masks<16>", "interp": "k_interp_full<0>", "hash": "k_b3_chunks"}[dom]
         ach = alg[dom] / (phases[dom] * 1e-3) / 1e9 if phases[dom] > 0 else 0.0
+        # measured HBM traffic of the same workload (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+        # tools/pmc_summary.py, committed under profiles/); only valid for the default workload on 1 GPU
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if world == 1 and args.layers == 153 and args.p_and == 0.5 and os.path.exists(pmc_path):
+            pk = json.load(open(pmc_path))["kernels"]
+            key = {"masks": "rv::k_aes_gf2_masks<16>", "interp": "rv::k_interp_full<0>", "hash": "rv::k_b3_chunks"}[dom]
+            if key in pk:
+                traffic = pk[key]["hbm_bytes_per_proof"]
         roofline = {
             "bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": None,
-            "note": "integer-VALU-bound path (bitsliced AES + BLAKE3); HBM fraction reported as north_star asks. "
-                    "achieved = algorithmic bytes of the dominant phase / its HIP-event time on the library stream",
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "note": "dominant phase by HIP-event time on the library's own streams; achieved = its algorithmic HBM bytes per "
+                    "proof (DESIGN.md §4) / its event time; traffic = PMC-measured HBM bytes per proof for that kernel "
+                    "(all its launches). The mask and hash phases are integer-VALU-bound (bitsliced AES, BLAKE3): no MFMA on this path.",
             "phase_ms": phases, "phase_launches": launches,
             "algorithmic_bytes": {k: int(v) for k, v in alg.items()},
         }
