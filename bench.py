@@ -78,10 +78,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # RV_BENCH_BACKEND=gloo lets several ranks share one GPU (used only to exercise the N>1 code path
+    # on a single-GPU box; the real multi-GPU run uses RCCL)
+    backend_name = os.environ.get("RV_BENCH_BACKEND", "nccl")
+    if backend_name != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend_name)
 
     import circuits
     import reverie_amd

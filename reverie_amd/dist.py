@@ -85,6 +85,11 @@ class HipShardBackend:
         _lib.lib().rv_shard_destroy(shard[0])
 
 
+def assemble_device_parts(comm: bytes, bufs, all_lens) -> bytes:
+    """bincode(Proof) from the (tensor, lens) pairs prove_sharded(device_resident=True) returns on rank 0"""
+    return assemble(comm, [(bytes(b.cpu().numpy().tobytes()[:sum(l)]), l) for b, l in zip(bufs, all_lens)])
+
+
 def assemble(comm: bytes, parts: List[Tuple[bytes, List[int]]]) -> bytes:
     """bincode(Proof) from per-shard blobs ordered by rep_begin."""
     out = [comm]
@@ -127,10 +132,14 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
         # ---- the one collective: all-gather of per-repetition digests
         if world == 1:
             h = backend.digests(shard)
+            on_gpu = False
         else:
-            dev = torch.device("cuda", torch.cuda.current_device()) if backend.device_type == "cuda" else torch.device("cpu")
+            # RCCL ("nccl") moves device tensors over xGMI; with gloo (CPU tests, or several ranks sharing one
+            # GPU) the 8 KiB travel through host memory instead
+            on_gpu = backend.device_type == "cuda" and dist.get_backend(group) == "nccl"
+            dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
             mine = torch.empty(count * 32, dtype=torch.uint8, device=dev)
-            if backend.device_type == "cuda":
+            if on_gpu:
                 backend.digests_into(shard, mine)
             else:
                 mine.copy_(torch.from_numpy(backend.digests(shard).reshape(-1)))
@@ -147,6 +156,14 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
             if world > 1:
                 all_lens = [None] * world
                 dist.all_gather_object(all_lens, lens, group=group)
+                if not on_gpu:  # gloo has no device point-to-point: stage through the host
+                    if rank == 0:
+                        bufs = [buf.cpu()] + [torch.empty(max(sum(l), 1), dtype=torch.uint8) for l in all_lens[1:]]
+                        for r in range(1, world):
+                            dist.recv(bufs[r], src=r, group=group)
+                        return comm, bufs, all_lens
+                    dist.send(buf.cpu(), dst=0, group=group)
+                    return comm, None, None
                 if rank == 0:
                     bufs = [buf] + [torch.empty(max(sum(l), 1), dtype=torch.uint8, device="cuda") for l in all_lens[1:]]
                     reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(1, world)]
