@@ -153,16 +153,18 @@ __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, 
     }
 }
 
-// Fast path for a full shard (R = 256, NQ = 64): one wavefront = one gate, so the gate record
-// is wave-uniform (scalar loads) and the per-kind ranges run as 4-way unrolled loops that put
-// every operand row of 4 gates in flight before the first use — the generic kernel above is
-// latency-bound on the dependent gate-record -> operand-row chain (2 HBM round trips per gate).
-template <int MODE>
-__device__ __forceinline__ void mul4(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t q, uint32_t onm) {
-    constexpr uint32_t NQ = 64;
+// Fast path (NQ = 64, 32, 16 or 8, i.e. R = 256 .. 32): a wavefront covers 64/NQ gates at a time and the
+// per-kind ranges run as 4-way unrolled loops that put every operand row of 4 x 64/NQ gates in flight
+// before the first use — the generic kernel above is latency-bound on the dependent
+// gate-record -> operand-row chain (2 HBM round trips per gate).  With NQ = 64 the gate index is
+// wave-uniform and the records come through scalar loads.
+template <int MODE, int NQ>
+__device__ __forceinline__ void mul4(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
+                                     uint32_t onm) {
+    constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
     Gate g[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) g[u] = gates[g0 + u];
+    for (int u = 0; u < 4; u++) g[u] = gates[g0 + u * GPW + sub];
     uint32_t lx[4], ly[4], lab[4], lnew[4], bx[4], by[4], sc[4], sr[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -170,8 +172,8 @@ __device__ __forceinline__ void mul4(const Gate* __restrict__ gates, uint32_t g0
         ly[u] = p.rows[(size_t)g[u].bm * NQ + q];
         lab[u] = p.rows[(size_t)g[u].m * NQ + q];
         lnew[u] = p.rows[(size_t)(g[u].m + 1) * NQ + q];
-        bx[u] = p.corr[(size_t)g[u].a * 32 + (q >> 1)];
-        by[u] = p.corr[(size_t)g[u].b * 32 + (q >> 1)];
+        bx[u] = p.corr[(size_t)g[u].a * H + (q >> 1)];
+        by[u] = p.corr[(size_t)g[u].b * H + (q >> 1)];
         if (MODE == MODE_VERIFY) {
             sc[u] = p.sup_corr[(size_t)g[u].ep * NQ + q];
             sr[u] = p.sup_rec[(size_t)g[u].x * NQ + q];
@@ -197,24 +199,25 @@ __device__ __forceinline__ void mul4(const Gate* __restrict__ gates, uint32_t g0
     }
 }
 
-__device__ __forceinline__ void xor4(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t q) {
-    constexpr uint32_t NQ = 64;
+template <int NQ>
+__device__ __forceinline__ void xor4(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q) {
+    constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
     Gate g[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) g[u] = gates[g0 + u];
+    for (int u = 0; u < 4; u++) g[u] = gates[g0 + u * GPW + sub];
     uint32_t x[4], y[4], bx[4], by[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         x[u] = p.rows[(size_t)g[u].am * NQ + q];
         y[u] = p.rows[(size_t)g[u].bm * NQ + q];
-        // 32 corr bytes per wire: lanes 0..31 carry them
-        bx[u] = (q < 32) ? p.corr[(size_t)g[u].a * 32 + q] : 0;
-        by[u] = (q < 32) ? p.corr[(size_t)g[u].b * 32 + q] : 0;
+        // H corr bytes per wire: the first H lanes of the gate's lane group carry them
+        bx[u] = (q < H) ? p.corr[(size_t)g[u].a * H + q] : 0;
+        by[u] = (q < H) ? p.corr[(size_t)g[u].b * H + q] : 0;
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         p.rows[(size_t)g[u].dm * NQ + q] = x[u] ^ y[u];
-        if (q < 32) p.corr[(size_t)g[u].dst * 32 + q] = (uint8_t)(bx[u] ^ by[u]);
+        if (q < H) p.corr[(size_t)g[u].dst * H + q] = (uint8_t)(bx[u] ^ by[u]);
     }
 }
 
@@ -223,42 +226,54 @@ __device__ __forceinline__ void interp_one(const Gate& g, const InterpParams& p,
     interp_one_impl<MODE>(g, p, NQ, q, onm);
 }
 
-template <int MODE>
+template <int MODE, int NQ>
 __global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end,
                                                      uint32_t hi, InterpParams p) {
-    const uint32_t q = threadIdx.x & 63;
+    constexpr uint32_t GPW = 64 / NQ;  // gates per wavefront per step
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t q = lane % NQ, sub = lane / NQ;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[q] : 0u;
+    constexpr uint32_t STEP = 4 * GPW;
     // G_MUL range
     {
-        const uint32_t full = lo + ((mul_end - lo) & ~3u);
-        for (uint32_t g0 = lo + wave * 4; g0 < full; g0 += n_waves * 4) mul4<MODE>(gates, g0, p, q, onm);
-        for (uint32_t gi = full + wave; gi < mul_end; gi += n_waves) interp_one<MODE>(gates[gi], p, 64, q, onm);
+        const uint32_t full = lo + ((mul_end - lo) / STEP) * STEP;
+        for (uint32_t g0 = lo + wave * STEP; g0 < full; g0 += n_waves * STEP) mul4<MODE, NQ>(gates, g0, p, sub, q, onm);
+        for (uint32_t gi = full + wave * GPW + sub; gi < mul_end; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
     }
     // G_XOR range
     {
-        const uint32_t full = mul_end + ((xor_end - mul_end) & ~3u);
-        for (uint32_t g0 = mul_end + wave * 4; g0 < full; g0 += n_waves * 4) xor4(gates, g0, p, q);
-        for (uint32_t gi = full + wave; gi < xor_end; gi += n_waves) interp_one<MODE>(gates[gi], p, 64, q, onm);
+        const uint32_t full = mul_end + ((xor_end - mul_end) / STEP) * STEP;
+        for (uint32_t g0 = mul_end + wave * STEP; g0 < full; g0 += n_waves * STEP) xor4<NQ>(gates, g0, p, sub, q);
+        for (uint32_t gi = full + wave * GPW + sub; gi < xor_end; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
     }
-    for (uint32_t gi = xor_end + wave; gi < hi; gi += n_waves) interp_one<MODE>(gates[gi], p, 64, q, onm);
+    for (uint32_t gi = xor_end + wave * GPW + sub; gi < hi; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
+}
+
+template <int NQ>
+static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end,
+                               uint32_t hi, const InterpParams& p) {
+    constexpr uint32_t GPW = 64 / NQ;
+    uint64_t waves = ((uint64_t)(hi - lo) + 4 * GPW - 1) / (4 * GPW);
+    uint64_t blocks = (waves + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (mode == MODE_PROVE)
+        hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, mul_end, xor_end, hi, p);
+    else
+        hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, mul_end, xor_end, hi, p);
 }
 
 void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end, uint32_t hi,
                    const InterpParams& p) {
     if (hi <= lo) return;
-    if (p.NQ == 64) {
-        // one gate per wavefront per step, 4 gates per unrolled step
-        uint64_t waves = ((uint64_t)(hi - lo) + 3) / 4;
-        uint64_t blocks = (waves + 3) / 4;
-        if (blocks > 4096) blocks = 4096;
-        if (blocks < 1) blocks = 1;
-        if (mode == MODE_PROVE)
-            hipLaunchKernelGGL(k_interp_full<MODE_PROVE>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, mul_end, xor_end, hi, p);
-        else
-            hipLaunchKernelGGL(k_interp_full<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, mul_end, xor_end, hi, p);
-        return;
+    switch (p.NQ) {
+    case 64: return launch_interp_full<64>(st, mode, d_gates, lo, mul_end, xor_end, hi, p);
+    case 32: return launch_interp_full<32>(st, mode, d_gates, lo, mul_end, xor_end, hi, p);
+    case 16: return launch_interp_full<16>(st, mode, d_gates, lo, mul_end, xor_end, hi, p);
+    case 8: return launch_interp_full<8>(st, mode, d_gates, lo, mul_end, xor_end, hi, p);
+    default: break;
     }
     const uint64_t want = (uint64_t)(hi - lo) * p.NQ;
     uint64_t blocks = (want + 255) / 256;
