@@ -59,6 +59,76 @@ def cpu_baseline(sample_layers: int):
     }, (prog, wit, wc, seeds, proof)
 
 
+def secondary(args, local):
+    """Configs 2, 3, 5: single-proof latency and batched throughput through the plain
+    rv_prove / rv_verify entry points (host bytes in, host bytes out), checked against the oracle."""
+    import hashlib
+    import threading
+
+    import bristol_gen
+    import circuits
+    import oracle_lib
+    import reverie_amd
+    from reverie_amd import bristol
+
+    seeds = rule_seeds()
+    if args.workload == "aes128":
+        key = bytes(range(16)); pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+        bits = lambda d: [(b >> (7 - k)) & 1 for b in d for k in range(8)]  # noqa: E731
+        prog, info = bristol.parse(bristol_gen.aes128(), expected_outputs=bits(bytes.fromhex("69c4e0d86a7b0430d8cdb78070b4c55a")))
+        w2, w64, wc, unit_n, unit = bits(key) + bits(pt), [], info["wire_counts"], info["n_and"], "AND gates/s"
+    elif args.workload == "sha256":
+        block = b"abc" + b"\x80" + bytes(52) + (24).to_bytes(8, "big")
+        bits = lambda d: [(b >> (7 - k)) & 1 for b in d for k in range(8)]  # noqa: E731
+        prog, info = bristol.parse(bristol_gen.sha256_block(), expected_outputs=bits(hashlib.sha256(b"abc").digest()))
+        w2, w64, wc, unit_n, unit = bits(block), [], info["wire_counts"], info["n_and"], "AND gates/s"
+    else:
+        prog, w64, wc, st = circuits.layered_z64(n_mul=args.z64_muls)
+        w2, unit_n, unit = [], st["mul"], "Z64 MUL gates/s"
+    ctxs = [reverie_amd.Context(local) for _ in range(args.batch)]
+    t0 = time.perf_counter()
+    circs = [reverie_amd.Circuit(prog, wc, c) for c in ctxs]
+    compile_s = (time.perf_counter() - t0) / args.batch
+    info = circs[0].info
+    proofs = [None] * args.batch
+
+    def worker(i, n):
+        for _ in range(n):
+            proofs[i] = reverie_amd.Proof.new(circs[i], w2, w64, seeds=seeds)
+
+    def run(n):
+        th = [threading.Thread(target=worker, args=(i, n)) for i in range(args.batch)]
+        t = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return time.perf_counter() - t
+
+    run(args.warmup)
+    dt = run(args.steps)
+    t0 = time.perf_counter()
+    ok = proofs[0].verify(circs[0])
+    verify_s = time.perf_counter() - t0
+    res = {
+        "metric": f"prover {unit} ({args.workload}); secondary config", "value": unit_n * args.steps * args.batch / dt, "unit": unit,
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64" if args.workload == "z64" else "u32", "data": "synthetic",
+        "config": {"workload": args.workload, "batch_in_flight": args.batch, "levels": info["levels"], "n_ops": info["n_ops"],
+                   "units_per_proof": unit_n, "compile_s": compile_s, "proof_bytes": len(proofs[0]),
+                   "latency_ms_per_proof": dt / args.steps * 1e3, "verify_ms": verify_s * 1e3, "verify_ok": ok,
+                   "boundary": "host bytes in / host proof bytes out (rv_prove), PCIe included"},
+    }
+    if not args.no_cpu_baseline and args.workload != "z64":
+        t0 = time.perf_counter()
+        want = oracle_lib.prove(prog, w2, w64, wc, seeds, threads=min(32, os.cpu_count() or 1))
+        cdt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": unit_n / cdt, "unit": unit, "cores": min(32, os.cpu_count() or 1), "kind": "port",
+                               "sample": f"the same circuit, 1 proof, {cdt * 1e3:.1f} ms"}
+        res["parity"] = {"proof_bit_exact_vs_cpu": bytes(proofs[0]) == want}
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +137,10 @@ def main():
     ap.add_argument("--layers", type=int, default=153, help="circuit depth (153 = the BASELINE workload)")
     ap.add_argument("--p-and", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="layered", choices=["layered", "aes128", "sha256", "z64"],
+                    help="layered = the headline BASELINE config 4; the others are the secondary configs 2, 3 and 5")
+    ap.add_argument("--batch", type=int, default=1, help="secondary workloads: independent proofs in flight (one context each)")
+    ap.add_argument("--z64-muls", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-layers", type=int, default=24)
     args = ap.parse_args()
 
@@ -96,6 +170,8 @@ def main():
     from reverie_amd import _lib
     from reverie_amd.dist import HipShardBackend, prove_sharded
 
+    if args.workload != "layered":
+        return secondary(args, local)
     ctx = reverie_amd.Context(local)
     prog, wit, wc, st = circuits.layered_gf2(layers=args.layers, p_and=args.p_and)
     t0 = time.perf_counter()

@@ -244,6 +244,10 @@ struct rv_circuit {
     Gate64* d_gates64 = nullptr;
     uint64_t* d_rec_offs64 = nullptr;
     uint64_t* d_in_offs64 = nullptr;
+    uint32_t* d_level_start = nullptr;
+    // maximal runs [first, last) of consecutive narrow GF(2)-only levels, executed by one workgroup each
+    std::vector<std::pair<uint32_t, uint32_t>> narrow_runs;
+    std::vector<int32_t> run_of_level;  // index into narrow_runs or -1
 };
 
 static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
@@ -285,11 +289,35 @@ extern "C" int rv_circuit_compile(rv_ctx* ctx, const rv_op* ops, size_t n_ops, s
         (rc = up(cc.in_rows.data(), cc.in_rows.size() * 4, (void**)&c->d_in_rows)) ||
         (rc = up(cc.gates64.data(), cc.gates64.size() * sizeof(Gate64), (void**)&c->d_gates64)) ||
         (rc = up(cc.rec_offs64.data(), cc.rec_offs64.size() * 8, (void**)&c->d_rec_offs64)) ||
-        (rc = up(cc.in_offs64.data(), cc.in_offs64.size() * 8, (void**)&c->d_in_offs64))) {
+        (rc = up(cc.in_offs64.data(), cc.in_offs64.size() * 8, (void**)&c->d_in_offs64)) ||
+        (rc = up(cc.level_start.data(), cc.level_start.size() * 4, (void**)&c->d_level_start))) {
         rv_circuit_destroy(c);
         return rc;
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    {
+        const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+        c->run_of_level.assign(n_levels, -1);
+        const uint32_t NARROW = 64;  // gates; one 1024-thread workgroup covers 16 full-width gates per step
+        size_t l = 0;
+        while (l < n_levels) {
+            auto narrow = [&](size_t i) {
+                const bool no64 = cc.level_start64.empty() || cc.level_start64[i + 1] == cc.level_start64[i];
+                return no64 && cc.level_start[i + 1] - cc.level_start[i] <= NARROW;
+            };
+            if (!narrow(l)) {
+                l++;
+                continue;
+            }
+            size_t e = l;
+            while (e < n_levels && narrow(e)) e++;
+            if (e - l >= 3) {
+                for (size_t i = l; i < e; i++) c->run_of_level[i] = (int32_t)c->narrow_runs.size();
+                c->narrow_runs.emplace_back((uint32_t)l, (uint32_t)e);
+            }
+            l = e;
+        }
+    }
     c->cc.info.device_bytes = cc.gates.size() * sizeof(Gate) + (cc.rec_rows.size() + cc.in_rows.size()) * 4 +
                               cc.gates64.size() * sizeof(Gate64) + (cc.rec_offs64.size() + cc.in_offs64.size()) * 8;
     c->cc.info.scratch_bytes = scratch_bytes_for(cc, RV_TOTAL_REPS);
@@ -305,6 +333,7 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     c->ctx->release(c->d_gates64);
     c->ctx->release(c->d_rec_offs64);
     c->ctx->release(c->d_in_offs64);
+    c->ctx->release(c->d_level_start);
     delete c;
 }
 
@@ -513,6 +542,21 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
                (waited == 0 ? 0 : s->mask_chunks[waited - 1].first) < cc.level_need_blocks[l]) {
             HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
             waited++;
+        }
+        if (s->c->run_of_level[l] >= 0) {
+            // a run of narrow levels: one launch for the whole run (its mask needs were waited for above
+            // level by level as the loop advances, so wait for the run's last level first)
+            const auto& run = s->c->narrow_runs[(size_t)s->c->run_of_level[l]];
+            if (l == run.first) {
+                while (waited < s->mask_chunks.size() &&
+                       (waited == 0 ? 0 : s->mask_chunks[waited - 1].first) < cc.level_need_blocks[run.second - 1]) {
+                    HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
+                    waited++;
+                }
+                launch_interp_narrow(sb, mode, s->c->d_gates, s->c->d_level_start, run.first, run.second, p);
+                ctx->count();
+            }
+            continue;
         }
         if (cc.level_start[l + 1] > cc.level_start[l]) {
             launch_interp(sb, mode, s->c->d_gates, cc.level_start[l], cc.level_mul_end[l], cc.level_xor_end[l],

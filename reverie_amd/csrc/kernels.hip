@@ -265,6 +265,38 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, ui
         hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, mul_end, xor_end, hi, p);
 }
 
+// Narrow levels (deep circuits: ripple-carry adders, AES/SHA rounds) would be launch-bound at one
+// kernel per level (~4.6 us each).  A run of consecutive narrow levels is executed by ONE 1024-thread
+// workgroup instead: level -> __syncthreads() -> level ...; all waves share the CU's L1, so the
+// workgroup-scope barrier is all the ordering the row/corr hand-off between levels needs.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_interp_narrow(const Gate* __restrict__ gates, const uint32_t* __restrict__ level_start,
+                                                        uint32_t l0, uint32_t l1, InterpParams p) {
+    const uint32_t NQ = p.NQ;
+    const uint32_t q = threadIdx.x % NQ;
+    const uint32_t worker = threadIdx.x / NQ, n_workers = 1024 / NQ;
+    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[q] : 0u;
+    uint32_t lo = level_start[l0];
+    for (uint32_t l = l0; l < l1; l++) {
+        const uint32_t hi = level_start[l + 1];
+        for (uint32_t gi = lo + worker; gi < hi; gi += n_workers) {
+            const Gate g = gates[gi];
+            interp_one_impl<MODE>(g, p, NQ, q, onm);
+        }
+        lo = hi;
+        __syncthreads();
+    }
+}
+
+void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const uint32_t* d_level_start, uint32_t l0, uint32_t l1,
+                          const InterpParams& p) {
+    if (l1 <= l0) return;
+    if (mode == MODE_PROVE)
+        hipLaunchKernelGGL(k_interp_narrow<MODE_PROVE>, dim3(1), dim3(1024), 0, st, d_gates, d_level_start, l0, l1, p);
+    else
+        hipLaunchKernelGGL(k_interp_narrow<MODE_VERIFY>, dim3(1), dim3(1024), 0, st, d_gates, d_level_start, l0, l1, p);
+}
+
 void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end, uint32_t hi,
                    const InterpParams& p) {
     if (hi <= lo) return;
