@@ -59,6 +59,7 @@ struct rv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // setup, AES masks, hashing, openings (VALU-heavy work)
     hipStream_t stream2 = nullptr;  // the interpreter (HBM-bound), pipelined against the mask generator
+    bool pipeline = true;           // RV_PIPELINE=0: one stream, phases strictly back to back (isolated kernel timing)
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
         if (!sync_pool.empty()) {
@@ -191,6 +192,7 @@ extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
     HIPCHK(hipSetDevice(device_ordinal));
     rv_ctx* c = new rv_ctx();
     c->device = device_ordinal;
+    if (const char* e = getenv("RV_PIPELINE")) c->pipeline = atoi(e) != 0;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (se != hipSuccess) {
@@ -475,7 +477,7 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
     HIPCHK(hipEventRecord(s->ev_setup, ctx->stream));
     // gf2 masks in chunks, one event each (the interpreter starts as soon as its first levels' masks exist)
     {
-        const uint64_t target = std::max<uint64_t>((n_blocks + 11) / 12, 2048);
+        const uint64_t target = ctx->pipeline ? std::max<uint64_t>((n_blocks + 11) / 12, 2048) : std::max<uint64_t>(n_blocks, 1);
         for (uint64_t b0 = 0; b0 < n_blocks; b0 += target) {
             const uint64_t nb = std::min(target, n_blocks - b0);
             launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, b0, nb, s->d_masks + (size_t)b0 * 128 * s->NQ);
@@ -508,11 +510,11 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
         if ((rc = dalloc(ctx, (size_t)cc.n_ssa64 * s->R, &s->d_wcorr64))) return rc;
         if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.on_words64, 1) * s->R, &s->d_on64))) return rc;
         if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.pre_words64, 1) * s->R, &s->d_pre64))) return rc;
-        HIPCHK(hipMemsetAsync(s->d_wmask64, 0, (size_t)s->R * 64, ctx->stream2));
-        HIPCHK(hipMemsetAsync(s->d_wcorr64, 0, (size_t)s->R * 8, ctx->stream2));
+        HIPCHK(hipMemsetAsync(s->d_wmask64, 0, (size_t)s->R * 64, ctx->pipeline ? ctx->stream2 : ctx->stream));
+        HIPCHK(hipMemsetAsync(s->d_wcorr64, 0, (size_t)s->R * 8, ctx->pipeline ? ctx->stream2 : ctx->stream));
     }
-    hipStream_t sb = ctx->stream2;
-    if (s->ev_setup) HIPCHK(hipStreamWaitEvent(sb, s->ev_setup, 0));
+    hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
+    if (s->ev_setup && ctx->pipeline) HIPCHK(hipStreamWaitEvent(sb, s->ev_setup, 0));
     HIPCHK(hipMemsetAsync(s->d_err, 0, sizeof(int), sb));
     HIPCHK(hipMemsetAsync(s->d_wires, 0, (size_t)(s->NQ / 2), sb));  // SSA 0 = default wire
     HIPCHK(hipMemsetAsync(s->d_masks + (size_t)cc.n_masks_pad * s->NQ, 0, (size_t)s->NQ * 4, sb));  // zero row
