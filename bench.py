@@ -105,8 +105,16 @@ def secondary(args, local):
             x.join()
         return time.perf_counter() - t
 
+    import ctypes as C2
+
+    from reverie_amd import _lib as L2
+
     run(args.warmup)
+    L2.lib().rv_ctx_profile(ctxs[0].handle, 1, 1, None)
     dt = run(args.steps)
+    prof = L2.Profile()
+    L2.lib().rv_ctx_profile(ctxs[0].handle, 0, 0, C2.byref(prof))
+    phases = {n: prof.ms[i] / max(args.steps, 1) for i, n in enumerate(L2.PHASES)}
     t0 = time.perf_counter()
     ok = proofs[0].verify(circs[0])
     verify_s = time.perf_counter() - t0
@@ -117,6 +125,7 @@ def secondary(args, local):
         "config": {"workload": args.workload, "batch_in_flight": args.batch, "levels": info["levels"], "n_ops": info["n_ops"],
                    "units_per_proof": unit_n, "compile_s": compile_s, "proof_bytes": len(proofs[0]),
                    "latency_ms_per_proof": dt / args.steps * 1e3, "verify_ms": verify_s * 1e3, "verify_ok": ok,
+                   "phase_ms_ctx0": phases,
                    "boundary": "host bytes in / host proof bytes out (rv_prove), PCIe included"},
     }
     if not args.no_cpu_baseline and args.workload != "z64":

@@ -329,7 +329,7 @@ __device__ __forceinline__ void transpose32(uint32_t* A) {
 // 128 bit-planes of a lane are transposed back to two little-endian u64 per (rep, player)
 // slot.  masks64[(2j+h)*S + slot] with S = NQ*32 slots, slot = rep*8 + player.
 template <int QW>
-__global__ __launch_bounds__(256) void k_aes_z64_masks(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep,
+__global__ __launch_bounds__(512, 2) void k_aes_z64_masks(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep,
                                                        uint32_t NQ, uint64_t n_blocks, uint32_t blocks_per_wg,
                                                        uint64_t* __restrict__ masks64) {
     __shared__ uint32_t lds_rk[11 * 128 * QW];
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_aes_z64_masks(const uint32_t* __restric
     const uint32_t n_qg = NQ / QW;
     const uint32_t qg = blockIdx.x % n_qg;
     const uint64_t chunk = blockIdx.x / n_qg;
-    for (uint32_t i = threadIdx.x; i < 11 * 128 * QW; i += 256) lds_rk[i] = rk[(size_t)(i / QW) * NQ + qg * QW + (i % QW)];
+    for (uint32_t i = threadIdx.x; i < 11 * 128 * QW; i += 512) lds_rk[i] = rk[(size_t)(i / QW) * NQ + qg * QW + (i % QW)];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ql = lane % QW, jsub = lane / QW;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_aes_z64_masks(const uint32_t* __restric
     const uint64_t S = (uint64_t)NQ * 32;
     const uint64_t j_lo = chunk * blocks_per_wg;
     const uint64_t j_hi = (j_lo + blocks_per_wg < n_blocks) ? j_lo + blocks_per_wg : n_blocks;
-    for (uint64_t jb = j_lo + (uint64_t)wave * JW; jb < j_hi; jb += 4 * JW) {
+    for (uint64_t jb = j_lo + (uint64_t)wave * JW; jb < j_hi; jb += 8 * JW) {
         const uint64_t j = jb + jsub;
         if (j >= j_hi) continue;
         uint32_t s[128], t[128];
@@ -420,10 +420,10 @@ static void launch_z64_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t* 
                           uint64_t* d_masks64) {
     const uint32_t n_qg = NQ / QW;
     constexpr uint32_t JW = 64 / QW;
-    uint64_t per = (n_blocks * n_qg + 1023) / 1024;
-    per = ((per + 4 * JW - 1) / (4 * JW)) * (4 * JW);
+    uint64_t per = (n_blocks * n_qg + 511) / 512;
+    per = ((per + 8 * JW - 1) / (8 * JW)) * (8 * JW);
     const uint64_t chunks = (n_blocks + per - 1) / per;
-    hipLaunchKernelGGL(k_aes_z64_masks<QW>, dim3((unsigned)(chunks * n_qg)), dim3(256), 0, st, d_rk, d_keep, NQ, n_blocks,
+    hipLaunchKernelGGL(k_aes_z64_masks<QW>, dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_rk, d_keep, NQ, n_blocks,
                        (uint32_t)per, d_masks64);
 }
 

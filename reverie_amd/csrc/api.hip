@@ -690,7 +690,10 @@ struct OpenLayout {
     size_t len[4], base[4], total;
 };
 
-static OpenLayout open_layout(const Compiled& cc, const uint8_t* omit_local, uint32_t R) {
+// `framed`: leave room for the bincode framing of a whole Proof around the four sections
+// (comm[32] | u64 n | gf2_online | u64 n | gf2_pre | u64 n | z64_online | u64 n | z64_pre), so a
+// single-shard proof can be produced in its final layout on the device and copied out once
+static OpenLayout open_layout(const Compiled& cc, const uint8_t* omit_local, uint32_t R, bool framed = false) {
     OpenLayout L{};
     // GF(2) vectors: 8 items per byte, plus the always-present extra chunk
     L.l2r = cc.n_rec / 8 + 1;
@@ -707,8 +710,9 @@ static OpenLayout open_layout(const Compiled& cc, const uint8_t* omit_local, uin
     L.len[1] = (size_t)L.n_pre * 48;
     L.len[2] = (size_t)L.n_on * L.sz64;
     L.len[3] = (size_t)L.n_pre * 48;
-    size_t off = 0;
+    size_t off = framed ? 32 : 0;
     for (int k = 0; k < 4; k++) {
+        if (framed) off += 8;
         L.base[k] = off;
         off += L.len[k];
     }
@@ -723,7 +727,8 @@ extern "C" int rv_shard_open_size(const rv_shard* s, const uint8_t omit[RV_TOTAL
     return RV_OK;
 }
 
-static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void* dst, void** dptr, size_t lens[4]);
+static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void* dst, void** dptr, size_t lens[4],
+                           bool framed = false);
 
 extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void** dptr, size_t lens[4]) {
     return shard_open_impl(s, omit, nullptr, dptr, lens);
@@ -735,7 +740,7 @@ extern "C" int rv_shard_open_into(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS]
     return shard_open_impl(s, omit, dst_device, &d, lens);
 }
 
-static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void* dst, void** dptr, size_t lens[4]) {
+static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void* dst, void** dptr, size_t lens[4], bool framed) {
     if (!s || !omit || !dptr || !lens) return RV_E_ARG;
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
@@ -743,7 +748,7 @@ static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void*
     const uint8_t* om = omit + s->rep_begin;
     for (uint32_t r = 0; r < s->R; r++)
         if (om[r] > 8) return RV_E_ARG;
-    const OpenLayout L = open_layout(cc, om, s->R);
+    const OpenLayout L = open_layout(cc, om, s->R, framed);
     std::vector<uint64_t> offs((size_t)8 * s->R);  // off2, off64, gf2 rec/corr/in dst, z64 rec/corr/in dst
     uint32_t k_on = 0, k_pre = 0;
     for (uint32_t r = 0; r < s->R; r++) {
@@ -899,14 +904,35 @@ extern "C" int rv_prove(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2
     if (rc) return rc;
     std::vector<uint8_t> h(RV_TOTAL_REPS * 32);
     uint8_t comm[32], omit[RV_TOTAL_REPS];
-    rv_shard_parts parts{};
-    if (!(rc = rv_shard_digests(s, h.data())) && !(rc = rv_combine_digests(h.data(), comm)) && !(rc = rv_challenge(comm, omit)) &&
-        !(rc = rv_shard_open(s, omit, &parts)))
-        rc = rv_assemble_proof(comm, &parts, 1, proof, proof_len);
-    free(parts.gf2_online);
-    free(parts.gf2_pre);
-    free(parts.z64_online);
-    free(parts.z64_pre);
+    uint8_t* out = nullptr;
+    do {
+        if ((rc = rv_shard_digests(s, h.data())) || (rc = rv_combine_digests(h.data(), comm)) || (rc = rv_challenge(comm, omit))) break;
+        // the whole proof is laid out on the device in its final bincode form and leaves in ONE copy
+        void* d = nullptr;
+        size_t lens[4];
+        if ((rc = shard_open_impl(s, omit, nullptr, &d, lens, true))) break;
+        const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
+        out = (uint8_t*)malloc(total);
+        if (!out) {
+            rc = RV_E_NOMEM;
+            break;
+        }
+        if (hipMemcpyAsync(out, d, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            rc = hip_fail(hipGetLastError(), "proof D2H", __FILE__, __LINE__);
+            break;
+        }
+        memcpy(out, comm, 32);
+        size_t off = 32;
+        const uint64_t counts[4] = {RV_ONLINE_REPS, RV_PREPROCESSING_REPS, RV_ONLINE_REPS, RV_PREPROCESSING_REPS};
+        for (int k = 0; k < 4; k++) {
+            put_le64(out + off, counts[k]);
+            off += 8 + lens[k];
+        }
+        *proof = out;
+        *proof_len = total;
+        out = nullptr;
+    } while (0);
+    free(out);
     rv_shard_destroy(s);
     return rc;
 }

@@ -180,8 +180,20 @@ __global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __rest
         uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
         if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
         uint32_t m[16];
+        if (blen == 64) {  // streams are 8-byte aligned and a block is 64 B: four 16-byte loads
+            const uint4* s4 = (const uint4*)(src + 16 * b);
 #pragma unroll
-        for (int k = 0; k < 16; k++) m[k] = (4u * k < blen) ? src[16 * b + k] : 0u;
+            for (int k = 0; k < 4; k++) {
+                const uint4 v = s4[k];
+                m[4 * k] = v.x;
+                m[4 * k + 1] = v.y;
+                m[4 * k + 2] = v.z;
+                m[4 * k + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) m[k] = (4u * k < blen) ? src[16 * b + k] : 0u;
+        }
         uint32_t o[8];
         b3::compress<false>(cv, m, c, blen, flags, o);
 #pragma unroll
