@@ -6,10 +6,14 @@
 #include "rv_blake3.h"
 
 #include <pthread.h>
+#if defined(__AVX2__)
+#include <immintrin.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
 typedef uint64_t u64;
+typedef uint32_t u32;
 typedef uint8_t u8;
 
 /* ------------------------------------------------------------------ small vectors */
@@ -99,11 +103,30 @@ uint64_t rvo_gf2_reconstruct(uint64_t t) { /* gf2/domain.rs:47-63 */
 /* byte_to_shares (gf2/domain.rs:293-378): 64 bytes (k = rep*8+player) -> 8 shares;
  * share j takes bit (7-j) of every byte, byte k lands at bit (63-k). */
 static void byte_to_shares(u64 dst[8], const u8 src[64]) {
+#if defined(__AVX2__)
+    /* the reference's own method (gf2/domain.rs:293-378): movemask of the byte MSBs, then shift
+     * every byte left by one (add to itself) — 8 rounds.  _mm256_set_epi8 puts src[0] in the top
+     * lane, so movemask bit 31 <- src[0]; here the bytes are loaded in memory order and reversed. */
+    const __m256i rev = _mm256_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6,
+                                         5, 4, 3, 2, 1, 0);
+    __m256i fst = _mm256_loadu_si256((const __m256i *)src);
+    __m256i snd = _mm256_loadu_si256((const __m256i *)(src + 32));
+    /* byte k must end at movemask bit (31 - k): reverse within 128-bit lanes, then swap the lanes */
+    fst = _mm256_permute2x128_si256(_mm256_shuffle_epi8(fst, rev), _mm256_shuffle_epi8(fst, rev), 1);
+    snd = _mm256_permute2x128_si256(_mm256_shuffle_epi8(snd, rev), _mm256_shuffle_epi8(snd, rev), 1);
+    for (int j = 0; j < 8; j++) {
+        const u64 top = (u32)_mm256_movemask_epi8(fst), bot = (u32)_mm256_movemask_epi8(snd);
+        fst = _mm256_add_epi8(fst, fst);
+        snd = _mm256_add_epi8(snd, snd);
+        dst[j] = (top << 32) | bot;
+    }
+#else
     for (int j = 0; j < 8; j++) {
         u64 w = 0;
         for (int k = 0; k < 64; k++) w |= (u64)((src[k] >> (7 - j)) & 1) << (63 - k);
         dst[j] = w;
     }
+#endif
 }
 
 typedef struct {
