@@ -153,21 +153,28 @@ __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, 
     }
 }
 
+#ifndef RV_B3_RPL
+#define RV_B3_RPL 4
+#endif
+#ifndef RV_INTERP_UNROLL
+#define RV_INTERP_UNROLL 4
+#endif
+
 // Fast path (NQ = 64, 32, 16 or 8, i.e. R = 256 .. 32): a wavefront covers 64/NQ gates at a time and the
 // per-kind ranges run as 4-way unrolled loops that put every operand row of 4 x 64/NQ gates in flight
 // before the first use — the generic kernel above is latency-bound on the dependent
 // gate-record -> operand-row chain (2 HBM round trips per gate).  With NQ = 64 the gate index is
 // wave-uniform and the records come through scalar loads.
-template <int MODE, int NQ>
-__device__ __forceinline__ void mul4(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
+template <int MODE, int NQ, int U>
+__device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
                                      uint32_t onm) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
-    Gate g[4];
+    Gate g[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) g[u] = gates[g0 + u * GPW + sub];
-    uint32_t lx[4], ly[4], lab[4], lnew[4], bx[4], by[4], sc[4], sr[4];
+    for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
+    uint32_t lx[U], ly[U], lab[U], lnew[U], bx[U], by[U], sc[U], sr[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
         lx[u] = p.rows[(size_t)g[u].am * NQ + q];
         ly[u] = p.rows[(size_t)g[u].bm * NQ + q];
         lab[u] = p.rows[(size_t)g[u].m * NQ + q];
@@ -180,7 +187,7 @@ __device__ __forceinline__ void mul4(const Gate* __restrict__ gates, uint32_t g0
         }
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
         const uint32_t cx = expand4((bx[u] >> (4 * (q & 1))) & 0xFu), cy = expand4((by[u] >> (4 * (q & 1))) & 0xFu);
         const uint32_t a = recon32(lx[u]), b = recon32(ly[u]), c = recon32(lab[u]);
         uint32_t delta = (a & b) ^ c;
@@ -199,15 +206,15 @@ __device__ __forceinline__ void mul4(const Gate* __restrict__ gates, uint32_t g0
     }
 }
 
-template <int NQ>
-__device__ __forceinline__ void xor4(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q) {
+template <int NQ, int U>
+__device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
-    Gate g[4];
+    Gate g[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) g[u] = gates[g0 + u * GPW + sub];
-    uint32_t x[4], y[4], bx[4], by[4];
+    for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
+    uint32_t x[U], y[U], bx[U], by[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
         x[u] = p.rows[(size_t)g[u].am * NQ + q];
         y[u] = p.rows[(size_t)g[u].bm * NQ + q];
         // H corr bytes per wire: the first H lanes of the gate's lane group carry them
@@ -215,7 +222,7 @@ __device__ __forceinline__ void xor4(const Gate* __restrict__ gates, uint32_t g0
         by[u] = (q < H) ? p.corr[(size_t)g[u].b * H + q] : 0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
         p.rows[(size_t)g[u].dm * NQ + q] = x[u] ^ y[u];
         if (q < H) p.corr[(size_t)g[u].dst * H + q] = (uint8_t)(bx[u] ^ by[u]);
     }
@@ -235,17 +242,18 @@ __global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ ga
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[q] : 0u;
-    constexpr uint32_t STEP = 4 * GPW;
+    constexpr int U = RV_INTERP_UNROLL;
+    constexpr uint32_t STEP = U * GPW;
     // G_MUL range
     {
         const uint32_t full = lo + ((mul_end - lo) / STEP) * STEP;
-        for (uint32_t g0 = lo + wave * STEP; g0 < full; g0 += n_waves * STEP) mul4<MODE, NQ>(gates, g0, p, sub, q, onm);
+        for (uint32_t g0 = lo + wave * STEP; g0 < full; g0 += n_waves * STEP) mulU<MODE, NQ, U>(gates, g0, p, sub, q, onm);
         for (uint32_t gi = full + wave * GPW + sub; gi < mul_end; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
     }
     // G_XOR range
     {
         const uint32_t full = mul_end + ((xor_end - mul_end) / STEP) * STEP;
-        for (uint32_t g0 = mul_end + wave * STEP; g0 < full; g0 += n_waves * STEP) xor4<NQ>(gates, g0, p, sub, q);
+        for (uint32_t g0 = mul_end + wave * STEP; g0 < full; g0 += n_waves * STEP) xorU<NQ, U>(gates, g0, p, sub, q);
         for (uint32_t gi = full + wave * GPW + sub; gi < xor_end; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
     }
     for (uint32_t gi = xor_end + wave * GPW + sub; gi < hi; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
@@ -255,7 +263,7 @@ template <int NQ>
 static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end,
                                uint32_t hi, const InterpParams& p) {
     constexpr uint32_t GPW = 64 / NQ;
-    uint64_t waves = ((uint64_t)(hi - lo) + 4 * GPW - 1) / (4 * GPW);
+    uint64_t waves = ((uint64_t)(hi - lo) + RV_INTERP_UNROLL * GPW - 1) / (RV_INTERP_UNROLL * GPW);
     uint64_t blocks = (waves + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
@@ -321,46 +329,64 @@ void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, u
 // (coalesced across the quads of a row), de-interleaves the 4 repetitions of its quad
 // word into 4 x 16 message words and runs the 4 compressions back to back.
 // ------------------------------------------------------------------------------------
+// RPL = repetitions per lane (4: one lane per quad word; 1: four lanes share a quad word).  Fewer
+// repetitions per lane = more, lighter wavefronts: 4 900 chunks x 64 lanes is only 1.6 rounds of the
+// chip at 3 waves/SIMD (40 % of the time is tail), RPL = 1 gives 19 600 waves at 7+ waves/SIMD.
+template <int RPL>
 __global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ,
                                                    uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/) {
+    constexpr uint32_t SUBS = 4 / RPL;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t c = tid / NQ;
-    const uint32_t q = (uint32_t)(tid % NQ);
+    const uint32_t lanes_per_chunk = NQ * SUBS;
+    const uint64_t c = tid / lanes_per_chunk;
+    const uint32_t ql = (uint32_t)(tid % lanes_per_chunk);
+    const uint32_t q = ql / SUBS, sub = ql % SUBS;
     if (c >= n_chunks) return;
     const uint64_t ev0 = c * 1024;
     const uint64_t len = (n_events - ev0 < 1024) ? (n_events - ev0) : 1024;
     const uint32_t nblk = len == 0 ? 1 : (uint32_t)((len + 63) / 64);
-    uint32_t cv[4][8];
+    uint32_t cv[RPL][8];
 #pragma unroll
-    for (int i = 0; i < 4; i++) b3::iv(cv[i]);
+    for (int i = 0; i < RPL; i++) b3::iv(cv[i]);
     for (uint32_t b = 0; b < nblk; b++) {
         const uint64_t e0 = ev0 + 64ull * b;
         const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
         uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
         if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
         uint32_t w[64];
+        if (blen == 64) {
+            // unguarded: a per-element "load or zero" select makes hipcc branch around every load and
+            // wait for it (64 dependent round trips per block)
 #pragma unroll
-        for (int e = 0; e < 64; e++) w[e] = (e0 + e < n_events) ? stream[(e0 + e) * NQ + q] : 0u;
+            for (int e = 0; e < 64; e++) w[e] = stream[(e0 + e) * NQ + q];
+        } else {
 #pragma unroll
-        for (int i4 = 0; i4 < 4; i4++) {
+            for (int e = 0; e < 64; e++) w[e] = (e0 + e < n_events) ? stream[(e0 + e) * NQ + q] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < RPL; i++) {
+            const uint32_t i4 = sub * RPL + i;  // repetition inside the quad word; its byte counts from the MSB
+            const uint32_t sel = 3 - i4;        // byte index for v_perm (0 = LSB)
             uint32_t m[16];
-            const int sh = 24 - 8 * i4;
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                m[k] = ((w[4 * k] >> sh) & 0xFFu) | (((w[4 * k + 1] >> sh) & 0xFFu) << 8) |
-                       (((w[4 * k + 2] >> sh) & 0xFFu) << 16) | (((w[4 * k + 3] >> sh) & 0xFFu) << 24);
+            for (int k = 0; k < 16; k++) {
+                // m = byte(w[4k]) | byte(w[4k+1]) << 8 | byte(w[4k+2]) << 16 | byte(w[4k+3]) << 24: two v_perm_b32
+                const uint32_t lo = __builtin_amdgcn_perm(w[4 * k + 1], w[4 * k], 0x0c0c0400u + sel * 0x0101u);
+                const uint32_t hi = __builtin_amdgcn_perm(w[4 * k + 3], w[4 * k + 2], 0x0c0c0400u + sel * 0x0101u);
+                m[k] = lo | (hi << 16);
+            }
             uint32_t o[8];
-            b3::compress<false>(cv[i4], m, c, blen, flags, o);
+            b3::compress<false>(cv[i], m, c, blen, flags, o);
 #pragma unroll
-            for (int k = 0; k < 8; k++) cv[i4][k] = o[k];
+            for (int k = 0; k < 8; k++) cv[i][k] = o[k];
         }
     }
     const uint32_t R = NQ * 4;
 #pragma unroll
-    for (int i4 = 0; i4 < 4; i4++) {
-        uint32_t* dst = cvs + ((size_t)c * R + 4 * q + i4) * 8;
+    for (int i = 0; i < RPL; i++) {
+        uint32_t* dst = cvs + ((size_t)c * R + 4 * q + sub * RPL + i) * 8;
 #pragma unroll
-        for (int k = 0; k < 8; k++) dst[k] = cv[i4][k];
+        for (int k = 0; k < 8; k++) dst[k] = cv[i][k];
     }
 }
 
@@ -386,15 +412,19 @@ __global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restric
         if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
         // P = the nibbles of events 4k..4k+3, one per byte; repetition i4 owns nibble bit 3-i4
         uint32_t m[4][16];
+        uint32_t nbs[64];
+        if (blen == 64) {
+#pragma unroll
+            for (int e = 0; e < 64; e++) nbs[e] = stream[(e0 + e) * h + o];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 64; e++) nbs[e] = (e0 + e < n_events) ? (uint32_t)stream[(e0 + e) * h + o] : 0u;
+        }
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             uint32_t P = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint64_t e = e0 + 4 * k + j;
-                const uint32_t nb = (e < n_events) ? (uint32_t)stream[e * h + o] : 0u;
-                P |= ((nb >> sh) & 0xFu) << (8 * j);
-            }
+            for (int j = 0; j < 4; j++) P |= ((nbs[4 * k + j] >> sh) & 0xFu) << (8 * j);
 #pragma unroll
             for (int i4 = 0; i4 < 4; i4++) {
                 const uint32_t t = (P >> (3 - i4)) & 0x01010101u;
@@ -476,8 +506,8 @@ void launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_event
     uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
     {
         const uint64_t threads = n * NQ;
-        hipLaunchKernelGGL(k_b3_chunks, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, n_events, NQ, n,
-                           d_cv_a);
+        hipLaunchKernelGGL(k_b3_chunks<RV_B3_RPL>, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), 0, st,
+                           d_stream, n_events, NQ, n, d_cv_a);
     }
     b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);
 }
