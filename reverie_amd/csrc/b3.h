@@ -89,6 +89,53 @@ RV_HD void compress(const uint32_t cv[8], const uint32_t m[16], uint64_t t, uint
     }
 }
 
+// N independent compressions in lockstep (same counter / length / flags, different cv and message):
+// the G function is one 12-deep dependency chain, so a single compression only offers 4-way ILP per
+// half round; interleaving N of them keeps the VALU issuing (the transcript kernels were stalled on
+// instruction issue for half of their cycles with one compression at a time).
+#define B3_GN(a, b, c, d, mx, my)                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < N; i_++) { \
+        B3_G(v[i_][a], v[i_][b], v[i_][c], v[i_][d], m[i_][mx], m[i_][my])                        \
+    }
+#define B3_ROUNDN(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    B3_GN(0, 4, 8, 12, s0, s1)                                                          \
+    B3_GN(1, 5, 9, 13, s2, s3)                                                          \
+    B3_GN(2, 6, 10, 14, s4, s5)                                                         \
+    B3_GN(3, 7, 11, 15, s6, s7)                                                         \
+    B3_GN(0, 5, 10, 15, s8, s9)                                                         \
+    B3_GN(1, 6, 11, 12, s10, s11)                                                       \
+    B3_GN(2, 7, 8, 13, s12, s13)                                                        \
+    B3_GN(3, 4, 9, 14, s14, s15)
+
+template <int N>
+RV_HD void compress_n(uint32_t cv[N][8], const uint32_t m[N][16], uint64_t t, uint32_t blen, uint32_t flags) {
+    uint32_t v[N][16];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[i][k] = cv[i][k];
+        v[i][8] = B3_IV0;
+        v[i][9] = B3_IV1;
+        v[i][10] = B3_IV2;
+        v[i][11] = B3_IV3;
+        v[i][12] = (uint32_t)t;
+        v[i][13] = (uint32_t)(t >> 32);
+        v[i][14] = blen;
+        v[i][15] = flags;
+    }
+    B3_ROUNDN(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    B3_ROUNDN(2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8)
+    B3_ROUNDN(3, 4, 10, 12, 13, 2, 7, 14, 6, 5, 9, 0, 11, 15, 8, 1)
+    B3_ROUNDN(10, 7, 12, 9, 14, 3, 13, 15, 4, 0, 11, 2, 5, 8, 1, 6)
+    B3_ROUNDN(12, 13, 9, 11, 15, 10, 14, 8, 7, 2, 5, 3, 0, 1, 6, 4)
+    B3_ROUNDN(9, 14, 11, 5, 8, 12, 15, 1, 13, 3, 0, 10, 2, 6, 4, 7)
+    B3_ROUNDN(11, 15, 5, 0, 1, 9, 8, 6, 14, 10, 2, 12, 3, 4, 7, 13)
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) cv[i][k] = v[i][k] ^ v[i][k + 8];
+}
+
 RV_HD void iv(uint32_t cv[8]) {
     cv[0] = B3_IV0;
     cv[1] = B3_IV1;

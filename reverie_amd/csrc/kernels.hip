@@ -363,23 +363,20 @@ __global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 64; e++) w[e] = (e0 + e < n_events) ? stream[(e0 + e) * NQ + q] : 0u;
         }
+        uint32_t m[RPL][16];
 #pragma unroll
         for (int i = 0; i < RPL; i++) {
             const uint32_t i4 = sub * RPL + i;  // repetition inside the quad word; its byte counts from the MSB
             const uint32_t sel = 3 - i4;        // byte index for v_perm (0 = LSB)
-            uint32_t m[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 // m = byte(w[4k]) | byte(w[4k+1]) << 8 | byte(w[4k+2]) << 16 | byte(w[4k+3]) << 24: two v_perm_b32
                 const uint32_t lo = __builtin_amdgcn_perm(w[4 * k + 1], w[4 * k], 0x0c0c0400u + sel * 0x0101u);
                 const uint32_t hi = __builtin_amdgcn_perm(w[4 * k + 3], w[4 * k + 2], 0x0c0c0400u + sel * 0x0101u);
-                m[k] = lo | (hi << 16);
+                m[i][k] = lo | (hi << 16);
             }
-            uint32_t o[8];
-            b3::compress<false>(cv[i], m, c, blen, flags, o);
-#pragma unroll
-            for (int k = 0; k < 8; k++) cv[i][k] = o[k];
         }
+        b3::compress_n<RPL>(cv, m, c, blen, flags);  // the lane's repetitions in lockstep
     }
     const uint32_t R = NQ * 4;
 #pragma unroll
@@ -431,13 +428,7 @@ __global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restric
                 m[i4][k] = (t << 8) - t;
             }
         }
-#pragma unroll
-        for (int i4 = 0; i4 < 4; i4++) {
-            uint32_t ov[8];
-            b3::compress<false>(cv[i4], m[i4], c, blen, flags, ov);
-#pragma unroll
-            for (int k = 0; k < 8; k++) cv[i4][k] = ov[k];
-        }
+        b3::compress_n<4>(cv, m, c, blen, flags);
     }
     const uint32_t R = NQ * 4;
 #pragma unroll
