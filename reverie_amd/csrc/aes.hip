@@ -190,6 +190,12 @@ __device__ __forceinline__ void round_cols(const uint32_t* s, uint32_t* n, const
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         uint32_t col[32];
+        // this column's 32 round-key words: issued first, consumed after the four S-boxes (~320 VALU ops),
+        // so the LDS latency is covered (SQ_WAIT_ANY was 20 % of the wave cycles with the reads next to their use)
+        uint32_t rkv[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) rkv[k] = rk[(32 * c + k) * QW];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int row = 0; row < 4; row++) {
             const int src = 8 * (4 * ((c + row) & 3) + row);
@@ -211,13 +217,13 @@ __device__ __forceinline__ void round_cols(const uint32_t* s, uint32_t* n, const
             // written as 3-input XORs (v_bitop3_b32 0x96): 27 ops per byte instead of 43
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const uint32_t rkv = rk[(32 * c + 8 * r + k) * QW];
+                const uint32_t rkw = rkv[8 * r + k];
                 const uint32_t lo = d[(k + 7) & 7];  // d[k-1], d[7] for k = 0
                 uint32_t v;
                 if (k == 1 || k == 3 || k == 4)
-                    v = XOR3(XOR3(lo, d[7], a1[k]), a2[k], a3[k]) ^ rkv;
+                    v = XOR3(XOR3(lo, d[7], a1[k]), a2[k], a3[k]) ^ rkw;
                 else
-                    v = XOR3(XOR3(lo, a1[k], a2[k]), a3[k], rkv);
+                    v = XOR3(XOR3(lo, a1[k], a2[k]), a3[k], rkw);
                 n[32 * c + 8 * r + k] = v;
             }
         }
