@@ -1,0 +1,125 @@
+"""`python -m reverie_amd` — the reference's `speed-reverie` command line for this path.
+
+Mirrors /root/reference/src/main.rs:167-290: `--operation {prove,verify,oneshot,oneshot-zk,
+version_info}`, `--program-path`, `--witness-path`, `--proof-path`, the same banners and the
+same `Ok(())` / `Err("Unverifiable Proof")` result lines.  Differences, stated plainly:
+
+* program files: the reference reads bincode(`Vec<mcircuit::CombineOperation>`), whose enum
+  layout cannot be verified here.  This front end reads Bristol / Bristol
+  Fashion text (README.md:14-16), or a raw little-endian array of 24-byte `rv_op` records
+  (`--program-format rvops`).  `--expected-outputs-path` (text of 0/1) appends the output
+  assertions to a Bristol circuit (see rv_bristol_parse).
+* proofs are the same bincode bytes.
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+
+import numpy as np
+
+from .ops import OP_DTYPE, largest_wires
+from .witness import parse_witness
+
+
+def load_program(path: str, fmt: str, expected_path=None):
+    data = open(path, "rb").read()
+    if fmt == "auto":
+        fmt = "rvops" if path.endswith(".rvops") else "bristol"
+    if fmt == "rvops":
+        if len(data) % OP_DTYPE.itemsize:
+            raise SystemExit("program file is not a whole number of 24-byte rv_op records")
+        prog = np.frombuffer(data, dtype=OP_DTYPE).copy()
+        return prog, largest_wires(prog)
+    from . import bristol
+
+    exp = parse_witness(open(expected_path, "rb").read()) if expected_path else None
+    prog, info = bristol.parse(data, expected_outputs=exp)
+    return prog, info["wire_counts"]
+
+
+def evaluate_clear(prog, witness):
+    """`oneshot`: cleartext evaluation (mcircuit::evaluate_composite_program, main.rs:115-132);
+    GF(2) gates only, like the CLI's witness type.  Raises on a failing AssertZero."""
+    n = int(max(prog["dst"].max(initial=0), prog["a"].max(initial=0), prog["b"].max(initial=0))) + 1
+    v = [0] * n
+    it = iter(witness)
+    for dom, opc, _r, d, a, b, imm in prog.tolist():
+        if dom == 3:
+            continue
+        if dom != 0:
+            raise SystemExit("oneshot supports GF(2) programs only (as the reference CLI's witness parser does)")
+        if opc == 0:
+            v[d] = next(it)
+        elif opc in (2, 4):
+            v[d] = v[a] ^ v[b]
+        elif opc in (3, 5):
+            v[d] = v[a] ^ (imm & 1)
+        elif opc == 6:
+            v[d] = v[a] & v[b]
+        elif opc == 7:
+            v[d] = v[a] & (imm & 1)
+        elif opc == 8:
+            if v[a]:
+                raise SystemExit("assertion failed: wire %d is not zero" % a)
+        elif opc == 9:
+            v[d] = imm & 1
+        elif opc == 1:
+            raise SystemExit("oneshot cannot evaluate Random gates in the clear")
+    return v
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(prog="speed-reverie", description="Gotta go fast (MI355X)")
+    ap.add_argument("--operation", required=True, choices=["prove", "verify", "oneshot", "oneshot-zk", "version_info"])
+    ap.add_argument("--witness-path")
+    ap.add_argument("--program-path")
+    ap.add_argument("--proof-path")
+    ap.add_argument("--program-format", default="auto", choices=["auto", "bristol", "rvops"])
+    ap.add_argument("--expected-outputs-path")
+    return ap
+
+
+def main(argv=None) -> int:
+    ap = build_parser()
+    a = ap.parse_args(argv)
+    need = {"prove": ("program_path", "witness_path", "proof_path"), "verify": ("program_path", "proof_path"),
+            "oneshot": ("program_path", "witness_path"), "oneshot-zk": ("program_path", "witness_path"), "version_info": ()}
+    for k in need[a.operation]:
+        if getattr(a, k) is None:
+            ap.error(f"--{k.replace('_', '-')} is required for --operation {a.operation}")
+    if a.operation == "version_info":
+        from . import _lib
+
+        print("reverie_version: speed-reverie (reverie_amd, C-ABI v%d, drop-in for reverie-zk 0.3.2)" % _lib.lib().rv_abi_version())
+        return 0
+    prog, wc = load_program(a.program_path, a.program_format, a.expected_outputs_path)
+    if a.operation == "oneshot":
+        print("Evaluating program in cleartext")
+        evaluate_clear(prog, parse_witness(open(a.witness_path, "rb").read()))
+        print("()")
+        return 0
+    from .proof import Circuit, Proof
+
+    circuit = Circuit(prog, wc)
+    if a.operation in ("prove", "oneshot-zk"):
+        wit = parse_witness(open(a.witness_path, "rb").read())
+        print("Evaluating program in ~zero knowledge~")
+        proof = Proof.new(circuit, wit, [])
+        if a.operation == "prove":
+            with open(a.proof_path, "wb") as f:
+                f.write(bytes(proof))
+            print("Ok(())")
+            return 0
+    else:
+        proof = Proof(open(a.proof_path, "rb").read())
+        print("Verifying Proof")
+    if proof.verify(circuit):
+        print("Ok(())")
+        return 0
+    print('Err("Unverifiable Proof")')
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

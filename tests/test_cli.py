@@ -1,0 +1,73 @@
+"""`python -m reverie_amd` (the reference's speed-reverie CLI, main.rs:167-290) and the witness parser."""
+import os
+
+import numpy as np
+import pytest
+
+import bristol_gen
+from reverie_amd.__main__ import build_parser, evaluate_clear, load_program, main
+from reverie_amd.witness import parse_witness
+
+
+def test_witness_parser():  # witness.rs:12-60
+    assert parse_witness(b"01 1\n0x1,0\n").tolist() == [0, 1, 1, 0, 1, 0]
+    assert parse_witness("").tolist() == []
+    assert parse_witness(b"abc\n").tolist() == []
+
+
+def test_app_is_well_formed():  # main.rs:296-299 (test_app)
+    ap = build_parser()
+    a = ap.parse_args(["--operation", "prove", "--program-path", "p", "--witness-path", "w", "--proof-path", "o"])
+    assert a.operation == "prove"
+    with pytest.raises(SystemExit):
+        ap.parse_args(["--operation", "bogus"])
+    with pytest.raises(SystemExit):
+        main(["--operation", "verify", "--program-path", "p"])  # proof path required
+
+
+def test_oneshot_cleartext(tmp_path, capsys):
+    p = tmp_path / "adder.txt"
+    p.write_text(bristol_gen.adder64())
+    a, b = 3, 5
+    w = tmp_path / "wit.txt"
+    w.write_text("".join(str((a >> i) & 1) for i in range(64)) + "\n" + "".join(str((b >> i) & 1) for i in range(64)))
+    e = tmp_path / "exp.txt"
+    e.write_text("".join(str((8 >> i) & 1) for i in range(64)))
+    assert main(["--operation", "oneshot", "--program-path", str(p), "--witness-path", str(w), "--expected-outputs-path", str(e)]) == 0
+    assert "Evaluating program in cleartext" in capsys.readouterr().out
+    e.write_text("".join(str((9 >> i) & 1) for i in range(64)))
+    with pytest.raises(SystemExit):
+        main(["--operation", "oneshot", "--program-path", str(p), "--witness-path", str(w), "--expected-outputs-path", str(e)])
+    prog, wc = load_program(str(p), "auto")
+    v = evaluate_clear(prog, parse_witness(w.read_bytes()))
+    assert sum(v[len(v) - 64 + i] << i for i in range(64)) == 8
+    raw = tmp_path / "adder.rvops"
+    raw.write_bytes(prog.tobytes())
+    prog2, wc2 = load_program(str(raw), "auto")
+    assert prog2.tobytes() == prog.tobytes() and wc2 == wc
+
+
+@pytest.mark.gpu
+def test_cli_prove_verify_roundtrip(tmp_path, capsys, oracle):
+    p = tmp_path / "adder.txt"
+    p.write_text(bristol_gen.adder64())
+    a, b = 0x0123456789ABCDEF, 0xFEDCBA9876543210
+    w = tmp_path / "wit.txt"
+    w.write_text(" ".join(str((a >> i) & 1) for i in range(64)) + "\n" + " ".join(str((b >> i) & 1) for i in range(64)))
+    e = tmp_path / "exp.txt"
+    e.write_text("".join(str((((a + b) & (2**64 - 1)) >> i) & 1) for i in range(64)))
+    out = tmp_path / "proof.bin"
+    common = ["--program-path", str(p), "--expected-outputs-path", str(e)]
+    assert main(["--operation", "prove", "--witness-path", str(w), "--proof-path", str(out)] + common) == 0
+    assert main(["--operation", "verify", "--proof-path", str(out)] + common) == 0
+    assert main(["--operation", "oneshot-zk", "--witness-path", str(w)] + common) == 0
+    txt = capsys.readouterr().out
+    assert txt.count("Ok(())") == 3 and "Verifying Proof" in txt
+    # the oracle accepts the CLI's proof file; a tampered file is reported like the reference does
+    prog, wc = load_program(str(p), "auto", str(e))
+    assert oracle.verify(prog, wc, out.read_bytes())
+    bad = bytearray(out.read_bytes())
+    bad[5] ^= 1
+    out.write_bytes(bytes(bad))
+    main(["--operation", "verify", "--proof-path", str(out)] + common)
+    assert 'Err("Unverifiable Proof")' in capsys.readouterr().out
