@@ -256,7 +256,7 @@ static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
     const size_t NQ = R / 4;
     size_t b = 0;
     b += cc.n_rows * NQ * 4;
-    b += cc.n_ssa * (NQ / 2);
+    b += cc.n_rows * (NQ / 2);
     b += cc.n_on * NQ * 4 + cc.n_pre * (NQ / 2);
     b += 4 * b3_stream_scratch_words(std::max(cc.n_on, cc.n_pre), R) * 4;
     b += (size_t)R * (16 + 128 + 8 * 176) + 11 * 128 * NQ * 4;
@@ -496,7 +496,7 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     int rc;
-    if ((rc = dalloc(ctx, (size_t)cc.n_ssa * (s->NQ / 2), &s->d_wires))) return rc;
+    if ((rc = dalloc(ctx, (size_t)cc.n_rows * (s->NQ / 2), &s->d_wires))) return rc;  // corr bits per base row
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_on, 1) * s->NQ, &s->d_on))) return rc;
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * (s->NQ / 2), &s->d_pre))) return rc;
     if ((rc = dalloc(ctx, 1, &s->d_err))) return rc;
@@ -516,8 +516,9 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
     hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
     if (s->ev_setup && ctx->pipeline) HIPCHK(hipStreamWaitEvent(sb, s->ev_setup, 0));
     HIPCHK(hipMemsetAsync(s->d_err, 0, sizeof(int), sb));
-    HIPCHK(hipMemsetAsync(s->d_wires, 0, (size_t)(s->NQ / 2), sb));  // SSA 0 = default wire
-    HIPCHK(hipMemsetAsync(s->d_masks + (size_t)cc.n_masks_pad * s->NQ, 0, (size_t)s->NQ * 4, sb));  // zero row
+    // the zero row (first computed row): mask 0, corr 0
+    HIPCHK(hipMemsetAsync(s->d_wires + (size_t)cc.n_masks_pad * (s->NQ / 2), 0, (size_t)(s->NQ / 2), sb));
+    HIPCHK(hipMemsetAsync(s->d_masks + (size_t)cc.n_masks_pad * s->NQ, 0, (size_t)s->NQ * 4, sb));
     p.NQ = s->NQ;
     p.rows = s->d_masks;
     p.corr = s->d_wires;
@@ -561,8 +562,7 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
             continue;
         }
         if (cc.level_start[l + 1] > cc.level_start[l]) {
-            launch_interp(sb, mode, s->c->d_gates, cc.level_start[l], cc.level_mul_end[l], cc.level_xor_end[l],
-                          cc.level_start[l + 1], p);
+            launch_interp(sb, mode, s->c->d_gates, cc.level_range[l], p);
             ctx->count();
         }
         if (has64 && cc.level_start64[l + 1] > cc.level_start64[l]) {

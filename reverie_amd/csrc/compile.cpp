@@ -1,6 +1,8 @@
 // see compile.h
 #include "compile.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <limits>
 
@@ -8,15 +10,29 @@ namespace rv {
 
 namespace {
 
+constexpr int K = RV_LIN_K;
+constexpr uint32_t COMP = 0x80000000u;  // computed-row flag (resolved to n_masks_pad + index at the end)
+constexpr uint32_t ZERO_ROW = COMP | 0;
+
+// a wire as a linear form over base rows: XOR of b[0..n) (sorted, distinct) plus the constant c
+struct Lin {
+    uint8_t n = 0, c = 0;
+    uint32_t b[K] = {0, 0, 0};
+};
+
 struct Builder {
     Compiled& out;
+    bool counting;  // pass 1: only number the SSA wires and count how often each is read
+    int lazy_k = 1; // largest base set a wire may keep symbolically (1 = aliases and constants only)
     // GF(2)
     std::vector<Gate> gates;      // program order
     std::vector<uint32_t> level;  // per gate
-    std::vector<int32_t> ssa_level;
-    std::vector<uint32_t> ssa_row;  // share row of each SSA wire: PRG mask index, or COMP | computed-row index
-    uint32_t n_comp = 1;            // computed rows; 0 = the all-zero row
-    std::vector<uint32_t> cur;      // gf2 wire index -> current SSA id
+    std::vector<Lin> lin;         // per SSA wire (pass 2)
+    std::vector<uint32_t>& uses;  // per SSA wire: reads (filled by pass 1, read by pass 2)
+    uint32_t n_ssa = 1;
+    std::vector<int32_t> lvl_prg, lvl_comp;  // level at which a base row becomes available
+    uint32_t n_comp = 1;                     // computed rows; 0 = the all-zero row
+    std::vector<uint32_t> cur;               // gf2 wire index -> current SSA id
     // Z64
     std::vector<Gate64> gates64;
     std::vector<uint32_t> level64;
@@ -25,79 +41,210 @@ struct Builder {
     uint32_t max_level = 0;
     bool any = false;
 
-    static constexpr uint32_t COMP = 0x80000000u;
-    explicit Builder(Compiled& o) : out(o) {
-        ssa_level.push_back(-1);
-        ssa_row.push_back(COMP | 0);
+    Builder(Compiled& o, bool counting_, std::vector<uint32_t>& uses_) : out(o), counting(counting_), uses(uses_) {
+        lin.emplace_back();  // SSA 0: the default wire = constant 0
+        lvl_comp.push_back(-1);
         ssa_level64.push_back(-1);
+        if (counting) uses.assign(1, 0);
     }
 
-    uint32_t new_ssa(int32_t lvl, uint32_t row) {
-        ssa_level.push_back(lvl);
-        ssa_row.push_back(row);
-        return (uint32_t)(ssa_level.size() - 1);
+    int32_t row_level(uint32_t r) const { return (r & COMP) ? lvl_comp[r & ~COMP] : lvl_prg[r]; }
+    int32_t lin_level(const Lin& L) const {
+        int32_t l = -1;
+        for (int i = 0; i < L.n; i++) l = std::max(l, row_level(L.b[i]));
+        return l;
+    }
+    void set_prg_level(uint32_t m, int32_t l) {
+        if (lvl_prg.size() <= m) lvl_prg.resize((size_t)m + 1, -1);
+        lvl_prg[m] = l;
+    }
+    uint32_t new_ssa(const Lin& L) {
+        if (counting)
+            uses.push_back(0);
+        else
+            lin.push_back(L);
+        return n_ssa++;
     }
     uint32_t new_ssa64(int32_t lvl) {
         ssa_level64.push_back(lvl);
         return (uint32_t)(ssa_level64.size() - 1);
+    }
+    void use(uint32_t ssa) {
+        if (counting) uses[ssa]++;
     }
     void note(uint32_t lvl) {
         if (lvl > max_level) max_level = lvl;
         any = true;
     }
     void emit(const Gate& g, uint32_t lvl) {
+        if (counting) return;
         gates.push_back(g);
         level.push_back(lvl);
         note(lvl);
     }
     void emit64(const Gate64& g, uint32_t lvl) {
+        if (counting) return;
         gates64.push_back(g);
         level64.push_back(lvl);
         note(lvl);
     }
+    static Lin base(uint32_t row) {
+        Lin L;
+        L.n = 1;
+        L.b[0] = row;
+        return L;
+    }
+    static void fill(Gate& g, const Lin& A, const Lin* B) {
+        for (int i = 0; i < K; i++) {
+            g.a[i] = i < A.n ? A.b[i] : ZERO_ROW;
+            g.b[i] = (B && i < B->n) ? B->b[i] : ZERO_ROW;
+        }
+        g.op |= (uint32_t)A.n << 8 | (uint32_t)(B ? B->n : 0) << 12 | (uint32_t)A.c << 16 | (uint32_t)(B ? B->c : 0) << 17;
+    }
+
+    // materialise the XOR of up to 2K base rows (+ constant) into a computed row
+    uint32_t materialise(const uint32_t* rows, int n, uint8_t c) {
+        Gate g{};
+        g.op = G_XORK;
+        int32_t lvl = -1;
+        for (int i = 0; i < n; i++) lvl = std::max(lvl, row_level(rows[i]));
+        lvl += 1;
+        const int na = std::min(n, K);
+        for (int i = 0; i < K; i++) {
+            g.a[i] = i < na ? rows[i] : ZERO_ROW;
+            g.b[i] = (K + i < n) ? rows[K + i] : ZERO_ROW;
+        }
+        g.op |= (uint32_t)na << 8 | (uint32_t)(n - na) << 12 | (uint32_t)c << 16;
+        g.dst = COMP | n_comp++;
+        lvl_comp.push_back(lvl);
+        emit(g, (uint32_t)lvl);
+        out.info.gf2_linear++;
+        return g.dst;
+    }
 
     // ---- GF(2) primitives on SSA ids (used by plain ops and by the B2A expansion) ----
-    uint32_t g_xor(uint32_t a, uint32_t b) {
-        Gate g{};
-        g.op = G_XOR;
-        g.a = a;
-        g.b = b;
-        g.am = ssa_row[a];
-        g.bm = ssa_row[b];
-        g.dm = COMP | n_comp++;
-        const int32_t lvl = std::max(ssa_level[a], ssa_level[b]) + 1;
-        g.dst = new_ssa(lvl, g.dm);
-        emit(g, (uint32_t)lvl);
-        out.info.gf2_linear++;
-        return g.dst;
+    uint32_t g_xor(uint32_t a, uint32_t b) {  // gf2/share.rs:220-238: Add and Sub are both XOR
+        use(a);
+        use(b);
+        if (counting) return new_ssa(Lin());
+        const Lin &A = lin[a], &B = lin[b];
+        uint32_t rows[2 * K];
+        int n = 0, i = 0, j = 0;  // symmetric difference of two sorted lists (x ^ x = 0)
+        while (i < A.n || j < B.n) {
+            if (j >= B.n || (i < A.n && A.b[i] < B.b[j]))
+                rows[n++] = A.b[i++];
+            else if (i >= A.n || B.b[j] < A.b[i])
+                rows[n++] = B.b[j++];
+            else {
+                i++;
+                j++;
+            }
+        }
+        const uint8_t c = A.c ^ B.c;
+        const uint32_t f = uses[n_ssa];  // how often the result will be read
+        // keep it symbolic when that costs no more row traffic than materialising it:
+        // f readers x (n - 1) extra rows  vs  n reads + 1 write
+        const bool lazy = n <= 1 || (n <= lazy_k && (uint64_t)f * (uint32_t)(n - 1) <= (uint32_t)(n + 1));
+        Lin L;
+        if (lazy) {
+            L.n = (uint8_t)n;
+            L.c = c;
+            for (int k = 0; k < n; k++) L.b[k] = rows[k];
+        } else {
+            L = base(materialise(rows, n, c));
+        }
+        return new_ssa(L);
+    }
+    uint32_t g_xorc(uint32_t a, uint32_t cbit) {  // AddConst / SubConst: free
+        use(a);
+        if (counting) return new_ssa(Lin());
+        Lin L = lin[a];
+        L.c ^= (uint8_t)cbit;
+        return new_ssa(L);
+    }
+    uint32_t g_andc(uint32_t a, uint32_t cbit) {  // MulConst: identity or the zero wire
+        use(a);
+        if (counting) return new_ssa(Lin());
+        return new_ssa(cbit ? lin[a] : Lin());
+    }
+    uint32_t g_const(uint32_t cbit) {
+        Lin L;
+        L.c = (uint8_t)cbit;
+        return new_ssa(L);
     }
     uint32_t g_mul(uint32_t a, uint32_t b) {  // interpreter/single.rs:25-69
+        use(a);
+        use(b);
+        const uint32_t m = (uint32_t)out.n_masks;
+        out.n_masks += 2;
+        const uint32_t eo = (uint32_t)out.n_on++, ep = (uint32_t)out.n_pre++, x = (uint32_t)out.n_rec++;
+        if (counting) return new_ssa(Lin());
         Gate g{};
         g.op = G_MUL;
-        g.a = a;
-        g.b = b;
-        g.am = ssa_row[a];
-        g.bm = ssa_row[b];
-        g.m = (uint32_t)out.n_masks;
-        out.n_masks += 2;
-        g.eo = (uint32_t)out.n_on++;
-        g.ep = (uint32_t)out.n_pre++;
-        g.x = (uint32_t)out.n_rec++;
-        out.rec_rows.push_back(g.eo);
-        const int32_t lvl = std::max(ssa_level[a], ssa_level[b]) + 1;
-        g.dst = new_ssa(lvl, g.m + 1);  // the output's mask IS the fresh mask lambda_new
+        fill(g, lin[a], &lin[b]);
+        g.m = m;
+        g.eo = eo;
+        g.ep = ep;
+        g.x = x;
+        out.rec_rows.push_back(eo);
+        const int32_t lvl = std::max(lin_level(lin[a]), lin_level(lin[b])) + 1;
+        g.dst = m + 1;  // the output's mask IS the fresh mask lambda_new
+        set_prg_level(m, lvl);
+        set_prg_level(m + 1, lvl);
         emit(g, (uint32_t)lvl);
         out.info.gf2_muls++;
-        return g.dst;
+        return new_ssa(base(m + 1));
     }
     uint32_t g_random() {
+        const uint32_t m = (uint32_t)out.n_masks++;
+        if (counting) return new_ssa(Lin());
         Gate g{};
         g.op = G_RANDOM;
-        g.m = (uint32_t)out.n_masks++;
-        g.dst = new_ssa(0, g.m);
+        fill(g, Lin(), nullptr);
+        g.m = m;
+        g.dst = m;
+        set_prg_level(m, 0);
         emit(g, 0);
         out.info.gf2_linear++;
-        return g.dst;
+        return new_ssa(base(m));
+    }
+    uint32_t g_input() {
+        const uint32_t m = (uint32_t)out.n_masks++, eo = (uint32_t)out.n_on++, x = (uint32_t)out.n_in++;
+        if (counting) return new_ssa(Lin());
+        Gate g{};
+        g.op = G_INPUT;
+        fill(g, Lin(), nullptr);
+        g.m = m;
+        g.dst = m;
+        g.eo = eo;
+        g.x = x;
+        out.in_rows.push_back(eo);
+        set_prg_level(m, 0);
+        emit(g, 0);
+        out.info.gf2_inputs++;
+        return new_ssa(base(m));
+    }
+    // AssertZero (recon = false) or B2A's recorded reconstruction (recon = true, returns the result wire)
+    uint32_t g_reveal(uint32_t a, bool recon) {
+        use(a);
+        const uint32_t eo = (uint32_t)out.n_on++, x = (uint32_t)out.n_rec++;
+        if (counting) return recon ? new_ssa(Lin()) : 0;
+        Gate g{};
+        g.op = recon ? G_RECON : G_ASSERT;
+        fill(g, lin[a], nullptr);
+        g.eo = eo;
+        g.x = x;
+        out.rec_rows.push_back(eo);
+        const int32_t lvl = lin_level(lin[a]) + 1;
+        uint32_t res = 0;
+        if (recon) {
+            g.dst = COMP | n_comp++;  // {mask 0, corr = revealed value}
+            lvl_comp.push_back(lvl);
+            res = new_ssa(base(g.dst));
+        }
+        emit(g, (uint32_t)lvl);
+        out.info.gf2_asserts++;
+        return res;
     }
 };
 
@@ -114,13 +261,11 @@ void sort_by_level(const std::vector<T>& in, const std::vector<uint32_t>& lvl, u
 
 }  // namespace
 
-int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out) {
-    out = Compiled();
-    Builder b(out);
+static int run_pass(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Builder& b) {
+    Compiled& out = b.out;
     b.cur.assign(gf2_wires, 0);
     b.cur64.assign(z64_wires, 0);
     rv_circuit_info& info = out.info;
-    info.n_ops = n_ops;
     const uint64_t LIM = std::numeric_limits<uint32_t>::max() - 512;
 
     for (size_t i = 0; i < n_ops; i++) {
@@ -134,19 +279,10 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
         case RV_DOM_GF2: {
             const size_t nw = b.cur.size();
             const uint32_t cbit = (uint32_t)(op.imm & 1);
-            Gate g{};
             switch (op.opcode) {
             case RV_OP_INPUT:
                 if (op.dst >= nw) return RV_E_WIRE_OOB;
-                g.op = G_INPUT;
-                g.m = (uint32_t)out.n_masks++;
-                g.eo = (uint32_t)out.n_on++;
-                g.x = (uint32_t)out.n_in++;
-                out.in_rows.push_back(g.eo);
-                g.dst = b.new_ssa(0, g.m);
-                b.cur[op.dst] = g.dst;
-                b.emit(g, 0);
-                info.gf2_inputs++;
+                b.cur[op.dst] = b.g_input();
                 break;
             case RV_OP_RANDOM:
                 if (op.dst >= nw) return RV_E_WIRE_OOB;
@@ -154,15 +290,10 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 break;
             case RV_OP_CONST:
                 if (op.dst >= nw) return RV_E_WIRE_OOB;
-                g.op = G_CONST;
-                g.x = cbit;
-                g.dst = b.new_ssa(0, Builder::COMP | 0);
-                b.cur[op.dst] = g.dst;
-                b.emit(g, 0);
-                info.gf2_linear++;
+                b.cur[op.dst] = b.g_const(cbit);
                 break;
             case RV_OP_ADD:
-            case RV_OP_SUB:  // gf2/share.rs:220-238: Add and Sub are both XOR
+            case RV_OP_SUB:
                 if (op.dst >= nw || op.a >= nw || op.b >= nw) return RV_E_WIRE_OOB;
                 b.cur[op.dst] = b.g_xor(b.cur[op.a], b.cur[op.b]);
                 break;
@@ -172,33 +303,17 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 break;
             case RV_OP_ADDCONST:
             case RV_OP_SUBCONST:
-            case RV_OP_MULCONST: {
                 if (op.dst >= nw || op.a >= nw) return RV_E_WIRE_OOB;
-                g.a = b.cur[op.a];
-                g.op = (op.opcode == RV_OP_MULCONST) ? G_ANDC : G_XORC;
-                g.x = cbit;
-                g.am = b.ssa_row[g.a];
-                const int32_t lvl = b.ssa_level[g.a] + 1;
-                // the mask is unchanged (AddConst, MulConst 1) or zero (MulConst 0): alias, no copy
-                g.dst = b.new_ssa(lvl, (g.op == G_ANDC && !cbit) ? (Builder::COMP | 0) : g.am);
-                b.cur[op.dst] = g.dst;
-                b.emit(g, (uint32_t)lvl);
-                info.gf2_linear++;
+                b.cur[op.dst] = b.g_xorc(b.cur[op.a], cbit);
                 break;
-            }
-            case RV_OP_ASSERTZERO: {
+            case RV_OP_MULCONST:
+                if (op.dst >= nw || op.a >= nw) return RV_E_WIRE_OOB;
+                b.cur[op.dst] = b.g_andc(b.cur[op.a], cbit);
+                break;
+            case RV_OP_ASSERTZERO:
                 if (op.a >= nw) return RV_E_WIRE_OOB;
-                g.op = G_ASSERT;
-                g.a = b.cur[op.a];
-                g.am = b.ssa_row[g.a];
-                g.eo = (uint32_t)out.n_on++;
-                g.x = (uint32_t)out.n_rec++;
-                out.rec_rows.push_back(g.eo);
-                const int32_t lvl = b.ssa_level[g.a] + 1;
-                b.emit(g, (uint32_t)lvl);
-                info.gf2_asserts++;
+                b.g_reveal(b.cur[op.a], false);
                 break;
-            }
             default:
                 return RV_E_BAD_OP;
             }
@@ -326,23 +441,12 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 carry = b.g_xor(t, carry);
             }
             res[63] = b.g_xor(carry, b.g_xor(a[63], bw[63]));
-            // 5. 64 recorded reconstructions; outputs get 64 CONSECUTIVE SSA ids
+            // 5. 64 recorded reconstructions; their results occupy 64 CONSECUTIVE computed rows
             int32_t lvl_max = 0;
-            uint32_t first_out = 0;
+            const uint32_t first_out = COMP | b.n_comp;
             for (int k = 0; k < 64; k++) {
-                Gate r{};
-                r.op = G_RECON;
-                r.a = res[k];
-                r.am = b.ssa_row[r.a];
-                r.eo = (uint32_t)out.n_on++;
-                r.x = (uint32_t)out.n_rec++;
-                out.rec_rows.push_back(r.eo);
-                const int32_t lvl = b.ssa_level[r.a] + 1;
-                r.dst = b.new_ssa(lvl, Builder::COMP | 0);
-                if (k == 0) first_out = r.dst;
-                b.emit(r, (uint32_t)lvl);
-                lvl_max = std::max(lvl_max, lvl);
-                info.gf2_asserts++;
+                b.g_reveal(res[k], true);
+                if (!b.counting) lvl_max = std::max(lvl_max, b.lvl_comp.back());
             }
             // 6. z64 wire = {0 - mu, Z - kappa}
             g.a = first_out;
@@ -356,31 +460,79 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
         default:
             return RV_E_BAD_OP;
         }
-        if (out.n_masks > LIM || b.ssa_level.size() > LIM || out.n_masks64 > LIM || b.ssa_level64.size() > LIM || out.n_on > LIM)
+        if (out.n_masks > LIM || b.n_ssa > LIM || b.n_comp > LIM / 2 || out.n_masks64 > LIM || b.ssa_level64.size() > LIM ||
+            out.n_on > LIM)
             return RV_E_UNSUPPORTED;
     }
+    return RV_OK;
+}
 
+int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out) {
+    std::vector<uint32_t> uses;
+    {
+        // pass 1: SSA numbering + read counts (the materialisation rule needs each wire's fan-out)
+        Compiled scratch;
+        Builder b1(scratch, true, uses);
+        int rc = run_pass(ops, n_ops, z64_wires, gf2_wires, b1);
+        if (rc) return rc;
+    }
+    // Wide circuits run fastest with every XOR materialised (exact two-row gates, HBM-bound); deep,
+    // narrow ones (ripple-carry adders, hash rounds) are bound by the number of dependency levels, and
+    // keeping XORs of up to RV_LIN_K rows symbolic shortens the chains (SHA-256: 5 386 -> 4 291 levels,
+    // 11.2 -> 6.9 ms per proof).  Decide from the K = 1 compile; RV_LAZY_K overrides.
+    int lazy_k = 1;
+    bool forced = false;
+    if (const char* e = getenv("RV_LAZY_K")) {
+        lazy_k = std::min(std::max(atoi(e), 1), K);
+        forced = true;
+    }
+    Builder* bp = nullptr;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        out = Compiled();
+        delete bp;
+        bp = new Builder(out, false, uses);
+        bp->lazy_k = lazy_k;
+        int rc = run_pass(ops, n_ops, z64_wires, gf2_wires, *bp);
+        if (rc) {
+            delete bp;
+            return rc;
+        }
+        const uint64_t n_levels_now = bp->any ? (uint64_t)bp->max_level + 1 : 0;
+        const bool deep_narrow = n_levels_now > 256 && bp->gates.size() / n_levels_now < 64 && bp->gates.size() < 5000000;
+        if (forced || lazy_k != 1 || !deep_narrow) break;
+        lazy_k = K;
+    }
+    Builder& b = *bp;
+    struct Guard {
+        Builder* p;
+        ~Guard() { delete p; }
+    } guard{bp};
+    rv_circuit_info& info = out.info;
+    info.n_ops = n_ops;
+    const uint64_t LIM = std::numeric_limits<uint32_t>::max() - 512;
     const uint32_t n_levels = b.any ? b.max_level + 1 : 0;
     sort_by_level(b.gates, b.level, n_levels, out.gates, out.level_start);
     sort_by_level(b.gates64, b.level64, n_levels, out.gates64, out.level_start64);
-    // group each level by kind (gates of one level are independent, so any order is valid):
-    // G_MUL first, then G_XOR, then everything else — lets the kernel run tight per-kind loops
-    out.level_mul_end.assign(n_levels, 0);
-    out.level_xor_end.assign(n_levels, 0);
+    // group each level by class (gates of one level are independent, so any order is valid); see LevelRange
+    out.level_range.assign(n_levels, LevelRange{});
     {
         std::vector<Gate> tmp;
+        auto cls = [](const Gate& g) -> int {
+            const uint32_t op = g_op(g);
+            if (op == G_MUL) return (g_na(g) == 1 && g_nb(g) == 1) ? 0 : 1;
+            if (op == G_XORK) return (g_na(g) == 2 && g_nb(g) == 0) ? 2 : 3;
+            return 4;
+        };
         for (uint32_t l = 0; l < n_levels; l++) {
             const uint32_t lo = out.level_start[l], hi = out.level_start[l + 1];
             tmp.assign(out.gates.begin() + lo, out.gates.begin() + hi);
-            uint32_t w = lo;
-            for (const Gate& g : tmp)
-                if (g.op == G_MUL) out.gates[w++] = g;
-            out.level_mul_end[l] = w;
-            for (const Gate& g : tmp)
-                if (g.op == G_XOR) out.gates[w++] = g;
-            out.level_xor_end[l] = w;
-            for (const Gate& g : tmp)
-                if (g.op != G_MUL && g.op != G_XOR) out.gates[w++] = g;
+            uint32_t w = lo, ends[5];
+            for (int c = 0; c < 5; c++) {
+                for (const Gate& g : tmp)
+                    if (cls(g) == c) out.gates[w++] = g;
+                ends[c] = w;
+            }
+            out.level_range[l] = LevelRange{lo, ends[0], ends[1], ends[2], ends[3], hi};
         }
     }
     // pipelining tables
@@ -394,19 +546,20 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 const Gate& g = out.gates[i];
                 uint32_t last = 0;
                 bool uses = true;
-                if (g.op == G_MUL)
+                const uint32_t op = g_op(g);
+                if (op == G_MUL)
                     last = g.m + 1;
-                else if (g.op == G_INPUT || g.op == G_RANDOM)
+                else if (op == G_INPUT || op == G_RANDOM)
                     last = g.m;
                 else
                     uses = false;
                 if (uses) need = std::max(need, last / 128 + 1);
-                if (g.op == G_MUL || g.op == G_INPUT || g.op == G_ASSERT || g.op == G_RECON) row_level[g.eo] = l;
+                if (op == G_MUL || op == G_INPUT || op == G_ASSERT || op == G_RECON) row_level[g.eo] = l;
             }
             out.level_need_blocks[l] = need;
         }
-        // aliased PRG rows are read by later levels too, but a row a gate reads through am/bm was
-        // consumed as a fresh mask by an EARLIER level's gate, so the prefix maximum covers it
+        // PRG rows are also read as operand bases by later levels, but such a row was consumed as a
+        // fresh mask by an EARLIER level's gate, so the prefix maximum covers it
         uint64_t e = 0;
         uint32_t run = 0;
         for (uint32_t l = 0; l < n_levels; l++) {
@@ -417,20 +570,24 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
             out.level_done_on[l] = (uint32_t)e;
         }
     }
-    out.n_ssa = b.ssa_level.size();
+    out.n_ssa = b.n_ssa;
     out.n_ssa64 = b.ssa_level64.size();
     // resolve share rows: PRG masks first (padded to whole AES blocks), computed rows after
     out.n_masks_pad = (out.n_masks + 127) / 128 * 128;
     out.n_rows = out.n_masks_pad + b.n_comp;
     if (out.n_rows > LIM) return RV_E_UNSUPPORTED;
     auto fix = [&](uint32_t& r) {
-        if (r & Builder::COMP) r = (uint32_t)(out.n_masks_pad + (r & ~Builder::COMP));
+        if (r & COMP) r = (uint32_t)(out.n_masks_pad + (r & ~COMP));
     };
     for (Gate& g : out.gates) {
-        fix(g.dm);
-        fix(g.am);
-        fix(g.bm);
+        fix(g.dst);
+        for (int i = 0; i < K; i++) {
+            fix(g.a[i]);
+            fix(g.b[i]);
+        }
     }
+    for (Gate64& g : out.gates64)
+        if (g.op == G64_B2A) fix(g.a);
     info.gf2_masks = out.n_masks;
     info.z64_masks = out.n_masks64;
     info.levels = n_levels;

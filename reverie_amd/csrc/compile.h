@@ -5,6 +5,10 @@
 // Everything that is a pure function of the op list is resolved here, once per circuit:
 //   * wire reuse        -> every write gets a fresh SSA id (id 0 = the all-zero default
 //                          wire a never-written index reads as, interpreter/single.rs:16)
+//   * linear gates      -> Add/Sub/AddConst/SubConst/MulConst/Const (single.rs:71-104) are folded
+//                          away: a wire is tracked as XOR of <= RV_LIN_K base rows + a constant;
+//                          only Mul / Input / Random / AssertZero and the occasional materialising
+//                          G_XORK reach the device, and dependency depth counts those only
 //   * ShareGen::next()  -> call number `m` per gate (generator/share.rs:54-65 is a pure
 //                          counter over the op list: Input 1, Random 1, Mul 2, in order)
 //   * transcript rows   -> position of each hashed event in the online / preprocessing
@@ -23,8 +27,8 @@ namespace rv {
 struct Compiled {
     std::vector<Gate> gates;            // sorted by level, program order inside a level
     std::vector<uint32_t> level_start;  // gates of level l = [level_start[l], level_start[l+1])
-    // inside a level gates are grouped by kind: [start, mul_end) G_MUL, [mul_end, xor_end) G_XOR, rest
-    std::vector<uint32_t> level_mul_end, level_xor_end;
+    // inside a level gates are grouped by class (see LevelRange)
+    std::vector<LevelRange> level_range;
     // pipelining aids (both monotone in l):
     std::vector<uint32_t> level_need_blocks;  // AES blocks (128 masks) that levels 0..l read
     std::vector<uint32_t> level_done_on;      // leading online-transcript rows complete once level l has run

@@ -22,31 +22,43 @@ namespace rv {
 //                               row n_masks_pad = the all-zero row.  A wire whose mask IS a
 //                               PRG mask (Input/Random/Mul outputs) or equals another wire's
 //                               (AddConst, MulConst) just points at that row: nothing is copied.
-//   corr   [n_ssa][NQ/2] bytes  wire corrections, ONE BIT per repetition (the reference keeps a
+//   corr   [n_rows][NQ/2] bytes corrections of the BASE wires (indexed by row id), ONE BIT per repetition (the reference keeps a
 //                               0x00/0xFF byte, src/algebra/gf2/recon.rs:13-25): quad q owns
 //                               nibble q&1 of byte q/2, nibble bit k <-> repetition 4q + 3 - k
 //   on     [n_on_events][NQ]    online transcript: one byte per rep per event
 //   pre    [n_pre_events][NQ/2] preprocessing transcript (corrections), one bit per rep, same
 //                               nibble layout; expanded to 0x00/0xFF bytes when hashed
 
-// compiled gate (device + host)
+// compiled gate (device + host).  XOR / AddConst / MulConst / Const never reach the device: the
+// compiler keeps every wire as "XOR of at most RV_LIN_K base rows, plus a constant" and only
+// materialises a row (G_XORK) when that set outgrows RV_LIN_K or is re-read often enough to pay
+// for itself.  A base row is either a PRG mask row (Input / Random / Mul outputs: their mask IS a
+// fresh mask) or a computed row; corr bits are stored per ROW id.
+constexpr int RV_LIN_K = 3;
 struct Gate {
-    uint32_t op;      // GateOp
-    uint32_t dst;     // SSA wire id written (= its corr row)
-    uint32_t a, b;    // SSA wire ids read
-    uint32_t dm;      // share row written (G_XOR only; other gates alias an existing row)
-    uint32_t am, bm;  // share rows of the operands
-    uint32_t m;       // first PRG mask index consumed (Input/Random: 1 mask, Mul: 2)
-    uint32_t eo;      // row in the online transcript (Input, Mul, AssertZero)
-    uint32_t ep;      // row in the preprocessing transcript (Mul)
-    uint32_t x;       // Input: witness index; Mul/AssertZero: reconstruction ordinal; *Const: constant
-    uint32_t pad;
+    uint32_t op;   // GateOp | na << 8 | nb << 12 | ca << 16 | cb << 17   (operand base counts, operand constants)
+    uint32_t dst;  // row written: G_XORK / G_RECON a computed row, G_MUL m + 1, G_INPUT / G_RANDOM m
+    uint32_t m;    // first PRG mask index consumed (Input/Random: 1 mask, Mul: 2)
+    uint32_t eo;   // row in the online transcript (Input, Mul, AssertZero, Recon)
+    uint32_t ep;   // row in the preprocessing transcript (Mul)
+    uint32_t x;    // Input: witness index; Mul/AssertZero/Recon: reconstruction ordinal
+    uint32_t a[RV_LIN_K], b[RV_LIN_K];  // base rows of operand a / b (G_XORK: up to 2K bases in a then b);
+                                        // unused slots hold the zero row
 };
 
 enum GateOp : uint32_t {
-    G_INPUT = 0, G_XOR, G_XORC, G_ANDC, G_MUL, G_ASSERT, G_RANDOM, G_CONST,
-    G_RECON  // B2A: transcript.reconstruct(mask) + corr, result kept as {mask 0, corr value}
+    G_INPUT = 0,
+    G_XORK,    // dst = XOR of the listed base rows (mask and corr), corr ^= ca
+    G_MUL,
+    G_ASSERT,
+    G_RANDOM,  // fresh mask m, corr 0
+    G_RECON    // B2A: transcript.reconstruct(mask) + corr, result kept as {mask 0, corr value}
 };
+__host__ __device__ inline uint32_t g_op(const Gate& g) { return g.op & 0xFFu; }
+__host__ __device__ inline uint32_t g_na(const Gate& g) { return (g.op >> 8) & 0xFu; }
+__host__ __device__ inline uint32_t g_nb(const Gate& g) { return (g.op >> 12) & 0xFu; }
+__host__ __device__ inline uint32_t g_ca(const Gate& g) { return (g.op >> 16) & 1u; }
+__host__ __device__ inline uint32_t g_cb(const Gate& g) { return (g.op >> 17) & 1u; }
 
 // Z64 ring (src/algebra/z64): one u64 per (repetition, player).
 //   masks64 [n_masks64][R*8] u64   (row m = m-th ShareGen<Z64>::next(), [rep][player])
@@ -95,7 +107,7 @@ enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1 };
 struct InterpParams {
     uint32_t NQ;
     uint32_t* rows;           // share rows (PRG masks + computed)
-    uint8_t* corr;            // [n_ssa][NQ/2]
+    uint8_t* corr;            // [n_rows][NQ/2]
     uint32_t* on;
     uint8_t* pre;             // [n_pre][NQ/2]
     const uint8_t* wit;       // prover: witness bits, one byte each
@@ -114,9 +126,12 @@ void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* 
                           uint64_t n_blocks, uint32_t* d_masks);
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
                        uint8_t* d_out);
-// gates [lo, mul_end) are G_MUL, [mul_end, xor_end) G_XOR, [xor_end, hi) anything else
-void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end, uint32_t hi,
-                   const InterpParams& p);
+// per-level class boundaries: [lo, mul11) G_MUL with one base per operand, [mul11, mul) other G_MUL,
+// [mul, xor2) G_XORK of two bases, [xor2, xork) other G_XORK, [xork, hi) anything else
+struct LevelRange {
+    uint32_t lo, mul11, mul, xor2, xork, hi;
+};
+void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p);
 // levels [l0, l1) (all narrow, GF(2) only) in one launch by a single workgroup
 void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const uint32_t* d_level_start, uint32_t l0, uint32_t l1,
                           const InterpParams& p);

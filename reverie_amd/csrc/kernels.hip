@@ -47,9 +47,28 @@ __device__ __forceinline__ void store_bits(uint8_t* base, size_t row, uint32_t N
     if (!(q & 1)) base[row * (NQ >> 1) + (q >> 1)] = (uint8_t)(n | (other << 4));
 }
 
+// XOR of the n listed base rows / their corr bits.  Unused slots hold the zero row, so all
+// RV_LIN_K slots are loaded unconditionally with STATIC indices (a runtime-indexed id array would
+// push the gate record into scratch memory; a per-slot branch would serialise the loads).
+__device__ __forceinline__ uint32_t gather_rows(const uint32_t* rows, const uint32_t* ids, uint32_t NQ, uint32_t q) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < RV_LIN_K; i++) v ^= rows[(size_t)ids[i] * NQ + q];
+    return v;
+}
+__device__ __forceinline__ uint32_t gather_corr_byte(const uint8_t* corr, const uint32_t* ids, uint32_t NQ, uint32_t o) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < RV_LIN_K; i++) v ^= corr[(size_t)ids[i] * (NQ >> 1) + o];
+    return v;
+}
+__device__ __forceinline__ uint32_t gather_corr(const uint8_t* corr, const uint32_t* ids, uint32_t NQ, uint32_t q) {
+    return (gather_corr_byte(corr, ids, NQ, q >> 1) >> (4 * (q & 1))) & 0xFu;
+}
+
 template <int MODE>
 __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParams& p, uint32_t NQ, uint32_t q, uint32_t onm) {
-    switch (g.op) {
+    switch (g_op(g)) {
     case G_INPUT: {
         const uint32_t lam = p.rows[(size_t)g.m * NQ + q];
         uint32_t corr;
@@ -63,31 +82,14 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         store_bits(p.corr, g.dst, NQ, q, corr);
         break;
     }
-    case G_XOR: {
-        p.rows[(size_t)g.dm * NQ + q] = p.rows[(size_t)g.am * NQ + q] ^ p.rows[(size_t)g.bm * NQ + q];
+    case G_XORK: {
+        p.rows[(size_t)g.dst * NQ + q] = gather_rows(p.rows, g.a, NQ, q) ^ gather_rows(p.rows, g.b, NQ, q);
         // corr bits: plain byte XOR, no expansion needed
         if (!(q & 1)) {
             const size_t h = NQ >> 1, o = q >> 1;
-            p.corr[(size_t)g.dst * h + o] = p.corr[(size_t)g.a * h + o] ^ p.corr[(size_t)g.b * h + o];
+            const uint32_t c = (g_ca(g) ? 0xFFu : 0u) ^ gather_corr_byte(p.corr, g.a, NQ, o) ^ gather_corr_byte(p.corr, g.b, NQ, o);
+            p.corr[(size_t)g.dst * h + o] = (uint8_t)c;
         }
-        break;
-    }
-    case G_XORC: {  // mask row aliased at compile time
-        if (!(q & 1)) {
-            const size_t h = NQ >> 1, o = q >> 1;
-            p.corr[(size_t)g.dst * h + o] = p.corr[(size_t)g.a * h + o] ^ (g.x ? 0xFFu : 0u);
-        }
-        break;
-    }
-    case G_ANDC: {
-        if (!(q & 1)) {
-            const size_t h = NQ >> 1, o = q >> 1;
-            p.corr[(size_t)g.dst * h + o] = g.x ? p.corr[(size_t)g.a * h + o] : (uint8_t)0;
-        }
-        break;
-    }
-    case G_CONST: {
-        if (!(q & 1)) p.corr[(size_t)g.dst * (NQ >> 1) + (q >> 1)] = g.x ? 0xFFu : 0u;
         break;
     }
     case G_RANDOM: {
@@ -95,9 +97,10 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         break;
     }
     case G_MUL: {
-        const uint32_t lx = p.rows[(size_t)g.am * NQ + q], ly = p.rows[(size_t)g.bm * NQ + q];
+        const uint32_t lx = gather_rows(p.rows, g.a, NQ, q), ly = gather_rows(p.rows, g.b, NQ, q);
         const uint32_t lab = p.rows[(size_t)g.m * NQ + q], lnew = p.rows[(size_t)(g.m + 1) * NQ + q];
-        const uint32_t cx = load_bits(p.corr, g.a, NQ, q), cy = load_bits(p.corr, g.b, NQ, q);
+        const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
+        const uint32_t cy = expand4(gather_corr(p.corr, g.b, NQ, q)) ^ (g_cb(g) ? 0xFFFFFFFFu : 0u);
         const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
         uint32_t delta = (a & b) ^ c;
         uint32_t s = (ly & cx) ^ (lx & cy) ^ lab ^ lnew;
@@ -117,20 +120,23 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     }
     case G_RECON: {
         // B2A's recorded reconstruction (combine.rs:181-183): value = reconstruct(mask) + corr
-        uint32_t m = p.rows[(size_t)g.am * NQ + q];
+        uint32_t m = gather_rows(p.rows, g.a, NQ, q);
         if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
         p.on[(size_t)g.eo * NQ + q] = m;
         uint32_t r = recon32(m);
         if (MODE == MODE_VERIFY) r &= onm;
-        store_bits(p.corr, g.dst, NQ, q, r ^ load_bits(p.corr, g.a, NQ, q));
+        const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
+        p.rows[(size_t)g.dst * NQ + q] = 0;
+        store_bits(p.corr, g.dst, NQ, q, r ^ cx);
         break;
     }
     case G_ASSERT: {
-        uint32_t m = p.rows[(size_t)g.am * NQ + q];
+        uint32_t m = gather_rows(p.rows, g.a, NQ, q);
         if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
         p.on[(size_t)g.eo * NQ + q] = m;
         if (MODE == MODE_PROVE) {
-            if ((recon32(m) ^ load_bits(p.corr, g.a, NQ, q)) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+            const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
+            if ((recon32(m) ^ cx) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
         }
         break;
     }
@@ -161,11 +167,13 @@ __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, 
 #endif
 
 // Fast path (NQ = 64, 32, 16 or 8, i.e. R = 256 .. 32): a wavefront covers 64/NQ gates at a time and the
-// per-kind ranges run as 4-way unrolled loops that put every operand row of 4 x 64/NQ gates in flight
+// per-class ranges run as 4-way unrolled loops that put every operand row of 4 x 64/NQ gates in flight
 // before the first use — the generic kernel above is latency-bound on the dependent
 // gate-record -> operand-row chain (2 HBM round trips per gate).  With NQ = 64 the gate index is
-// wave-uniform and the records come through scalar loads.
-template <int MODE, int NQ, int U>
+// wave-uniform and the records come through scalar loads.  KA / KB = operand base rows actually
+// loaded per gate: exact for the common one-base-per-operand class, RV_LIN_K (unused slots point at
+// the L1-hot zero row) for the rest.
+template <int MODE, int NQ, int U, int KA, int KB>
 __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
                                      uint32_t onm) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
@@ -175,12 +183,22 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
     uint32_t lx[U], ly[U], lab[U], lnew[U], bx[U], by[U], sc[U], sr[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        lx[u] = p.rows[(size_t)g[u].am * NQ + q];
-        ly[u] = p.rows[(size_t)g[u].bm * NQ + q];
+        lx[u] = 0;
+        ly[u] = 0;
+        bx[u] = 0;
+        by[u] = 0;
+#pragma unroll
+        for (int i = 0; i < KA; i++) {
+            lx[u] ^= p.rows[(size_t)g[u].a[i] * NQ + q];
+            bx[u] ^= p.corr[(size_t)g[u].a[i] * H + (q >> 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            ly[u] ^= p.rows[(size_t)g[u].b[i] * NQ + q];
+            by[u] ^= p.corr[(size_t)g[u].b[i] * H + (q >> 1)];
+        }
         lab[u] = p.rows[(size_t)g[u].m * NQ + q];
         lnew[u] = p.rows[(size_t)(g[u].m + 1) * NQ + q];
-        bx[u] = p.corr[(size_t)g[u].a * H + (q >> 1)];
-        by[u] = p.corr[(size_t)g[u].b * H + (q >> 1)];
         if (MODE == MODE_VERIFY) {
             sc[u] = p.sup_corr[(size_t)g[u].ep * NQ + q];
             sr[u] = p.sup_rec[(size_t)g[u].x * NQ + q];
@@ -188,7 +206,8 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const uint32_t cx = expand4((bx[u] >> (4 * (q & 1))) & 0xFu), cy = expand4((by[u] >> (4 * (q & 1))) & 0xFu);
+        const uint32_t cx = expand4((bx[u] >> (4 * (q & 1))) & 0xFu) ^ (g_ca(g[u]) ? 0xFFFFFFFFu : 0u);
+        const uint32_t cy = expand4((by[u] >> (4 * (q & 1))) & 0xFu) ^ (g_cb(g[u]) ? 0xFFFFFFFFu : 0u);
         const uint32_t a = recon32(lx[u]), b = recon32(ly[u]), c = recon32(lab[u]);
         uint32_t delta = (a & b) ^ c;
         uint32_t s = (ly[u] & cx) ^ (lx[u] & cy) ^ lab[u] ^ lnew[u];
@@ -206,25 +225,30 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
     }
 }
 
-template <int NQ, int U>
+// G_XORK: N = base rows loaded per gate (2: a[0], a[1]; 6: a[0..2], b[0..2] with zero-row padding)
+template <int NQ, int U, int N>
 __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
     Gate g[U];
 #pragma unroll
     for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
-    uint32_t x[U], y[U], bx[U], by[U];
+    uint32_t x[U], bx[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        x[u] = p.rows[(size_t)g[u].am * NQ + q];
-        y[u] = p.rows[(size_t)g[u].bm * NQ + q];
-        // H corr bytes per wire: the first H lanes of the gate's lane group carry them
-        bx[u] = (q < H) ? p.corr[(size_t)g[u].a * H + q] : 0;
-        by[u] = (q < H) ? p.corr[(size_t)g[u].b * H + q] : 0;
+        x[u] = 0;
+        bx[u] = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t id = (N == 2) ? g[u].a[i] : (i < RV_LIN_K ? g[u].a[i] : g[u].b[i - RV_LIN_K]);
+            x[u] ^= p.rows[(size_t)id * NQ + q];
+            // H corr bytes per row: the first H lanes of the gate's lane group carry them
+            if (q < H) bx[u] ^= p.corr[(size_t)id * H + q];
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        p.rows[(size_t)g[u].dm * NQ + q] = x[u] ^ y[u];
-        if (q < H) p.corr[(size_t)g[u].dst * H + q] = (uint8_t)(bx[u] ^ by[u]);
+        p.rows[(size_t)g[u].dst * NQ + q] = x[u];
+        if (q < H) p.corr[(size_t)g[u].dst * H + q] = (uint8_t)(bx[u] ^ (g_ca(g[u]) ? 0xFFu : 0u));
     }
 }
 
@@ -234,8 +258,7 @@ __device__ __forceinline__ void interp_one(const Gate& g, const InterpParams& p,
 }
 
 template <int MODE, int NQ>
-__global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end,
-                                                     uint32_t hi, InterpParams p) {
+__global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p) {
     constexpr uint32_t GPW = 64 / NQ;  // gates per wavefront per step
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t q = lane % NQ, sub = lane / NQ;
@@ -244,33 +267,39 @@ __global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ ga
     const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[q] : 0u;
     constexpr int U = RV_INTERP_UNROLL;
     constexpr uint32_t STEP = U * GPW;
-    // G_MUL range
-    {
-        const uint32_t full = lo + ((mul_end - lo) / STEP) * STEP;
-        for (uint32_t g0 = lo + wave * STEP; g0 < full; g0 += n_waves * STEP) mulU<MODE, NQ, U>(gates, g0, p, sub, q, onm);
-        for (uint32_t gi = full + wave * GPW + sub; gi < mul_end; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
-    }
-    // G_XOR range
-    {
-        const uint32_t full = mul_end + ((xor_end - mul_end) / STEP) * STEP;
-        for (uint32_t g0 = mul_end + wave * STEP; g0 < full; g0 += n_waves * STEP) xorU<NQ, U>(gates, g0, p, sub, q);
-        for (uint32_t gi = full + wave * GPW + sub; gi < xor_end; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
-    }
-    for (uint32_t gi = xor_end + wave * GPW + sub; gi < hi; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
+    uint32_t full;
+    // G_MUL, one base per operand
+    full = r.lo + ((r.mul11 - r.lo) / STEP) * STEP;
+    for (uint32_t g0 = r.lo + wave * STEP; g0 < full; g0 += n_waves * STEP) mulU<MODE, NQ, U, 1, 1>(gates, g0, p, sub, q, onm);
+    for (uint32_t gi = full + wave * GPW + sub; gi < r.mul11; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
+    // other G_MUL
+    full = r.mul11 + ((r.mul - r.mul11) / STEP) * STEP;
+    for (uint32_t g0 = r.mul11 + wave * STEP; g0 < full; g0 += n_waves * STEP)
+        mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K>(gates, g0, p, sub, q, onm);
+    for (uint32_t gi = full + wave * GPW + sub; gi < r.mul; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
+    // G_XORK of two bases
+    full = r.mul + ((r.xor2 - r.mul) / STEP) * STEP;
+    for (uint32_t g0 = r.mul + wave * STEP; g0 < full; g0 += n_waves * STEP) xorU<NQ, U, 2>(gates, g0, p, sub, q);
+    for (uint32_t gi = full + wave * GPW + sub; gi < r.xor2; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
+    // other G_XORK
+    full = r.xor2 + ((r.xork - r.xor2) / STEP) * STEP;
+    for (uint32_t g0 = r.xor2 + wave * STEP; g0 < full; g0 += n_waves * STEP) xorU<NQ, U, 2 * RV_LIN_K>(gates, g0, p, sub, q);
+    for (uint32_t gi = full + wave * GPW + sub; gi < r.xork; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
+    // everything else
+    for (uint32_t gi = r.xork + wave * GPW + sub; gi < r.hi; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
 }
 
 template <int NQ>
-static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end,
-                               uint32_t hi, const InterpParams& p) {
+static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p) {
     constexpr uint32_t GPW = 64 / NQ;
-    uint64_t waves = ((uint64_t)(hi - lo) + RV_INTERP_UNROLL * GPW - 1) / (RV_INTERP_UNROLL * GPW);
+    uint64_t waves = ((uint64_t)(r.hi - r.lo) + RV_INTERP_UNROLL * GPW - 1) / (RV_INTERP_UNROLL * GPW);
     uint64_t blocks = (waves + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     if (mode == MODE_PROVE)
-        hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, mul_end, xor_end, hi, p);
+        hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
     else
-        hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, mul_end, xor_end, hi, p);
+        hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
 }
 
 // Narrow levels (deep circuits: ripple-carry adders, AES/SHA rounds) would be launch-bound at one
@@ -305,23 +334,22 @@ void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const u
         hipLaunchKernelGGL(k_interp_narrow<MODE_VERIFY>, dim3(1), dim3(1024), 0, st, d_gates, d_level_start, l0, l1, p);
 }
 
-void launch_interp(hipStream_t st, int mode, const Gate* d_gates, uint32_t lo, uint32_t mul_end, uint32_t xor_end, uint32_t hi,
-                   const InterpParams& p) {
-    if (hi <= lo) return;
+void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p) {
+    if (r.hi <= r.lo) return;
     switch (p.NQ) {
-    case 64: return launch_interp_full<64>(st, mode, d_gates, lo, mul_end, xor_end, hi, p);
-    case 32: return launch_interp_full<32>(st, mode, d_gates, lo, mul_end, xor_end, hi, p);
-    case 16: return launch_interp_full<16>(st, mode, d_gates, lo, mul_end, xor_end, hi, p);
-    case 8: return launch_interp_full<8>(st, mode, d_gates, lo, mul_end, xor_end, hi, p);
+    case 64: return launch_interp_full<64>(st, mode, d_gates, r, p);
+    case 32: return launch_interp_full<32>(st, mode, d_gates, r, p);
+    case 16: return launch_interp_full<16>(st, mode, d_gates, r, p);
+    case 8: return launch_interp_full<8>(st, mode, d_gates, r, p);
     default: break;
     }
-    const uint64_t want = (uint64_t)(hi - lo) * p.NQ;
+    const uint64_t want = (uint64_t)(r.hi - r.lo) * p.NQ;
     uint64_t blocks = (want + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (mode == MODE_PROVE)
-        hipLaunchKernelGGL(k_interp<MODE_PROVE>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, hi, p);
+        hipLaunchKernelGGL(k_interp<MODE_PROVE>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);
     else
-        hipLaunchKernelGGL(k_interp<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, hi, p);
+        hipLaunchKernelGGL(k_interp<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);
 }
 
 // ------------------------------------------------------------------------------------
