@@ -255,6 +255,50 @@ def test_tamper_and_cross_verify(rv, oracle, rule_seeds):
         assert (got, got_err) == (want, want_err), pos
 
 
+def test_verify_fuzz_matches_oracle(rv, oracle):
+    """bit flips, length-field corruption and truncations of a mixed GF(2)/Z64/B2A proof: the HIP verifier
+    must return exactly what the oracle returns (true / false / malformed) and never crash"""
+    rng = np.random.default_rng(777)
+    prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=250)
+    seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+    good = oracle.prove(prog, w2, w64, wc, seeds)
+    c = rv.Circuit(prog, wc)
+    assert rv.Proof(good).verify(c)
+
+    def both(data):
+        try:
+            w = oracle.verify(prog, wc, data)
+        except oracle.OracleError as e:
+            w = ("err", e.code)
+        try:
+            g = rv.Proof(data).verify(c)
+        except rv.ReverieError as e:
+            g = ("err", e.code)
+        return w, g
+
+    n_false = n_err = 0
+    for trial in range(160):
+        bad = bytearray(good)
+        kind = trial % 4
+        if kind == 0:  # single bit flip anywhere
+            pos = int(rng.integers(0, len(bad)))
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:  # corrupt a byte early in an online record (omit / keys / length fields)
+            pos = 40 + int(rng.integers(0, 4000))
+            bad[pos] = int(rng.integers(0, 256))
+        elif kind == 2:  # truncate
+            bad = bad[:int(rng.integers(0, len(bad)))]
+        else:  # overwrite a u64 length field of the first gf2 online record with a small / huge value
+            off = 32 + 8 + 1 + 128 + int(rng.integers(0, 2)) * 0
+            val = int(rng.choice([0, 1, 7, 8, 9, 2**32, 2**63]))
+            bad[off:off + 8] = val.to_bytes(8, "little")
+        w, g = both(bytes(bad))
+        assert w == g, (trial, kind, w, g)
+        n_false += w is False
+        n_err += isinstance(w, tuple)
+    assert n_false > 20 and n_err > 20
+
+
 def test_errors(rv, rule_seeds):
     m, prog, w2, w64, wc, gold = load_case("adder64")
     bad = list(w2)
