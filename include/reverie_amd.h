@@ -191,6 +191,10 @@ void rv_shard_destroy(rv_shard *s);
  * in HBM (gf2_online | gf2_pre | z64_online | z64_pre) and returns the device pointer,
  * valid until the shard is destroyed. */
 int rv_shard_open_device(rv_shard *s, const uint8_t omit[RV_TOTAL_REPS], void **dptr, size_t lens[4]);
+/* Bytes of one OpenOnline record of the gf2 / z64 ProofSingle for this circuit (every record of a
+ * section has the same size; an OpenPreprocessing record is always 48 bytes).  Lets every rank
+ * compute every other rank's blob sizes from the challenge alone. */
+int rv_circuit_record_sizes(const rv_circuit *c, size_t *gf2_online_record, size_t *z64_online_record);
 /* Sizes rv_shard_open* will produce for this challenge, without opening */
 int rv_shard_open_size(const rv_shard *s, const uint8_t omit[RV_TOTAL_REPS], size_t lens[4]);
 /* As rv_shard_open_device, but writes the concatenated blobs into caller-owned HBM

@@ -720,6 +720,15 @@ static OpenLayout open_layout(const Compiled& cc, const uint8_t* omit_local, uin
     return L;
 }
 
+extern "C" int rv_circuit_record_sizes(const rv_circuit* c, size_t* gf2_online_record, size_t* z64_online_record) {
+    if (!c || !gf2_online_record || !z64_online_record) return RV_E_ARG;
+    const uint8_t none[8] = {8, 8, 8, 8, 8, 8, 8, 8};
+    const OpenLayout L = open_layout(c->cc, none, 8);
+    *gf2_online_record = (size_t)L.sz2;
+    *z64_online_record = (size_t)L.sz64;
+    return RV_OK;
+}
+
 extern "C" int rv_shard_open_size(const rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], size_t lens[4]) {
     if (!s || !omit || !lens) return RV_E_ARG;
     const OpenLayout L = open_layout(s->c->cc, omit + s->rep_begin, s->R);

@@ -60,6 +60,17 @@ class HipShardBackend:
         """device-to-device into a torch CUDA tensor (the all-gather input)"""
         _lib.check(_lib.lib().rv_shard_digests_to_device(shard[0], C.c_void_p(tensor.data_ptr())))
 
+    def all_open_sizes(self, omit: np.ndarray, world: int) -> List[List[int]]:
+        """blob sizes of every rank's shard for this challenge — a pure function of the challenge and the
+        circuit, so no collective is needed to learn them"""
+        sz2, sz64 = self.circuit.record_sizes()
+        out = []
+        for r in range(world):
+            b, n = shard_range(r, world)
+            n_on = int((omit[b:b + n] < 8).sum())
+            out.append([n_on * sz2, (n - n_on) * 48, n_on * sz64, (n - n_on) * 48])
+        return out
+
     def open_sizes(self, shard, omit: np.ndarray) -> List[int]:
         lens = (C.c_size_t * 4)()
         _lib.check(_lib.lib().rv_shard_open_size(shard[0], _ptr(omit), lens))
@@ -154,8 +165,8 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
             buf = torch.empty(max(sum(lens), 1), dtype=torch.uint8, device="cuda")
             backend.open_into(shard, omit, buf)
             if world > 1:
-                all_lens = [None] * world
-                dist.all_gather_object(all_lens, lens, group=group)
+                all_lens = backend.all_open_sizes(omit, world)
+                assert all_lens[rank] == lens
                 if not on_gpu:  # gloo has no device point-to-point: stage through the host
                     if rank == 0:
                         bufs = [buf.cpu()] + [torch.empty(max(sum(l), 1), dtype=torch.uint8) for l in all_lens[1:]]

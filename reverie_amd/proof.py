@@ -75,6 +75,12 @@ class Circuit:
         _lib.check(_lib.lib().rv_circuit_get_info(self.handle, C.byref(ci)))
         return {n: int(getattr(ci, n)) for n, _ in ci._fields_}
 
+    def record_sizes(self) -> Tuple[int, int]:
+        """bytes of one OpenOnline record in the gf2 / z64 section of a proof of this circuit"""
+        a, b = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.lib().rv_circuit_record_sizes(self.handle, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def close(self):
         if self.handle:
             _lib.lib().rv_circuit_destroy(self.handle)
