@@ -256,7 +256,7 @@ def main():
             "interp": (st["and"] * (48 + 4 * row + 3 * row // 8 + row + row // 8) + st["xor"] * (48 + 3 * row + 3 * row // 8)),
             "hash": (info["gf2_muls"] + info["gf2_inputs"] + info["gf2_asserts"]) * row + info["gf2_muls"] * row // 8,
         }
-        kname = {"masks": "k_aes_gf2_masks<16>", "interp": "k_interp_full<0>", "hash": "k_b3_chunks"}[dom]
+        kname = {"masks": "k_aes_gf2_masks<16>", "interp": "k_interp_full<MODE_PROVE, 64>", "hash": "k_b3_chunks<4>"}[dom]
         ach = alg[dom] / (tphase[dom] * 1e-3) / 1e9 if tphase[dom] > 0 else 0.0
         # measured HBM traffic of the same workload (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
         # tools/pmc_summary.py, committed under profiles/); only valid for the default workload on 1 GPU
@@ -264,9 +264,10 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if world == 1 and args.layers == 153 and args.p_and == 0.5 and os.path.exists(pmc_path):
             pk = json.load(open(pmc_path))["kernels"]
-            key = {"masks": "rv::k_aes_gf2_masks<16>", "interp": "rv::k_interp_full<0>", "hash": "rv::k_b3_chunks"}[dom]
-            if key in pk:
-                traffic = pk[key]["hbm_bytes_per_proof"]
+            prefix = {"masks": "rv::k_aes_gf2_masks<", "interp": "rv::k_interp_full<0", "hash": "rv::k_b3_chunks<"}[dom]
+            hits = [v["hbm_bytes_per_proof"] for k, v in pk.items() if k.startswith(prefix)]
+            if hits:
+                traffic = sum(hits)
         roofline = {
             "bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
