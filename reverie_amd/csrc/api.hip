@@ -267,7 +267,20 @@ static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
     return b;
 }
 
+static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
+                                  rv_circuit** out);
+
 extern "C" int rv_circuit_compile(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
+                                  rv_circuit** out) {
+    try {  // no C++ exception may cross the C boundary
+        return rv_circuit_compile_impl(ctx, ops, n_ops, z64_wires, gf2_wires, out);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
+}
+
+static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
                                   rv_circuit** out) {
     if (!ctx || !out || (n_ops && !ops)) return RV_E_ARG;
     *out = nullptr;
@@ -598,13 +611,27 @@ static int shard_join(rv_shard* s) {
     return RV_OK;
 }
 
+static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
+                               size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out);
+
 extern "C" int rv_shard_commit(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
+                               size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out) {
+    try {  // no C++ exception may cross the C boundary
+        return rv_shard_commit_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, rep_begin, rep_count, out);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
+}
+
+static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
                                size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out) {
     if (!ctx || !c || !out || !seeds) return RV_E_ARG;
     if (rep_count == 0 || rep_count % 8 || rep_begin % 8 || rep_begin + rep_count > RV_TOTAL_REPS) return RV_E_ARG;
     *out = nullptr;
     const Compiled& cc = c->cc;
     if (n_gf2 < cc.n_in || n_z64 < cc.n_in64) return RV_E_WITNESS_SHORT;
+    if ((cc.n_in && !wit_gf2) || (cc.n_in64 && !wit_z64)) return RV_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     rv_shard* s = new rv_shard();
     s->ctx = ctx;
@@ -893,7 +920,20 @@ extern "C" int rv_assemble_proof(const uint8_t comm[RV_HASH_SIZE], const rv_shar
     return RV_OK;
 }
 
+static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
+                        size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len);
+
 extern "C" int rv_prove(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
+                        size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len) {
+    try {  // no C++ exception may cross the C boundary
+        return rv_prove_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, proof, proof_len);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
+}
+
+static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
                         size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len) {
     if (!ctx || !c || !proof || !proof_len) return RV_E_ARG;
     *proof = nullptr;
@@ -1026,7 +1066,20 @@ bool format_ok(const Parsed& p) {  // ProofSingle::check_format, proof/mod.rs:11
 }
 }  // namespace
 
+static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t slot_begin,
+                               uint32_t slot_count, uint8_t* digests);
+
 extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t slot_begin,
+                               uint32_t slot_count, uint8_t* digests) {
+    try {  // no C++ exception may cross the C boundary
+        return rv_verify_shard_impl(ctx, c, proof, proof_len, slot_begin, slot_count, digests);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
+}
+
+static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t slot_begin,
                                uint32_t slot_count, uint8_t* digests) {
     if (!ctx || !c || !proof || !digests) return RV_E_ARG;
     if (slot_count == 0 || slot_count % 8 || slot_begin % 8 || slot_begin + slot_count > RV_TOTAL_REPS) return RV_E_ARG;
@@ -1221,7 +1274,18 @@ extern "C" int rv_verify_finish(const uint8_t* proof, size_t proof_len, const ui
     return RV_OK;
 }
 
+static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, int* ok);
+
 extern "C" int rv_verify(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, int* ok) {
+    try {  // no C++ exception may cross the C boundary
+        return rv_verify_impl(ctx, c, proof, proof_len, ok);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
+}
+
+static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, int* ok) {
     if (!ctx || !c || !proof || !ok) return RV_E_ARG;
     *ok = 0;
     Parsed P;

@@ -58,8 +58,20 @@ rv_op mk(uint8_t opcode, uint32_t dst, uint32_t a, uint32_t b, uint64_t imm) {
 
 }  // namespace
 
+static int parse_impl(const char* text, size_t len, int format, const uint8_t* expected_outputs, rv_op** ops, size_t* n_ops,
+                      rv_bristol_info* info);
+
 extern "C" int rv_bristol_parse(const char* text, size_t len, int format, const uint8_t* expected_outputs, rv_op** ops,
                                 size_t* n_ops, rv_bristol_info* info) {
+    try {  // no C++ exception may cross the C boundary
+        return parse_impl(text, len, format, expected_outputs, ops, n_ops, info);
+    } catch (...) {
+        return RV_E_NOMEM;
+    }
+}
+
+static int parse_impl(const char* text, size_t len, int format, const uint8_t* expected_outputs, rv_op** ops, size_t* n_ops,
+                      rv_bristol_info* info) {
     if (!text || !ops || !n_ops) return RV_E_ARG;
     *ops = nullptr;
     *n_ops = 0;
@@ -108,6 +120,7 @@ extern "C" int rv_bristol_parse(const char* text, size_t len, int format, const 
     bi.n_inputs = n_in;
     bi.n_outputs = n_out;
     std::vector<rv_op> out;
+    if (n_gates > len / 8 + 1) return RV_E_BAD_OP;  // every gate line needs at least 8 characters
     out.reserve((size_t)(n_in + n_gates + 2 * n_out));
     for (uint64_t w = 0; w < n_in; w++) out.push_back(mk(RV_OP_INPUT, (uint32_t)w, 0, 0, 0));
     std::vector<std::string> g;
