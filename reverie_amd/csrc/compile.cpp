@@ -1,6 +1,7 @@
 // see compile.h
 #include "compile.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -591,6 +592,21 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
     info.gf2_masks = out.n_masks;
     info.z64_masks = out.n_masks64;
     info.levels = n_levels;
+    if (getenv("RV_COMPILE_STATS")) {  // interpreter HBM traffic model per 4-repetition quad column (x NQ x 4 B per row)
+        uint64_t rd = 0, wr = 0, crd = 0, n_mul = 0, n_xor = 0, n_mul11 = 0;
+        for (const Gate& g : out.gates) {
+            const uint32_t op = g_op(g), n = g_na(g) + g_nb(g);
+            if (op == G_MUL) {
+                rd += n + 2, crd += n, wr += 1, n_mul++;
+                n_mul11 += (g_na(g) == 1 && g_nb(g) == 1);
+            } else if (op == G_XORK) {
+                rd += n, crd += n, wr += 1, n_xor++;
+            }
+        }
+        fprintf(stderr, "[rv compile] lazy_k=%d levels=%u mul=%llu (one-base %llu) xork=%llu row_reads=%llu row_writes=%llu corr_reads=%llu\n",
+                b.lazy_k, n_levels, (unsigned long long)n_mul, (unsigned long long)n_mul11, (unsigned long long)n_xor,
+                (unsigned long long)rd, (unsigned long long)wr, (unsigned long long)crd);
+    }
     return RV_OK;
 }
 

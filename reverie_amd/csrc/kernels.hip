@@ -181,27 +181,52 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
 #pragma unroll
     for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
     uint32_t lx[U], ly[U], lab[U], lnew[U], bx[U], by[U], sc[U], sr[U];
+    // slots >= 1 are loaded only when the operand really has that many bases (a wave-uniform branch at
+    // NQ = 64); every load is issued before any value is used
+    uint32_t ra[U][KA], ca[U][KA], rb[U][KB], cb[U][KB];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        lx[u] = 0;
-        ly[u] = 0;
-        bx[u] = 0;
-        by[u] = 0;
+        const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
 #pragma unroll
         for (int i = 0; i < KA; i++) {
-            lx[u] ^= p.rows[(size_t)g[u].a[i] * NQ + q];
-            bx[u] ^= p.corr[(size_t)g[u].a[i] * H + (q >> 1)];
+            ra[u][i] = 0;
+            ca[u][i] = 0;
+            if (i == 0 || i < na) {
+                ra[u][i] = p.rows[(size_t)g[u].a[i] * NQ + q];
+                ca[u][i] = p.corr[(size_t)g[u].a[i] * H + (q >> 1)];
+            }
         }
 #pragma unroll
         for (int i = 0; i < KB; i++) {
-            ly[u] ^= p.rows[(size_t)g[u].b[i] * NQ + q];
-            by[u] ^= p.corr[(size_t)g[u].b[i] * H + (q >> 1)];
+            rb[u][i] = 0;
+            cb[u][i] = 0;
+            if (i == 0 || i < nb) {
+                rb[u][i] = p.rows[(size_t)g[u].b[i] * NQ + q];
+                cb[u][i] = p.corr[(size_t)g[u].b[i] * H + (q >> 1)];
+            }
         }
         lab[u] = p.rows[(size_t)g[u].m * NQ + q];
         lnew[u] = p.rows[(size_t)(g[u].m + 1) * NQ + q];
         if (MODE == MODE_VERIFY) {
             sc[u] = p.sup_corr[(size_t)g[u].ep * NQ + q];
             sr[u] = p.sup_rec[(size_t)g[u].x * NQ + q];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        lx[u] = ra[u][0];
+        bx[u] = ca[u][0];
+        ly[u] = rb[u][0];
+        by[u] = cb[u][0];
+#pragma unroll
+        for (int i = 1; i < KA; i++) {
+            lx[u] ^= ra[u][i];
+            bx[u] ^= ca[u][i];
+        }
+#pragma unroll
+        for (int i = 1; i < KB; i++) {
+            ly[u] ^= rb[u][i];
+            by[u] ^= cb[u][i];
         }
     }
 #pragma unroll
@@ -232,17 +257,31 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
     Gate g[U];
 #pragma unroll
     for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
-    uint32_t x[U], bx[U];
+    uint32_t x[U], bx[U], rr[U][N], cc[U][N];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t id = (N == 2) ? g[u].a[i] : (i < RV_LIN_K ? g[u].a[i] : g[u].b[i - RV_LIN_K]);
+            rr[u][i] = 0;
+            cc[u][i] = 0;
+            // only the slots the gate uses (N == 2: both by construction)
+            if (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) {
+                rr[u][i] = p.rows[(size_t)id * NQ + q];
+                // H corr bytes per row: the first H lanes of the gate's lane group carry them
+                if (q < H) cc[u][i] = p.corr[(size_t)id * H + q];
+            }
+        }
+    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
         x[u] = 0;
         bx[u] = 0;
 #pragma unroll
         for (int i = 0; i < N; i++) {
-            const uint32_t id = (N == 2) ? g[u].a[i] : (i < RV_LIN_K ? g[u].a[i] : g[u].b[i - RV_LIN_K]);
-            x[u] ^= p.rows[(size_t)id * NQ + q];
-            // H corr bytes per row: the first H lanes of the gate's lane group carry them
-            if (q < H) bx[u] ^= p.corr[(size_t)id * H + q];
+            x[u] ^= rr[u][i];
+            bx[u] ^= cc[u][i];
         }
     }
 #pragma unroll
