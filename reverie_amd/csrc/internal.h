@@ -165,7 +165,7 @@ struct OnlineList {
 };
 void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint32_t NQ, const OnlineList& ol,
                               uint8_t* d_out);
-// kind 0: omitted player's bit of a share row; 1: smeared byte of a row; 2: bit-per-rep stream [n][NQ/2]
+// kind 0: omitted player's bit of a share row; 1: smeared byte of a row
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,
                          uint32_t NQ, int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
 void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,

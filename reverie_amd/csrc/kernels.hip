@@ -618,124 +618,171 @@ void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, 
 // Openings.  kind 0: omitted player's bit of a recorded broadcast share (PackSelected,
 // gf2/share.rs:87-149); kind 1: a 0x00/0xFF recon byte (Pack, gf2/recon.rs:189-239).
 // Items are packed 8 per byte MSB-first; the output vector has n_items/8 + 1 bytes (the
-// reference always emits one more chunk).  Thread = (output byte t, quad q): reads 8 rows,
-// produces the byte for each of its 4 repetitions, stores only for opened ones.
+// reference always emits one more chunk).
+//
+// A workgroup produces EX_TB consecutive output bytes of EVERY opened repetition: the packed
+// bytes are first collected in LDS ([slot][byte]) and then written out as contiguous runs.
+// (Writing each byte straight from the lane that computed it cost 40 single-byte partial-line
+// writes per 16 lines read: the kernel was bound by write transactions, not by HBM bytes.)
 // ------------------------------------------------------------------------------------
-template <int BPT>  // output bytes per thread: 8*BPT rows in flight per lane
-__global__ __launch_bounds__(256) void k_extract_bits(const void* __restrict__ stream_, const uint32_t* __restrict__ rows,
-                                                      uint64_t n_items, uint32_t NQ, int kind,
+constexpr uint32_t EX_TB = 128;
+
+// slot of every opened repetition (rank among the opened ones) and its output offset, into LDS
+__device__ __forceinline__ uint32_t ex_slots(const uint8_t* __restrict__ omit, const uint64_t* __restrict__ dst_off, uint32_t R,
+                                             uint8_t* s_slot /*[256]*/, uint64_t* s_dst /*[RV_ONLINE_REPS]*/, uint32_t* s_cnt /*[5]*/) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool on = tid < R && omit[tid] < 8;
+    const unsigned long long bal = __ballot(on);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; w++) base += s_cnt[w];
+    const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    s_slot[tid] = (on && slot < RV_ONLINE_REPS) ? (uint8_t)slot : (uint8_t)0xFF;
+    if (on && slot < RV_ONLINE_REPS) s_dst[slot] = dst_off[tid];
+    uint32_t n = 0;
+    for (uint32_t w = 0; w < 4; w++) n += s_cnt[w];
+    __syncthreads();
+    return n < RV_ONLINE_REPS ? n : RV_ONLINE_REPS;
+}
+
+// contiguous write-out of the collected bytes: s_buf[slot][0 .. nb)
+__device__ __forceinline__ void ex_flush(const uint8_t* s_buf, const uint64_t* s_dst, uint32_t n_slots, uint64_t t0, uint32_t nb,
+                                         uint8_t* __restrict__ out) {
+    for (uint32_t idx = threadIdx.x; idx < n_slots * EX_TB; idx += blockDim.x) {
+        const uint32_t k = idx / EX_TB, i = idx % EX_TB;
+        if (i < nb) out[s_dst[k] + t0 + i] = s_buf[k * EX_TB + i];
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows,
+                                                      uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */,
                                                       const uint8_t* __restrict__ omit /*[R]*/,
                                                       const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out) {
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t t0 = (tid / NQ) * BPT;
-    const uint32_t q = (uint32_t)(tid % NQ);
+    __shared__ uint8_t s_buf[RV_ONLINE_REPS * EX_TB];
+    __shared__ uint32_t s_rows[8 * EX_TB];
+    __shared__ uint8_t s_slot[256];
+    __shared__ uint64_t s_dst[RV_ONLINE_REPS];
+    __shared__ uint32_t s_cnt[4];
     const uint64_t n_bytes = n_items / 8 + 1;
-    if (t0 >= n_bytes) return;
-    uint32_t om[4];
-    bool any = false;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        om[i] = omit[4 * q + i];
-        any |= om[i] < 8;
-    }
-    if (!any) return;
-    const uint32_t* stream = (const uint32_t*)stream_;
-    const uint8_t* bits = (const uint8_t*)stream_;
-    // all row indices first, then all rows: two memory round trips per thread
-    uint64_t row[8 * BPT];
-    uint32_t w[8 * BPT];
-#pragma unroll
-    for (int j = 0; j < 8 * BPT; j++) {
-        uint64_t it = 8 * t0 + j;
+    const uint64_t t0 = (uint64_t)blockIdx.x * tb;
+    const uint32_t nb = (uint32_t)((n_bytes - t0 < tb) ? n_bytes - t0 : tb);
+    // this workgroup's row ids, one coalesced pass (ordinals past the end repeat the last item; masked below)
+    for (uint32_t i = threadIdx.x; i < 8 * nb; i += 256) {
+        uint64_t it = 8 * t0 + i;
         if (it >= n_items) it = n_items ? n_items - 1 : 0;
-        row[j] = rows ? rows[it] : it;
+        s_rows[i] = rows ? rows[it] : (uint32_t)it;
     }
+    const uint32_t n_slots = ex_slots(omit, dst_off, 4 * NQ, s_slot, s_dst, s_cnt);  // contains the barrier for s_rows
+    if (!n_slots) return;
+    // thread = (output byte, quad); with NQ = 64 a wavefront reads 8 whole rows per step
+    for (uint32_t idx = threadIdx.x; idx < nb * NQ; idx += 256) {
+        const uint32_t tl = idx / NQ, q = idx % NQ;
+        uint32_t sl[4], om[4];
+        bool any = false;
 #pragma unroll
-    for (int j = 0; j < 8 * BPT; j++) {
-        if (kind == 2)
-            w[j] = n_items ? (((uint32_t)bits[row[j] * (NQ >> 1) + (q >> 1)] >> (4 * (q & 1))) & 0xFu) : 0u;
-        else
-            w[j] = n_items ? stream[row[j] * NQ + q] : 0u;
-    }
+        for (int i = 0; i < 4; i++) {
+            sl[i] = s_slot[4 * q + i];
+            om[i] = omit[4 * q + i];
+            any |= sl[i] != 0xFF;
+        }
+        if (!any) continue;
+        const uint64_t it0 = 8 * (t0 + tl);
+        uint32_t w[8];
 #pragma unroll
-    for (int bt = 0; bt < BPT; bt++) {
-        const uint64_t t = t0 + bt;
-        if (t >= n_bytes) break;
+        for (int j = 0; j < 8; j++) w[j] = n_items ? stream[(size_t)s_rows[8 * tl + j] * NQ + q] : 0u;
         uint32_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            if (8 * t + j < n_items) {
+            if (it0 + j < n_items) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    uint32_t bit;
-                    if (kind == 2)
-                        bit = (w[8 * bt + j] >> (3 - i)) & 1u;
-                    else
-                        bit = (w[8 * bt + j] >> ((kind == 0) ? (31u - 8u * i - (om[i] & 7u)) : (24u - 8u * i))) & 1u;
+                    const uint32_t bit = (w[j] >> ((KIND == 0) ? (31u - 8u * i - (om[i] & 7u)) : (24u - 8u * i))) & 1u;
                     acc[i] |= bit << (7 - j);
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            if (om[i] < 8) out[dst_off[4 * q + i] + t] = (uint8_t)acc[i];
+            if (sl[i] != 0xFF) s_buf[sl[i] * EX_TB + tl] = (uint8_t)acc[i];
     }
+    __syncthreads();
+    ex_flush(s_buf, s_dst, n_slots, t0, nb, out);
 }
 
-// Bit-per-rep source (the preprocessing stream): lane = event row, so a wavefront covers 64
-// consecutive events; for every opened repetition one ballot yields its 64 bits = 8 output
-// bytes (bit-reversed + byte-swapped into the MSB-first packing).  n_bytes includes the
-// always-present extra chunk.
+// Bit-per-rep source (the preprocessing stream, [n][NQ/2] bytes; nibble bit k of quad q <-> repetition 4q+3-k):
+// the workgroup's 8*tb rows are contiguous in HBM and are copied to LDS in one coalesced pass; thread =
+// (output byte, opened repetition) then picks its 8 bits out of LDS.
 __global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ,
-                                                           OnlineList ol, uint8_t* __restrict__ out) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                                           uint32_t tb /* <= EX_TB */, OnlineList ol, uint8_t* __restrict__ out) {
+    __shared__ uint8_t s_buf[RV_ONLINE_REPS * EX_TB];
+    __shared__ uint64_t s_dst[RV_ONLINE_REPS];
+    __shared__ uint32_t s_pos[RV_ONLINE_REPS];  // byte in the row << 3 | bit in the byte
+    __shared__ __attribute__((aligned(16))) uint8_t s_pre[8 * EX_TB * 32];
     const uint64_t n_bytes = n_items / 8 + 1;
-    const uint64_t e = wave * 64 + lane;
-    if (wave * 8 >= n_bytes) return;
+    const uint64_t t0 = (uint64_t)blockIdx.x * tb;
+    const uint32_t nb = (uint32_t)((n_bytes - t0 < tb) ? n_bytes - t0 : tb);
     const uint32_t h = NQ >> 1;  // bytes per row
-    // the lane's whole row once (h <= 32 bytes), then every opened repetition from registers
-    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (e < n_items) {
-        const uint8_t* rowp = bits + e * h;
-        if (h == 32) {
-            const uint4 lo = *(const uint4*)rowp, hi = *(const uint4*)(rowp + 16);
-            w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
-            w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
-        } else {
-            for (uint32_t i = 0; i < h; i++) w[i >> 2] |= (uint32_t)rowp[i] << (8 * (i & 3));
+    const uint64_t r0 = 8 * t0;
+    const uint32_t n_rows = (uint32_t)(r0 >= n_items ? 0 : (n_items - r0 < 8ull * nb ? n_items - r0 : 8ull * nb));
+    const uint8_t* src = bits + r0 * h;  // 8-byte aligned (r0 is a multiple of 8); 16-byte when h is even
+    const uint32_t total = n_rows * h;
+    if ((h & 1) == 0) {
+        for (uint32_t i = threadIdx.x * 16; i + 16 <= total; i += 256 * 16) *(uint4*)(s_pre + i) = *(const uint4*)(src + i);
+        for (uint32_t i = (total & ~15u) + threadIdx.x; i < total; i += 256) s_pre[i] = src[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < total; i += 256) s_pre[i] = src[i];
+    }
+    if (threadIdx.x < ol.n) {
+        const uint32_t r = ol.rep[threadIdx.x];
+        s_dst[threadIdx.x] = ol.dst[threadIdx.x];
+        s_pos[threadIdx.x] = ((r >> 3) << 3) | (4 * ((r >> 2) & 1) + 3 - (r & 3));
+    }
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < nb * ol.n; idx += 256) {
+        const uint32_t k = idx % ol.n, tl = idx / ol.n;
+        const uint32_t pos = s_pos[k], byte = pos >> 3, bit = pos & 7;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t row = 8 * tl + j;
+            if (row < n_rows) acc |= (((uint32_t)s_pre[row * h + byte] >> bit) & 1u) << (7 - j);
         }
+        s_buf[k * EX_TB + tl] = (uint8_t)acc;
     }
-    const bool writer = lane < 8 && wave * 8 + lane < n_bytes;
-#pragma unroll
-    for (int k = 0; k < RV_ONLINE_REPS; k++) {
-        if (k >= (int)ol.n) break;
-        const uint32_t r = ol.rep[k];  // kernel-argument data: scalar, no dependent global load
-        const uint32_t wi = r >> 5, rr = r & 31;
-        const uint32_t pos = 8 * ((rr >> 3) & 3) + 4 * ((rr >> 2) & 1) + 3 - (rr & 3);
-        // wave-uniform word select without dynamic register indexing
-        uint32_t word = w[0];
-#pragma unroll
-        for (int i = 1; i < 8; i++) word = (wi == (uint32_t)i) ? w[i] : word;
-        const unsigned long long bal = __ballot((word >> pos) & 1u);
-        const unsigned long long rev = __brevll(bal);  // event 64w+8t+j -> bit 63-8t-j
-        if (writer) out[ol.dst[k] + wave * 8 + lane] = (uint8_t)(rev >> (56 - 8 * lane));
-    }
+    __syncthreads();
+    ex_flush(s_buf, s_dst, ol.n, t0, nb, out);
+}
+
+static uint32_t ex_tb_for(uint64_t n_bytes) {
+    // output bytes per workgroup: the full EX_TB when that still yields several workgroups per CU, fewer for
+    // short vectors (a workgroup walks its bytes in a serial loop)
+    uint32_t tb = EX_TB;
+    while (tb > 8 && (n_bytes + tb - 1) / tb < 2048) tb /= 2;
+    return tb;
 }
 
 void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint32_t NQ, const OnlineList& ol,
                               uint8_t* d_out) {
     if (!ol.n) return;
-    const uint64_t waves = (n_items / 8 + 1 + 7) / 8;
-    hipLaunchKernelGGL(k_extract_from_bits, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, d_bits, n_items, NQ, ol, d_out);
+    const uint64_t n_bytes = n_items / 8 + 1;
+    const uint32_t tb = ex_tb_for(n_bytes);
+    hipLaunchKernelGGL(k_extract_from_bits, dim3((unsigned)((n_bytes + tb - 1) / tb)), dim3(256), 0, st, d_bits, n_items, NQ, tb, ol,
+                       d_out);
 }
 
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ,
                          int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out) {
-    constexpr int BPT = 1;  // 2 and 4 rows-in-flight variants measured slower (0.88 vs 0.78 ms)
-    const uint64_t threads = ((n_items / 8 + 1 + BPT - 1) / BPT) * NQ;
-    hipLaunchKernelGGL(k_extract_bits<BPT>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, d_rows, n_items,
-                       NQ, kind, d_omit, d_dst_off, d_out);
+    const uint64_t n_bytes = n_items / 8 + 1;
+    const uint32_t tb = ex_tb_for(n_bytes);
+    const dim3 grid((unsigned)((n_bytes + tb - 1) / tb));
+    if (kind == 0)
+        hipLaunchKernelGGL(k_extract_rows<0>, grid, dim3(256), 0, st, (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
+                           d_dst_off, d_out);
+    else
+        hipLaunchKernelGGL(k_extract_rows<1>, grid, dim3(256), 0, st, (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
+                           d_dst_off, d_out);
 }
 
 // Inverse for the verifier (Pack::unpack / PackSelected::unpack_selected): builds dense
