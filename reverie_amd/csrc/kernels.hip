@@ -506,51 +506,108 @@ __global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restric
     }
 }
 
-// one tree level: out[i] = parent(in[2i], in[2i+1]); an odd last node is promoted unchanged
-__global__ void k_b3_parents(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t R, uint32_t* __restrict__ out) {
+// LG tree levels per launch: thread = (group of G = 2^LG consecutive nodes, repetition).  One level is
+// out[i] = parent(in[2i], in[2i+1]) with an odd last node promoted unchanged; groups are aligned to G, so
+// reducing a group locally level by level gives exactly the nodes LG global levels would (the ragged
+// last group follows the same promote rule).  The ROOT flag belongs to the merge of the last two nodes of
+// the whole tree, which can only happen inside the only group of a launch.
+template <int LG>
+__global__ __launch_bounds__(256) void k_b3_reduce(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t R,
+                                                   uint32_t* __restrict__ out) {
+    constexpr int G = 1 << LG;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t n_out = (n_in + 1) / 2;
-    const uint64_t i = tid / R;
+    const uint64_t n_out = (n_in + G - 1) / G;
+    const uint64_t g = tid / R;
     const uint32_t r = (uint32_t)(tid % R);
-    if (i >= n_out) return;
-    const uint32_t* l = in + ((size_t)(2 * i) * R + r) * 8;
-    uint32_t o[8];
-    if (2 * i + 1 < n_in) {
-        const uint32_t* rr = in + ((size_t)(2 * i + 1) * R + r) * 8;
-        uint32_t lv[8], rv_[8];
+    if (g >= n_out) return;
+    uint32_t cnt = (uint32_t)((n_in - G * g < (uint64_t)G) ? n_in - G * g : G);
+    uint32_t cv[G][8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            lv[k] = l[k];
-            rv_[k] = rr[k];
+    for (int i = 0; i < G; i++) {
+        if ((uint32_t)i < cnt) {
+            const uint4* src = (const uint4*)(in + ((size_t)(G * g + i) * R + r) * 8);
+            const uint4 lo = src[0], hi = src[1];
+            cv[i][0] = lo.x; cv[i][1] = lo.y; cv[i][2] = lo.z; cv[i][3] = lo.w;
+            cv[i][4] = hi.x; cv[i][5] = hi.y; cv[i][6] = hi.z; cv[i][7] = hi.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) cv[i][k] = 0;
         }
-        b3::parent(lv, rv_, n_in == 2 ? b3::ROOT : 0u, o);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) o[k] = l[k];
     }
-    uint32_t* d = out + ((size_t)i * R + r) * 8;
 #pragma unroll
-    for (int k = 0; k < 8; k++) d[k] = o[k];
+    for (int lvl = 0; lvl < LG; lvl++) {
+        const uint32_t flags = (n_out == 1 && cnt == 2) ? b3::ROOT : 0u;
+#pragma unroll
+        for (int i = 0; i < (G >> (lvl + 1)); i++) {
+            if ((uint32_t)(2 * i + 1) < cnt) {
+                uint32_t o[8];
+                b3::parent(cv[2 * i], cv[2 * i + 1], flags, o);
+#pragma unroll
+                for (int k = 0; k < 8; k++) cv[i][k] = o[k];
+            } else if ((uint32_t)(2 * i) < cnt) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) cv[i][k] = cv[2 * i][k];
+            }
+        }
+        cnt = (cnt + 1) / 2;
+    }
+    uint4* d = (uint4*)(out + ((size_t)g * R + r) * 8);
+    d[0] = make_uint4(cv[0][0], cv[0][1], cv[0][2], cv[0][3]);
+    d[1] = make_uint4(cv[0][4], cv[0][5], cv[0][6], cv[0][7]);
 }
 
-__global__ void k_copy_words(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n) {
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < n) out[tid] = in[tid];
+// The top of the tree (at most B3_TAIL nodes per repetition): one workgroup per repetition walks the
+// remaining levels through LDS, a barrier per level instead of a launch per level.
+constexpr uint32_t B3_TAIL = 512;
+__global__ __launch_bounds__(256) void k_b3_tree_tail(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R,
+                                                      uint32_t* __restrict__ digest) {
+    __shared__ uint32_t cv[B3_TAIL][8 + 1];  // +1: odd row stride, no bank conflicts on the strided pair reads
+    const uint32_t r = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < n_in * 8; i += 256) cv[i >> 3][i & 7] = in[((size_t)(i >> 3) * R + r) * 8 + (i & 7)];
+    __syncthreads();
+    uint32_t cnt = n_in;
+    while (cnt > 1) {
+        const uint32_t half = (cnt + 1) / 2;
+        const uint32_t i = threadIdx.x;
+        uint32_t o[8];
+        if (i < half) {
+            if (2 * i + 1 < cnt) {
+                uint32_t l[8], rr[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    l[k] = cv[2 * i][k];
+                    rr[k] = cv[2 * i + 1][k];
+                }
+                b3::parent(l, rr, cnt == 2 ? b3::ROOT : 0u, o);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) o[k] = cv[2 * i][k];
+            }
+        }
+        __syncthreads();
+        if (i < half) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) cv[i][k] = o[k];
+        }
+        __syncthreads();
+        cnt = half;
+    }
+    if (threadIdx.x < 8) digest[(size_t)r * 8 + threadIdx.x] = cv[0][threadIdx.x];
 }
 
-// pairwise tree reduction of n chunk chaining values per repetition, then copy of the roots
+// tree reduction of n chunk chaining values per repetition; the roots land in d_digest ([R][8] words)
 void b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest) {
-    while (n > 1) {
-        const uint64_t n_out = (n + 1) / 2;
+    while (n > B3_TAIL) {  // two levels per launch while the level is wide
+        const uint64_t n_out = (n + 3) / 4;
         const uint64_t threads = n_out * R;
-        hipLaunchKernelGGL(k_b3_parents, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, cur, n, R, nxt);
+        hipLaunchKernelGGL(k_b3_reduce<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, cur, n, R, nxt);
         uint32_t* t = cur;
         cur = nxt;
         nxt = t;
         n = n_out;
     }
-    const uint64_t words = (uint64_t)R * 8;
-    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, cur, d_digest, words);
+    // a single chunk is already its own root (the chunk kernels applied the ROOT flag): cnt == 1 just copies
+    hipLaunchKernelGGL(k_b3_tree_tail, dim3(R), dim3(256), 0, st, cur, (uint32_t)n, R, d_digest);
 }
 
 size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R) {
