@@ -200,6 +200,13 @@ int rv_shard_open_size(const rv_shard *s, const uint8_t omit[RV_TOTAL_REPS], siz
 /* As rv_shard_open_device, but writes the concatenated blobs into caller-owned HBM
  * (sum of rv_shard_open_size bytes), e.g. a torch tensor handed to RCCL afterwards */
 int rv_shard_open_into(rv_shard *s, const uint8_t omit[RV_TOTAL_REPS], void *dst_device, size_t lens[4]);
+/* Fiat-Shamir without leaving the device, for a shard that holds ALL 256 repetitions (rep_begin 0, rep_count 256):
+ * comm = BLAKE3(digests) (combine_hashes, proof/mod.rs:102-108), the challenge (RandomOracle + challenge_to_opening,
+ * crypto/ro.rs:8-20, proof/mod.rs:68-83) and the openings, with no host round trip in between.  Equivalent to
+ * rv_shard_digests -> rv_combine_digests -> rv_challenge -> rv_shard_open_into; returns comm and the opening map.
+ * dst_device capacity: the sum rv_shard_open_size reports for ANY 40/216 map (sizes do not depend on which
+ * repetitions open).  RV_E_ARG for a partial shard. */
+int rv_shard_open_self(rv_shard *s, void *dst_device, uint8_t comm[RV_HASH_SIZE], uint8_t omit[RV_TOTAL_REPS], size_t lens[4]);
 
 /* combine_hashes (proof/mod.rs:102-108): comm = BLAKE3(h[0] || ... || h[255]) */
 int rv_combine_digests(const uint8_t *h /* 256 x 32 */, uint8_t comm[RV_HASH_SIZE]);

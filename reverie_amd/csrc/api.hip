@@ -763,46 +763,67 @@ extern "C" int rv_shard_open_size(const rv_shard* s, const uint8_t omit[RV_TOTAL
     return RV_OK;
 }
 
-static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void* dst, void** dptr, size_t lens[4],
-                           bool framed = false);
+static int shard_open_impl(rv_shard* s, const uint8_t* omit /* NULL: device Fiat-Shamir */, void* dst, void** dptr, size_t lens[4],
+                           bool framed = false, uint8_t* comm_out = nullptr, uint8_t* omit_out = nullptr);
 
 extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void** dptr, size_t lens[4]) {
+    if (!omit) return RV_E_ARG;
     return shard_open_impl(s, omit, nullptr, dptr, lens);
 }
 
 extern "C" int rv_shard_open_into(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void* dst_device, size_t lens[4]) {
-    if (!dst_device) return RV_E_ARG;
+    if (!dst_device || !omit) return RV_E_ARG;
     void* d = nullptr;
     return shard_open_impl(s, omit, dst_device, &d, lens);
 }
 
-static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void* dst, void** dptr, size_t lens[4], bool framed) {
-    if (!s || !omit || !dptr || !lens) return RV_E_ARG;
+// `omit` == NULL: Fiat-Shamir on the device (k_fs_challenge) from the shard's own digests; only for a shard that
+// holds all 256 repetitions.  comm_out / omit_out (nullable) then receive comm and the opening map.
+static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** dptr, size_t lens[4], bool framed, uint8_t* comm_out,
+                           uint8_t* omit_out) {
+    if (!s || !dptr || !lens) return RV_E_ARG;
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     HIPCHK(hipSetDevice(ctx->device));
-    const uint8_t* om = omit + s->rep_begin;
+    const bool self = omit == nullptr;
+    if (self && (s->rep_begin != 0 || s->R != RV_TOTAL_REPS)) return RV_E_ARG;
+    uint8_t canon[RV_TOTAL_REPS];  // any map with the 40 / 216 split gives the layout: sizes do not depend on WHICH reps open
+    if (self) {
+        for (uint32_t r = 0; r < RV_TOTAL_REPS; r++) canon[r] = r < RV_ONLINE_REPS ? 0 : RV_PLAYERS;
+    }
+    const uint8_t* om = self ? canon : omit + s->rep_begin;
     for (uint32_t r = 0; r < s->R; r++)
         if (om[r] > 8) return RV_E_ARG;
     const OpenLayout L = open_layout(cc, om, s->R, framed);
-    std::vector<uint64_t> offs((size_t)8 * s->R);  // off2, off64, gf2 rec/corr/in dst, z64 rec/corr/in dst
-    uint32_t k_on = 0, k_pre = 0;
-    for (uint32_t r = 0; r < s->R; r++) {
-        if (om[r] < 8) {
-            offs[r] = L.base[0] + (uint64_t)k_on * L.sz2;
-            offs[s->R + r] = L.base[2] + (uint64_t)k_on * L.sz64;
-            offs[2 * s->R + r] = offs[r] + 137;
-            offs[3 * s->R + r] = offs[r] + 145 + L.l2r;
-            offs[4 * s->R + r] = offs[r] + 153 + L.l2r + L.l2c;
-            offs[5 * s->R + r] = offs[s->R + r] + 137;
-            offs[6 * s->R + r] = offs[s->R + r] + 145 + L.l64r;
-            offs[7 * s->R + r] = offs[s->R + r] + 153 + L.l64r + L.l64c;
-            k_on++;
-        } else {
-            offs[r] = L.base[1] + (uint64_t)k_pre * 48;
-            offs[s->R + r] = L.base[3] + (uint64_t)k_pre * 48;
-            k_pre++;
+    constexpr size_t OL_WORDS = (sizeof(OnlineList) + 7) / 8;
+    // off2, off64, gf2 rec/corr/in dst, z64 rec/corr/in dst; then the OnlineList
+    std::vector<uint64_t> offs((size_t)8 * s->R + OL_WORDS);
+    if (!self) {
+        uint32_t k_on = 0, k_pre = 0;
+        OnlineList ol{};
+        for (uint32_t r = 0; r < s->R; r++) {
+            if (om[r] < 8) {
+                offs[r] = L.base[0] + (uint64_t)k_on * L.sz2;
+                offs[s->R + r] = L.base[2] + (uint64_t)k_on * L.sz64;
+                offs[2 * s->R + r] = offs[r] + 137;
+                offs[3 * s->R + r] = offs[r] + 145 + L.l2r;
+                offs[4 * s->R + r] = offs[r] + 153 + L.l2r + L.l2c;
+                offs[5 * s->R + r] = offs[s->R + r] + 137;
+                offs[6 * s->R + r] = offs[s->R + r] + 145 + L.l64r;
+                offs[7 * s->R + r] = offs[s->R + r] + 153 + L.l64r + L.l64c;
+                if (ol.n < RV_ONLINE_REPS) {
+                    ol.rep[ol.n] = r;
+                    ol.dst[ol.n] = offs[3 * s->R + r];
+                    ol.n++;
+                }
+                k_on++;
+            } else {
+                offs[r] = L.base[1] + (uint64_t)k_pre * 48;
+                offs[s->R + r] = L.base[3] + (uint64_t)k_pre * 48;
+                k_pre++;
+            }
         }
+        memcpy(&offs[(size_t)8 * s->R], &ol, sizeof ol);
     }
     int rc;
     ctx->release(s->d_omit);
@@ -811,31 +832,33 @@ static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void*
     s->d_omit = nullptr;
     s->d_offs = nullptr;
     s->d_out = nullptr;
-    if ((rc = dalloc(ctx, s->R, &s->d_omit)) || (rc = dalloc(ctx, offs.size(), &s->d_offs))) return rc;
+    // d_omit: [R] omit, then (device Fiat-Shamir) 32 bytes of comm
+    if ((rc = dalloc(ctx, s->R + 32, &s->d_omit)) || (rc = dalloc(ctx, offs.size(), &s->d_offs))) return rc;
     uint8_t* d_out = (uint8_t*)dst;
     if (!d_out) {
         if ((rc = dalloc(ctx, std::max<size_t>(L.total, 1), &s->d_out))) return rc;
         d_out = s->d_out;
     }
-    HIPCHK(hipMemcpyAsync(s->d_omit, om, s->R, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(s->d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    const OnlineList* d_ol = (const OnlineList*)(s->d_offs + (size_t)8 * s->R);
     const size_t DW = (size_t)s->R * 8;
     ctx->phase(RV_PH_OPEN);
+    if (self) {
+        FsLayout F{};
+        for (int k = 0; k < 4; k++) F.base[k] = L.base[k];
+        F.sz2 = L.sz2, F.sz64 = L.sz64, F.l2r = L.l2r, F.l2c = L.l2c, F.l64r = L.l64r, F.l64c = L.l64c;
+        launch_fs_challenge(ctx->stream, s->d_h, F, s->d_omit + s->R, s->d_omit, s->d_offs, (OnlineList*)d_ol);
+        ctx->count();
+        if (framed) HIPCHK(hipMemcpyAsync(d_out, s->d_omit + s->R, 32, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(s->d_omit, om, s->R, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(s->d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     ctx->count(L.n_on ? 4 : 1);
     launch_open_headers(ctx->stream, s->R, s->d_omit, s->d_seeds, s->d_keys, s->d_dig + 1 * DW, s->d_dig + 3 * DW, s->d_offs,
                         s->d_offs + s->R, L.l2r, L.l2c, L.l2i, L.l64r, L.l64c, L.l64i, d_out);
     if (L.n_on) {
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
-        {
-            OnlineList ol{};
-            for (uint32_t r = 0; r < s->R; r++)
-                if (om[r] < 8 && ol.n < RV_ONLINE_REPS) {
-                    ol.rep[ol.n] = r;
-                    ol.dst[ol.n] = offs[3 * s->R + r];
-                    ol.n++;
-                }
-            launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, ol, d_out);
-        }
+        launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out);
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
         launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_rec_offs64, cc.n_rec64, 1, s->R, s->d_omit,
                          s->d_offs + 5 * s->R, d_out);
@@ -846,12 +869,27 @@ static int shard_open_impl(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void*
     }
     HIPCHK(hipGetLastError());
     ctx->phase(-1);
-    // the host vector `offs` must outlive the async copy
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (self) {
+        uint8_t back[RV_TOTAL_REPS + 32];
+        if (comm_out || omit_out) HIPCHK(hipMemcpyAsync(back, s->d_omit, sizeof back, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (omit_out) memcpy(omit_out, back, RV_TOTAL_REPS);
+        if (comm_out) memcpy(comm_out, back + RV_TOTAL_REPS, 32);
+    } else {
+        // the host vector `offs` must outlive the async copy
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     ctx->collect();
     *dptr = d_out;
     for (int k = 0; k < 4; k++) lens[k] = L.len[k];
     return RV_OK;
+}
+
+extern "C" int rv_shard_open_self(rv_shard* s, void* dst_device, uint8_t comm[RV_HASH_SIZE], uint8_t omit[RV_TOTAL_REPS],
+                                  size_t lens[4]) {
+    if (!dst_device || !comm || !omit) return RV_E_ARG;
+    void* d = nullptr;
+    return shard_open_impl(s, nullptr, dst_device, &d, lens, false, comm, omit);
 }
 
 extern "C" int rv_shard_open(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], rv_shard_parts* parts) {
@@ -951,15 +989,14 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
     rv_shard* s = nullptr;
     int rc = rv_shard_commit(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, 0, RV_TOTAL_REPS, &s);
     if (rc) return rc;
-    std::vector<uint8_t> h(RV_TOTAL_REPS * 32);
-    uint8_t comm[32], omit[RV_TOTAL_REPS];
+    uint8_t comm[32];
     uint8_t* out = nullptr;
     do {
-        if ((rc = rv_shard_digests(s, h.data())) || (rc = rv_combine_digests(h.data(), comm)) || (rc = rv_challenge(comm, omit))) break;
-        // the whole proof is laid out on the device in its final bincode form and leaves in ONE copy
+        // commitment, challenge and openings all on the device (k_fs_challenge); the whole proof is laid out there
+        // in its final bincode form and leaves in ONE copy
         void* d = nullptr;
         size_t lens[4];
-        if ((rc = shard_open_impl(s, omit, nullptr, &d, lens, true))) break;
+        if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, comm, nullptr))) break;
         const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
         out = (uint8_t*)malloc(total);
         if (!out) {

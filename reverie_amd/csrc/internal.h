@@ -163,8 +163,17 @@ struct OnlineList {
     uint32_t rep[RV_ONLINE_REPS];
     uint64_t dst[RV_ONLINE_REPS];
 };
-void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint32_t NQ, const OnlineList& ol,
-                              uint8_t* d_out);
+void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint32_t NQ,
+                              const OnlineList* d_ol /* device */, uint8_t* d_out);
+// Fiat-Shamir on the device for a shard that holds all 256 repetitions (proof/mod.rs:68-108,158-175):
+// comm = BLAKE3(h[0..256)), the challenge map, and from it everything the opening kernels consume
+// (omit[256], the 8 x 256 output offsets, the OnlineList) without a host round trip.
+struct FsLayout {
+    uint64_t base[4];  // section starts: gf2 online, gf2 preprocessing, z64 online, z64 preprocessing
+    uint64_t sz2, sz64, l2r, l2c, l64r, l64c;
+};
+void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint8_t* d_comm, uint8_t* d_omit, uint64_t* d_offs,
+                         OnlineList* d_ol);
 // kind 0: omitted player's bit of a share row; 1: smeared byte of a row
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,
                          uint32_t NQ, int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);

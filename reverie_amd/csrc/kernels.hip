@@ -772,11 +772,14 @@ __global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict
 // the workgroup's 8*tb rows are contiguous in HBM and are copied to LDS in one coalesced pass; thread =
 // (output byte, opened repetition) then picks its 8 bits out of LDS.
 __global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ,
-                                                           uint32_t tb /* <= EX_TB */, OnlineList ol, uint8_t* __restrict__ out) {
+                                                           uint32_t tb /* <= EX_TB */, const OnlineList* __restrict__ olp,
+                                                           uint8_t* __restrict__ out) {
     __shared__ uint8_t s_buf[RV_ONLINE_REPS * EX_TB];
     __shared__ uint64_t s_dst[RV_ONLINE_REPS];
     __shared__ uint32_t s_pos[RV_ONLINE_REPS];  // byte in the row << 3 | bit in the byte
     __shared__ __attribute__((aligned(16))) uint8_t s_pre[8 * EX_TB * 32];
+    const uint32_t n_ol = olp->n < RV_ONLINE_REPS ? olp->n : RV_ONLINE_REPS;
+    if (!n_ol) return;
     const uint64_t n_bytes = n_items / 8 + 1;
     const uint64_t t0 = (uint64_t)blockIdx.x * tb;
     const uint32_t nb = (uint32_t)((n_bytes - t0 < tb) ? n_bytes - t0 : tb);
@@ -791,14 +794,14 @@ __global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __rest
     } else {
         for (uint32_t i = threadIdx.x; i < total; i += 256) s_pre[i] = src[i];
     }
-    if (threadIdx.x < ol.n) {
-        const uint32_t r = ol.rep[threadIdx.x];
-        s_dst[threadIdx.x] = ol.dst[threadIdx.x];
+    if (threadIdx.x < n_ol) {
+        const uint32_t r = olp->rep[threadIdx.x];
+        s_dst[threadIdx.x] = olp->dst[threadIdx.x];
         s_pos[threadIdx.x] = ((r >> 3) << 3) | (4 * ((r >> 2) & 1) + 3 - (r & 3));
     }
     __syncthreads();
-    for (uint32_t idx = threadIdx.x; idx < nb * ol.n; idx += 256) {
-        const uint32_t k = idx % ol.n, tl = idx / ol.n;
+    for (uint32_t idx = threadIdx.x; idx < nb * n_ol; idx += 256) {
+        const uint32_t k = idx % n_ol, tl = idx / n_ol;
         const uint32_t pos = s_pos[k], byte = pos >> 3, bit = pos & 7;
         uint32_t acc = 0;
 #pragma unroll
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __rest
         s_buf[k * EX_TB + tl] = (uint8_t)acc;
     }
     __syncthreads();
-    ex_flush(s_buf, s_dst, ol.n, t0, nb, out);
+    ex_flush(s_buf, s_dst, n_ol, t0, nb, out);
 }
 
 static uint32_t ex_tb_for(uint64_t n_bytes) {
@@ -820,13 +823,132 @@ static uint32_t ex_tb_for(uint64_t n_bytes) {
     return tb;
 }
 
-void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint32_t NQ, const OnlineList& ol,
+void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint32_t NQ, const OnlineList* d_ol,
                               uint8_t* d_out) {
-    if (!ol.n) return;
     const uint64_t n_bytes = n_items / 8 + 1;
     const uint32_t tb = ex_tb_for(n_bytes);
-    hipLaunchKernelGGL(k_extract_from_bits, dim3((unsigned)((n_bytes + tb - 1) / tb)), dim3(256), 0, st, d_bits, n_items, NQ, tb, ol,
+    hipLaunchKernelGGL(k_extract_from_bits, dim3((unsigned)((n_bytes + tb - 1) / tb)), dim3(256), 0, st, d_bits, n_items, NQ, tb, d_ol,
                        d_out);
+}
+
+// ------------------------------------------------------------------------------------
+// Fiat-Shamir on the device (one wavefront).  combine_hashes (proof/mod.rs:102-108): comm =
+// BLAKE3 of the 256 digests = 8 chunks (lanes 0..7, 16 chained compressions each) + a 3-level
+// tree.  RandomOracle (crypto/ro.rs:8-20) + challenge_to_opening (proof/mod.rs:68-83): XOF of
+// "random-oracle challenge" || 0x00 || comm; 16-byte draws, u128 LE mod 256 then mod 8 = the
+// first byte of each draw; every lane produces one 64-byte XOF block = two (rep, omit) pairs,
+// lane 0 replays them in order (a re-drawn repetition overwrites its omit) until 40 distinct.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_fs_challenge(const uint8_t* __restrict__ h, FsLayout L, uint8_t* __restrict__ comm,
+                                                     uint8_t* __restrict__ omit, uint64_t* __restrict__ offs,
+                                                     OnlineList* __restrict__ ol) {
+    __shared__ uint32_t s_cv[8][8], s_t1[4][8], s_t2[2][8], s_comm[8];
+    __shared__ uint32_t s_msg[16];
+    __shared__ uint8_t s_draw[128][2];
+    __shared__ uint8_t s_omit[RV_TOTAL_REPS];
+    __shared__ uint32_t s_count;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t* hw = (const uint32_t*)h;
+    if (lane < 8) {
+        uint32_t cv[8], m[16], o[8];
+        b3::iv(cv);
+        for (uint32_t b = 0; b < 16; b++) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) m[k] = hw[lane * 256 + b * 16 + k];
+            b3::compress<false>(cv, m, lane, 64, (b == 0 ? b3::CHUNK_START : 0u) | (b == 15 ? b3::CHUNK_END : 0u), o);
+#pragma unroll
+            for (int k = 0; k < 8; k++) cv[k] = o[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) s_cv[lane][k] = cv[k];
+    }
+    for (uint32_t r = lane; r < RV_TOTAL_REPS; r += 64) s_omit[r] = RV_PLAYERS;
+    if (lane == 0) s_count = 0;
+    __syncthreads();
+    if (lane < 4) b3::parent(s_cv[2 * lane], s_cv[2 * lane + 1], 0, s_t1[lane]);
+    __syncthreads();
+    if (lane < 2) b3::parent(s_t1[2 * lane], s_t1[2 * lane + 1], 0, s_t2[lane]);
+    __syncthreads();
+    if (lane == 0) {
+        b3::parent(s_t2[0], s_t2[1], b3::ROOT, s_comm);
+        // the random oracle's one input block: context string, a zero byte, comm; 56 bytes, zero padded
+        const char ctx[] = "random-oracle challenge";  // proof/mod.rs:18
+        uint8_t blk[64];
+        for (int i = 0; i < 64; i++) blk[i] = 0;
+        for (int i = 0; i < 23; i++) blk[i] = (uint8_t)ctx[i];
+        for (int i = 0; i < 8; i++) {
+            comm[4 * i + 0] = blk[24 + 4 * i + 0] = (uint8_t)(s_comm[i]);
+            comm[4 * i + 1] = blk[24 + 4 * i + 1] = (uint8_t)(s_comm[i] >> 8);
+            comm[4 * i + 2] = blk[24 + 4 * i + 2] = (uint8_t)(s_comm[i] >> 16);
+            comm[4 * i + 3] = blk[24 + 4 * i + 3] = (uint8_t)(s_comm[i] >> 24);
+        }
+        for (int i = 0; i < 16; i++)
+            s_msg[i] = (uint32_t)blk[4 * i] | ((uint32_t)blk[4 * i + 1] << 8) | ((uint32_t)blk[4 * i + 2] << 16) |
+                       ((uint32_t)blk[4 * i + 3] << 24);
+    }
+    __syncthreads();
+    uint32_t m[16], cv[8];
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = s_msg[k];
+    b3::iv(cv);
+    for (uint64_t base = 0;; base += 64) {
+        uint32_t o[16];
+        b3::compress<true>(cv, m, base + lane, 56, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, o);
+        s_draw[2 * lane][0] = (uint8_t)o[0];
+        s_draw[2 * lane][1] = (uint8_t)(o[4] & 7u);
+        s_draw[2 * lane + 1][0] = (uint8_t)o[8];
+        s_draw[2 * lane + 1][1] = (uint8_t)(o[12] & 7u);
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t count = s_count;
+            for (uint32_t i = 0; i < 128 && count < RV_ONLINE_REPS; i++) {
+                const uint32_t rep = s_draw[i][0];
+                if (s_omit[rep] == RV_PLAYERS) count++;
+                s_omit[rep] = s_draw[i][1];
+            }
+            s_count = count;
+        }
+        __syncthreads();
+        if (s_count >= RV_ONLINE_REPS) break;
+    }
+    // offsets of every repetition's record and of its vectors (the same arithmetic as the host path)
+    constexpr uint32_t R = RV_TOTAL_REPS;
+    uint32_t k_on = 0, k_pre = 0;
+    for (uint32_t c = 0; c < R / 64; c++) {
+        const uint32_t r = 64 * c + lane;
+        const uint32_t om = s_omit[r];
+        const bool on = om < RV_PLAYERS;
+        const unsigned long long bal = __ballot(on);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const uint32_t my_on = k_on + (uint32_t)__popcll(bal & lt), my_pre = k_pre + (uint32_t)__popcll(~bal & lt);
+        omit[r] = (uint8_t)om;
+        uint64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (on) {
+            v[0] = L.base[0] + (uint64_t)my_on * L.sz2;
+            v[1] = L.base[2] + (uint64_t)my_on * L.sz64;
+            v[2] = v[0] + 137;
+            v[3] = v[0] + 145 + L.l2r;
+            v[4] = v[0] + 153 + L.l2r + L.l2c;
+            v[5] = v[1] + 137;
+            v[6] = v[1] + 145 + L.l64r;
+            v[7] = v[1] + 153 + L.l64r + L.l64c;
+            ol->rep[my_on] = r;
+            ol->dst[my_on] = v[3];
+        } else {
+            v[0] = L.base[1] + (uint64_t)my_pre * 48;
+            v[1] = L.base[3] + (uint64_t)my_pre * 48;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) offs[(size_t)j * R + r] = v[j];
+        k_on += (uint32_t)__popcll(bal);
+        k_pre += 64 - (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) ol->n = RV_ONLINE_REPS;
+}
+
+void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint8_t* d_comm, uint8_t* d_omit, uint64_t* d_offs,
+                         OnlineList* d_ol) {
+    hipLaunchKernelGGL(k_fs_challenge, dim3(1), dim3(64), 0, st, d_h, L, d_comm, d_omit, d_offs, d_ol);
 }
 
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ,

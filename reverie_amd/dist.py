@@ -81,6 +81,15 @@ class HipShardBackend:
         _lib.check(_lib.lib().rv_shard_open_into(shard[0], _ptr(omit), C.c_void_p(tensor.data_ptr()), lens))
         return [int(x) for x in lens]
 
+    def open_self(self, shard, tensor):
+        """Single-shard proofs: commitment, challenge and openings on the device (rv_shard_open_self).
+        -> (comm bytes, omit[256], lens[4])"""
+        lens = (C.c_size_t * 4)()
+        comm = np.zeros(32, np.uint8)
+        omit = np.zeros(TOTAL_REPS, np.uint8)
+        _lib.check(_lib.lib().rv_shard_open_self(shard[0], C.c_void_p(tensor.data_ptr()), _ptr(comm), _ptr(omit), lens))
+        return comm.tobytes(), omit, [int(x) for x in lens]
+
     def open(self, shard, omit: np.ndarray):
         """-> (blob bytes [gf2_on | gf2_pre | z64_on | z64_pre], lens[4], n_online, n_pre)"""
         parts = _lib.ShardParts()
@@ -140,6 +149,14 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
     seeds = np.asarray(seeds, dtype=np.uint8).reshape(TOTAL_REPS, 16)
     shard = backend.commit(wit_gf2, wit_z64, seeds[begin:begin + count], begin, count)
     try:
+        if world == 1 and device_resident and backend.device_type == "cuda" and hasattr(backend, "open_self"):
+            # one shard holds every repetition: Fiat-Shamir stays on the device, no host round trip
+            canon = np.full(TOTAL_REPS, 8, np.uint8)
+            canon[:40] = 0  # sizes depend only on the 40 / 216 split
+            lens = backend.open_sizes(shard, canon)
+            buf = torch.empty(max(sum(lens), 1), dtype=torch.uint8, device="cuda")
+            comm, _, lens = backend.open_self(shard, buf)
+            return comm, [buf], [lens]
         # ---- the one collective: all-gather of per-repetition digests
         if world == 1:
             h = backend.digests(shard)

@@ -346,6 +346,36 @@ def test_full_size_properties(rv, rule_seeds):
     assert not rv.Proof(bytes(bad)).verify(c)
 
 
+def test_single_shard_host_and_device_fiat_shamir(rv, oracle):
+    """One shard holding all 256 repetitions: the host-side challenge path (digests -> rv_combine_digests ->
+    rv_challenge -> open) and the device-side one (rv_shard_open_self) must give the oracle's proof."""
+    from reverie_amd.dist import HipShardBackend, assemble_device_parts, prove_sharded
+    from reverie_amd.proof import challenge, combine_digests
+
+    rng = np.random.default_rng(777)
+    for n_gates in (1, 300):
+        prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=n_gates)
+        seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+        want = oracle.prove(prog, w2, w64, wc, seeds, threads=2)
+        c = rv.Circuit(prog, wc)
+        be = HipShardBackend(c)
+        assert prove_sharded(be, w2, w64, seeds) == want  # host challenge
+        comm, bufs, lens = prove_sharded(be, w2, w64, seeds, device_resident=True)  # device challenge
+        assert assemble_device_parts(comm, bufs, lens) == want
+        # the opening map the device derived is the host's
+        shard = be.commit(w2, w64, seeds, 0, 256)
+        try:
+            import torch
+
+            h = be.digests(shard)
+            buf = torch.empty(max(sum(lens[0]), 1), dtype=torch.uint8, device="cuda")
+            comm2, omit2, _ = be.open_self(shard, buf)
+            assert comm2 == combine_digests(h) == want[:32]
+            assert (omit2 == challenge(comm2)).all()
+        finally:
+            be.destroy(shard)
+
+
 # ---------------------------------------------------------------- sharded path on the GPU
 def _two_rank_worker(rank, world, port, out_path):
     import sys
