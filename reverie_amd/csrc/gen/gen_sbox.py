@@ -177,6 +177,9 @@ def parse():
     return gates
 
 
+LUT3_COST = 1.15
+
+
 def lut3_synthesis():
     """Greedy packing of the 2-input XOR/AND/XNOR netlist into <=3-input LUTs (gfx950 has
     v_bitop3_b32: any 3-input boolean function in one VALU op).  A gate is inlined into its
@@ -206,10 +209,18 @@ def lut3_synthesis():
             return fn(e)
         return f
 
-    # rule: a gate disappears if EVERY consumer can absorb it and stay within 3 inputs
+    # Cost-aware rule.  Measured on gfx950 (tools/mb/valu_mb.hip, occ_mb.hip): a 3-source VOP3 op
+    # (v_bitop3_b32) issues at 4 cycles per wavefront, a VOP2 logic op at ~2.4 with two wavefronts per SIMD,
+    # so a LUT3 costs LUT3_COST two-input ops.  A gate is absorbed into ALL its consumers (duplicated when
+    # it has several) only when that lowers the total cost; minimising the op count instead (every absorption
+    # taken) gave 80 ops / 60 LUT3 = 119 two-input equivalents, worse than the plain 113-gate netlist.
+    def cost(ins):
+        return LUT3_COST if len(ins) == 3 else 1.0
+
     changed = True
     while changed:
         changed = False
+        best = None
         for w in list(order):
             if w not in nodes or w in outputs:
                 continue
@@ -226,10 +237,16 @@ def lut3_synthesis():
                     ok = False
                     break
                 merged[n] = (union, compose(fn, wfn, w))
-            if ok:
-                nodes.update(merged)
-                del nodes[w]
-                changed = True
+            if not ok:
+                continue
+            gain = cost(wins) + sum(cost(nodes[n][0]) for n in cons) - sum(cost(m[0]) for m in merged.values())
+            if gain > 1e-9 and (best is None or gain > best[0]):
+                best = (gain, w, merged)
+        if best:
+            _, w, merged = best
+            nodes.update(merged)
+            del nodes[w]
+            changed = True
     final = [n for n in order if n in nodes]
     luts = []
     for n in final:
@@ -240,6 +257,83 @@ def lut3_synthesis():
             env = {name: (idx >> (len(ins) - 1 - k)) & 1 for k, name in enumerate(ins)}
             if fn(env):
                 tt |= 1 << idx
+        luts.append((n, ins, tt))
+    return luts
+
+
+def lut3_mapping_exact():
+    """Minimum-cost cover of the netlist by <=3-input LUTs (classic cut-based technology mapping, solved
+    exactly as a small 0/1 program with scipy's HiGHS): x[n,c] = node n is implemented as cut c;
+    every output is implemented; an implemented cut needs its non-input leaves implemented."""
+    import itertools
+
+    import numpy as np
+    from scipy.optimize import Bounds, LinearConstraint, milp
+
+    gates = parse()
+    fan = {dst: (x, y) for dst, _, x, y, _ in gates}
+    fn = {}
+    for dst, op, x, y, neg in gates:
+        fn[dst] = (op, x, y, neg)
+    order = [g[0] for g in gates]
+    outputs = [f"S{i}" for i in range(8)]
+
+    def value(n, env):
+        if n in env:
+            return env[n]
+        op, x, y, neg = fn[n]
+        a, b = value(x, env), value(y, env)
+        v = (a ^ b ^ (1 if neg else 0)) if op == "^" else (a & b)
+        env[n] = v
+        return v
+
+    cuts = {}  # node -> list of frozenset(leaves)
+    for n in order:
+        x, y = fan[n]
+        cx = [frozenset([x])] + (cuts.get(x, []))
+        cy = [frozenset([y])] + (cuts.get(y, []))
+        cs = set()
+        for a, b in itertools.product(cx, cy):
+            u = a | b
+            if len(u) <= 3:
+                cs.add(u)
+        cuts[n] = sorted(cs, key=lambda c: (len(c), sorted(c)))
+    var = []  # (node, cut)
+    for n in order:
+        for c in cuts[n]:
+            var.append((n, c))
+    idx = {v: i for i, v in enumerate(var)}
+    cost = np.array([LUT3_COST if len(c) == 3 else 1.0 for _, c in var])
+    rows, lo, hi = [], [], []
+    by_node = {n: [idx[(n, c)] for c in cuts[n]] for n in order}
+    for o in outputs:  # outputs implemented exactly once
+        r = np.zeros(len(var))
+        r[by_node[o]] = 1
+        rows.append(r); lo.append(1); hi.append(1)
+    for n in order:  # at most one implementation per node
+        r = np.zeros(len(var))
+        r[by_node[n]] = 1
+        rows.append(r); lo.append(0); hi.append(1)
+    for (n, c), i in idx.items():  # leaves of a chosen cut must exist
+        for leaf in c:
+            if leaf in fan:
+                r = np.zeros(len(var))
+                r[by_node[leaf]] = 1
+                r[i] -= 1
+                rows.append(r); lo.append(0); hi.append(np.inf)
+    res = milp(cost, constraints=LinearConstraint(np.array(rows), lo, hi), integrality=np.ones(len(var)), bounds=Bounds(0, 1),
+               options={"time_limit": 120})
+    assert res.success, res.message
+    chosen = [var[i] for i in range(len(var)) if res.x[i] > 0.5]
+    luts = []
+    pos = {n: k for k, n in enumerate(order)}
+    for n, c in sorted(chosen, key=lambda v: pos[v[0]]):
+        ins = tuple(sorted(c, key=lambda w: (w in fan, pos.get(w, -1), w)))
+        tt = 0
+        for a in range(1 << len(ins)):
+            env = {name: (a >> (len(ins) - 1 - k)) & 1 for k, name in enumerate(ins)}
+            if value(n, env):
+                tt |= 1 << a
         luts.append((n, ins, tt))
     return luts
 
@@ -259,7 +353,7 @@ def main():
         assert evaluate(x) == sbox_def(x), f"S-box circuit wrong at {x:#x}"
     lines = CIRCUIT.strip().splitlines()
     n_and = sum("&" in l for l in lines)
-    luts = lut3_synthesis()
+    luts = lut3_mapping_exact()
     for x in range(256):
         assert eval_luts(luts, x) == sbox_def(x), f"LUT3 netlist wrong at {x:#x}"
     n3 = sum(len(ins) == 3 for _, ins, _ in luts)
@@ -272,7 +366,10 @@ def main():
             out.append(f"const uint32_t {n} = __builtin_amdgcn_bitop3_b32({ins[0]}, {ins[1]}, {ins[2]}, 0x{tt:02x});")
         else:
             a_, b_ = ins
-            expr = {0x6: f"{a_} ^ {b_}", 0x8: f"{a_} & {b_}", 0x9: f"~({a_} ^ {b_})"}[tt]
+            expr = {0x6: f"{a_} ^ {b_}", 0x8: f"{a_} & {b_}", 0x9: f"~({a_} ^ {b_})", 0xe: f"{a_} | {b_}"}.get(tt)
+            if expr is None:  # some other 2-input function: a LUT3 that ignores its third operand
+                tt3 = sum(((tt >> (i >> 1)) & 1) << i for i in range(8))
+                expr = f"__builtin_amdgcn_bitop3_b32({a_}, {b_}, {b_}, 0x{tt3:02x})"
             out.append(f"const uint32_t {n} = {expr};")
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aes_sbox.inc")
     open(path, "w").write("\n".join(out) + "\n")
@@ -280,7 +377,8 @@ def main():
     tpath = os.path.join(os.path.dirname(path), "aes_sbox_table.inc")
     open(tpath, "w").write("// GENERATED by gen/gen_sbox.py from the FIPS-197 S-box definition (used only by the tiny\n"
                            "// key-schedule / seed-expansion kernels; the mask generator uses the bitsliced circuit).\n" + tab + "\n")
-    print("verified 256/256;", len(lines), "gates,", n_and, "AND ->", len(luts), "LUT ops (", n3, "three-input ) ->", path)
+    print("verified 256/256;", len(lines), "gates,", n_and, "AND ->", len(luts), "LUT ops (", n3, "three-input ) cost",
+          n3 * LUT3_COST + (len(luts) - n3), "two-input equivalents ->", path)
 
 
 if __name__ == "__main__":
