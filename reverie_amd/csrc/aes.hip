@@ -93,20 +93,38 @@ __global__ void k_key_schedule(const uint8_t* __restrict__ keys, uint32_t n_slot
     uint8_t key[16], rk[176];
     for (int i = 0; i < 16; i++) key[i] = keys[16 * t + i];
     key_expand(key, rk);
-    for (int i = 0; i < 176; i++) rkbytes[176 * (size_t)t + i] = rk[i];
+    uint8_t* dst = rkbytes + RK_BYTES * (size_t)t;
+    for (int i = 0; i < 176; i++) dst[i] = rk[i];
+    // first-round constants (layout: internal.h).  Round 0 of a CTR block with j < 2^24: x = rk0 ^ (0,..,0,j2,j1,j0).
+    uint8_t sb[16], k1[16];
+    for (int i = 0; i < 13; i++) sb[i] = SBOX_TAB[rk[i]];
+    sb[13] = sb[14] = sb[15] = 0;  // the varying bytes' S-box outputs are added by the mask kernel (MixColumns is linear)
+    for (int c = 0; c < 4; c++) {
+        const uint8_t a0 = sb[4 * ((c + 0) & 3) + 0], a1 = sb[4 * ((c + 1) & 3) + 1], a2 = sb[4 * ((c + 2) & 3) + 2],
+                      a3 = sb[4 * ((c + 3) & 3) + 3];
+        const uint8_t all = a0 ^ a1 ^ a2 ^ a3;
+        k1[4 * c + 0] = a0 ^ all ^ xtime8(a0 ^ a1) ^ rk[16 + 4 * c + 0];
+        k1[4 * c + 1] = a1 ^ all ^ xtime8(a1 ^ a2) ^ rk[16 + 4 * c + 1];
+        k1[4 * c + 2] = a2 ^ all ^ xtime8(a2 ^ a3) ^ rk[16 + 4 * c + 2];
+        k1[4 * c + 3] = a3 ^ all ^ xtime8(a3 ^ a0) ^ rk[16 + 4 * c + 3];
+    }
+    for (int i = 0; i < 16; i++) dst[176 + i] = 0;
+    for (int r = 0; r < 4; r++) dst[176 + r] = SBOX_TAB[k1[12 + r]];
+    for (int i = 13; i < 16; i++) dst[176 + i] = rk[i];
+    for (int i = 0; i < 16; i++) dst[192 + i] = k1[i];
 }
 
 // rk[(round*128 + 8*byte + bit)*NQ + q] = bit `bit` of round-key byte `byte` of the 32
 // slots of quad q, slot (i4, p) at bit 31 - (8*i4 + p).  Slots are numbered rep*8 + p.
 __global__ void k_bitslice_rk(const uint8_t* __restrict__ rkbytes, uint32_t NQ, uint32_t* __restrict__ rk) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 11u * 128u * NQ) return;
+    if (t >= RK_AREAS * 128u * NQ) return;
     uint32_t q = t % NQ, idx = t / NQ;
-    uint32_t byte = idx >> 3, bit = idx & 7;  // byte in 0..175
+    uint32_t byte = idx >> 3, bit = idx & 7;  // byte in 0..RK_BYTES-1
     uint32_t w = 0;
     for (uint32_t s = 0; s < 32; s++) {
         uint32_t slot = q * 32 + s;
-        w |= (uint32_t)((rkbytes[176 * (size_t)slot + byte] >> bit) & 1) << (31 - s);
+        w |= (uint32_t)((rkbytes[RK_BYTES * (size_t)slot + byte] >> bit) & 1) << (31 - s);
     }
     rk[t] = w;
 }
@@ -118,7 +136,7 @@ __global__ void k_aes_blocks(const uint8_t* __restrict__ rkbytes, uint32_t n_key
     if (t >= (uint64_t)n_keys * n_blocks) return;
     uint64_t k = t / n_blocks, b = t % n_blocks;
     uint8_t rk[176], in[16], o[16];
-    for (int i = 0; i < 176; i++) rk[i] = rkbytes[176 * k + i];
+    for (int i = 0; i < 176; i++) rk[i] = rkbytes[RK_BYTES * k + i];
     ctr_block(first + b, in);
     encrypt_bytes(rk, in, o);
     for (int i = 0; i < 16; i++) out[16 * t + i] = o[i];
@@ -185,8 +203,10 @@ __device__ __forceinline__ void mix_ark(const uint32_t* t, uint32_t* s, const ui
 // Output column c only needs the four S-box outputs it consumes, so at most one column of
 // temporaries (32 registers) is live beside the old and the new state: this is what lets the
 // kernel fit 2 wavefronts per SIMD (<= 256 registers) without scratch spills.
-template <int QW>
-__device__ __forceinline__ void round_cols(const uint32_t* s, uint32_t* n, const uint32_t* rk) {
+// SECOND = round 2 of a block with j < 2^24: state column 3 is a per-key constant, so the four S-boxes it
+// feeds are read from LDS (sk = S(round-1 output bytes 12..15), bit k of byte r at sk[(8*r + k)*QW]).
+template <int QW, bool SECOND = false>
+__device__ __forceinline__ void round_cols(const uint32_t* s, uint32_t* n, const uint32_t* rk, const uint32_t* sk = nullptr) {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         uint32_t col[32];
@@ -199,6 +219,11 @@ __device__ __forceinline__ void round_cols(const uint32_t* s, uint32_t* n, const
 #pragma unroll
         for (int row = 0; row < 4; row++) {
             const int src = 8 * (4 * ((c + row) & 3) + row);
+            if (SECOND && ((c + row) & 3) == 3) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) col[8 * row + k] = sk[(8 * row + k) * QW];
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < 8; k++) col[8 * row + k] = s[src + k];
             sbox8(col[8 * row + 7], col[8 * row + 6], col[8 * row + 5], col[8 * row + 4], col[8 * row + 3], col[8 * row + 2],
@@ -233,18 +258,63 @@ __device__ __forceinline__ void round_cols(const uint32_t* s, uint32_t* n, const
     }
 }
 
-// rounds 1..9 on s (result back in s), two rounds per loop trip so no register shuffling is
-// needed at the back edge; t is the ping-pong buffer
+// Rounds 0..9 of CTR block j (< 2^24) into s; t is the ping-pong buffer.  rkl: this lane's LDS round keys with the
+// rk0 / rk1 areas replaced by the first-round constants (internal.h: RK_BYTES): only state bytes 13..15 meet the
+// counter, so round 1 is 3 S-boxes plus the linear spread of those three bytes over K1 instead of 16 S-boxes and a
+// full MixColumns, and round 2 reads 4 of its 16 S-box outputs from LDS.  Rounds 3..9 run two per loop trip so no
+// register shuffling is needed at the back edge.
 template <int QW>
-__device__ __forceinline__ void middle_rounds(uint32_t* s, uint32_t* t, const uint32_t* rkl) {
-#pragma unroll 1
-    for (int r = 1; r < 9; r += 2) {
-        round_cols<QW>(s, t, rkl + r * 128 * QW);
-        round_cols<QW>(t, s, rkl + (r + 1) * 128 * QW);
-    }
-    round_cols<QW>(s, t, rkl + 9 * 128 * QW);
+__device__ __forceinline__ void rounds_0_to_9(uint64_t j, uint32_t* s, uint32_t* t, const uint32_t* rkl) {
+    const uint32_t* a0 = rkl;             // area 0: SK (bytes 0..3), rk0[13..15] (bytes 13..15)
+    const uint32_t* k1 = rkl + 128 * QW;  // area 1: K1
 #pragma unroll
-    for (int i = 0; i < 128; i++) s[i] = t[i];
+    for (int i = 0; i < 128; i++) s[i] = k1[i * QW];
+#pragma unroll
+    for (int b = 13; b < 16; b++) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t cb = (uint32_t)0 - (uint32_t)((j >> (8 * (15 - b) + k)) & 1);
+            v[k] = a0[(8 * b + k) * QW] ^ cb;
+        }
+        sbox8(v[7], v[6], v[5], v[4], v[3], v[2], v[1], v[0]);
+        // ShiftRows sends byte 12 + r (row r of column 3) to column (3 - r) & 3; MixColumns then adds
+        // 2v to row r, 3v to row r - 1, v to the other two rows of that column
+        const int r = b - 12, c = (3 - r) & 3;
+        const uint32_t x[8] = {v[7], v[0] ^ v[7], v[1], v[2] ^ v[7], v[3] ^ v[7], v[4], v[5], v[6]};  // xtime(v)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t& o = s[32 * c + 8 * i + k];
+                if (i == r)
+                    o ^= x[k];
+                else if (((i + 1) & 3) == r)
+                    o = XOR3(o, x[k], v[k]);
+                else
+                    o ^= v[k];
+            }
+        }
+    }
+    round_cols<QW, true>(s, t, rkl + 2 * 128 * QW, a0);
+#pragma unroll 1
+    for (int r = 3; r < 9; r += 2) {
+        round_cols<QW>(t, s, rkl + r * 128 * QW);
+        round_cols<QW>(s, t, rkl + (r + 1) * 128 * QW);
+    }
+    round_cols<QW>(t, s, rkl + 9 * 128 * QW);
+}
+
+// this workgroup's round keys into LDS: lds[(area*128 + idx)*QW + ql] for quads qg*QW .. qg*QW+QW-1.  LDS areas
+// 0 and 1 hold the first-round constants (global areas 11 and 12), not rk0 / rk1 (see rounds_0_to_9)
+template <int QW>
+__device__ __forceinline__ void stage_round_keys(const uint32_t* __restrict__ rk, uint32_t NQ, uint32_t qg, uint32_t* lds_rk) {
+    for (uint32_t i = threadIdx.x; i < 11 * 128 * QW; i += blockDim.x) {
+        const uint32_t area = i / (128 * QW), w = i % (128 * QW);
+        const uint32_t ga = area == 0 ? 11u : (area == 1 ? 12u : area);
+        lds_rk[i] = rk[(size_t)(ga * 128 + w / QW) * NQ + qg * QW + (w % QW)];
+    }
+    __syncthreads();
 }
 
 // Mask generator.  A workgroup owns QW consecutive quads (QW*32 AES keys) and keeps their
@@ -263,8 +333,7 @@ __global__ __launch_bounds__(512, 2) void k_aes_gf2_masks(const uint32_t* __rest
     const uint32_t qg = blockIdx.x % n_qg;
     const uint64_t chunk = blockIdx.x / n_qg;
     // stage this workgroup's round keys: rk[(round*128+idx)*NQ + qg*QW + ql]
-    for (uint32_t i = threadIdx.x; i < 11 * 128 * QW; i += 512) lds_rk[i] = rk[(size_t)(i / QW) * NQ + qg * QW + (i % QW)];
-    __syncthreads();
+    stage_round_keys<QW>(rk, NQ, qg, lds_rk);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ql = lane % QW, jsub = lane / QW;
     const uint32_t q = qg * QW + ql;
@@ -277,17 +346,7 @@ __global__ __launch_bounds__(512, 2) void k_aes_gf2_masks(const uint32_t* __rest
         if (jl >= j_hi) continue;
         const uint64_t j = first_block + jl;
         uint32_t s[128], t[128];
-        // round 0: counter block BE128(j) (bytes 8..15 carry j) xor rk[0]
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                uint32_t cb = 0;
-                if (i >= 8) cb = (uint32_t)0 - (uint32_t)((j >> (8 * (15 - i) + k)) & 1);
-                s[8 * i + k] = rkl[(8 * i + k) * QW] ^ cb;
-            }
-        }
-        middle_rounds<QW>(s, t, rkl);
+        rounds_0_to_9<QW>(j, s, t, rkl);
         sub_shift(s, t);
         const uint32_t* rk10 = rkl + 10 * 128 * QW;
         uint32_t* out = masks + (size_t)jl * 128 * NQ + q;
@@ -312,7 +371,7 @@ void launch_key_schedule(hipStream_t st, const uint8_t* d_keys, uint32_t n_slots
     hipLaunchKernelGGL(k_key_schedule, dim3((n_slots + 63) / 64), dim3(64), 0, st, d_keys, n_slots, d_rkbytes);
 }
 void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, uint32_t* d_rk) {
-    uint32_t n = 11u * 128u * NQ;
+    uint32_t n = RK_AREAS * 128u * NQ;
     hipLaunchKernelGGL(k_bitslice_rk, dim3((n + 255) / 256), dim3(256), 0, st, d_rkbytes, NQ, d_rk);
 }
 // 32x32 bit-matrix transpose (Hacker's Delight 7-3), fully unrolled: registers only
@@ -343,8 +402,7 @@ __global__ __launch_bounds__(512, 2) void k_aes_z64_masks(const uint32_t* __rest
     const uint32_t n_qg = NQ / QW;
     const uint32_t qg = blockIdx.x % n_qg;
     const uint64_t chunk = blockIdx.x / n_qg;
-    for (uint32_t i = threadIdx.x; i < 11 * 128 * QW; i += 512) lds_rk[i] = rk[(size_t)(i / QW) * NQ + qg * QW + (i % QW)];
-    __syncthreads();
+    stage_round_keys<QW>(rk, NQ, qg, lds_rk);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ql = lane % QW, jsub = lane / QW;
     const uint32_t q = qg * QW + ql;
@@ -357,16 +415,7 @@ __global__ __launch_bounds__(512, 2) void k_aes_z64_masks(const uint32_t* __rest
         const uint64_t j = jb + jsub;
         if (j >= j_hi) continue;
         uint32_t s[128], t[128];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                uint32_t cb = 0;
-                if (i >= 8) cb = (uint32_t)0 - (uint32_t)((j >> (8 * (15 - i) + k)) & 1);
-                s[8 * i + k] = rkl[(8 * i + k) * QW] ^ cb;
-            }
-        }
-        middle_rounds<QW>(s, t, rkl);
+        rounds_0_to_9<QW>(j, s, t, rkl);
         sub_shift(s, t);
         const uint32_t* rk10 = rkl + 10 * 128 * QW;
 #pragma unroll

@@ -259,7 +259,7 @@ static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
     b += cc.n_rows * (NQ / 2);
     b += cc.n_on * NQ * 4 + cc.n_pre * (NQ / 2);
     b += 4 * b3_stream_scratch_words(std::max(cc.n_on, cc.n_pre), R) * 4;
-    b += (size_t)R * (16 + 128 + 8 * 176) + 11 * 128 * NQ * 4;
+    b += (size_t)R * (16 + 128 + 8 * RK_BYTES) + RK_AREAS * 128 * NQ * 4;
     // Z64: masks, wires, contiguous transcripts
     b += ((cc.n_masks64 + 1) / 2 * 2) * (size_t)R * 64;
     b += cc.n_ssa64 * (size_t)R * 72;
@@ -464,11 +464,11 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
     if (n_blocks64) {
         if ((rc = dalloc(ctx, (size_t)n_blocks64 * 2 * s->R * 8, &s->d_masks64))) return rc;
         if (s->d_keys64) {  // verifier: separate key set for the z64 transcript (reuses d_rkbytes as scratch below)
-            if ((rc = dalloc(ctx, (size_t)11 * 128 * s->NQ, &s->d_rk64))) return rc;
+            if ((rc = dalloc(ctx, (size_t)RK_AREAS * 128 * s->NQ, &s->d_rk64))) return rc;
         }
     }
-    if ((rc = dalloc(ctx, (size_t)s->R * 8 * 176, &s->d_rkbytes))) return rc;
-    if ((rc = dalloc(ctx, (size_t)11 * 128 * s->NQ, &s->d_rk))) return rc;
+    if ((rc = dalloc(ctx, (size_t)s->R * 8 * RK_BYTES, &s->d_rkbytes))) return rc;
+    if ((rc = dalloc(ctx, (size_t)RK_AREAS * 128 * s->NQ, &s->d_rk))) return rc;
     const uint64_t n_blocks = cc.n_masks_pad / 128;
     if ((rc = dalloc(ctx, (size_t)cc.n_rows * s->NQ, &s->d_masks))) return rc;
     launch_key_schedule(ctx->stream, s->d_keys, s->R * 8, s->d_rkbytes);
@@ -1358,7 +1358,7 @@ extern "C" int rv_hook_prg_blocks(rv_ctx* ctx, const uint8_t* keys, size_t n_key
     HIPCHK(hipSetDevice(ctx->device));
     uint8_t *dk = nullptr, *drk = nullptr, *dout = nullptr;
     int rc;
-    if ((rc = dalloc(ctx, n_keys * 16, &dk)) || (rc = dalloc(ctx, n_keys * 176, &drk)) || (rc = dalloc(ctx, n_keys * n_blocks * 16, &dout)))
+    if ((rc = dalloc(ctx, n_keys * 16, &dk)) || (rc = dalloc(ctx, n_keys * RK_BYTES, &drk)) || (rc = dalloc(ctx, n_keys * n_blocks * 16, &dout)))
         return rc;
     HIPCHK(hipMemcpyAsync(dk, keys, n_keys * 16, hipMemcpyHostToDevice, ctx->stream));
     launch_key_schedule(ctx->stream, dk, (uint32_t)n_keys, drk);
@@ -1384,8 +1384,8 @@ extern "C" int rv_hook_sharegen_gf2(rv_ctx* ctx, const uint8_t* keys, const uint
     }
     const uint64_t n_blocks = (n + 127) / 128;
     int rc;
-    if ((rc = dalloc(ctx, (size_t)R * 128, &dk)) || (rc = dalloc(ctx, (size_t)R * 8 * 176, &drk)) ||
-        (rc = dalloc(ctx, (size_t)11 * 128 * NQ, &d_rk)) || (rc = dalloc(ctx, NQ, &d_keep)) ||
+    if ((rc = dalloc(ctx, (size_t)R * 128, &dk)) || (rc = dalloc(ctx, (size_t)R * 8 * RK_BYTES, &drk)) ||
+        (rc = dalloc(ctx, (size_t)RK_AREAS * 128 * NQ, &d_rk)) || (rc = dalloc(ctx, NQ, &d_keep)) ||
         (rc = dalloc(ctx, (size_t)n_blocks * 128 * NQ, &d_masks)))
         return rc;
     HIPCHK(hipMemcpyAsync(dk, keys, (size_t)R * 128, hipMemcpyHostToDevice, ctx->stream));
@@ -1419,8 +1419,8 @@ extern "C" int rv_hook_sharegen_z64(rv_ctx* ctx, const uint8_t* keys, const uint
     }
     const uint64_t n_blocks = (n + 1) / 2;
     int rc;
-    if ((rc = dalloc(ctx, (size_t)R * 128, &dk)) || (rc = dalloc(ctx, (size_t)R * 8 * 176, &drk)) ||
-        (rc = dalloc(ctx, (size_t)11 * 128 * NQ, &d_rk)) || (rc = dalloc(ctx, NQ, &d_keep)) ||
+    if ((rc = dalloc(ctx, (size_t)R * 128, &dk)) || (rc = dalloc(ctx, (size_t)R * 8 * RK_BYTES, &drk)) ||
+        (rc = dalloc(ctx, (size_t)RK_AREAS * 128 * NQ, &d_rk)) || (rc = dalloc(ctx, NQ, &d_keep)) ||
         (rc = dalloc(ctx, (size_t)n_blocks * 2 * R * 8, &d_masks)))
         return rc;
     HIPCHK(hipMemcpyAsync(dk, keys, (size_t)R * 128, hipMemcpyHostToDevice, ctx->stream));

@@ -577,6 +577,8 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
     out.n_masks_pad = (out.n_masks + 127) / 128 * 128;
     out.n_rows = out.n_masks_pad + b.n_comp;
     if (out.n_rows > LIM) return RV_E_UNSUPPORTED;
+    // the mask kernels take CTR block indices below 2^24 (first-round constants, internal.h); more would not fit HBM anyway
+    if (out.n_masks_pad / 128 > RV_MAX_CTR_BLOCKS || (out.n_masks64 + 1) / 2 > RV_MAX_CTR_BLOCKS) return RV_E_UNSUPPORTED;
     auto fix = [&](uint32_t& r) {
         if (r & COMP) r = (uint32_t)(out.n_masks_pad + (r & ~COMP));
     };

@@ -120,8 +120,18 @@ struct InterpParams {
 
 // ---- launchers (implemented in the .hip files) ----
 void launch_expand_seeds(hipStream_t st, const uint8_t* d_seeds, uint32_t n_reps, uint8_t* d_keys /*[n][8][16]*/);
-void launch_key_schedule(hipStream_t st, const uint8_t* d_keys, uint32_t n_slots, uint8_t* d_rkbytes /*[n][176]*/);
-void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, uint32_t* d_rk /*[11][128][NQ]*/);
+// Per AES key: the 11 round keys (176 bytes) followed by 32 bytes of first-round constants (k_key_schedule):
+// CTR blocks with index j < 2^24 differ from the all-zero block only in bytes 13..15, so SubBytes of round 1 on
+// bytes 0..12, most of its MixColumns and the four round-2 S-boxes fed by state column 3 depend on the key alone.
+//   [176..179] SK   = S(round-1 output column 3)            (round-2 S-box outputs of state bytes 12..15)
+//   [189..191] rk0[13..15]                                  (the three bytes that meet the counter)
+//   [192..207] K1   = round-1 output with S(byte 13..15) taken as zero (columns 0..2), the constant column 3
+// Bitsliced they form two more 128-word areas after the 11 round keys.
+constexpr uint32_t RK_BYTES = 208;
+constexpr uint32_t RK_AREAS = 13;
+constexpr uint64_t RV_MAX_CTR_BLOCKS = 1ull << 24;
+void launch_key_schedule(hipStream_t st, const uint8_t* d_keys, uint32_t n_slots, uint8_t* d_rkbytes /*[n][RK_BYTES]*/);
+void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, uint32_t* d_rk /*[RK_AREAS][128][NQ]*/);
 void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
                           uint64_t n_blocks, uint32_t* d_masks);
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
