@@ -242,6 +242,17 @@ typedef struct rv_bristol_info {
 int rv_bristol_parse(const char *text, size_t len, int format, const uint8_t *expected_outputs, rv_op **ops, size_t *n_ops,
                      rv_bristol_info *info);
 
+/* ---- program files (host only, no GPU) ---------------------------------------------------
+ * The reference CLI reads its gate stream as bincode 1.3 of Vec<mcircuit::CombineOperation>
+ * (src/main.rs:66,98,122).  rv_program_from_bincode turns such a file into rv_op records, rv_program_to_bincode
+ * writes one.  The enum's variant order comes from the un-vendored `mcircuit` crate and is the one SURVEY A.7
+ * recalls (GF2, Z64, B2A, SizeHint; Input, Random, Add, AddConst, Sub, SubConst, Mul, MulConst, AssertZero, Const):
+ * it cannot be verified here, so nothing selects this format automatically.  Wire indices above 2^32-1 ->
+ * RV_E_UNSUPPORTED; a truncated file, an unknown variant or a bool that is not 0/1 -> RV_E_BAD_OP.  Outputs are
+ * library-allocated (rv_free). */
+int rv_program_from_bincode(const uint8_t *data, size_t len, rv_op **ops, size_t *n_ops);
+int rv_program_to_bincode(const rv_op *ops, size_t n_ops, uint8_t **data, size_t *len);
+
 /* ---- parity-test hooks: each mirrors one reference function so tests can compare the
  * HIP path with the oracle piecewise ---- */
 /* PRG::new + gen (crypto/prg.rs:16-37) on the GPU: n_keys keys, blocks [first, first+n_blocks) each */

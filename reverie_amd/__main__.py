@@ -5,9 +5,10 @@ version_info}`, `--program-path`, `--witness-path`, `--proof-path`, the same ban
 same `Ok(())` / `Err("Unverifiable Proof")` result lines.  Differences, stated plainly:
 
 * program files: the reference reads bincode(`Vec<mcircuit::CombineOperation>`), whose enum
-  layout cannot be verified here.  This front end reads Bristol / Bristol
-  Fashion text (README.md:14-16), or a raw little-endian array of 24-byte `rv_op` records
-  (`--program-format rvops`).  `--expected-outputs-path` (text of 0/1) appends the output
+  layout cannot be verified here: that reader exists (`--program-format
+  mcircuit-bincode`, reverie_amd/csrc/program.cpp) but is never chosen automatically.  By
+  default this front end reads Bristol / Bristol Fashion text (README.md:14-16), or a raw
+  little-endian array of 24-byte `rv_op` records (`--program-format rvops`).  `--expected-outputs-path` (text of 0/1) appends the output
   assertions to a Bristol circuit (see rv_bristol_parse).
 * proofs are the same bincode bytes.
 """
@@ -26,6 +27,11 @@ def load_program(path: str, fmt: str, expected_path=None):
     data = open(path, "rb").read()
     if fmt == "auto":
         fmt = "rvops" if path.endswith(".rvops") else "bristol"
+    if fmt == "mcircuit-bincode":
+        from . import program_file
+
+        prog = program_file.loads(data)
+        return prog, largest_wires(prog)
     if fmt == "rvops":
         if len(data) % OP_DTYPE.itemsize:
             raise SystemExit("program file is not a whole number of 24-byte rv_op records")
@@ -75,7 +81,7 @@ def build_parser():
     ap.add_argument("--witness-path")
     ap.add_argument("--program-path")
     ap.add_argument("--proof-path")
-    ap.add_argument("--program-format", default="auto", choices=["auto", "bristol", "rvops"])
+    ap.add_argument("--program-format", default="auto", choices=["auto", "bristol", "rvops", "mcircuit-bincode"])
     ap.add_argument("--expected-outputs-path")
     return ap
 

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void k_aes_gf2_masks(const uint32_t* __rest
         for (int i = 0; i < 16; i++) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const uint32_t v = (t[8 * i + k] ^ rk10[(8 * i + k) * QW]) & kp;
+                const uint32_t v = __builtin_amdgcn_bitop3_b32(t[8 * i + k], rk10[(8 * i + k) * QW], kp, 0x28);  // (t ^ rk) & kp
                 out[(size_t)(8 * i + (7 - k)) * NQ] = v;
             }
         }

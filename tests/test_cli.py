@@ -45,6 +45,13 @@ def test_oneshot_cleartext(tmp_path, capsys):
     raw.write_bytes(prog.tobytes())
     prog2, wc2 = load_program(str(raw), "auto")
     assert prog2.tobytes() == prog.tobytes() and wc2 == wc
+    # the reference's own program-file format (bincode of Vec<CombineOperation>), only on request
+    from reverie_amd import program_file
+
+    bc = tmp_path / "adder.bin"
+    bc.write_bytes(program_file.dumps(prog))
+    prog3, wc3 = load_program(str(bc), "mcircuit-bincode")
+    assert prog3.tobytes() == prog.tobytes() and wc3 == wc
 
 
 @pytest.mark.gpu
