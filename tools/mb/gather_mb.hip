@@ -89,6 +89,41 @@ __global__ __launch_bounds__(256) void k_sliced(const Rec* __restrict__ recs, ui
     }
 }
 
+
+// QUARTER: the access pattern a fused AES + Mul kernel would have: a 512-thread workgroup owns 16 quads
+// (64 B of every row) and 88 KiB of LDS (so ONE workgroup = 8 wavefronts per CU); lane = (gate sub-index 0..3,
+// quad 0..15); per step a lane has U gates in flight: 2 operand gathers of 64-byte segments each, then a
+// 64-byte segment of the online row and of the output row written.  No streaming mask reads (they would be
+// in registers).  Records come through LDS-free vector loads (16 B per gate, 16 lanes share one).
+template <int U>
+__global__ __launch_bounds__(512) void k_quarter(const Rec* __restrict__ recs, uint32_t n, const uint32_t* __restrict__ win,
+                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ on) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t qg = blockIdx.x & 3, chunk = blockIdx.x >> 2, n_chunks = gridDim.x >> 2;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t q = qg * 16 + (lane & 15), sub = lane >> 4;
+    if (lane == 999) lds[threadIdx.x] = n;
+    const uint32_t per = (n + n_chunks - 1) / n_chunks;
+    const uint32_t lo = chunk * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t g0 = lo + (wave * 4 + sub) * U; g0 + U <= hi; g0 += 32 * U) {
+        Rec r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) r[u] = recs[g0 + u];
+        uint32_t x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            x[u] = win[(size_t)r[u].a * 64 + q];
+            y[u] = win[(size_t)r[u].b * 64 + q];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t v = x[u] & y[u];
+            on[(size_t)(g0 + u) * 64 + q] = v ^ r[u].m;
+            out[(size_t)r[u].dst * 64 + q] = v;
+        }
+    }
+}
+
 static uint64_t sm(uint64_t& s) { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 
 int main() {
@@ -129,6 +164,26 @@ int main() {
                     printf("%-6s stream=%d window=%8u rows blocks=%5d  %.3f ms  %.2f ns/gate... %.2f TB/s algorithmic (%s)\n", variant ? "SLICED" : "WIDE", stream,
                            win_rows, blocks, best, best * 1e6 / n, bytes / (best * 1e-3) / 1e12, variant ? "slice gathers 8x the records" : "");
                 }
+            if (!stream) {
+                hipFuncSetAttribute((const void*)k_quarter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 1024);
+                hipFuncSetAttribute((const void*)k_quarter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 1024);
+                for (int U : {8, 16})
+                    for (int blocks : {256 * 4, 512 * 4}) {
+                        float best = 1e9f;
+                        for (int rep = 0; rep < 4; rep++) {
+                            hipEventRecord(a);
+                            if (U == 8) hipLaunchKernelGGL((k_quarter<8>), dim3(blocks), dim3(512), 88 * 1024, 0, d_recs, n, d_win, d_out, d_on);
+                            else hipLaunchKernelGGL((k_quarter<16>), dim3(blocks), dim3(512), 88 * 1024, 0, d_recs, n, d_win, d_out, d_on);
+                            hipEventRecord(b); hipEventSynchronize(b);
+                            float ms; hipEventElapsedTime(&ms, a, b);
+                            if (ms < best) best = ms;
+                        }
+                        CK(hipGetLastError());
+                        const double qb = (double)n * (16 + 4 * 256);
+                        printf("QUARTER U=%2d window=%8u rows blocks=%5d  %.3f ms  %.3f ns/gate  %.2f TB/s algorithmic (2 gathers + 2 row writes, 8 waves/CU)\n", U, win_rows,
+                               blocks, best, best * 1e6 / n, qb / (best * 1e-3) / 1e12);
+                    }
+            }
             hipFree(d_recs); hipFree(d_win); hipFree(d_masks); hipFree(d_out); hipFree(d_on);
         }
     return 0;
