@@ -148,7 +148,9 @@ int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
  *          (the reference takes Vec<bool>);  wit_z64: u64 witness elements.
  * seeds:   256 x 16 bytes, one per repetition (the reference draws them from OsRng,
  *          proof/mod.rs:131-134).  NULL => drawn from the OS (getrandom).
- * *proof:  bincode(Proof), allocated by the library, released with rv_free. */
+ * *proof:  bincode(Proof), allocated by the library, released with rv_free.  Proofs of a megabyte and more come in
+ *          page-locked memory from a small process-wide pool (the device-to-host copy runs at PCIe rate and
+ *          rv_free recycles the buffer for the next proof); the pointer is ordinary readable/writable host memory. */
 int rv_prove(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64,
              size_t n_z64, const uint8_t *seeds, uint8_t **proof, size_t *proof_len);
 

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "b3.h"
@@ -221,7 +222,73 @@ extern "C" int rv_ctx_sync(rv_ctx* ctx) {
     return RV_OK;
 }
 
-extern "C" void rv_free(void* p) { free(p); }
+// Large outputs (proofs of big circuits: 50-640 MB) are returned in page-locked host memory from a small
+// process-wide pool: the device-to-host copy then runs at PCIe rate instead of through the runtime's pageable
+// staging path (~3x slower), and rv_free hands the buffer back for the next proof instead of unpinning it.
+namespace {
+struct PinnedPool {
+    struct Buf {
+        void* p;
+        size_t cap;
+        bool used;
+    };
+    std::mutex mu;
+    std::vector<Buf> bufs;
+    static constexpr size_t MIN_BYTES = 1u << 20;  // below this plain malloc is as fast
+    static constexpr size_t KEEP_FREE = 3;         // idle buffers kept for reuse
+    void* get(size_t n) {
+        if (n < MIN_BYTES) return nullptr;
+        std::lock_guard<std::mutex> g(mu);
+        int best = -1;
+        for (size_t i = 0; i < bufs.size(); i++)
+            if (!bufs[i].used && bufs[i].cap >= n && (best < 0 || bufs[i].cap < bufs[(size_t)best].cap)) best = (int)i;
+        if (best >= 0) {
+            bufs[(size_t)best].used = true;
+            return bufs[(size_t)best].p;
+        }
+        void* p = nullptr;
+        const size_t cap = (n + (n >> 3) + 0xFFFFF) & ~(size_t)0xFFFFF;  // 12 % headroom, whole MiB
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;  // caller falls back to malloc
+        }
+        bufs.push_back(Buf{p, cap, true});
+        return p;
+    }
+    bool put(void* p) {
+        std::lock_guard<std::mutex> g(mu);
+        bool found = false;
+        for (Buf& b : bufs)
+            if (b.p == p) {
+                b.used = false;
+                found = true;
+            }
+        if (!found) return false;
+        size_t idle = 0;
+        for (const Buf& b : bufs) idle += !b.used;
+        for (size_t i = 0; i < bufs.size() && idle > KEEP_FREE;) {  // drop the smallest idle buffers first
+            size_t victim = bufs.size();
+            for (size_t k = 0; k < bufs.size(); k++)
+                if (!bufs[k].used && (victim == bufs.size() || bufs[k].cap < bufs[victim].cap)) victim = k;
+            if (victim == bufs.size()) break;
+            (void)hipHostFree(bufs[victim].p);
+            bufs.erase(bufs.begin() + (long)victim);
+            idle--;
+        }
+        return true;
+    }
+};
+PinnedPool g_pinned;
+}  // namespace
+
+static void* out_alloc(size_t n) {
+    void* p = g_pinned.get(n);
+    return p ? p : malloc(n ? n : 1);
+}
+
+extern "C" void rv_free(void* p) {
+    if (p && !g_pinned.put(p)) free(p);
+}
 
 extern "C" int rv_ctx_profile(rv_ctx* ctx, int enable, int reset, rv_profile* out) {
     if (!ctx) return RV_E_ARG;
@@ -998,7 +1065,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         size_t lens[4];
         if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, comm, nullptr))) break;
         const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
-        out = (uint8_t*)malloc(total);
+        out = (uint8_t*)out_alloc(total);
         if (!out) {
             rc = RV_E_NOMEM;
             break;
@@ -1018,7 +1085,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         *proof_len = total;
         out = nullptr;
     } while (0);
-    free(out);
+    rv_free(out);
     rv_shard_destroy(s);
     return rc;
 }
@@ -1233,47 +1300,75 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
             return fail(RV_E_DEVICE);         \
         }                                     \
     } while (0)
+    // ---- staging (one copy each instead of one per repetition): opened player keys (online.rs:101-113) and the
+    //      online commitments the preprocessing slots carry over from the proof (preprocess.rs:55-57)
+    const size_t DW = (size_t)R * 8;
+    std::vector<uint8_t> hkeys((size_t)R * 128, 0), hco((size_t)R * 32, 0), hkeys64, hco64((size_t)R * 32, 0);
+    if (has64) hkeys64.assign((size_t)R * 128, 0);
+    for (uint32_t r = 0; r < R; r++) {
+        if (omit[r] < 8) {
+            memcpy(&hkeys[(size_t)r * 128], proof + P.gf2.on[slot_begin + r].keys, 128);
+            if (has64 && omit64[r] < 8) memcpy(&hkeys64[(size_t)r * 128], proof + P.z64.on[slot_begin + r].keys, 128);
+        } else {
+            const uint32_t k = slot_begin + r - RV_ONLINE_REPS;
+            memcpy(&hco[(size_t)r * 32], proof + P.gf2.pre[k].comm_online, 32);
+            memcpy(&hco64[(size_t)r * 32], proof + P.z64.pre[k].comm_online, 32);
+        }
+    }
+    uint8_t *d_hkeys = nullptr, *d_hco = nullptr, *d_hkeys64 = nullptr, *d_hco64 = nullptr;
+    if ((rc = dalloc(ctx, hkeys.size(), &d_hkeys))) return fail(rc);
+    track(d_hkeys);
+    if ((rc = dalloc(ctx, hco.size(), &d_hco))) return fail(rc);
+    track(d_hco);
+    if ((rc = dalloc(ctx, hco64.size(), &d_hco64))) return fail(rc);
+    track(d_hco64);
+    if (has64) {
+        if ((rc = dalloc(ctx, hkeys64.size(), &d_hkeys64))) return fail(rc);
+        track(d_hkeys64);
+    }
+    // ---- stream 1: everything the mask generator needs, then the masks themselves
     HC(hipMemcpyAsync(s->d_seeds, seeds.data(), seeds.size(), hipMemcpyHostToDevice, ctx->stream));
     HC(hipMemcpyAsync(s->d_omit, omit.data(), omit.size(), hipMemcpyHostToDevice, ctx->stream));
-    HC(hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, ctx->stream));
-    HC(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HC(hipMemcpyAsync(d_keep, keep.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
     HC(hipMemcpyAsync(d_onm, onm.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
+    HC(hipMemcpyAsync(d_hkeys, hkeys.data(), hkeys.size(), hipMemcpyHostToDevice, ctx->stream));
+    HC(hipMemcpyAsync(d_hco, hco.data(), hco.size(), hipMemcpyHostToDevice, ctx->stream));
+    HC(hipMemcpyAsync(d_hco64, hco64.data(), hco64.size(), hipMemcpyHostToDevice, ctx->stream));
     ctx->phase(RV_PH_SETUP);
-    ctx->count();
+    ctx->count(2);
     launch_expand_seeds(ctx->stream, s->d_seeds, R, s->d_keys);
-    // online slots take the opened player keys straight from the proof (online.rs:101-113)
-    for (uint32_t r = 0; r < R; r++)
-        if (omit[r] < 8) HC(hipMemcpyAsync(s->d_keys + (size_t)r * 128, proof + P.gf2.on[slot_begin + r].keys, 128, hipMemcpyHostToDevice, ctx->stream));
+    launch_overlay_rows(ctx->stream, (uint32_t*)s->d_keys, (const uint32_t*)d_hkeys, s->d_omit, R, 32, 1);
     if (has64) {
         HC(hipMemcpyAsync(d_seeds64, seeds64.data(), seeds64.size(), hipMemcpyHostToDevice, ctx->stream));
         HC(hipMemcpyAsync(s->d_omit64, omit64.data(), omit64.size(), hipMemcpyHostToDevice, ctx->stream));
-        HC(hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         HC(hipMemcpyAsync(d_keep64, keep64.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
+        HC(hipMemcpyAsync(d_hkeys64, hkeys64.data(), hkeys64.size(), hipMemcpyHostToDevice, ctx->stream));
         launch_expand_seeds(ctx->stream, d_seeds64, R, s->d_keys64);
-        ctx->count();
-        for (uint32_t r = 0; r < R; r++)
-            if (omit64[r] < 8) HC(hipMemcpyAsync(s->d_keys64 + (size_t)r * 128, proof + P.z64.on[slot_begin + r].keys, 128, hipMemcpyHostToDevice, ctx->stream));
+        launch_overlay_rows(ctx->stream, (uint32_t*)s->d_keys64, (const uint32_t*)d_hkeys64, s->d_omit64, R, 32, 1);
+        ctx->count(2);
     }
-    ctx->phase(RV_PH_SETUP);
-    ctx->count(3);
-    launch_unpack_bits(ctx->stream, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
-    launch_unpack_bits(ctx->stream, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr);
-    launch_unpack_bits(ctx->stream, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec);
+    ctx->phase(-1);
+    if ((rc = shard_setup_prg(s, d_keep, d_keep64))) return fail(rc);
+    // ---- the interpreter's stream: the proof itself (tens of MB from pageable memory: the host blocks in this
+    //      copy while the mask kernels above already run) and the supplied-value rows unpacked from it
+    hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
+    HC(hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, sb));
+    HC(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, sb));
+    if (s->ev_setup && ctx->pipeline) HC(hipStreamWaitEvent(sb, s->ev_setup, 0));  // d_omit / d_omit64 come from stream 1
+    launch_unpack_bits(sb, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
+    launch_unpack_bits(sb, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr);
+    launch_unpack_bits(sb, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec);
     Interp64Params p64{};
     if (has64) {
-        launch_unpack64(ctx->stream, d_proof, d_src64 + 4 * R, d_src64 + 5 * R, s->d_omit64, cc.n_in64, R, d_sup_in64);
-        launch_unpack64(ctx->stream, d_proof, d_src64 + 2 * R, d_src64 + 3 * R, s->d_omit64, cc.n_corr64, R, d_sup_corr64);
-        launch_unpack64(ctx->stream, d_proof, d_src64 + 0 * R, d_src64 + 1 * R, s->d_omit64, cc.n_rec64, R, d_sup_rec64);
-        ctx->count(3);
+        HC(hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, sb));
+        launch_unpack64(sb, d_proof, d_src64 + 4 * R, d_src64 + 5 * R, s->d_omit64, cc.n_in64, R, d_sup_in64);
+        launch_unpack64(sb, d_proof, d_src64 + 2 * R, d_src64 + 3 * R, s->d_omit64, cc.n_corr64, R, d_sup_corr64);
+        launch_unpack64(sb, d_proof, d_src64 + 0 * R, d_src64 + 1 * R, s->d_omit64, cc.n_rec64, R, d_sup_rec64);
         p64.omit = s->d_omit64;
         p64.sup_in = d_sup_in64;
         p64.sup_corr = d_sup_corr64;
         p64.sup_rec = d_sup_rec64;
     }
-    // the supplied-value rows above are queued before the mask chunks so the interpreter stream only
-    // has to wait for the setup event, not for the whole mask generator
-    if ((rc = shard_setup_prg(s, d_keep, d_keep64))) return fail(rc);
     InterpParams p{};
     p.on_mask = d_onm;
     p.sup_in = d_sup_in;
@@ -1281,13 +1376,8 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     p.sup_rec = d_sup_rec;
     if ((rc = shard_run(s, MODE_VERIFY, p, p64))) return fail(rc);
     // preprocessing slots: the online commitment is the one carried by the proof (preprocess.rs:55-57)
-    const size_t DW = (size_t)R * 8;
-    for (uint32_t r = 0; r < R; r++)
-        if (omit[r] >= 8) {
-            const uint32_t k = slot_begin + r - RV_ONLINE_REPS;
-            HC(hipMemcpyAsync(s->d_dig + 1 * DW + (size_t)r * 8, proof + P.gf2.pre[k].comm_online, 32, hipMemcpyHostToDevice, ctx->stream));
-            HC(hipMemcpyAsync(s->d_dig + 3 * DW + (size_t)r * 8, proof + P.z64.pre[k].comm_online, 32, hipMemcpyHostToDevice, ctx->stream));
-        }
+    launch_overlay_rows(ctx->stream, s->d_dig + 1 * DW, (const uint32_t*)d_hco, s->d_omit, R, 8, 0);
+    launch_overlay_rows(ctx->stream, s->d_dig + 3 * DW, (const uint32_t*)d_hco64, s->d_omit, R, 8, 0);
     if ((rc = shard_join(s))) return fail(rc);
     HC(hipMemcpyAsync(digests, s->d_h, (size_t)R * 32, hipMemcpyDeviceToHost, ctx->stream));
     HC(hipStreamSynchronize(ctx->stream));

@@ -189,6 +189,8 @@ void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d
                          uint32_t NQ, int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
 void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
                         const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out);
+void launch_overlay_rows(hipStream_t st, uint32_t* d_dst, const uint32_t* d_src, const uint8_t* d_omit, uint32_t R,
+                         uint32_t row_words, int want_online);
 void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys,
                          const uint32_t* d_on2, const uint32_t* d_on64, const uint64_t* d_off2, const uint64_t* d_off64,
                          uint64_t lens2_rec, uint64_t lens2_corr, uint64_t lens2_in, uint64_t lens64_rec, uint64_t lens64_corr,

@@ -666,6 +666,21 @@ __global__ void k_join(const uint32_t* __restrict__ pre2, const uint32_t* __rest
     for (int k = 0; k < 8; k++) d[k] = o[k];
 }
 
+// verifier set-up: rows of `src` replace those of `dst` for the repetitions with (omit[r] < 8) == want_online
+// (opened player keys and carried-over online commitments arrive in ONE staging copy instead of one tiny
+// host-to-device copy per repetition)
+__global__ void k_overlay_rows(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, const uint8_t* __restrict__ omit,
+                               uint32_t R, uint32_t row_words, int want_online) {
+    const uint32_t r = blockIdx.x;
+    if (r >= R || (int)(omit[r] < RV_PLAYERS) != want_online) return;
+    for (uint32_t t = threadIdx.x; t < row_words; t += blockDim.x) dst[(size_t)r * row_words + t] = src[(size_t)r * row_words + t];
+}
+
+void launch_overlay_rows(hipStream_t st, uint32_t* d_dst, const uint32_t* d_src, const uint8_t* d_omit, uint32_t R,
+                         uint32_t row_words, int want_online) {
+    hipLaunchKernelGGL(k_overlay_rows, dim3(R), dim3(32), 0, st, d_dst, d_src, d_omit, R, row_words, want_online);
+}
+
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
                  uint32_t R, uint8_t* d_h) {
     hipLaunchKernelGGL(k_join, dim3((R + 63) / 64), dim3(64), 0, st, d_pre2, d_on2, d_pre64, d_on64, R, d_h);

@@ -108,18 +108,38 @@ def _witness(wit_gf2, wit_z64):
 
 
 class Proof:
-    def __init__(self, data: bytes):
-        self.data = bytes(data)
+    """bincode(Proof) bytes.  A proof that came out of rv_prove stays in the library's (page-locked) buffer
+    until it is dropped — `bytes(proof)` copies it out, `verify` reads it in place."""
+
+    def __init__(self, data: bytes = b"", _owned=None):
+        self._bytes = None if _owned is not None else bytes(data)
+        self._ptr, self._len = _owned if _owned is not None else (None, len(self._bytes))
+        if _owned is not None:
+            import weakref
+
+            weakref.finalize(self, _lib.lib().rv_free, self._ptr)
+
+    @property
+    def data(self) -> bytes:
+        if self._bytes is None:
+            self._bytes = C.string_at(self._ptr, self._len)
+        return self._bytes
 
     def __bytes__(self):
         return self.data
 
     def __len__(self):
-        return len(self.data)
+        return self._len
 
     @property
     def comm(self) -> bytes:
-        return self.data[:32]
+        return C.string_at(self._ptr, 32) if self._bytes is None else self._bytes[:32]
+
+    def _buffer(self):
+        """(pointer, length) of the proof bytes without copying them"""
+        if self._ptr is not None:
+            return self._ptr, self._len
+        return C.cast(C.c_char_p(self._bytes), C.c_void_p), self._len
 
     @staticmethod
     def new(circuit, wit_gf2: Sequence[int], wit_z64: Sequence[int], wire_counts: Optional[Tuple[int, int]] = None,
@@ -136,15 +156,13 @@ class Proof:
         n = C.c_size_t()
         _lib.check(_lib.lib().rv_prove(c.ctx.handle, c.handle, _ptr(g), C.c_size_t(len(g)), _ptr(z), C.c_size_t(len(z)),
                                        _ptr(s), C.byref(out), C.byref(n)))
-        data = C.string_at(out, n.value)
-        _lib.lib().rv_free(out)
-        return Proof(data)
+        return Proof(_owned=(C.c_void_p(out.value), n.value))
 
     def verify(self, circuit, wire_counts: Optional[Tuple[int, int]] = None, ctx: Optional[Context] = None) -> bool:
         c = _as_circuit(circuit, wire_counts, ctx)
         ok = C.c_int()
-        buf = (C.c_uint8 * len(self.data)).from_buffer_copy(self.data)
-        _lib.check(_lib.lib().rv_verify(c.ctx.handle, c.handle, buf, C.c_size_t(len(self.data)), C.byref(ok)))
+        buf, n = self._buffer()
+        _lib.check(_lib.lib().rv_verify(c.ctx.handle, c.handle, buf, C.c_size_t(n), C.byref(ok)))
         return bool(ok.value)
 
 
