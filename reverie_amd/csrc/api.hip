@@ -314,8 +314,13 @@ struct rv_circuit {
     uint64_t* d_rec_offs64 = nullptr;
     uint64_t* d_in_offs64 = nullptr;
     uint32_t* d_level_start = nullptr;
+    LevelRange* d_level_range = nullptr;
     // maximal runs [first, last) of consecutive narrow GF(2)-only levels, executed by one workgroup each
-    std::vector<std::pair<uint32_t, uint32_t>> narrow_runs;
+    struct NarrowRun {
+        uint32_t first, second;  // levels [first, second)
+        int tiny;                // 1: the plain per-gate kernel, 0: the class-loop kernel (every level > 32 gates)
+    };
+    std::vector<NarrowRun> narrow_runs;
     std::vector<int32_t> run_of_level;  // index into narrow_runs or -1
 };
 
@@ -372,7 +377,8 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
         (rc = up(cc.gates64.data(), cc.gates64.size() * sizeof(Gate64), (void**)&c->d_gates64)) ||
         (rc = up(cc.rec_offs64.data(), cc.rec_offs64.size() * 8, (void**)&c->d_rec_offs64)) ||
         (rc = up(cc.in_offs64.data(), cc.in_offs64.size() * 8, (void**)&c->d_in_offs64)) ||
-        (rc = up(cc.level_start.data(), cc.level_start.size() * 4, (void**)&c->d_level_start))) {
+        (rc = up(cc.level_start.data(), cc.level_start.size() * 4, (void**)&c->d_level_start)) ||
+        (rc = up(cc.level_range.data(), cc.level_range.size() * sizeof(LevelRange), (void**)&c->d_level_range))) {
         rv_circuit_destroy(c);
         return rc;
     }
@@ -380,7 +386,8 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
     {
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
         c->run_of_level.assign(n_levels, -1);
-        const uint32_t NARROW = 64;  // gates; one 1024-thread workgroup covers 16 full-width gates per step
+        // gates; one 1024-thread workgroup covers 64 full-width gates per (4-way unrolled) step
+        static const uint32_t NARROW = std::min<uint32_t>(getenv("RV_NARROW") ? (uint32_t)atoi(getenv("RV_NARROW")) : 256, 512);  // <= NARROW_WIN / 2
         size_t l = 0;
         while (l < n_levels) {
             auto narrow = [&](size_t i) {
@@ -394,11 +401,33 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
             size_t e = l;
             while (e < n_levels && narrow(e)) e++;
             if (e - l >= 3) {
-                for (size_t i = l; i < e; i++) c->run_of_level[i] = (int32_t)c->narrow_runs.size();
-                c->narrow_runs.emplace_back((uint32_t)l, (uint32_t)e);
+                // split the run: stretches of >= 8 levels that are all wider than 32 gates go to the class-loop kernel
+                // (4 gates per wavefront step, ~2 us per 64 gates), everything else to the per-gate kernel (one gate
+                // per wavefront, 1.2 us per 16 gates; measured on SHA-256 / AES-128)
+                auto wide = [&](size_t i) { return cc.level_start[i + 1] - cc.level_start[i] > 32; };
+                size_t a = l;
+                while (a < e) {
+                    size_t b = a;
+                    const bool w = wide(a);
+                    while (b < e && wide(b) == w) b++;
+                    const int tiny = (w && b - a >= 8) ? 0 : 1;
+                    if (tiny && a > l && !c->narrow_runs.empty() && c->narrow_runs.back().second == a && c->narrow_runs.back().tiny) {
+                        c->narrow_runs.back().second = (uint32_t)b;  // merge with the preceding per-gate piece
+                    } else {
+                        c->narrow_runs.push_back(rv_circuit::NarrowRun{(uint32_t)a, (uint32_t)b, tiny});
+                    }
+                    for (size_t i = a; i < b; i++) c->run_of_level[i] = (int32_t)c->narrow_runs.size() - 1;
+                    a = b;
+                }
             }
             l = e;
         }
+    }
+    if (getenv("RV_COMPILE_STATS")) {
+        size_t n_tiny = 0, n_med = 0, lv_tiny = 0, lv_med = 0;
+        for (const auto& r : c->narrow_runs) (r.tiny ? n_tiny : n_med)++, (r.tiny ? lv_tiny : lv_med) += r.second - r.first;
+        fprintf(stderr, "[rv circuit] narrow runs: %zu per-gate (%zu levels), %zu class-loop (%zu levels), %zu levels launched one by one\n",
+                n_tiny, lv_tiny, n_med, lv_med, c->run_of_level.size() - lv_tiny - lv_med);
     }
     c->cc.info.device_bytes = cc.gates.size() * sizeof(Gate) + (cc.rec_rows.size() + cc.in_rows.size()) * 4 +
                               cc.gates64.size() * sizeof(Gate64) + (cc.rec_offs64.size() + cc.in_offs64.size()) * 8;
@@ -416,6 +445,7 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     c->ctx->release(c->d_rec_offs64);
     c->ctx->release(c->d_in_offs64);
     c->ctx->release(c->d_level_start);
+    c->ctx->release(c->d_level_range);
     delete c;
 }
 
@@ -636,7 +666,7 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
                     HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
                     waited++;
                 }
-                launch_interp_narrow(sb, mode, s->c->d_gates, s->c->d_level_start, run.first, run.second, p);
+                launch_interp_narrow(sb, mode, s->c->d_gates, s->c->d_level_range, run.first, run.second, run.tiny, p);
                 ctx->count();
             }
             continue;

@@ -605,6 +605,13 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 rd += n, crd += n, wr += 1, n_xor++;
             }
         }
+        uint32_t hist[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t l = 0; l < n_levels; l++) {
+            const uint32_t w = out.level_start[l + 1] - out.level_start[l];
+            hist[w <= 16 ? 0 : w <= 32 ? 1 : w <= 64 ? 2 : w <= 128 ? 3 : w <= 256 ? 4 : w <= 1024 ? 5 : 6]++;
+        }
+        fprintf(stderr, "[rv compile] level widths: <=16:%u <=32:%u <=64:%u <=128:%u <=256:%u <=1024:%u more:%u\n", hist[0], hist[1], hist[2],
+                hist[3], hist[4], hist[5], hist[6]);
         fprintf(stderr, "[rv compile] lazy_k=%d levels=%u mul=%llu (one-base %llu) xork=%llu row_reads=%llu row_writes=%llu corr_reads=%llu\n",
                 b.lazy_k, n_levels, (unsigned long long)n_mul, (unsigned long long)n_mul11, (unsigned long long)n_xor,
                 (unsigned long long)rd, (unsigned long long)wr, (unsigned long long)crd);

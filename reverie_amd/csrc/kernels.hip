@@ -13,6 +13,8 @@
 // NQ consecutive lanes cover every repetition of the shard for one gate, so a wavefront
 // reads/writes whole 256-byte rows.  Gates of one dependency level are independent and
 // are spread over the grid; levels are separate launches.
+#include <stdlib.h>
+
 #include "b3.h"
 #include "internal.h"
 
@@ -296,36 +298,57 @@ __device__ __forceinline__ void interp_one(const Gate& g, const InterpParams& p,
     interp_one_impl<MODE>(g, p, NQ, q, onm);
 }
 
-template <int MODE, int NQ>
-__global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p) {
+// One dependency level, class by class (LevelRange), executed by wavefronts `wave` of `n_waves`: shared by the
+// one-launch-per-level kernel (all wavefronts of the grid) and the narrow-run kernel (the 16 wavefronts of one
+// workgroup, gate records in LDS).  ROTATE (narrow runs): work is dealt to the wavefronts round-robin ACROSS the
+// classes (`slot` = wave-steps handed out so far) — a level of five gates in three classes must land on five
+// different wavefronts, not three times on wave 0.  All gates that do not fill a 4-way unrolled step go through ONE
+// loop at the end, so the big per-gate switch exists once in the instruction stream.
+template <int MODE, int NQ, bool ROTATE>
+__device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const LevelRange& r, const InterpParams& p, uint32_t wave,
+                                          uint32_t n_waves, uint32_t lane, uint32_t onm) {
     constexpr uint32_t GPW = 64 / NQ;  // gates per wavefront per step
-    const uint32_t lane = threadIdx.x & 63;
     const uint32_t q = lane % NQ, sub = lane / NQ;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[q] : 0u;
     constexpr int U = RV_INTERP_UNROLL;
     constexpr uint32_t STEP = U * GPW;
-    uint32_t full;
-    // G_MUL, one base per operand
-    full = r.lo + ((r.mul11 - r.lo) / STEP) * STEP;
-    for (uint32_t g0 = r.lo + wave * STEP; g0 < full; g0 += n_waves * STEP) mulU<MODE, NQ, U, 1, 1>(gates, g0, p, sub, q, onm);
-    for (uint32_t gi = full + wave * GPW + sub; gi < r.mul11; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
-    // other G_MUL
-    full = r.mul11 + ((r.mul - r.mul11) / STEP) * STEP;
-    for (uint32_t g0 = r.mul11 + wave * STEP; g0 < full; g0 += n_waves * STEP)
-        mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K>(gates, g0, p, sub, q, onm);
-    for (uint32_t gi = full + wave * GPW + sub; gi < r.mul; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
-    // G_XORK of two bases
-    full = r.mul + ((r.xor2 - r.mul) / STEP) * STEP;
-    for (uint32_t g0 = r.mul + wave * STEP; g0 < full; g0 += n_waves * STEP) xorU<NQ, U, 2>(gates, g0, p, sub, q);
-    for (uint32_t gi = full + wave * GPW + sub; gi < r.xor2; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
-    // other G_XORK
-    full = r.xor2 + ((r.xork - r.xor2) / STEP) * STEP;
-    for (uint32_t g0 = r.xor2 + wave * STEP; g0 < full; g0 += n_waves * STEP) xorU<NQ, U, 2 * RV_LIN_K>(gates, g0, p, sub, q);
-    for (uint32_t gi = full + wave * GPW + sub; gi < r.xork; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
-    // everything else
-    for (uint32_t gi = r.xork + wave * GPW + sub; gi < r.hi; gi += n_waves * GPW) interp_one<MODE>(gates[gi], p, NQ, q, onm);
+    uint32_t slot = 0;
+    auto my = [&](uint32_t used) { return ROTATE ? (wave + n_waves - used % n_waves) % n_waves : wave; };
+    const uint32_t begin[5] = {r.lo, r.mul11, r.mul, r.xor2, r.xork}, end[5] = {r.mul11, r.mul, r.xor2, r.xork, r.hi};
+    uint32_t rest[5];  // first gate of each class that is left to the common loop
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t n_full = (end[c] - begin[c]) / STEP;
+        rest[c] = begin[c] + n_full * STEP;
+        for (uint32_t g0 = begin[c] + my(slot) * STEP; g0 < rest[c]; g0 += n_waves * STEP) {
+            if (c == 0) mulU<MODE, NQ, U, 1, 1>(gates, g0, p, sub, q, onm);                  // G_MUL, one base per operand
+            if (c == 1) mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K>(gates, g0, p, sub, q, onm);    // other G_MUL
+            if (c == 2) xorU<NQ, U, 2>(gates, g0, p, sub, q);                                // G_XORK of two bases
+            if (c == 3) xorU<NQ, U, 2 * RV_LIN_K>(gates, g0, p, sub, q);                     // other G_XORK
+        }
+        slot += n_full;
+    }
+    rest[4] = begin[4];
+    uint32_t cum[6];  // wave-steps (GPW gates each) of the common loop, per class
+    cum[0] = 0;
+#pragma unroll
+    for (int c = 0; c < 5; c++) cum[c + 1] = cum[c] + (end[c] - rest[c] + GPW - 1) / GPW;
+    for (uint32_t t = my(slot); t < cum[5]; t += n_waves) {
+        uint32_t c0 = rest[0], e0 = end[0], base = 0;
+#pragma unroll
+        for (int c = 1; c < 5; c++)
+            if (t >= cum[c]) c0 = rest[c], e0 = end[c], base = cum[c];
+        const uint32_t gi = c0 + (t - base) * GPW + sub;
+        if (gi < e0) interp_one<MODE>(gates[gi], p, NQ, q, onm);
+    }
+}
+
+template <int MODE, int NQ>
+__global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[lane % NQ] : 0u;
+    run_level<MODE, NQ, false>(gates, r, p, wave, n_waves, lane, onm);
 }
 
 template <int NQ>
@@ -345,32 +368,73 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
 // kernel per level (~4.6 us each).  A run of consecutive narrow levels is executed by ONE 1024-thread
 // workgroup instead: level -> __syncthreads() -> level ...; all waves share the CU's L1, so the
 // workgroup-scope barrier is all the ordering the row/corr hand-off between levels needs.
-template <int MODE>
-__global__ __launch_bounds__(1024) void k_interp_narrow(const Gate* __restrict__ gates, const uint32_t* __restrict__ level_start,
+// Per level the dependent chain used to be level_start[l+1] -> gate record -> operand rows (three L2 round trips,
+// 1.57 us per level on SHA-256); the level table of the run and a rolling window of gate records now sit in LDS
+// (filled by coalesced loads, one refill per NARROW_WIN gates), and a level runs through the same 4-way unrolled
+// class loops as a full launch, so it costs one round trip per 64 gates plus the barrier.
+// NQ = 0: generic row width (one gate per NQ lanes, no unrolling).
+constexpr uint32_t NARROW_MAX_LEVELS = 1024;  // levels per launch (longer runs are split)
+constexpr uint32_t NARROW_WIN = 1024;         // gate records resident in LDS (48 KiB) >= 2 x the widest narrow level
+template <int MODE, int NQT>
+__global__ __launch_bounds__(1024) void k_interp_narrow(const Gate* __restrict__ gates, const LevelRange* __restrict__ level_range,
                                                         uint32_t l0, uint32_t l1, InterpParams p) {
-    const uint32_t NQ = p.NQ;
-    const uint32_t q = threadIdx.x % NQ;
-    const uint32_t worker = threadIdx.x / NQ, n_workers = 1024 / NQ;
-    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[q] : 0u;
-    uint32_t lo = level_start[l0];
-    for (uint32_t l = l0; l < l1; l++) {
-        const uint32_t hi = level_start[l + 1];
-        for (uint32_t gi = lo + worker; gi < hi; gi += n_workers) {
-            const Gate g = gates[gi];
-            interp_one_impl<MODE>(g, p, NQ, q, onm);
+    __shared__ LevelRange s_lr[NARROW_MAX_LEVELS];
+    __shared__ __attribute__((aligned(16))) Gate s_g[NARROW_WIN];
+    const uint32_t NQ = NQT ? (uint32_t)NQT : p.NQ;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[NQT ? lane % NQ : threadIdx.x % NQ] : 0u;
+    const uint32_t n_lv = l1 - l0;
+    {
+        const uint32_t* src = (const uint32_t*)(level_range + l0);
+        uint32_t* dst = (uint32_t*)s_lr;
+        for (uint32_t i = threadIdx.x; i < n_lv * (uint32_t)(sizeof(LevelRange) / 4); i += 1024) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t g_end = s_lr[n_lv - 1].hi;
+    uint32_t win_lo = s_lr[0].lo, win_hi = win_lo;  // gates [win_lo, win_hi) are in s_g
+    for (uint32_t l = 0; l < n_lv; l++) {
+        const LevelRange r = s_lr[l];
+        if (r.hi > win_hi) {  // workgroup-uniform: the previous level's barrier has retired every reader of the old window
+            win_lo = r.lo;
+            win_hi = (r.lo + NARROW_WIN < g_end) ? r.lo + NARROW_WIN : g_end;
+            const uint4* src = (const uint4*)(gates + win_lo);
+            uint4* dst = (uint4*)s_g;
+            for (uint32_t i = threadIdx.x; i < (win_hi - win_lo) * (uint32_t)(sizeof(Gate) / 16); i += 1024) dst[i] = src[i];
+            __syncthreads();
         }
-        lo = hi;
+        const Gate* g = s_g - win_lo;  // indexed by absolute gate number
+        if (NQT) {
+            run_level<MODE, NQT ? NQT : 64, true>(g, r, p, wave, 16, lane, onm);
+        } else {
+            const uint32_t q = threadIdx.x % NQ, worker = threadIdx.x / NQ, n_workers = 1024 / NQ;
+            for (uint32_t gi = r.lo + worker; gi < r.hi; gi += n_workers) interp_one_impl<MODE>(g[gi], p, NQ, q, onm);
+        }
         __syncthreads();
     }
 }
 
-void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const uint32_t* d_level_start, uint32_t l0, uint32_t l1,
-                          const InterpParams& p) {
-    if (l1 <= l0) return;
+template <int NQT>
+static void launch_narrow_nq(hipStream_t st, int mode, const Gate* d_gates, const LevelRange* d_lr, uint32_t a, uint32_t b,
+                             const InterpParams& p) {
     if (mode == MODE_PROVE)
-        hipLaunchKernelGGL(k_interp_narrow<MODE_PROVE>, dim3(1), dim3(1024), 0, st, d_gates, d_level_start, l0, l1, p);
+        hipLaunchKernelGGL((k_interp_narrow<MODE_PROVE, NQT>), dim3(1), dim3(1024), 0, st, d_gates, d_lr, a, b, p);
     else
-        hipLaunchKernelGGL(k_interp_narrow<MODE_VERIFY>, dim3(1), dim3(1024), 0, st, d_gates, d_level_start, l0, l1, p);
+        hipLaunchKernelGGL((k_interp_narrow<MODE_VERIFY, NQT>), dim3(1), dim3(1024), 0, st, d_gates, d_lr, a, b, p);
+}
+
+void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const LevelRange* d_level_range, uint32_t l0, uint32_t l1,
+                          int tiny, const InterpParams& p) {
+    for (uint32_t a = l0; a < l1; a += NARROW_MAX_LEVELS) {
+        const uint32_t b = (a + NARROW_MAX_LEVELS < l1) ? a + NARROW_MAX_LEVELS : l1;
+        // NQT = 0 is the plain per-gate loop (also the fallback for row widths without a class-loop instantiation)
+        switch (tiny ? 0u : p.NQ) {
+        case 64: launch_narrow_nq<64>(st, mode, d_gates, d_level_range, a, b, p); break;
+        case 32: launch_narrow_nq<32>(st, mode, d_gates, d_level_range, a, b, p); break;
+        case 16: launch_narrow_nq<16>(st, mode, d_gates, d_level_range, a, b, p); break;
+        case 8: launch_narrow_nq<8>(st, mode, d_gates, d_level_range, a, b, p); break;
+        default: launch_narrow_nq<0>(st, mode, d_gates, d_level_range, a, b, p); break;
+        }
+    }
 }
 
 void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p) {
