@@ -376,6 +376,59 @@ def test_single_shard_host_and_device_fiat_shamir(rv, oracle):
             be.destroy(shard)
 
 
+@pytest.mark.parametrize("n_shards", [2, 4, 8])
+def test_shards_in_one_process_bristol_circuits(rv, oracle, rule_seeds, n_shards):
+    """Repetition shards of 128 / 64 / 32 (row widths 32 / 16 / 8 quads, the per-GPU shapes of 2 / 4 / 8 GPUs) run one
+    after the other on this GPU: AES-128 (levels of 64-256 gates: the class-loop narrow kernel) and SHA-256 (levels of
+    <=32 gates: the per-gate narrow kernel), host-side challenge, both the prover and the sharded verifier."""
+    import bristol_gen
+    from reverie_amd import _lib, bristol
+    from reverie_amd.dist import HipShardBackend, assemble, shard_range
+    from reverie_amd.proof import challenge, combine_digests
+
+    bits = lambda d: [(b >> (7 - k)) & 1 for b in d for k in range(8)]  # noqa: E731
+    key = bytes(range(16)); pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+    cases = [(bristol_gen.aes128(), bits(bytes.fromhex("69c4e0d86a7b0430d8cdb78070b4c55a")), bits(key) + bits(pt))]
+    if n_shards == 4:
+        import hashlib
+
+        block = b"abc" + b"\x80" + bytes(52) + (24).to_bytes(8, "big")
+        cases.append((bristol_gen.sha256_block(), bits(hashlib.sha256(b"abc").digest()), bits(block)))
+    for text, expect, wit in cases:
+        prog, info = bristol.parse(text, expected_outputs=expect)
+        wc = info["wire_counts"]
+        want = oracle.prove(prog, wit, [], wc, rule_seeds, threads=4)
+        c = rv.Circuit(prog, wc)
+        be = HipShardBackend(c)
+        shards = []
+        try:
+            for r in range(n_shards):
+                b, n = shard_range(r, n_shards)
+                shards.append(be.commit(wit, [], rule_seeds[b:b + n], b, n))
+            h = np.concatenate([be.digests(s) for s in shards])
+            comm = combine_digests(h)
+            omit = challenge(comm)
+            parts = [be.open(s, omit)[:2] for s in shards]
+        finally:
+            for s in shards:
+                be.destroy(s)
+        proof = assemble(comm, parts)
+        assert proof == want
+        # sharded verifier (rv_verify_shard over slot ranges, then rv_verify_finish)
+        L = _lib.lib()
+        dig = np.zeros((256, 32), np.uint8)
+        buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
+        per = 256 // n_shards
+        for r in range(n_shards):
+            part = np.zeros((per, 32), np.uint8)
+            _lib.check(L.rv_verify_shard(c.ctx.handle, c.handle, buf, C.c_size_t(len(proof)), C.c_uint32(r * per), C.c_uint32(per),
+                                         part.ctypes.data_as(C.c_void_p)))
+            dig[r * per:(r + 1) * per] = part
+        ok = C.c_int()
+        _lib.check(L.rv_verify_finish(buf, C.c_size_t(len(proof)), dig.ctypes.data_as(C.c_void_p), C.byref(ok)))
+        assert ok.value == 1
+
+
 # ---------------------------------------------------------------- sharded path on the GPU
 def _two_rank_worker(rank, world, port, out_path):
     import sys
