@@ -287,12 +287,26 @@ def main():
                        "parallelism": f"reps/{world}", "levels": info["levels"], "compile_s": compile_s},
             "roofline": roofline,
         }
-    # verification of the last proof (all ranks participate in nothing here: rank 0 only, single GPU verify)
+    # ---- parity gate, outside the timed region (rank 0; the other ranks wait at the final barrier):
+    # the last timed proof must verify; with N > 1 the sharded proof must equal, byte for byte, the proof one GPU
+    # produces from the same seeds; and (N = 1) a prefix of the workload must equal the CPU oracle's proof
+    if rank == 0:
+        from reverie_amd.dist import assemble_device_parts
+
+        comm, bufs, all_lens = out
+        last = reverie_amd.Proof(assemble_device_parts(comm, bufs, all_lens))
+        parity = {"last_timed_proof_verifies": bool(last.verify(circuit)), "proof_bytes": len(last)}
+        if world > 1:
+            single = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
+            parity["sharded_proof_equals_single_gpu_proof"] = bytes(single) == bytes(last)
+        result["parity"] = parity
+        if not all(v for k, v in parity.items() if k != "proof_bytes"):
+            result["value"] = 0.0
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         base, (sprog, swit, swc, sseeds, sproof) = cpu_baseline(args.cpu_sample_layers)
         got = reverie_amd.Proof.new(reverie_amd.Circuit(sprog, swc, ctx), swit, [], seeds=sseeds)
         result["cpu_baseline"] = base
-        result["parity"] = {"sample_proof_bit_exact_vs_cpu": bytes(got) == sproof}
+        result["parity"]["sample_proof_bit_exact_vs_cpu"] = bytes(got) == sproof
         if bytes(got) != sproof:
             result["value"] = 0.0
     if rank == 0:
