@@ -162,38 +162,54 @@ void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t l
         hipLaunchKernelGGL(k_interp64<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, hi, p);
 }
 
-// ---- BLAKE3 over R contiguous little-endian streams: thread = (rep, chunk) ----
+// ---- BLAKE3 over R contiguous little-endian streams: thread = (chunk, rep), chunk fastest ----
+// Adjacent lanes hash adjacent 1 KiB chunks of the SAME stream, so a wavefront walks one contiguous 64 KiB region
+// (the first version put the repetitions of one chunk in adjacent lanes: 64 MB apart, every 16-byte load a different
+// DRAM page, 1.2 TB/s).  A lane fetches a whole 128-byte line (two blocks, eight 16-byte loads issued together) and
+// then runs the two dependent compressions, so each line crosses L2 -> L1 once instead of eight times.
 __global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __restrict__ streams, uint64_t n_bytes, uint32_t R,
                                                           uint64_t n_chunks, uint32_t* __restrict__ cvs) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t c = tid / R;
-    const uint32_t r = (uint32_t)(tid % R);
-    if (c >= n_chunks) return;
+    const uint64_t c = tid % n_chunks;
+    const uint32_t r = (uint32_t)(tid / n_chunks);
+    if (r >= R) return;
     const uint64_t b0 = c * 1024;
     const uint64_t len = (n_bytes - b0 < 1024) ? (n_bytes - b0) : 1024;  // multiple of 8
     const uint32_t nblk = len == 0 ? 1 : (uint32_t)((len + 63) / 64);
     const uint32_t* src = streams + ((size_t)r * n_bytes + b0) / 4;
     uint32_t cv[8];
     b3::iv(cv);
-    for (uint32_t b = 0; b < nblk; b++) {
+    uint32_t b = 0;
+    if (len == 1024 && n_chunks > 1) {  // the common case: 16 full blocks, two per step
+        for (; b < 16; b += 2) {
+            const uint4* s4 = (const uint4*)(src + 16 * b);
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = s4[k];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint32_t m[16], o[8];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    m[4 * k] = v[4 * h + k].x;
+                    m[4 * k + 1] = v[4 * h + k].y;
+                    m[4 * k + 2] = v[4 * h + k].z;
+                    m[4 * k + 3] = v[4 * h + k].w;
+                }
+                const uint32_t flags = (b + h == 0 ? b3::CHUNK_START : 0u) | (b + h == 15 ? b3::CHUNK_END : 0u);
+                b3::compress<false>(cv, m, c, 64, flags, o);
+#pragma unroll
+                for (int k = 0; k < 8; k++) cv[k] = o[k];
+            }
+        }
+    }
+    for (; b < nblk; b++) {
         const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
         uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
         if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
         uint32_t m[16];
-        if (blen == 64) {  // streams are 8-byte aligned and a block is 64 B: four 16-byte loads
-            const uint4* s4 = (const uint4*)(src + 16 * b);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint4 v = s4[k];
-                m[4 * k] = v.x;
-                m[4 * k + 1] = v.y;
-                m[4 * k + 2] = v.z;
-                m[4 * k + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) m[k] = (4u * k < blen) ? src[16 * b + k] : 0u;
-        }
+        for (int k = 0; k < 16; k++) m[k] = (4u * k < blen) ? src[16 * b + k] : 0u;
         uint32_t o[8];
         b3::compress<false>(cv, m, c, blen, flags, o);
 #pragma unroll
