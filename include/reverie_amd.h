@@ -154,6 +154,16 @@ int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
 int rv_prove(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64,
              size_t n_z64, const uint8_t *seeds, uint8_t **proof, size_t *proof_len);
 
+/* ---- many proofs of one circuit ------------------------------------------------------------
+ * `batch` independent Proof::new calls (witness b at wit_gf2 + b*n_gf2 / wit_z64 + b*n_z64, seeds b at
+ * seeds + b*256*16, NULL => OS randomness) executed together: every dependency level of the circuit is
+ * launched once for the whole batch.  This is what makes deep, narrow circuits (AES, SHA-256: thousands of
+ * levels of a few gates, latency-bound) use the GPU; the reference reaches the same goal with one rayon task per
+ * proof.  proofs[b] / proof_lens[b] as rv_prove (rv_free each).  Each proof is byte-identical to what rv_prove
+ * returns for the same witness and seeds.  Mixed / Z64 circuits fall back to one rv_prove per proof. */
+int rv_prove_batch(rv_ctx *ctx, const rv_circuit *c, size_t batch, const uint8_t *wit_gf2, size_t n_gf2,
+                   const uint64_t *wit_z64, size_t n_z64, const uint8_t *seeds, uint8_t **proofs, size_t *proof_lens);
+
 /* ---- Proof::verify ----------------------------------------------------------------
  * *ok follows the reference exactly: 0 when a ProofSingle has the wrong number of
  * repetitions or the recomputed commitment differs, 1 otherwise.  Bytes that cannot be

@@ -60,6 +60,7 @@ struct rv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // setup, AES masks, hashing, openings (VALU-heavy work)
     hipStream_t stream2 = nullptr;  // the interpreter (HBM-bound), pipelined against the mask generator
+    std::vector<hipStream_t> batch_streams;  // rv_prove_batch: the per-proof phases of different proofs overlap on these
     bool pipeline = true;           // RV_PIPELINE=0: one stream, phases strictly back to back (isolated kernel timing)
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
@@ -211,6 +212,7 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     ctx->trim();
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
+    for (hipStream_t st : ctx->batch_streams) (void)hipStreamDestroy(st);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
@@ -601,8 +603,9 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
     return RV_OK;
 }
 
-// interpreter over all levels + transcript digests + joins
-static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64) {
+// The interpreter phase of a shard in three steps (shard_run = all three; rv_prove_batch interleaves them over several
+// shards): buffers + parameter blocks, the level loop, the transcript digests.
+static int shard_run_alloc(rv_shard* s, InterpParams& p, Interp64Params& p64) {
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     int rc;
@@ -635,7 +638,6 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
     p.on = s->d_on;
     p.pre = s->d_pre;
     p.err = s->d_err;
-    const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
     p64.R = s->R;
     p64.wmask = s->d_wmask64;
     p64.wcorr = s->d_wcorr64;
@@ -648,6 +650,15 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
     p64.masks2 = s->d_masks;
     p64.NQ = s->NQ;
     p64.err = s->d_err;
+    return RV_OK;
+}
+
+static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const Interp64Params& p64) {
+    rv_ctx* ctx = s->ctx;
+    const Compiled& cc = s->c->cc;
+    const bool has64 = !cc.gates64.empty();
+    hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
+    const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
     ctx->phase(RV_PH_INTERP, sb);
     size_t waited = 0;  // mask chunks already waited for
     for (size_t l = 0; l < n_levels; l++) {
@@ -680,6 +691,13 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
             ctx->count();
         }
     }
+    return RV_OK;
+}
+
+static int shard_run_hash(rv_shard* s) {
+    rv_ctx* ctx = s->ctx;
+    const Compiled& cc = s->c->cc;
+    hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
     {
         hipEvent_t done = ctx->get_sync_event();
         HIPCHK(hipEventRecord(done, sb));
@@ -695,6 +713,12 @@ static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64
     launch_b3_contig(ctx->stream, s->d_pre64, cc.pre_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 2 * DW);
     launch_b3_contig(ctx->stream, s->d_on64, cc.on_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 3 * DW);
     ctx->phase(-1);
+    return RV_OK;
+}
+
+static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64) {
+    int rc;
+    if ((rc = shard_run_alloc(s, p, p64)) || (rc = shard_run_levels(s, mode, p, p64)) || (rc = shard_run_hash(s))) return rc;
     return RV_OK;
 }
 
@@ -861,7 +885,7 @@ extern "C" int rv_shard_open_size(const rv_shard* s, const uint8_t omit[RV_TOTAL
 }
 
 static int shard_open_impl(rv_shard* s, const uint8_t* omit /* NULL: device Fiat-Shamir */, void* dst, void** dptr, size_t lens[4],
-                           bool framed = false, uint8_t* comm_out = nullptr, uint8_t* omit_out = nullptr);
+                           bool framed = false, uint8_t* comm_out = nullptr, uint8_t* omit_out = nullptr, bool no_sync = false);
 
 extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void** dptr, size_t lens[4]) {
     if (!omit) return RV_E_ARG;
@@ -877,7 +901,7 @@ extern "C" int rv_shard_open_into(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS]
 // `omit` == NULL: Fiat-Shamir on the device (k_fs_challenge) from the shard's own digests; only for a shard that
 // holds all 256 repetitions.  comm_out / omit_out (nullable) then receive comm and the opening map.
 static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** dptr, size_t lens[4], bool framed, uint8_t* comm_out,
-                           uint8_t* omit_out) {
+                           uint8_t* omit_out, bool no_sync) {
     if (!s || !dptr || !lens) return RV_E_ARG;
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
@@ -966,6 +990,12 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
     }
     HIPCHK(hipGetLastError());
     ctx->phase(-1);
+    if (self && no_sync) {
+        // rv_prove_batch: nothing on the host depends on this proof yet; the caller synchronises once per batch
+        *dptr = d_out;
+        for (int k = 0; k < 4; k++) lens[k] = L.len[k];
+        return RV_OK;
+    }
     if (self) {
         uint8_t back[RV_TOTAL_REPS + 32];
         if (comm_out || omit_out) HIPCHK(hipMemcpyAsync(back, s->d_omit, sizeof back, hipMemcpyDeviceToHost, ctx->stream));
@@ -1118,6 +1148,204 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
     rv_free(out);
     rv_shard_destroy(s);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// rv_prove_batch: `batch` proofs of ONE circuit, different witnesses and seeds, in one pass.
+// Deep narrow circuits (AES, SHA: thousands of dependency levels of a few gates) are latency-bound: one proof keeps
+// a single workgroup busy, and proofs in flight on separate contexts stop scaling at ~16 (host launch overhead).
+// Here every level / narrow-run launch carries all proofs (grid.y resp. one workgroup per proof), so the latency
+// chain is paid once per batch; the per-proof phases around it (keys, masks, digests, openings) are queued proof
+// after proof on the same stream with a single synchronisation at the end.
+// ------------------------------------------------------------------------------------
+static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, const uint8_t* wit_gf2, size_t n_gf2,
+                               const uint64_t* wit_z64, size_t n_z64, const uint8_t* seeds, uint8_t** proofs, size_t* proof_lens) {
+    if (!ctx || !c || !proofs || !proof_lens || !batch) return RV_E_ARG;
+    const Compiled& cc = c->cc;
+    for (size_t b = 0; b < batch; b++) proofs[b] = nullptr, proof_lens[b] = 0;
+    if (n_gf2 < cc.n_in || n_z64 < cc.n_in64) return RV_E_WITNESS_SHORT;
+    if ((cc.n_in && !wit_gf2) || (cc.n_in64 && !wit_z64)) return RV_E_ARG;
+    std::vector<uint8_t> os_seeds;
+    if (!seeds) {  // OsRng (proof/mod.rs:131-134)
+        os_seeds.resize(batch * RV_TOTAL_REPS * 16);
+        size_t got = 0;
+        while (got < os_seeds.size()) {
+            ssize_t n = getrandom(os_seeds.data() + got, os_seeds.size() - got, 0);
+            if (n <= 0) return RV_E_DEVICE;
+            got += (size_t)n;
+        }
+        seeds = os_seeds.data();
+    }
+    auto one_by_one = [&]() {  // Z64 / mixed circuits and batches of one: the plain entry point, proof after proof
+        for (size_t b = 0; b < batch; b++) {
+            int rc = rv_prove(ctx, c, wit_gf2 ? wit_gf2 + b * n_gf2 : nullptr, n_gf2, wit_z64 ? wit_z64 + b * n_z64 : nullptr, n_z64,
+                              seeds + b * RV_TOTAL_REPS * 16, &proofs[b], &proof_lens[b]);
+            if (rc) {
+                for (size_t k = 0; k <= b; k++) rv_free(proofs[k]), proofs[k] = nullptr, proof_lens[k] = 0;
+                return rc;
+            }
+        }
+        return (int)RV_OK;
+    };
+    if (batch == 1 || !cc.gates64.empty()) return one_by_one();
+    HIPCHK(hipSetDevice(ctx->device));
+    const bool was_pipelined = ctx->pipeline;
+    ctx->pipeline = false;  // everything of a batch goes down ONE stream
+    std::vector<rv_shard*> sh(batch, nullptr);
+    std::vector<InterpParams> pp(batch);
+    InterpParams* d_pp = nullptr;
+    int rc = RV_OK;
+    uint8_t** staging_ptr = nullptr;  // set once the staging buffer variable below exists
+    auto cleanup = [&](int code) {
+        for (hipStream_t st : ctx->batch_streams) (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (rv_shard* s : sh)
+            if (s) {
+                s->destroy();
+                delete s;
+            }
+        ctx->release(d_pp);
+        if (staging_ptr && *staging_ptr) g_pinned.put(*staging_ptr);
+        ctx->pipeline = was_pipelined;
+        if (code)
+            for (size_t b = 0; b < batch; b++) rv_free(proofs[b]), proofs[b] = nullptr, proof_lens[b] = 0;
+        return code;
+    };
+    const uint32_t R = RV_TOTAL_REPS;
+    // The per-proof phases are strings of small kernels (a few hundred microseconds of mostly idle GPU per proof):
+    // proofs take turns on a handful of streams so that they overlap; the shard code issues everything on
+    // ctx->stream, which is pointed at the proof's stream while its work is queued (single host thread).
+    constexpr size_t N_STREAMS = 8;
+    while (ctx->batch_streams.size() < N_STREAMS) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return cleanup(RV_E_DEVICE);
+        ctx->batch_streams.push_back(st);
+    }
+    hipStream_t const main_stream = ctx->stream;
+    struct StreamSwap {
+        rv_ctx* c;
+        hipStream_t keep;
+        StreamSwap(rv_ctx* c_, hipStream_t st) : c(c_), keep(c_->stream) { c->stream = st; }
+        ~StreamSwap() { c->stream = keep; }
+    };
+    auto stream_of = [&](size_t b) { return ctx->batch_streams[b % N_STREAMS]; };
+    auto fork_join = [&](bool to_side) -> int {  // main -> side streams (true) or side streams -> main (false)
+        hipEvent_t e = ctx->get_sync_event();
+        if (to_side) {
+            if (hipEventRecord(e, main_stream) != hipSuccess) return RV_E_DEVICE;
+            for (hipStream_t st : ctx->batch_streams)
+                if (hipStreamWaitEvent(st, e, 0) != hipSuccess) return RV_E_DEVICE;
+            sh[0]->misc_events.push_back(e);
+        } else {
+            sh[0]->misc_events.push_back(e);
+            for (hipStream_t st : ctx->batch_streams) {
+                hipEvent_t f = ctx->get_sync_event();
+                if (hipEventRecord(f, st) != hipSuccess || hipStreamWaitEvent(main_stream, f, 0) != hipSuccess) return RV_E_DEVICE;
+                sh[0]->misc_events.push_back(f);
+            }
+        }
+        return RV_OK;
+    };
+    // ---- per proof: seeds, witness, keys, masks, buffers
+    for (size_t b = 0; b < batch && !rc; b++) {
+        StreamSwap on_side(ctx, stream_of(b));
+        rv_shard* s = sh[b] = new rv_shard();
+        s->ctx = ctx;
+        s->c = c;
+        s->rep_begin = 0;
+        s->R = R;
+        s->NQ = R / 4;
+        if ((rc = dalloc(ctx, (size_t)R * 16, &s->d_seeds)) || (rc = dalloc(ctx, (size_t)R * 128, &s->d_keys)) ||
+            (rc = dalloc(ctx, std::max<size_t>(cc.n_in, 1), &s->d_wit)))
+            break;
+        if (hipMemcpyAsync(s->d_seeds, seeds + b * R * 16, (size_t)R * 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            (cc.n_in && hipMemcpyAsync(s->d_wit, wit_gf2 + b * n_gf2, cc.n_in, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)) {
+            rc = RV_E_DEVICE;
+            break;
+        }
+        launch_expand_seeds(ctx->stream, s->d_seeds, R, s->d_keys);
+        if ((rc = shard_setup_prg(s, nullptr))) break;
+        Interp64Params p64{};
+        pp[b] = InterpParams{};
+        pp[b].wit = s->d_wit;
+        if ((rc = shard_run_alloc(s, pp[b], p64))) break;
+    }
+    if (rc) return cleanup(rc);
+    if ((rc = fork_join(false))) return cleanup(rc);
+    // ---- all proofs level by level
+    if ((rc = dalloc(ctx, batch, &d_pp))) return cleanup(rc);
+    if (hipMemcpyAsync(d_pp, pp.data(), batch * sizeof(InterpParams), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return cleanup(RV_E_DEVICE);
+    {
+        const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+        for (size_t l = 0; l < n_levels; l++) {
+            if (c->run_of_level[l] >= 0) {
+                const auto& run = c->narrow_runs[(size_t)c->run_of_level[l]];
+                if (l == run.first)
+                    launch_interp_narrow_batched(ctx->stream, c->d_gates, c->d_level_range, run.first, run.second, run.tiny, d_pp, (uint32_t)batch);
+                continue;
+            }
+            launch_interp_batched(ctx->stream, c->d_gates, cc.level_range[l], d_pp, (uint32_t)batch);
+        }
+    }
+    // ---- per proof: digests, commitment + challenge + openings on the device, proof bytes to the host
+    uint8_t* staging = nullptr;
+    staging_ptr = &staging;
+    size_t slot = 0;
+    size_t lens[4] = {0, 0, 0, 0};  // the same for every proof of the circuit (40 / 216 split)
+    if ((rc = fork_join(true))) return cleanup(rc);
+    for (size_t b = 0; b < batch && !rc; b++) {
+        StreamSwap on_side(ctx, stream_of(b));
+        rv_shard* s = sh[b];
+        if ((rc = shard_run_hash(s)) || (rc = shard_join(s))) break;
+        void* d = nullptr;
+        if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, nullptr, nullptr, /*no_sync=*/true))) break;
+        const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
+        if (!staging) {
+            // one page-locked staging area for the whole batch: a device-to-host copy into pageable memory would
+            // block the host until that proof's kernels have run, serialising the batch
+            slot = (total + 4 + 63) & ~(size_t)63;
+            staging = (uint8_t*)g_pinned.get(std::max<size_t>(slot * batch, PinnedPool::MIN_BYTES));
+            if (!staging) {
+                rc = RV_E_NOMEM;
+                break;
+            }
+        }
+        proof_lens[b] = total;
+        if (hipMemcpyAsync(staging + b * slot, d, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(staging + b * slot + total, s->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+            rc = RV_E_DEVICE;
+            break;
+        }
+    }
+    if (rc) return cleanup(rc);
+    if ((rc = fork_join(false))) return cleanup(rc);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(hip_fail(hipGetLastError(), "batch sync", __FILE__, __LINE__));
+    for (size_t b = 0; b < batch; b++) {
+        int err = 0;
+        memcpy(&err, staging + b * slot + proof_lens[b], sizeof err);
+        if (err) return cleanup(RV_E_WITNESS_INVALID);
+        proofs[b] = (uint8_t*)out_alloc(proof_lens[b]);
+        if (!proofs[b]) return cleanup(RV_E_NOMEM);
+        memcpy(proofs[b], staging + b * slot, proof_lens[b]);
+        size_t off = 32;
+        const uint64_t counts[4] = {RV_ONLINE_REPS, RV_PREPROCESSING_REPS, RV_ONLINE_REPS, RV_PREPROCESSING_REPS};
+        for (int k = 0; k < 4; k++) {
+            put_le64(proofs[b] + off, counts[k]);
+            off += 8 + lens[k];
+        }
+    }
+    ctx->prof.calls += batch;
+    return cleanup(RV_OK);
+}
+
+extern "C" int rv_prove_batch(rv_ctx* ctx, const rv_circuit* c, size_t batch, const uint8_t* wit_gf2, size_t n_gf2,
+                              const uint64_t* wit_z64, size_t n_z64, const uint8_t* seeds, uint8_t** proofs, size_t* proof_lens) {
+    try {  // no C++ exception may cross the C boundary
+        return rv_prove_batch_impl(ctx, c, batch, wit_gf2, n_gf2, wit_z64, n_z64, seeds, proofs, proof_lens);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
 }
 
 // ------------------------------------------------------------------------------------

@@ -15,6 +15,8 @@
 // are spread over the grid; levels are separate launches.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "b3.h"
 #include "internal.h"
 
@@ -351,6 +353,18 @@ __global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ ga
     run_level<MODE, NQ, false>(gates, r, p, wave, n_waves, lane, onm);
 }
 
+// Batched proofs of one circuit (rv_prove_batch): blockIdx.y selects the proof; its buffers come from a device array
+// of InterpParams.  The gate stream is shared, so one launch per level serves every proof in the batch.
+template <int MODE, int NQ>
+__global__ __launch_bounds__(256) void k_interp_full_b(const Gate* __restrict__ gates, LevelRange r, const InterpParams* __restrict__ pp) {
+    const InterpParams p = pp[blockIdx.y];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[lane % NQ] : 0u;
+    run_level<MODE, NQ, false>(gates, r, p, wave, n_waves, lane, onm);
+}
+
 template <int NQ>
 static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p) {
     constexpr uint32_t GPW = 64 / NQ;
@@ -376,8 +390,8 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
 constexpr uint32_t NARROW_MAX_LEVELS = 1024;  // levels per launch (longer runs are split)
 constexpr uint32_t NARROW_WIN = 1024;         // gate records resident in LDS (48 KiB) >= 2 x the widest narrow level
 template <int MODE, int NQT>
-__global__ __launch_bounds__(1024) void k_interp_narrow(const Gate* __restrict__ gates, const LevelRange* __restrict__ level_range,
-                                                        uint32_t l0, uint32_t l1, InterpParams p) {
+__device__ __forceinline__ void interp_narrow_body(const Gate* __restrict__ gates, const LevelRange* __restrict__ level_range,
+                                                   uint32_t l0, uint32_t l1, const InterpParams& p) {
     __shared__ LevelRange s_lr[NARROW_MAX_LEVELS];
     __shared__ __attribute__((aligned(16))) Gate s_g[NARROW_WIN];
     const uint32_t NQ = NQT ? (uint32_t)NQT : p.NQ;
@@ -411,6 +425,19 @@ __global__ __launch_bounds__(1024) void k_interp_narrow(const Gate* __restrict__
         }
         __syncthreads();
     }
+}
+
+template <int MODE, int NQT>
+__global__ __launch_bounds__(1024) void k_interp_narrow(const Gate* __restrict__ gates, const LevelRange* __restrict__ level_range,
+                                                        uint32_t l0, uint32_t l1, InterpParams p) {
+    interp_narrow_body<MODE, NQT>(gates, level_range, l0, l1, p);
+}
+// batched proofs: one workgroup per proof (blockIdx.x), see k_interp_full_b
+template <int MODE, int NQT>
+__global__ __launch_bounds__(1024) void k_interp_narrow_b(const Gate* __restrict__ gates, const LevelRange* __restrict__ level_range,
+                                                          uint32_t l0, uint32_t l1, const InterpParams* __restrict__ pp) {
+    const InterpParams p = pp[blockIdx.x];
+    interp_narrow_body<MODE, NQT>(gates, level_range, l0, l1, p);
 }
 
 template <int NQT>
@@ -453,6 +480,27 @@ void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRan
         hipLaunchKernelGGL(k_interp<MODE_PROVE>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);
     else
         hipLaunchKernelGGL(k_interp<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);
+}
+
+// rv_prove_batch: `batch` full proofs (256 repetitions, NQ = 64) of one circuit, prover side only
+void launch_interp_batched(hipStream_t st, const Gate* d_gates, const LevelRange& r, const InterpParams* d_pp, uint32_t batch) {
+    if (r.hi <= r.lo || !batch) return;
+    uint64_t waves = ((uint64_t)(r.hi - r.lo) + RV_INTERP_UNROLL - 1) / RV_INTERP_UNROLL;
+    uint64_t blocks = (waves + 3) / 4;
+    const uint64_t cap = std::max<uint64_t>(4096 / batch, 1);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((k_interp_full_b<MODE_PROVE, 64>), dim3((unsigned)blocks, batch), dim3(256), 0, st, d_gates, r, d_pp);
+}
+
+void launch_interp_narrow_batched(hipStream_t st, const Gate* d_gates, const LevelRange* d_level_range, uint32_t l0, uint32_t l1,
+                                  int tiny, const InterpParams* d_pp, uint32_t batch) {
+    for (uint32_t a = l0; a < l1 && batch; a += NARROW_MAX_LEVELS) {
+        const uint32_t b = (a + NARROW_MAX_LEVELS < l1) ? a + NARROW_MAX_LEVELS : l1;
+        if (tiny)
+            hipLaunchKernelGGL((k_interp_narrow_b<MODE_PROVE, 0>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
+        else
+            hipLaunchKernelGGL((k_interp_narrow_b<MODE_PROVE, 64>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
+    }
 }
 
 // ------------------------------------------------------------------------------------

@@ -158,6 +158,29 @@ class Proof:
                                        _ptr(s), C.byref(out), C.byref(n)))
         return Proof(_owned=(C.c_void_p(out.value), n.value))
 
+    @staticmethod
+    def new_batch(circuit, wits_gf2, wits_z64=None, wire_counts: Optional[Tuple[int, int]] = None, seeds=None,
+                  ctx: Optional[Context] = None) -> "list[Proof]":
+        """`len(wits_gf2)` proofs of one circuit in one pass (rv_prove_batch): every dependency level is launched
+        once for the whole batch.  wits_gf2: [B][n] bits; wits_z64: [B][m] words or None; seeds: [B][256][16] bytes or
+        None (OS randomness).  Each proof equals Proof.new(circuit, wits_gf2[b], wits_z64[b], seeds=seeds[b])."""
+        c = _as_circuit(circuit, wire_counts, ctx)
+        g = np.ascontiguousarray(np.asarray(wits_gf2, dtype=np.uint8))
+        if g.ndim != 2:
+            raise ValueError("wits_gf2 must be [batch][n_bits]")
+        batch = g.shape[0]
+        z = np.ascontiguousarray(np.asarray(wits_z64 if wits_z64 is not None else np.zeros((batch, 0)), dtype=np.uint64))
+        if z.ndim != 2 or z.shape[0] != batch:
+            raise ValueError("wits_z64 must be [batch][n_words]")
+        s = None
+        if seeds is not None:
+            s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint8)).reshape(batch, TOTAL_REPS, 16)
+        outs = (C.c_void_p * batch)()
+        lens = (C.c_size_t * batch)()
+        _lib.check(_lib.lib().rv_prove_batch(c.ctx.handle, c.handle, C.c_size_t(batch), _ptr(g), C.c_size_t(g.shape[1]), _ptr(z),
+                                             C.c_size_t(z.shape[1]), _ptr(s), outs, lens))
+        return [Proof(_owned=(C.c_void_p(outs[b]), int(lens[b]))) for b in range(batch)]
+
     def verify(self, circuit, wire_counts: Optional[Tuple[int, int]] = None, ctx: Optional[Context] = None) -> bool:
         c = _as_circuit(circuit, wire_counts, ctx)
         ok = C.c_int()

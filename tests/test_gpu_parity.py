@@ -346,6 +346,46 @@ def test_full_size_properties(rv, rule_seeds):
     assert not rv.Proof(bytes(bad)).verify(c)
 
 
+def test_prove_batch_equals_single_proofs(rv, oracle, rule_seeds):
+    """rv_prove_batch: B proofs of one circuit, different witnesses and seeds, must each equal the single-proof entry
+    point and the oracle — on a circuit with narrow runs of both kinds and launched levels (AES-128: valid and
+    invalid witnesses), and on a mixed GF(2)/Z64 circuit (fallback path)."""
+    import bristol_gen
+    from reverie_amd import bristol
+    from reverie_amd._lib import ReverieError
+
+    bits = lambda d: [(b >> (7 - k)) & 1 for b in d for k in range(8)]  # noqa: E731
+    # statement: AES-128 of the witness (key || plaintext) -- no output assertion, so every witness is valid
+    prog, info = bristol.parse(bristol_gen.aes128())
+    wc = info["wire_counts"]
+    rng = np.random.default_rng(2024)
+    B = 5
+    wits = rng.integers(0, 2, (B, 256), dtype=np.uint8)
+    seeds = rng.integers(0, 256, (B, 256, 16), dtype=np.uint8)
+    c = rv.Circuit(prog, wc)
+    got = rv.Proof.new_batch(c, wits, seeds=seeds)
+    assert len(got) == B
+    for b in range(B):
+        assert bytes(got[b]) == bytes(rv.Proof.new(c, wits[b], [], seeds=seeds[b])) == oracle.prove(prog, wits[b], [], wc, seeds[b], threads=2)
+        assert got[b].verify(c)
+    # one invalid witness fails the whole call, like a panic in one rayon task would
+    key = bytes(range(16)); pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+    prog2, info2 = bristol.parse(bristol_gen.aes128(), expected_outputs=bits(bytes.fromhex("69c4e0d86a7b0430d8cdb78070b4c55a")))
+    c2 = rv.Circuit(prog2, info2["wire_counts"])
+    good = np.array(bits(key) + bits(pt), np.uint8)
+    bad = good.copy(); bad[3] ^= 1
+    ok2 = rv.Proof.new_batch(c2, np.stack([good, good]), seeds=seeds[:2])
+    assert bytes(ok2[1]) == bytes(rv.Proof.new(c2, good, [], seeds=seeds[1]))
+    with pytest.raises(ReverieError):
+        rv.Proof.new_batch(c2, np.stack([good, bad, good]), seeds=seeds[:3])
+    # mixed circuit: falls back to one rv_prove per proof, same results
+    progm, w2, w64, wcm = circuits.random_mixed(np.random.default_rng(5), n_gates=200)
+    cm = rv.Circuit(progm, wcm)
+    gm = rv.Proof.new_batch(cm, np.stack([w2, w2]), np.stack([w64, w64]), seeds=seeds[:2])
+    for b in range(2):
+        assert bytes(gm[b]) == oracle.prove(progm, w2, w64, wcm, seeds[b], threads=2)
+
+
 def test_single_shard_host_and_device_fiat_shamir(rv, oracle):
     """One shard holding all 256 repetitions: the host-side challenge path (digests -> rv_combine_digests ->
     rv_challenge -> open) and the device-side one (rv_shard_open_self) must give the oracle's proof."""
