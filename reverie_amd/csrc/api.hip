@@ -709,9 +709,21 @@ static int shard_run_hash(rv_shard* s) {
     const size_t DW = (size_t)s->R * 8;
     launch_b3_stream_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
     launch_b3_stream(ctx->stream, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 1 * DW);
-    // Z64 transcripts (for a pure GF(2) circuit: BLAKE3 of the empty string)
-    launch_b3_contig(ctx->stream, s->d_pre64, cc.pre_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 2 * DW);
-    launch_b3_contig(ctx->stream, s->d_on64, cc.on_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 3 * DW);
+    // Z64 transcripts; for a pure GF(2) circuit both are empty and every digest is BLAKE3("") (one fill, not four launches)
+    if (cc.pre_words64 == 0 && cc.on_words64 == 0) {
+        static const std::vector<uint32_t> empty = [] {
+            b3::Hasher hs;
+            uint8_t out[32];
+            hs.finalize(out);
+            std::vector<uint32_t> w(8);
+            for (int k = 0; k < 8; k++) w[k] = (uint32_t)out[4 * k] | ((uint32_t)out[4 * k + 1] << 8) | ((uint32_t)out[4 * k + 2] << 16) | ((uint32_t)out[4 * k + 3] << 24);
+            return w;
+        }();
+        launch_fill_digests(ctx->stream, dig + 2 * DW, 2 * s->R, empty.data());
+    } else {
+        launch_b3_contig(ctx->stream, s->d_pre64, cc.pre_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 2 * DW);
+        launch_b3_contig(ctx->stream, s->d_on64, cc.on_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 3 * DW);
+    }
     ctx->phase(-1);
     return RV_OK;
 }

@@ -793,6 +793,20 @@ void launch_overlay_rows(hipStream_t st, uint32_t* d_dst, const uint32_t* d_src,
     hipLaunchKernelGGL(k_overlay_rows, dim3(R), dim3(32), 0, st, d_dst, d_src, d_omit, R, row_words, want_online);
 }
 
+// n_rows copies of one 32-byte digest (the Z64 transcripts of a pure GF(2) circuit are empty: BLAKE3(""))
+struct Digest8 {
+    uint32_t w[8];
+};
+__global__ void k_fill_digests(uint32_t* __restrict__ dst, uint32_t n_rows, Digest8 d) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows * 8) dst[i] = d.w[i & 7];
+}
+void launch_fill_digests(hipStream_t st, uint32_t* d_dst, uint32_t n_rows, const uint32_t digest[8]) {
+    Digest8 d;
+    for (int k = 0; k < 8; k++) d.w[k] = digest[k];
+    hipLaunchKernelGGL(k_fill_digests, dim3((n_rows * 8 + 255) / 256), dim3(256), 0, st, d_dst, n_rows, d);
+}
+
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
                  uint32_t R, uint8_t* d_h) {
     hipLaunchKernelGGL(k_join, dim3((R + 63) / 64), dim3(64), 0, st, d_pre2, d_on2, d_pre64, d_on64, R, d_h);
