@@ -224,14 +224,15 @@ def main():
     dt = time.perf_counter() - t0
     prof = _lib.Profile()
     L.rv_ctx_profile(ctx.handle, 0, 0, C.byref(prof))
-    # Kernel-quality numbers (roofline) come from a short second pass with the phases run strictly back to
-    # back on ONE stream (RV_PIPELINE=0): in the pipelined run above the mask generator and the interpreter
-    # overlap, so their event-timed spans include each other's stalls.
+    # Kernel-quality numbers (roofline) need per-phase times that do not include another phase's stalls.  By default the
+    # library runs a proof's phases back to back on ONE stream, so the HIP-event times of the timed run are exactly
+    # that.  Only with RV_PIPELINE=1 (mask generator and interpreter on two streams) a short second single-stream pass
+    # provides them.
     iso = None
-    if world == 1:
+    if world == 1 and os.environ.get("RV_PIPELINE") == "1":
         os.environ["RV_PIPELINE"] = "0"
         ctx2 = reverie_amd.Context(local)
-        os.environ.pop("RV_PIPELINE")
+        os.environ["RV_PIPELINE"] = "1"
         c2 = reverie_amd.Circuit(prog, wc, ctx2)
         b2 = HipShardBackend(c2)
         prove_sharded(b2, wit, [], seeds, device_resident=True)
@@ -283,10 +284,10 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-            "note": "dominant phase by HIP-event time on the library's own stream, phases run back to back (RV_PIPELINE=0 pass); "
-                    "achieved = its algorithmic HBM bytes per proof (DESIGN.md §4) / that time; `value` is from the pipelined run; traffic = PMC-measured HBM bytes per proof for that kernel "
+            "note": "dominant phase by HIP-event time on the library's own stream (phases of a proof run back to back on one stream); "
+                    "achieved = its algorithmic HBM bytes per proof (DESIGN.md §4) / that time, both from the timed run itself; traffic = PMC-measured HBM bytes per proof for that kernel "
                     "(all its launches). The mask and hash phases are integer-VALU-bound (bitsliced AES, BLAKE3): no MFMA on this path.",
-            "phase_ms_isolated": iso, "phase_ms_pipelined_span": phases, "phase_launches": launches,
+            "phase_ms_isolated": tphase, "phase_ms_timed_run": phases, "phase_launches": launches,
             "algorithmic_bytes": {k: int(v) for k, v in alg.items()},
         }
         result = {

@@ -61,7 +61,7 @@ struct rv_ctx {
     hipStream_t stream = nullptr;   // setup, AES masks, hashing, openings (VALU-heavy work)
     hipStream_t stream2 = nullptr;  // the interpreter (HBM-bound), pipelined against the mask generator
     std::vector<hipStream_t> batch_streams;  // rv_prove_batch: the per-proof phases of different proofs overlap on these
-    bool pipeline = true;           // RV_PIPELINE=0: one stream, phases strictly back to back (isolated kernel timing)
+    bool pipeline = false;          // RV_PIPELINE=1: mask generator and interpreter on two streams, chunk-wise (measured slower: DESIGN.md)
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
         if (!sync_pool.empty()) {
