@@ -154,6 +154,15 @@ int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
 int rv_prove(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64,
              size_t n_z64, const uint8_t *seeds, uint8_t **proof, size_t *proof_len);
 
+/* ---- Proof::new with the openings left in device memory ------------------------------------
+ * The whole prover (commit, Fiat-Shamir, openings) with ONE host synchronisation, for callers that keep working on
+ * the GPU (bench.py's HBM-resident metric): writes [gf2 online | gf2 preprocessing | z64 online | z64 preprocessing]
+ * (lens[4]) to dst_device and returns comm and the opening map; rv_assemble_proof frames them as bincode(Proof).
+ * Capacity of dst_device: 40 * record sizes (rv_circuit_record_sizes) + 2 * 216 * 48.  seeds must not be NULL. */
+int rv_prove_device(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64,
+                    size_t n_z64, const uint8_t *seeds, void *dst_device, uint8_t comm[RV_HASH_SIZE],
+                    uint8_t omit[RV_TOTAL_REPS], size_t lens[4]);
+
 /* ---- many proofs of one circuit ------------------------------------------------------------
  * `batch` independent Proof::new calls (witness b at wit_gf2 + b*n_gf2 / wit_z64 + b*n_z64, seeds b at
  * seeds + b*256*16, NULL => OS randomness) executed together: every dependency level of the circuit is

@@ -744,8 +744,11 @@ static int shard_join(rv_shard* s) {
     return RV_OK;
 }
 
+// defer_sync: do not wait for the device (nor look at the invalid-witness flag): the caller queues more work behind
+// the commitment and checks s->d_err itself after its own synchronisation
 static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
-                               size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out);
+                               size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out,
+                               bool defer_sync = false);
 
 extern "C" int rv_shard_commit(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
                                size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out) {
@@ -758,7 +761,8 @@ extern "C" int rv_shard_commit(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
 }
 
 static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
-                               size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out) {
+                               size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out,
+                               bool defer_sync) {
     if (!ctx || !c || !out || !seeds) return RV_E_ARG;
     if (rep_count == 0 || rep_count % 8 || rep_begin % 8 || rep_begin + rep_count > RV_TOTAL_REPS) return RV_E_ARG;
     *out = nullptr;
@@ -799,6 +803,11 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     p64.wit = s->d_wit64;
     if ((rc = shard_run(s, MODE_PROVE, p, p64))) return fail(rc);
     if ((rc = shard_join(s))) return fail(rc);
+    if (defer_sync) {
+        ctx->prof.calls++;
+        *out = s;
+        return RV_OK;
+    }
     int err = 0;
     if (hipMemcpyAsync(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return fail(RV_E_DEVICE);
     hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -1126,27 +1135,33 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         seeds = os_seeds;
     }
     rv_shard* s = nullptr;
-    int rc = rv_shard_commit(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, 0, RV_TOTAL_REPS, &s);
+    int rc = rv_shard_commit_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, 0, RV_TOTAL_REPS, &s, /*defer_sync=*/true);
     if (rc) return rc;
-    uint8_t comm[32];
     uint8_t* out = nullptr;
     do {
         // commitment, challenge and openings all on the device (k_fs_challenge); the whole proof is laid out there
-        // in its final bincode form and leaves in ONE copy
+        // in its final bincode form (comm included) and leaves in ONE copy; the host waits for the device once
         void* d = nullptr;
         size_t lens[4];
-        if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, comm, nullptr))) break;
+        if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, nullptr, nullptr, /*no_sync=*/true))) break;
         const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
         out = (uint8_t*)out_alloc(total);
         if (!out) {
             rc = RV_E_NOMEM;
             break;
         }
-        if (hipMemcpyAsync(out, d, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        int err = 0;
+        if (hipMemcpyAsync(out, d, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
             rc = hip_fail(hipGetLastError(), "proof D2H", __FILE__, __LINE__);
             break;
         }
-        memcpy(out, comm, 32);
+        ctx->collect();
+        if (err) {
+            rc = RV_E_WITNESS_INVALID;
+            break;
+        }
         size_t off = 32;
         const uint64_t counts[4] = {RV_ONLINE_REPS, RV_PREPROCESSING_REPS, RV_ONLINE_REPS, RV_PREPROCESSING_REPS};
         for (int k = 0; k < 4; k++) {
@@ -1160,6 +1175,47 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
     rv_free(out);
     rv_shard_destroy(s);
     return rc;
+}
+
+static int rv_prove_device_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
+                                size_t n_z64, const uint8_t* seeds, void* dst_device, uint8_t comm[RV_HASH_SIZE],
+                                uint8_t omit[RV_TOTAL_REPS], size_t lens[4]) {
+    if (!ctx || !c || !seeds || !dst_device || !comm || !omit || !lens) return RV_E_ARG;
+    rv_shard* s = nullptr;
+    int rc = rv_shard_commit_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, 0, RV_TOTAL_REPS, &s, /*defer_sync=*/true);
+    if (rc) return rc;
+    do {
+        void* d = nullptr;
+        if ((rc = shard_open_impl(s, nullptr, dst_device, &d, lens, false, nullptr, nullptr, /*no_sync=*/true))) break;
+        uint8_t back[RV_TOTAL_REPS + 32];
+        int err = 0;
+        if (hipMemcpyAsync(back, s->d_omit, sizeof back, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            rc = hip_fail(hipGetLastError(), "rv_prove_device", __FILE__, __LINE__);
+            break;
+        }
+        ctx->collect();
+        if (err) {
+            rc = RV_E_WITNESS_INVALID;
+            break;
+        }
+        memcpy(omit, back, RV_TOTAL_REPS);
+        memcpy(comm, back + RV_TOTAL_REPS, 32);
+    } while (0);
+    rv_shard_destroy(s);
+    return rc;
+}
+
+extern "C" int rv_prove_device(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
+                               size_t n_z64, const uint8_t* seeds, void* dst_device, uint8_t comm[RV_HASH_SIZE],
+                               uint8_t omit[RV_TOTAL_REPS], size_t lens[4]) {
+    try {  // no C++ exception may cross the C boundary
+        return rv_prove_device_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, dst_device, comm, omit, lens);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
 }
 
 // ------------------------------------------------------------------------------------

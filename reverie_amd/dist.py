@@ -90,6 +90,24 @@ class HipShardBackend:
         _lib.check(_lib.lib().rv_shard_open_self(shard[0], C.c_void_p(tensor.data_ptr()), _ptr(comm), _ptr(omit), lens))
         return comm.tobytes(), omit, [int(x) for x in lens]
 
+    def single_shard_sizes(self) -> List[int]:
+        """blob sizes of a proof whose one shard holds all 256 repetitions (40 opened, 216 not)"""
+        sz2, sz64 = self.circuit.record_sizes()
+        return [40 * sz2, 216 * 48, 40 * sz64, 216 * 48]
+
+    def prove_device(self, wit_gf2, wit_z64, seeds, tensor):
+        """rv_prove_device: the whole prover with one host synchronisation, openings into `tensor` (device)
+        -> (comm bytes, omit[256], lens[4])"""
+        g = np.ascontiguousarray(np.asarray(wit_gf2, dtype=np.uint8))
+        z = np.ascontiguousarray(np.asarray(wit_z64, dtype=np.uint64))
+        s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint8)).reshape(TOTAL_REPS, 16)
+        lens = (C.c_size_t * 4)()
+        comm = np.zeros(32, np.uint8)
+        omit = np.zeros(TOTAL_REPS, np.uint8)
+        _lib.check(_lib.lib().rv_prove_device(self.circuit.ctx.handle, self.circuit.handle, _ptr(g), C.c_size_t(len(g)), _ptr(z),
+                                              C.c_size_t(len(z)), _ptr(s), C.c_void_p(tensor.data_ptr()), _ptr(comm), _ptr(omit), lens))
+        return comm.tobytes(), omit, [int(x) for x in lens]
+
     def open(self, shard, omit: np.ndarray):
         """-> (blob bytes [gf2_on | gf2_pre | z64_on | z64_pre], lens[4], n_online, n_pre)"""
         parts = _lib.ShardParts()
@@ -147,16 +165,15 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
         rank, world = 0, 1
     begin, count = shard_range(rank, world)
     seeds = np.asarray(seeds, dtype=np.uint8).reshape(TOTAL_REPS, 16)
+    if world == 1 and device_resident and backend.device_type == "cuda" and hasattr(backend, "prove_device"):
+        # one shard holds every repetition: commitment, Fiat-Shamir and openings stay on the device and the host
+        # waits for it once (rv_prove_device)
+        lens = backend.single_shard_sizes()
+        buf = torch.empty(max(sum(lens), 1), dtype=torch.uint8, device="cuda")
+        comm, _, lens = backend.prove_device(wit_gf2, wit_z64, seeds, buf)
+        return comm, [buf], [lens]
     shard = backend.commit(wit_gf2, wit_z64, seeds[begin:begin + count], begin, count)
     try:
-        if world == 1 and device_resident and backend.device_type == "cuda" and hasattr(backend, "open_self"):
-            # one shard holds every repetition: Fiat-Shamir stays on the device, no host round trip
-            canon = np.full(TOTAL_REPS, 8, np.uint8)
-            canon[:40] = 0  # sizes depend only on the 40 / 216 split
-            lens = backend.open_sizes(shard, canon)
-            buf = torch.empty(max(sum(lens), 1), dtype=torch.uint8, device="cuda")
-            comm, _, lens = backend.open_self(shard, buf)
-            return comm, [buf], [lens]
         # ---- the one collective: all-gather of per-repetition digests
         if world == 1:
             h = backend.digests(shard)
