@@ -205,6 +205,8 @@ extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
     return RV_OK;
 }
 
+static void pinned_pool_trim();  // idle page-locked output buffers (defined with the pool below)
+
 extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -216,6 +218,7 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
+    pinned_pool_trim();
 }
 
 extern "C" int rv_ctx_sync(rv_ctx* ctx) {
@@ -279,9 +282,22 @@ struct PinnedPool {
         }
         return true;
     }
+    void trim() {  // give idle page-locked buffers back (called when a context goes away)
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < bufs.size();) {
+            if (!bufs[i].used) {
+                (void)hipHostFree(bufs[i].p);
+                bufs.erase(bufs.begin() + (long)i);
+            } else {
+                i++;
+            }
+        }
+    }
 };
 PinnedPool g_pinned;
 }  // namespace
+
+static void pinned_pool_trim() { g_pinned.trim(); }
 
 static void* out_alloc(size_t n) {
     void* p = g_pinned.get(n);
