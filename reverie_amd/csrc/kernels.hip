@@ -169,6 +169,12 @@ __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, 
 #ifndef RV_INTERP_UNROLL
 #define RV_INTERP_UNROLL 4
 #endif
+#ifndef RV_INTERP_UNROLL_SMALL
+#define RV_INTERP_UNROLL_SMALL 2
+#endif
+// gates a wavefront keeps in flight per step and gate group: narrow rows (small repetition shards, several gates per
+// wavefront already) may want fewer
+__host__ __device__ constexpr int interp_unroll(int NQ) { return NQ >= 64 ? RV_INTERP_UNROLL : RV_INTERP_UNROLL_SMALL; }
 
 // Fast path (NQ = 64, 32, 16 or 8, i.e. R = 256 .. 32): a wavefront covers 64/NQ gates at a time and the
 // per-class ranges run as 4-way unrolled loops that put every operand row of 4 x 64/NQ gates in flight
@@ -311,7 +317,7 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
                                           uint32_t n_waves, uint32_t lane, uint32_t onm) {
     constexpr uint32_t GPW = 64 / NQ;  // gates per wavefront per step
     const uint32_t q = lane % NQ, sub = lane / NQ;
-    constexpr int U = RV_INTERP_UNROLL;
+    constexpr int U = interp_unroll(NQ);
     constexpr uint32_t STEP = U * GPW;
     uint32_t slot = 0;
     auto my = [&](uint32_t used) { return ROTATE ? (wave + n_waves - used % n_waves) % n_waves : wave; };
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) void k_interp_full_b(const Gate* __restrict__ 
 template <int NQ>
 static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p) {
     constexpr uint32_t GPW = 64 / NQ;
-    uint64_t waves = ((uint64_t)(r.hi - r.lo) + RV_INTERP_UNROLL * GPW - 1) / (RV_INTERP_UNROLL * GPW);
+    uint64_t waves = ((uint64_t)(r.hi - r.lo) + interp_unroll(NQ) * GPW - 1) / (interp_unroll(NQ) * GPW);
     uint64_t blocks = (waves + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
