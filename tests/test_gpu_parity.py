@@ -331,6 +331,17 @@ def test_os_seeds_prove_verify(rv, oracle):
     assert p1.verify(prog, wc) and oracle.verify(prog, wc, bytes(p2))
 
 
+def test_full_size_bit_exact_vs_oracle(rv, oracle, rule_seeds):
+    """BASELINE config 4 at FULL size (10^7 gates, 5.0e6 AND, 50 MB proof): the GPU proof equals the oracle's byte
+    for byte (the oracle needs a few seconds of 8-32 threads and ~3.5 GB for it)."""
+    prog, wit, wc, st = circuits.layered_gf2()
+    c = rv.Circuit(prog, wc)
+    got = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+    want = oracle.prove(prog, wit, [], wc, rule_seeds, threads=min(32, os.cpu_count() or 1))
+    assert len(got) == len(want) == 50196120
+    assert bytes(got) == want
+
+
 def test_full_size_properties(rv, rule_seeds):
     """BASELINE config 4 at full size (10^7 gates): size-independent properties only —
     prove -> verify accepts, a flipped transcript bit is rejected, proof length is as derived."""
