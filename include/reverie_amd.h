@@ -98,6 +98,7 @@ uint32_t rv_abi_version(void);
 /* ---- context ---- */
 int rv_ctx_create(int device_ordinal, rv_ctx **out);
 void rv_ctx_destroy(rv_ctx *ctx);
+/* A context owns the device memory of the circuits and shards created on it: destroy those first. */
 /* block until all work queued on the context's stream has finished */
 int rv_ctx_sync(rv_ctx *ctx);
 

@@ -66,12 +66,38 @@ SYMBOLS = [
 _lib = None
 
 
+def _pin_hip_runtime():
+    """A process must run ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64 next to torch/lib, this library
+    links the system one; whichever is loaded first wins the SONAME, and if that is the system copy a later
+    `import torch` finds no GPU ("No HIP GPUs are available") or corrupts the heap at exit.  So when PyTorch is
+    installed its copy is loaded first (without importing torch), and both sides then share it — the arrangement
+    bench.py and the multi-GPU path (which import torch first anyway) have always run in."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ReverieError(7, f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                   "(make -C reverie_amd/csrc); there is no CPU fallback")
+        _pin_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.rv_strerror.restype = C.c_char_p
         L.rv_last_error.restype = C.c_char_p

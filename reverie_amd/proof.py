@@ -83,7 +83,8 @@ class Circuit:
 
     def close(self):
         if self.handle:
-            _lib.lib().rv_circuit_destroy(self.handle)
+            if self.ctx.handle:  # a circuit lives in its context's arena: once that is gone there is nothing left to free
+                _lib.lib().rv_circuit_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):

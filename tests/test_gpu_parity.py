@@ -397,6 +397,52 @@ def test_prove_batch_equals_single_proofs(rv, oracle, rule_seeds):
         assert bytes(gm[b]) == oracle.prove(progm, w2, w64, wcm, seeds[b], threads=2)
 
 
+def test_two_stream_pipeline_mode(rv, oracle, rule_seeds, monkeypatch):
+    """RV_PIPELINE=1 (mask generator and interpreter on two streams, chunk-wise; no longer the default) must give the
+    same proofs: a layered circuit wide enough for several mask chunks, and a mixed GF(2)/Z64 one."""
+    import reverie_amd
+
+    monkeypatch.setenv("RV_PIPELINE", "1")
+    ctx = reverie_amd.Context(0)
+    monkeypatch.delenv("RV_PIPELINE")
+    live = []  # circuits must be destroyed before their context
+    try:
+        prog, wit, wc, st = circuits.layered_gf2(n_in=64, width=8192, layers=80, fold_to=16)
+        c = rv.Circuit(prog, wc, ctx)
+        live.append(c)
+        proof = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+        assert bytes(proof) == oracle.prove(prog, wit, [], wc, rule_seeds, threads=4)
+        assert proof.verify(c)
+        progm, w2, w64, wcm = circuits.random_mixed(np.random.default_rng(31), n_gates=400)
+        cm = rv.Circuit(progm, wcm, ctx)
+        live.append(cm)
+        pm = rv.Proof.new(cm, w2, w64, seeds=rule_seeds)
+        assert bytes(pm) == oracle.prove(progm, w2, w64, wcm, rule_seeds, threads=2)
+        assert pm.verify(cm)
+    finally:
+        for x in live:
+            x.close()
+        ctx.close()
+
+
+def test_prove_device_invalid_witness(rv, rule_seeds):
+    """rv_prove_device defers the invalid-witness check to its single synchronisation: it must still report it"""
+    import torch
+
+    from reverie_amd._lib import ReverieError
+    from reverie_amd.dist import HipShardBackend
+
+    prog = program([GF2.Input(0), GF2.Input(1), GF2.Mul(2, 0, 1), GF2.AssertZero(2)])
+    c = rv.Circuit(prog, (0, 3))
+    be = HipShardBackend(c)
+    buf = torch.empty(max(sum(be.single_shard_sizes()), 1), dtype=torch.uint8, device="cuda")
+    comm, omit, lens = be.prove_device([1, 0], [], rule_seeds, buf)
+    assert len(comm) == 32 and int((omit < 8).sum()) == 40 and lens == be.single_shard_sizes()
+    with pytest.raises(ReverieError) as e:
+        be.prove_device([1, 1], [], rule_seeds, buf)
+    assert e.value.code == 1  # RV_E_WITNESS_INVALID
+
+
 def test_single_shard_host_and_device_fiat_shamir(rv, oracle):
     """One shard holding all 256 repetitions: the host-side challenge path (digests -> rv_combine_digests ->
     rv_challenge -> open) and the device-side one (rv_shard_open_self) must give the oracle's proof."""
