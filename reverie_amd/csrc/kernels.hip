@@ -896,20 +896,20 @@ __global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict
         uint32_t w[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) w[j] = n_items ? stream[(size_t)s_rows[8 * tl + j] * NQ + q] : 0u;
-        uint32_t acc[4] = {0, 0, 0, 0};
+        // rows past the end contribute zero bits (their loads were clamped to the last item)
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (it0 + j < n_items) {
+        for (int j = 0; j < 8; j++)
+            if (it0 + j >= n_items) w[j] = 0;
+        // only the opened repetitions of the quad (usually one of the four) are worth the bit gathering
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t bit = (w[j] >> ((KIND == 0) ? (31u - 8u * i - (om[i] & 7u)) : (24u - 8u * i))) & 1u;
-                    acc[i] |= bit << (7 - j);
-                }
-            }
+        for (int i = 0; i < 4; i++) {
+            if (sl[i] == 0xFF) continue;
+            const uint32_t sh = (KIND == 0) ? (31u - 8u * i - (om[i] & 7u)) : (24u - 8u * i);
+            uint32_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc |= ((w[j] >> sh) & 1u) << (7 - j);
+            s_buf[sl[i] * EX_TB + tl] = (uint8_t)acc;
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (sl[i] != 0xFF) s_buf[sl[i] * EX_TB + tl] = (uint8_t)acc[i];
     }
     __syncthreads();
     ex_flush(s_buf, s_dst, n_slots, t0, nb, out);
