@@ -174,7 +174,13 @@ __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, 
 #endif
 // gates a wavefront keeps in flight per step and gate group: narrow rows (small repetition shards, several gates per
 // wavefront already) may want fewer
-__host__ __device__ constexpr int interp_unroll(int NQ) { return NQ >= 64 ? RV_INTERP_UNROLL : RV_INTERP_UNROLL_SMALL; }
+#ifndef RV_INTERP_UNROLL_FAST
+#define RV_INTERP_UNROLL_FAST 4
+#endif
+// `general` = the kernel variant that also carries the multi-base Mul / Xor loops (more registers)
+__host__ __device__ constexpr int interp_unroll(int NQ, bool general = true) {
+    return NQ >= 64 ? (general ? RV_INTERP_UNROLL : RV_INTERP_UNROLL_FAST) : RV_INTERP_UNROLL_SMALL;
+}
 
 // Fast path (NQ = 64, 32, 16 or 8, i.e. R = 256 .. 32): a wavefront covers 64/NQ gates at a time and the
 // per-class ranges run as 4-way unrolled loops that put every operand row of 4 x 64/NQ gates in flight
@@ -312,12 +318,15 @@ __device__ __forceinline__ void interp_one(const Gate& g, const InterpParams& p,
 // classes (`slot` = wave-steps handed out so far) — a level of five gates in three classes must land on five
 // different wavefronts, not three times on wave 0.  All gates that do not fill a 4-way unrolled step go through ONE
 // loop at the end, so the big per-gate switch exists once in the instruction stream.
-template <int MODE, int NQ, bool ROTATE>
+// GENERAL = false: the level has no multi-base Mul / Xor gates (LevelRange classes 1 and 3 empty — every level of
+// a circuit compiled with one base per wire, e.g. the wide layered workload): those loops are compiled out, which
+// is what keeps the kernel at 64 registers = 8 wavefronts per SIMD instead of 6.
+template <int MODE, int NQ, bool ROTATE, bool GENERAL = true>
 __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const LevelRange& r, const InterpParams& p, uint32_t wave,
                                           uint32_t n_waves, uint32_t lane, uint32_t onm) {
     constexpr uint32_t GPW = 64 / NQ;  // gates per wavefront per step
     const uint32_t q = lane % NQ, sub = lane / NQ;
-    constexpr int U = interp_unroll(NQ);
+    constexpr int U = interp_unroll(NQ, GENERAL);
     constexpr uint32_t STEP = U * GPW;
     uint32_t slot = 0;
     auto my = [&](uint32_t used) { return ROTATE ? (wave + n_waves - used % n_waves) % n_waves : wave; };
@@ -329,9 +338,9 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
         rest[c] = begin[c] + n_full * STEP;
         for (uint32_t g0 = begin[c] + my(slot) * STEP; g0 < rest[c]; g0 += n_waves * STEP) {
             if (c == 0) mulU<MODE, NQ, U, 1, 1>(gates, g0, p, sub, q, onm);                  // G_MUL, one base per operand
-            if (c == 1) mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K>(gates, g0, p, sub, q, onm);    // other G_MUL
+            if (c == 1 && GENERAL) mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K>(gates, g0, p, sub, q, onm);    // other G_MUL
             if (c == 2) xorU<NQ, U, 2>(gates, g0, p, sub, q);                                // G_XORK of two bases
-            if (c == 3) xorU<NQ, U, 2 * RV_LIN_K>(gates, g0, p, sub, q);                     // other G_XORK
+            if (c == 3 && GENERAL) xorU<NQ, U, 2 * RV_LIN_K>(gates, g0, p, sub, q);                     // other G_XORK
         }
         slot += n_full;
     }
@@ -350,13 +359,13 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
     }
 }
 
-template <int MODE, int NQ>
+template <int MODE, int NQ, bool GENERAL>
 __global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[lane % NQ] : 0u;
-    run_level<MODE, NQ, false>(gates, r, p, wave, n_waves, lane, onm);
+    run_level<MODE, NQ, false, GENERAL>(gates, r, p, wave, n_waves, lane, onm);
 }
 
 // Batched proofs of one circuit (rv_prove_batch): blockIdx.y selects the proof; its buffers come from a device array
@@ -374,14 +383,23 @@ __global__ __launch_bounds__(256) void k_interp_full_b(const Gate* __restrict__ 
 template <int NQ>
 static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p) {
     constexpr uint32_t GPW = 64 / NQ;
-    uint64_t waves = ((uint64_t)(r.hi - r.lo) + interp_unroll(NQ) * GPW - 1) / (interp_unroll(NQ) * GPW);
+    const bool general = r.mul != r.mul11 || r.xork != r.xor2;  // any multi-base Mul / Xor gate in this level?
+    const uint32_t u = (uint32_t)interp_unroll(NQ, general);
+    uint64_t waves = ((uint64_t)(r.hi - r.lo) + u * GPW - 1) / (u * GPW);
     uint64_t blocks = (waves + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    if (mode == MODE_PROVE)
-        hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
-    else
-        hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
+    if (mode == MODE_PROVE) {
+        if (general)
+            hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
+        else
+            hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
+    } else {
+        if (general)
+            hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
+        else
+            hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
+    }
 }
 
 // Narrow levels (deep circuits: ripple-carry adders, AES/SHA rounds) would be launch-bound at one
