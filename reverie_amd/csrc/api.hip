@@ -601,8 +601,11 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
         ctx->count(1);
     }
     // everything the interpreter reads besides gf2 masks is queued on `stream` before this point
-    s->ev_setup = ctx->get_sync_event();
-    HIPCHK(hipEventRecord(s->ev_setup, ctx->stream));
+    // (events only when two streams are in play: on one stream the order is the queue order)
+    if (ctx->pipeline) {
+        s->ev_setup = ctx->get_sync_event();
+        HIPCHK(hipEventRecord(s->ev_setup, ctx->stream));
+    }
     // gf2 masks in chunks, one event each (the interpreter starts as soon as its first levels' masks exist)
     {
         const uint64_t target = ctx->pipeline ? std::max<uint64_t>((n_blocks + 11) / 12, 2048) : std::max<uint64_t>(n_blocks, 1);
@@ -610,9 +613,11 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
             const uint64_t nb = std::min(target, n_blocks - b0);
             launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, b0, nb, s->d_masks + (size_t)b0 * 128 * s->NQ);
             ctx->count();
-            hipEvent_t e = ctx->get_sync_event();
-            HIPCHK(hipEventRecord(e, ctx->stream));
-            s->mask_chunks.emplace_back(b0 + nb, e);
+            if (ctx->pipeline) {
+                hipEvent_t e = ctx->get_sync_event();
+                HIPCHK(hipEventRecord(e, ctx->stream));
+                s->mask_chunks.emplace_back(b0 + nb, e);
+            }
         }
     }
     ctx->phase(-1);
@@ -644,10 +649,9 @@ static int shard_run_alloc(rv_shard* s, InterpParams& p, Interp64Params& p64) {
     }
     hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
     if (s->ev_setup && ctx->pipeline) HIPCHK(hipStreamWaitEvent(sb, s->ev_setup, 0));
-    HIPCHK(hipMemsetAsync(s->d_err, 0, sizeof(int), sb));
-    // the zero row (first computed row): mask 0, corr 0
-    HIPCHK(hipMemsetAsync(s->d_wires + (size_t)cc.n_masks_pad * (s->NQ / 2), 0, (size_t)(s->NQ / 2), sb));
-    HIPCHK(hipMemsetAsync(s->d_masks + (size_t)cc.n_masks_pad * s->NQ, 0, (size_t)s->NQ * 4, sb));
+    // error flag and the zero row (first computed row: mask 0, corr 0), one launch
+    launch_shard_init(sb, s->d_err, s->d_masks + (size_t)cc.n_masks_pad * s->NQ, s->NQ,
+                      s->d_wires + (size_t)cc.n_masks_pad * (s->NQ / 2), s->NQ / 2);
     p.NQ = s->NQ;
     p.rows = s->d_masks;
     p.corr = s->d_wires;
@@ -714,7 +718,7 @@ static int shard_run_hash(rv_shard* s) {
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
-    {
+    if (sb != ctx->stream) {
         hipEvent_t done = ctx->get_sync_event();
         HIPCHK(hipEventRecord(done, sb));
         HIPCHK(hipStreamWaitEvent(ctx->stream, done, 0));

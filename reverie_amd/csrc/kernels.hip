@@ -831,6 +831,19 @@ void launch_fill_digests(hipStream_t st, uint32_t* d_dst, uint32_t n_rows, const
     hipLaunchKernelGGL(k_fill_digests, dim3((n_rows * 8 + 255) / 256), dim3(256), 0, st, d_dst, n_rows, d);
 }
 
+// start of the interpreter phase: clear the invalid-witness flag and the all-zero row (mask words, corr-bit words)
+__global__ void k_shard_init(int* __restrict__ err, uint32_t* __restrict__ zero_mask, uint32_t n_mask_words,
+                             uint8_t* __restrict__ zero_corr, uint32_t n_corr_bytes) {
+    const uint32_t i = threadIdx.x;
+    if (i == 0) *err = 0;
+    if (i < n_mask_words) zero_mask[i] = 0;
+    if (i < n_corr_bytes) zero_corr[i] = 0;
+}
+void launch_shard_init(hipStream_t st, int* d_err, uint32_t* d_zero_mask, uint32_t n_mask_words, uint8_t* d_zero_corr,
+                       uint32_t n_corr_bytes) {
+    hipLaunchKernelGGL(k_shard_init, dim3(1), dim3(64), 0, st, d_err, d_zero_mask, n_mask_words, d_zero_corr, n_corr_bytes);
+}
+
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
                  uint32_t R, uint8_t* d_h) {
     hipLaunchKernelGGL(k_join, dim3((R + 63) / 64), dim3(64), 0, st, d_pre2, d_on2, d_pre64, d_on64, R, d_h);
