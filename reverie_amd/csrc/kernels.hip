@@ -318,9 +318,10 @@ __device__ __forceinline__ void interp_one(const Gate& g, const InterpParams& p,
 // classes (`slot` = wave-steps handed out so far) — a level of five gates in three classes must land on five
 // different wavefronts, not three times on wave 0.  All gates that do not fill a 4-way unrolled step go through ONE
 // loop at the end, so the big per-gate switch exists once in the instruction stream.
-// GENERAL = false: the level has no multi-base Mul / Xor gates (LevelRange classes 1 and 3 empty — every level of
-// a circuit compiled with one base per wire, e.g. the wide layered workload): those loops are compiled out, which
-// is what keeps the kernel at 64 registers = 8 wavefronts per SIMD instead of 6.
+// GENERAL = false: the level has (next to) no multi-base Mul / Xor gates (LevelRange classes 1 and 3 — the case for
+// a circuit compiled with one base per wire, e.g. the wide layered workload): their unrolled loops are compiled
+// out, which keeps the kernel at 45 registers = 8 wavefronts per SIMD instead of 6; stray gates of those classes
+// take the common per-gate loop.
 template <int MODE, int NQ, bool ROTATE, bool GENERAL = true>
 __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const LevelRange& r, const InterpParams& p, uint32_t wave,
                                           uint32_t n_waves, uint32_t lane, uint32_t onm) {
@@ -334,7 +335,8 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
     uint32_t rest[5];  // first gate of each class that is left to the common loop
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const uint32_t n_full = (end[c] - begin[c]) / STEP;
+        // without the multi-base loops (GENERAL = false) the few gates of those classes all go to the common loop
+        const uint32_t n_full = (!GENERAL && (c == 1 || c == 3)) ? 0u : (end[c] - begin[c]) / STEP;
         rest[c] = begin[c] + n_full * STEP;
         for (uint32_t g0 = begin[c] + my(slot) * STEP; g0 < rest[c]; g0 += n_waves * STEP) {
             if (c == 0) mulU<MODE, NQ, U, 1, 1>(gates, g0, p, sub, q, onm);                  // G_MUL, one base per operand
@@ -383,7 +385,9 @@ __global__ __launch_bounds__(256) void k_interp_full_b(const Gate* __restrict__ 
 template <int NQ>
 static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p) {
     constexpr uint32_t GPW = 64 / NQ;
-    const bool general = r.mul != r.mul11 || r.xork != r.xor2;  // any multi-base Mul / Xor gate in this level?
+    // enough multi-base Mul / Xor gates in this level to be worth the variant with their unrolled loops?  (a handful
+    // -- constant operands in an otherwise one-base circuit -- run through the common per-gate loop instead)
+    const bool general = (r.mul - r.mul11) + (r.xork - r.xor2) >= 64;
     const uint32_t u = (uint32_t)interp_unroll(NQ, general);
     uint64_t waves = ((uint64_t)(r.hi - r.lo) + u * GPW - 1) / (u * GPW);
     uint64_t blocks = (waves + 3) / 4;
