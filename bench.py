@@ -321,6 +321,38 @@ def main():
         result["parity"] = parity
         if not all(v for k, v in parity.items() if k != "proof_bytes"):
             result["value"] = 0.0
+    if rank == 0 and world == 1:
+        # informational, outside the timed region: the same workload with TWO proofs in flight (two contexts, two host
+        # threads) -- one proof's VALU-bound phases overlap the other's memory-bound interpreter.  `value` above stays
+        # the one-proof-at-a-time number.
+        import threading
+
+        ctx_b = reverie_amd.Context(local)
+        circ_b = reverie_amd.Circuit(prog, wc, ctx_b)
+        pair = [backend, HipShardBackend(circ_b)]
+
+        def fly(i, n):
+            torch.cuda.set_device(local)
+            for _ in range(n):
+                prove_sharded(pair[i], wit, [], seeds, device_resident=True)
+
+        def run_pair(n):
+            th = [threading.Thread(target=fly, args=(i, n)) for i in range(2)]
+            t = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t
+
+        run_pair(2)
+        n2 = max(args.steps // 2, 4)
+        dt2 = run_pair(n2)
+        result["two_proofs_in_flight"] = {"value": n_and * 2 * n2 / dt2, "unit": "AND gates/s", "ms_per_proof": dt2 / (2 * n2) * 1e3,
+                                          "proofs": 2 * n2}
+        circ_b.close()
+        ctx_b.close()
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         n_layers = args.cpu_sample_layers or args.layers
         base, (sprog, swit, swc, sseeds, sproof) = cpu_baseline(n_layers, args.p_and)

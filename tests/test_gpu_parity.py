@@ -389,6 +389,17 @@ def test_prove_batch_equals_single_proofs(rv, oracle, rule_seeds):
     assert bytes(ok2[1]) == bytes(rv.Proof.new(c2, good, [], seeds=seeds[1]))
     with pytest.raises(ReverieError):
         rv.Proof.new_batch(c2, np.stack([good, bad, good]), seeds=seeds[:3])
+    # a circuit of more than 2^20 gates takes the two-proofs-in-flight path (two host threads, worker contexts)
+    progl, witl, wcl, stl = circuits.layered_gf2(layers=17)
+    cl = rv.Circuit(progl, wcl)
+    wl = np.tile(np.asarray(witl, np.uint8), (3, 1))
+    try:
+        gl = rv.Proof.new_batch(cl, wl[[0, 0, 0]], seeds=seeds[:3])
+        for b in range(3):
+            assert bytes(gl[b]) == bytes(rv.Proof.new(cl, witl, [], seeds=seeds[b]))
+        assert bytes(gl[0]) == oracle.prove(progl, witl, [], wcl, seeds[0], threads=4)
+    finally:
+        cl.close()
     # mixed circuit: falls back to one rv_prove per proof, same results
     progm, w2, w64, wcm = circuits.random_mixed(np.random.default_rng(5), n_gates=200)
     cm = rv.Circuit(progm, wcm)
