@@ -379,6 +379,16 @@ def test_prove_batch_equals_single_proofs(rv, oracle, rule_seeds):
     for b in range(B):
         assert bytes(got[b]) == bytes(rv.Proof.new(c, wits[b], [], seeds=seeds[b])) == oracle.prove(prog, wits[b], [], wc, seeds[b], threads=2)
         assert got[b].verify(c)
+    # a larger batch (more proofs than side streams) of a small random circuit: every proof against the single path
+    rng2 = np.random.default_rng(77)
+    progr, witr, wcr = circuits.random_gf2(rng2, n_in=12, n_gates=900, n_wires=40)
+    cr = rv.Circuit(progr, wcr)
+    nb = 21
+    seedsr = rng2.integers(0, 256, (nb, 256, 16), dtype=np.uint8)
+    gr = rv.Proof.new_batch(cr, np.tile(np.asarray(witr, np.uint8), (nb, 1)), seeds=seedsr)
+    for b in range(nb):
+        assert bytes(gr[b]) == bytes(rv.Proof.new(cr, witr, [], seeds=seedsr[b]))
+    assert bytes(gr[20]) == oracle.prove(progr, witr, [], wcr, seedsr[20], threads=2)
     # one invalid witness fails the whole call, like a panic in one rayon task would
     key = bytes(range(16)); pt = bytes.fromhex("00112233445566778899aabbccddeeff")
     prog2, info2 = bristol.parse(bristol_gen.aes128(), expected_outputs=bits(bytes.fromhex("69c4e0d86a7b0430d8cdb78070b4c55a")))
