@@ -367,7 +367,10 @@ __global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ ga
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[lane % NQ] : 0u;
-    run_level<MODE, NQ, false, GENERAL>(gates, r, p, wave, n_waves, lane, onm);
+    // ROTATE here too: a wavefront then runs ONE step of one class instead of a Mul step followed by an Xor step
+    // (two generations of short-lived wavefronts beat one generation of twice-as-long ones: 2.52 -> 2.40 ms;
+    // interleaving the two classes wave by wave instead of class after class is worse again, 2.56)
+    run_level<MODE, NQ, true, GENERAL>(gates, r, p, wave, n_waves, lane, onm);
 }
 
 // Batched proofs of one circuit (rv_prove_batch): blockIdx.y selects the proof; its buffers come from a device array
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256) void k_interp_full_b(const Gate* __restrict__ 
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[lane % NQ] : 0u;
-    run_level<MODE, NQ, false>(gates, r, p, wave, n_waves, lane, onm);
+    run_level<MODE, NQ, true>(gates, r, p, wave, n_waves, lane, onm);
 }
 
 template <int NQ>
