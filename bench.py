@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--fused-batch", type=int, default=0,
                     help="secondary GF(2) workloads: proofs per rv_prove_batch call (every level launched once for the whole batch)")
     ap.add_argument("--z64-muls", type=int, default=1_000_000)
+    ap.add_argument("--two-in-flight", action="store_true",
+                    help="also measure the workload with two proofs in flight (reported as two_proofs_in_flight; off by default so "
+                         "that a rocprofv3 summary of the default command only contains the timed configuration)")
     ap.add_argument("--cpu-sample-layers", type=int, default=0,
                     help="layers of the workload the CPU oracle proves (0 = all of them: the whole timed workload)")
     args = ap.parse_args()
@@ -321,7 +324,7 @@ def main():
         result["parity"] = parity
         if not all(v for k, v in parity.items() if k != "proof_bytes"):
             result["value"] = 0.0
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.two_in_flight:
         # informational, outside the timed region: the same workload with TWO proofs in flight (two contexts, two host
         # threads) -- one proof's VALU-bound phases overlap the other's memory-bound interpreter.  `value` above stays
         # the one-proof-at-a-time number.
