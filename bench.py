@@ -276,7 +276,9 @@ def main():
             "interp": (st["and"] * (48 + 4 * row + 3 * row // 8 + row + row // 8) + st["xor"] * (48 + 3 * row + 3 * row // 8)),
             "hash": (info["gf2_muls"] + info["gf2_inputs"] + info["gf2_asserts"]) * row + info["gf2_muls"] * row // 8,
         }
-        kname = {"masks": "k_aes_gf2_masks<16>", "interp": "k_interp_full<MODE_PROVE, 64>", "hash": "k_b3_chunks<4>"}[dom]
+        # names as rocprofv3 prints them (profiles/r01_k_bench_kernel_stats.txt); <0, 64, false> = prover mode, 64 quad
+        # words per row (256 repetitions), the variant without the multi-base gate loops
+        kname = {"masks": "rv::k_aes_gf2_masks<16>", "interp": "rv::k_interp_full<0, 64, false>", "hash": "rv::k_b3_chunks<4>"}[dom]
         ach = alg[dom] / (tphase[dom] * 1e-3) / 1e9 if tphase[dom] > 0 else 0.0
         # measured HBM traffic of the same workload (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
         # tools/pmc_summary.py, committed under profiles/); only valid for the default workload on 1 GPU
