@@ -730,8 +730,8 @@ static int shard_run_hash(rv_shard* s) {
     ctx->phase(RV_PH_HASH);
     uint32_t* dig = s->d_dig;
     const size_t DW = (size_t)s->R * 8;
-    launch_b3_stream_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
-    launch_b3_stream(ctx->stream, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 1 * DW);
+    uint32_t n_launch = launch_b3_stream_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
+    n_launch += launch_b3_stream(ctx->stream, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 1 * DW);
     // Z64 transcripts; for a pure GF(2) circuit both are empty and every digest is BLAKE3("") (one fill, not four launches)
     if (cc.pre_words64 == 0 && cc.on_words64 == 0) {
         static const std::vector<uint32_t> empty = [] {
@@ -743,10 +743,12 @@ static int shard_run_hash(rv_shard* s) {
             return w;
         }();
         launch_fill_digests(ctx->stream, dig + 2 * DW, 2 * s->R, empty.data());
+        n_launch += 1;
     } else {
-        launch_b3_contig(ctx->stream, s->d_pre64, cc.pre_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 2 * DW);
-        launch_b3_contig(ctx->stream, s->d_on64, cc.on_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 3 * DW);
+        n_launch += launch_b3_contig(ctx->stream, s->d_pre64, cc.pre_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 2 * DW);
+        n_launch += launch_b3_contig(ctx->stream, s->d_on64, cc.on_words64, s->R, s->d_cv[0], s->d_cv[1], dig + 3 * DW);
     }
+    ctx->count(n_launch);
     ctx->phase(-1);
     return RV_OK;
 }

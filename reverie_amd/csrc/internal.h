@@ -156,20 +156,20 @@ void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t l
 void launch_aes_z64_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t n_blocks,
                           uint64_t* d_masks64);
 // BLAKE3 of R contiguous streams of n_words u64 each -> digests[R][8]
-void launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
+uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
                       uint32_t* d_digest);
 void launch_extract64(hipStream_t st, const uint64_t* d_stream, uint64_t stride_words, const uint64_t* d_offs /*[n_items]*/,
                       uint64_t n_items, int add_omit, uint32_t R, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
 void launch_unpack64(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
                      const uint8_t* d_omit, uint64_t n_items, uint32_t R, uint64_t* d_out);
 // BLAKE3 over a row-format transcript: digests[R][8] words
-void launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
+uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
                       uint32_t* d_cv_b, uint32_t* d_digest /*[R][8]*/);
 // same for a bit-per-rep transcript [n_events][NQ/2] (each bit hashed as a 0x00/0xFF byte)
-void launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
+uint32_t launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
                            uint32_t* d_cv_b, uint32_t* d_digest);
 size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R);
-void b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest);
+uint32_t b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest);
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
                  uint32_t R, uint8_t* d_h /*[R][32]*/);
 // the (at most 40) opened repetitions of a shard with the output offset of one of their vectors;

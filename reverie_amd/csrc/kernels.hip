@@ -739,7 +739,8 @@ __global__ __launch_bounds__(256) void k_b3_tree_tail(const uint32_t* __restrict
 }
 
 // tree reduction of n chunk chaining values per repetition; the roots land in d_digest ([R][8] words)
-void b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest) {
+uint32_t b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest) {
+    uint32_t launches = 1;
     while (n > B3_TAIL) {  // two levels per launch while the level is wide
         const uint64_t n_out = (n + 3) / 4;
         const uint64_t threads = n_out * R;
@@ -748,9 +749,11 @@ void b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, ui
         cur = nxt;
         nxt = t;
         n = n_out;
+        launches++;
     }
     // a single chunk is already its own root (the chunk kernels applied the ROOT flag): cnt == 1 just copies
     hipLaunchKernelGGL(k_b3_tree_tail, dim3(R), dim3(256), 0, st, cur, (uint32_t)n, R, d_digest);
+    return launches;
 }
 
 size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R) {
@@ -758,7 +761,7 @@ size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R) {
     return (size_t)n_chunks * R * 8;  // per ping-pong buffer
 }
 
-void launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
+uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
                       uint32_t* d_cv_b, uint32_t* d_digest) {
     const uint32_t R = NQ * 4;
     uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
@@ -767,17 +770,17 @@ void launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_event
         hipLaunchKernelGGL(k_b3_chunks<RV_B3_RPL>, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), 0, st,
                            d_stream, n_events, NQ, n, d_cv_a);
     }
-    b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);
+    return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
 }
 
-void launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
+uint32_t launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
                            uint32_t* d_cv_b, uint32_t* d_digest) {
     const uint32_t R = NQ * 4;
     const uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
     const uint64_t threads = n * NQ;
     hipLaunchKernelGGL(k_b3_chunks_bits, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, n_events, NQ, n,
                        d_cv_a);
-    b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);
+    return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
 }
 
 // Transcript::hash + CombineInstance::hash: h = B3(B3(pre2||on2) || B3(pre64||on64))

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __rest
     for (int k = 0; k < 8; k++) dst[k] = cv[k];
 }
 
-void launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
+uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
                       uint32_t* d_digest) {
     const uint64_t n_bytes = n_words * 8;
     uint64_t n = n_bytes == 0 ? 1 : (n_bytes + 1023) / 1024;
@@ -229,7 +229,7 @@ void launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_word
         hipLaunchKernelGGL(k_b3_chunks_contig, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
                            (const uint32_t*)d_streams, n_bytes, R, n, d_cv_a);
     }
-    b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);
+    return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
 }
 
 // ---- openings: 8 bytes LE per item (z64/share.rs:36-49, z64/recon.rs:45-66) ----
