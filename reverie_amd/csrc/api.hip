@@ -7,6 +7,7 @@
 #include <sys/random.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <string>
 #include <mutex>
@@ -379,11 +380,15 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
     *out = nullptr;
     rv_circuit* c = new rv_circuit();
     c->ctx = ctx;
+    const auto t_begin = std::chrono::steady_clock::now();
     int rc = compile_ops(ops, n_ops, z64_wires, gf2_wires, c->cc);
     if (rc) {
         delete c;
         return rc;
     }
+    if (getenv("RV_COMPILE_STATS"))
+        fprintf(stderr, "[rv circuit] compile_ops: %.3f s for %zu ops\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), n_ops);
     HIPCHK(hipSetDevice(ctx->device));
     const Compiled& cc = c->cc;
     auto up = [&](const void* src, size_t bytes, void** dst) -> int {

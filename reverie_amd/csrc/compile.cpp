@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <limits>
 
 namespace rv {
@@ -43,6 +44,16 @@ struct Builder {
     bool any = false;
 
     Builder(Compiled& o, bool counting_, std::vector<uint32_t>& uses_) : out(o), counting(counting_), uses(uses_) {
+        if (!counting) {
+            // pass 1 left one entry per SSA wire in `uses`: size the big vectors once (10^7 gates x 48 B would otherwise
+            // be copied several times over while the vector grows)
+            const size_t n = uses.size();
+            lin.reserve(n + 1);
+            gates.reserve(n);
+            level.reserve(n);
+            lvl_comp.reserve(n / 2 + 16);
+            lvl_prg.reserve(n + 16);
+        }
         lin.emplace_back();  // SSA 0: the default wire = constant 0
         lvl_comp.push_back(-1);
         ssa_level64.push_back(-1);
@@ -56,7 +67,7 @@ struct Builder {
         return l;
     }
     void set_prg_level(uint32_t m, int32_t l) {
-        if (lvl_prg.size() <= m) lvl_prg.resize((size_t)m + 1, -1);
+        if (lvl_prg.size() <= m) lvl_prg.resize((size_t)m + 1, -1);  // grows by one or two per gate: amortised by the reserve / doubling
         lvl_prg[m] = l;
     }
     uint32_t new_ssa(const Lin& L) {
@@ -469,6 +480,11 @@ static int run_pass(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
 }
 
 int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (getenv("RV_COMPILE_STATS"))
+            fprintf(stderr, "[rv compile] %-28s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
     std::vector<uint32_t> uses;
     {
         // pass 1: SSA numbering + read counts (the materialisation rule needs each wire's fan-out)
@@ -477,6 +493,7 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
         int rc = run_pass(ops, n_ops, z64_wires, gf2_wires, b1);
         if (rc) return rc;
     }
+    lap("pass 1 (SSA, read counts) done");
     // Wide circuits run fastest with every XOR materialised (exact two-row gates, HBM-bound); deep,
     // narrow ones (ripple-carry adders, hash rounds) are bound by the number of dependency levels, and
     // keeping XORs of up to RV_LIN_K rows symbolic shortens the chains (SHA-256: 5 386 -> 4 291 levels,
@@ -503,6 +520,7 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
         if (forced || lazy_k != 1 || !deep_narrow) break;
         lazy_k = K;
     }
+    lap("pass 2 (gates) done");
     Builder& b = *bp;
     struct Guard {
         Builder* p;
@@ -512,30 +530,36 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
     info.n_ops = n_ops;
     const uint64_t LIM = std::numeric_limits<uint32_t>::max() - 512;
     const uint32_t n_levels = b.any ? b.max_level + 1 : 0;
-    sort_by_level(b.gates, b.level, n_levels, out.gates, out.level_start);
-    sort_by_level(b.gates64, b.level64, n_levels, out.gates64, out.level_start64);
-    // group each level by class (gates of one level are independent, so any order is valid); see LevelRange
+    // GF(2) gates: one stable counting sort by (level, class) -- gates of one level are independent, so grouping them by
+    // class inside the level is free; see LevelRange for the classes
     out.level_range.assign(n_levels, LevelRange{});
     {
-        std::vector<Gate> tmp;
-        auto cls = [](const Gate& g) -> int {
+        auto cls = [](const Gate& g) -> uint32_t {
             const uint32_t op = g_op(g);
-            if (op == G_MUL) return (g_na(g) == 1 && g_nb(g) == 1) ? 0 : 1;
-            if (op == G_XORK) return (g_na(g) == 2 && g_nb(g) == 0) ? 2 : 3;
-            return 4;
+            if (op == G_MUL) return (g_na(g) == 1 && g_nb(g) == 1) ? 0u : 1u;
+            if (op == G_XORK) return (g_na(g) == 2 && g_nb(g) == 0) ? 2u : 3u;
+            return 4u;
         };
-        for (uint32_t l = 0; l < n_levels; l++) {
-            const uint32_t lo = out.level_start[l], hi = out.level_start[l + 1];
-            tmp.assign(out.gates.begin() + lo, out.gates.begin() + hi);
-            uint32_t w = lo, ends[5];
-            for (int c = 0; c < 5; c++) {
-                for (const Gate& g : tmp)
-                    if (cls(g) == c) out.gates[w++] = g;
-                ends[c] = w;
-            }
-            out.level_range[l] = LevelRange{lo, ends[0], ends[1], ends[2], ends[3], hi};
+        const size_t n = b.gates.size();
+        std::vector<uint32_t> pos((size_t)n_levels * 5 + 1, 0);
+        std::vector<uint8_t> kc(n);
+        for (size_t i = 0; i < n; i++) {
+            kc[i] = (uint8_t)cls(b.gates[i]);
+            pos[(size_t)b.level[i] * 5 + kc[i] + 1]++;
         }
+        for (size_t k = 0; k < (size_t)n_levels * 5; k++) pos[k + 1] += pos[k];
+        out.level_start.assign(n_levels + 1, 0);
+        for (uint32_t l = 0; l < n_levels; l++) {
+            const uint32_t* e = &pos[(size_t)l * 5];
+            out.level_start[l] = e[0];
+            out.level_range[l] = LevelRange{e[0], e[1], e[2], e[3], e[4], e[5]};
+        }
+        out.level_start[n_levels] = (uint32_t)n;
+        out.gates.resize(n);
+        for (size_t i = 0; i < n; i++) out.gates[pos[(size_t)b.level[i] * 5 + kc[i]]++] = b.gates[i];
     }
+    sort_by_level(b.gates64, b.level64, n_levels, out.gates64, out.level_start64);
+    lap("sorted by level and class");
     // pipelining tables
     out.level_need_blocks.assign(n_levels, 0);
     out.level_done_on.assign(n_levels, 0);
@@ -594,6 +618,7 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
     info.gf2_masks = out.n_masks;
     info.z64_masks = out.n_masks64;
     info.levels = n_levels;
+    lap("tables and row fix-up done");
     if (getenv("RV_COMPILE_STATS")) {  // interpreter HBM traffic model per 4-repetition quad column (x NQ x 4 B per row)
         uint64_t rd = 0, wr = 0, crd = 0, n_mul = 0, n_xor = 0, n_mul11 = 0;
         for (const Gate& g : out.gates) {
