@@ -229,6 +229,13 @@ int rv_shard_open_into(rv_shard *s, const uint8_t omit[RV_TOTAL_REPS], void *dst
  * dst_device capacity: the sum rv_shard_open_size reports for ANY 40/216 map (sizes do not depend on which
  * repetitions open).  RV_E_ARG for a partial shard. */
 int rv_shard_open_self(rv_shard *s, void *dst_device, uint8_t comm[RV_HASH_SIZE], uint8_t omit[RV_TOTAL_REPS], size_t lens[4]);
+/* The sharded counterpart: all_digests_device = the 256 x 32 bytes every rank holds on its GPU after the all-gather.
+ * Commitment, challenge and this shard's openings without a host round trip; comm / omit as above.  How many of the
+ * shard's repetitions open depends on the challenge, so dst_device must hold the worst case:
+ *   min(40, rep_count) * (gf2 record + z64 record) + 2 * rep_count * 48 bytes (rv_circuit_record_sizes);
+ * lens[4] reports what was written: [gf2 online | gf2 preprocessing | z64 online | z64 preprocessing], contiguous. */
+int rv_shard_open_gathered(rv_shard *s, const void *all_digests_device, void *dst_device, uint8_t comm[RV_HASH_SIZE],
+                           uint8_t omit[RV_TOTAL_REPS], size_t lens[4]);
 
 /* combine_hashes (proof/mod.rs:102-108): comm = BLAKE3(h[0] || ... || h[255]) */
 int rv_combine_digests(const uint8_t *h /* 256 x 32 */, uint8_t comm[RV_HASH_SIZE]);

@@ -59,7 +59,7 @@ SYMBOLS = [
     "rv_shard_commit", "rv_shard_digests_device", "rv_shard_digests", "rv_shard_open", "rv_shard_destroy",
     "rv_shard_open_device", "rv_combine_digests", "rv_challenge", "rv_assemble_proof", "rv_verify_shard",
     "rv_verify_finish", "rv_hook_prg_blocks", "rv_hook_expand_seed", "rv_hook_sharegen_gf2", "rv_hook_sharegen_z64",
-    "rv_hook_blake3", "rv_hook_shard_stream_digests", "rv_ctx_profile", "rv_shard_digests_to_device", "rv_shard_open_size", "rv_shard_open_into", "rv_shard_open_self",
+    "rv_hook_blake3", "rv_hook_shard_stream_digests", "rv_ctx_profile", "rv_shard_digests_to_device", "rv_shard_open_size", "rv_shard_open_into", "rv_shard_open_self", "rv_shard_open_gathered",
     "rv_bristol_parse", "rv_circuit_record_sizes", "rv_program_from_bincode", "rv_program_to_bincode", "rv_prove_batch", "rv_prove_device",
 ]
 

@@ -936,7 +936,8 @@ extern "C" int rv_shard_open_size(const rv_shard* s, const uint8_t omit[RV_TOTAL
 }
 
 static int shard_open_impl(rv_shard* s, const uint8_t* omit /* NULL: device Fiat-Shamir */, void* dst, void** dptr, size_t lens[4],
-                           bool framed = false, uint8_t* comm_out = nullptr, uint8_t* omit_out = nullptr, bool no_sync = false);
+                           bool framed = false, uint8_t* comm_out = nullptr, uint8_t* omit_out = nullptr, bool no_sync = false,
+                           const uint8_t* d_all_h = nullptr /* device: all 256 digests (sharded proofs after the all-gather) */);
 
 extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void** dptr, size_t lens[4]) {
     if (!omit) return RV_E_ARG;
@@ -952,13 +953,16 @@ extern "C" int rv_shard_open_into(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS]
 // `omit` == NULL: Fiat-Shamir on the device (k_fs_challenge) from the shard's own digests; only for a shard that
 // holds all 256 repetitions.  comm_out / omit_out (nullable) then receive comm and the opening map.
 static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** dptr, size_t lens[4], bool framed, uint8_t* comm_out,
-                           uint8_t* omit_out, bool no_sync) {
+                           uint8_t* omit_out, bool no_sync, const uint8_t* d_all_h) {
     if (!s || !dptr || !lens) return RV_E_ARG;
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     HIPCHK(hipSetDevice(ctx->device));
     const bool self = omit == nullptr;
-    if (self && (s->rep_begin != 0 || s->R != RV_TOTAL_REPS)) return RV_E_ARG;
+    const bool whole = s->rep_begin == 0 && s->R == RV_TOTAL_REPS;
+    // device Fiat-Shamir needs all 256 digests: the shard's own when it holds every repetition, else the gathered ones;
+    // a partial shard's output size depends on the challenge, so the caller provides the buffer (worst case, see header)
+    if (self && !whole && (!d_all_h || !dst || framed || no_sync)) return RV_E_ARG;
     uint8_t canon[RV_TOTAL_REPS];  // any map with the 40 / 216 split gives the layout: sizes do not depend on WHICH reps open
     if (self) {
         for (uint32_t r = 0; r < RV_TOTAL_REPS; r++) canon[r] = r < RV_ONLINE_REPS ? 0 : RV_PLAYERS;
@@ -1004,8 +1008,9 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
     s->d_omit = nullptr;
     s->d_offs = nullptr;
     s->d_out = nullptr;
-    // d_omit: [R] omit, then (device Fiat-Shamir) 32 bytes of comm
-    if ((rc = dalloc(ctx, s->R + 32, &s->d_omit)) || (rc = dalloc(ctx, offs.size(), &s->d_offs))) return rc;
+    // d_omit: [R] omit of the shard, then (device Fiat-Shamir) comm[32], the whole opening map [256], {n_on, n_pre}
+    constexpr size_t FS_TAIL = 32 + RV_TOTAL_REPS + 8;
+    if ((rc = dalloc(ctx, s->R + FS_TAIL, &s->d_omit)) || (rc = dalloc(ctx, offs.size(), &s->d_offs))) return rc;
     uint8_t* d_out = (uint8_t*)dst;
     if (!d_out) {
         if ((rc = dalloc(ctx, std::max<size_t>(L.total, 1), &s->d_out))) return rc;
@@ -1018,17 +1023,20 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
         FsLayout F{};
         for (int k = 0; k < 4; k++) F.base[k] = L.base[k];
         F.sz2 = L.sz2, F.sz64 = L.sz64, F.l2r = L.l2r, F.l2c = L.l2c, F.l64r = L.l64r, F.l64c = L.l64c;
-        launch_fs_challenge(ctx->stream, s->d_h, F, s->d_omit + s->R, s->d_omit, s->d_offs, (OnlineList*)d_ol);
+        F.framed = whole ? 1u : 0u;  // a whole shard opens 40 / 216: L is exact; a partial one gets its section starts on the device
+        launch_fs_challenge(ctx->stream, d_all_h ? d_all_h : s->d_h, F, s->rep_begin, s->R, s->d_omit + s->R, s->d_omit,
+                            s->d_omit + s->R + 32, s->d_offs, (OnlineList*)d_ol, (uint32_t*)(s->d_omit + s->R + 32 + RV_TOTAL_REPS));
         ctx->count();
         if (framed) HIPCHK(hipMemcpyAsync(d_out, s->d_omit + s->R, 32, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
         HIPCHK(hipMemcpyAsync(s->d_omit, om, s->R, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(s->d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     }
-    ctx->count(L.n_on ? 4 : 1);
+    const bool any_on = self || L.n_on;  // (device mode: how many of the shard's repetitions open is not known on the host yet)
+    ctx->count(any_on ? 4 : 1);
     launch_open_headers(ctx->stream, s->R, s->d_omit, s->d_seeds, s->d_keys, s->d_dig + 1 * DW, s->d_dig + 3 * DW, s->d_offs,
                         s->d_offs + s->R, L.l2r, L.l2c, L.l2i, L.l64r, L.l64c, L.l64i, d_out);
-    if (L.n_on) {
+    if (any_on) {
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
         launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out);
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
@@ -1048,11 +1056,20 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
         return RV_OK;
     }
     if (self) {
-        uint8_t back[RV_TOTAL_REPS + 32];
-        if (comm_out || omit_out) HIPCHK(hipMemcpyAsync(back, s->d_omit, sizeof back, hipMemcpyDeviceToHost, ctx->stream));
+        uint8_t back[FS_TAIL];
+        HIPCHK(hipMemcpyAsync(back, s->d_omit + s->R, sizeof back, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        if (omit_out) memcpy(omit_out, back, RV_TOTAL_REPS);
-        if (comm_out) memcpy(comm_out, back + RV_TOTAL_REPS, 32);
+        if (comm_out) memcpy(comm_out, back, 32);
+        if (omit_out) memcpy(omit_out, back + 32, RV_TOTAL_REPS);
+        uint32_t cnt[2];
+        memcpy(cnt, back + 32 + RV_TOTAL_REPS, sizeof cnt);
+        ctx->collect();
+        *dptr = d_out;
+        lens[0] = (size_t)cnt[0] * L.sz2;
+        lens[1] = (size_t)cnt[1] * 48;
+        lens[2] = (size_t)cnt[0] * L.sz64;
+        lens[3] = (size_t)cnt[1] * 48;
+        return RV_OK;
     } else {
         // the host vector `offs` must outlive the async copy
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1068,6 +1085,13 @@ extern "C" int rv_shard_open_self(rv_shard* s, void* dst_device, uint8_t comm[RV
     if (!dst_device || !comm || !omit) return RV_E_ARG;
     void* d = nullptr;
     return shard_open_impl(s, nullptr, dst_device, &d, lens, false, comm, omit);
+}
+
+extern "C" int rv_shard_open_gathered(rv_shard* s, const void* all_digests_device, void* dst_device, uint8_t comm[RV_HASH_SIZE],
+                                      uint8_t omit[RV_TOTAL_REPS], size_t lens[4]) {
+    if (!all_digests_device || !dst_device || !comm || !omit) return RV_E_ARG;
+    void* d = nullptr;
+    return shard_open_impl(s, nullptr, dst_device, &d, lens, false, comm, omit, false, (const uint8_t*)all_digests_device);
 }
 
 extern "C" int rv_shard_open(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], rv_shard_parts* parts) {
@@ -1217,7 +1241,7 @@ static int rv_prove_device_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     do {
         void* d = nullptr;
         if ((rc = shard_open_impl(s, nullptr, dst_device, &d, lens, false, nullptr, nullptr, /*no_sync=*/true))) break;
-        uint8_t back[RV_TOTAL_REPS + 32];
+        uint8_t back[RV_TOTAL_REPS + 32];  // omit of the (whole) shard, then comm
         int err = 0;
         if (hipMemcpyAsync(back, s->d_omit, sizeof back, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||

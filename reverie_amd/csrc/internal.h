@@ -185,11 +185,15 @@ void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_
 // comm = BLAKE3(h[0..256)), the challenge map, and from it everything the opening kernels consume
 // (omit[256], the 8 x 256 output offsets, the OnlineList) without a host round trip.
 struct FsLayout {
-    uint64_t base[4];  // section starts: gf2 online, gf2 preprocessing, z64 online, z64 preprocessing
+    uint64_t base[4];  // framed: the four section starts (gf2 online, gf2 preprocessing, z64 online, z64 preprocessing);
+                       // otherwise only base[0] = start of the output, the rest follow from the number of opened reps
     uint64_t sz2, sz64, l2r, l2c, l64r, l64c;
+    uint32_t framed;
 };
-void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint8_t* d_comm, uint8_t* d_omit, uint64_t* d_offs,
-                         OnlineList* d_ol);
+// d_h: all 256 digests.  Produces for the shard (rep_begin, R): d_omit[R], d_offs[8*R], *d_ol, and d_res = {opened,
+// not opened} repetition counts; d_comm[32]; d_omit_all[256] (nullable) = the whole opening map
+void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint32_t rep_begin, uint32_t R, uint8_t* d_comm,
+                         uint8_t* d_omit, uint8_t* d_omit_all, uint64_t* d_offs, OnlineList* d_ol, uint32_t* d_res);
 // kind 0: omitted player's bit of a share row; 1: smeared byte of a row
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,
                          uint32_t NQ, int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);

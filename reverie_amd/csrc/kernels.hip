@@ -1027,9 +1027,15 @@ void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_
 // first byte of each draw; every lane produces one 64-byte XOF block = two (rep, omit) pairs,
 // lane 0 replays them in order (a re-drawn repetition overwrites its omit) until 40 distinct.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_fs_challenge(const uint8_t* __restrict__ h, FsLayout L, uint8_t* __restrict__ comm,
-                                                     uint8_t* __restrict__ omit, uint64_t* __restrict__ offs,
-                                                     OnlineList* __restrict__ ol) {
+// The shard form (rep_begin, R): h holds ALL 256 digests (after the all-gather they are on every GPU), the challenge is
+// derived for all repetitions, and the offsets / OnlineList / omit[0..R) are produced for the shard's own repetitions.
+// How many of them are opened is only known here, so the section starts (online records, then preprocessing records,
+// per domain) are computed on the device from L.base[0] (= start of the output, 40 past it when framed) and returned
+// in res = {n_online_local, n_preprocessing_local}; omit_all (nullable) receives the full map for the host.
+__global__ __launch_bounds__(64) void k_fs_challenge(const uint8_t* __restrict__ h, FsLayout L, uint32_t rep_begin, uint32_t R,
+                                                     uint8_t* __restrict__ comm, uint8_t* __restrict__ omit,
+                                                     uint8_t* __restrict__ omit_all, uint64_t* __restrict__ offs,
+                                                     OnlineList* __restrict__ ol, uint32_t* __restrict__ res) {
     __shared__ uint32_t s_cv[8][8], s_t1[4][8], s_t2[2][8], s_comm[8];
     __shared__ uint32_t s_msg[16];
     __shared__ uint8_t s_draw[128][2];
@@ -1100,43 +1106,73 @@ __global__ __launch_bounds__(64) void k_fs_challenge(const uint8_t* __restrict__
         if (s_count >= RV_ONLINE_REPS) break;
     }
     // offsets of every repetition's record and of its vectors (the same arithmetic as the host path)
-    constexpr uint32_t R = RV_TOTAL_REPS;
-    uint32_t k_on = 0, k_pre = 0;
-    for (uint32_t c = 0; c < R / 64; c++) {
+    if (omit_all)
+        for (uint32_t r = lane; r < RV_TOTAL_REPS; r += 64) omit_all[r] = s_omit[r];
+    uint32_t n_on = 0;  // opened repetitions of this shard
+    for (uint32_t c = 0; c < (R + 63) / 64; c++) {
         const uint32_t r = 64 * c + lane;
-        const uint32_t om = s_omit[r];
-        const bool on = om < RV_PLAYERS;
-        const unsigned long long bal = __ballot(on);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const uint32_t my_on = k_on + (uint32_t)__popcll(bal & lt), my_pre = k_pre + (uint32_t)__popcll(~bal & lt);
-        omit[r] = (uint8_t)om;
-        uint64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (on) {
-            v[0] = L.base[0] + (uint64_t)my_on * L.sz2;
-            v[1] = L.base[2] + (uint64_t)my_on * L.sz64;
-            v[2] = v[0] + 137;
-            v[3] = v[0] + 145 + L.l2r;
-            v[4] = v[0] + 153 + L.l2r + L.l2c;
-            v[5] = v[1] + 137;
-            v[6] = v[1] + 145 + L.l64r;
-            v[7] = v[1] + 153 + L.l64r + L.l64c;
-            ol->rep[my_on] = r;
-            ol->dst[my_on] = v[3];
-        } else {
-            v[0] = L.base[1] + (uint64_t)my_pre * 48;
-            v[1] = L.base[3] + (uint64_t)my_pre * 48;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) offs[(size_t)j * R + r] = v[j];
-        k_on += (uint32_t)__popcll(bal);
-        k_pre += 64 - (uint32_t)__popcll(bal);
+        n_on += (uint32_t)__popcll(__ballot(r < R && s_omit[rep_begin + r] < RV_PLAYERS));
     }
-    if (lane == 0) ol->n = RV_ONLINE_REPS;
+    const uint32_t n_pre = R - n_on;
+    // sections: [gf2 online | gf2 preprocessing | z64 online | z64 preprocessing]; when the caller frames the
+    // output as bincode(Proof) (single shard) L.base[] already holds the four starts, otherwise only base[0] counts
+    uint64_t base[4];
+    if (L.framed) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) base[k] = L.base[k];
+    } else {
+        base[0] = L.base[0];
+        base[1] = base[0] + (uint64_t)n_on * L.sz2;
+        base[2] = base[1] + (uint64_t)n_pre * 48;
+        base[3] = base[2] + (uint64_t)n_on * L.sz64;
+    }
+    uint32_t k_on = 0, k_pre = 0;
+    for (uint32_t c = 0; c < (R + 63) / 64; c++) {
+        const uint32_t r = 64 * c + lane;
+        const bool valid = r < R;
+        const uint32_t om = valid ? s_omit[rep_begin + r] : RV_PLAYERS;
+        const bool on = valid && om < RV_PLAYERS;
+        const unsigned long long bal = __ballot(on), val = __ballot(valid);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const uint32_t my_on = k_on + (uint32_t)__popcll(bal & lt), my_pre = k_pre + (uint32_t)__popcll(~bal & val & lt);
+        if (valid) {
+            omit[r] = (uint8_t)om;
+            uint64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (on) {
+                v[0] = base[0] + (uint64_t)my_on * L.sz2;
+                v[1] = base[2] + (uint64_t)my_on * L.sz64;
+                v[2] = v[0] + 137;
+                v[3] = v[0] + 145 + L.l2r;
+                v[4] = v[0] + 153 + L.l2r + L.l2c;
+                v[5] = v[1] + 137;
+                v[6] = v[1] + 145 + L.l64r;
+                v[7] = v[1] + 153 + L.l64r + L.l64c;
+                if (my_on < RV_ONLINE_REPS) {
+                    ol->rep[my_on] = r;
+                    ol->dst[my_on] = v[3];
+                }
+            } else {
+                v[0] = base[1] + (uint64_t)my_pre * 48;
+                v[1] = base[3] + (uint64_t)my_pre * 48;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) offs[(size_t)j * R + r] = v[j];
+        }
+        k_on += (uint32_t)__popcll(bal);
+        k_pre += (uint32_t)__popcll(~bal & val);
+    }
+    if (lane == 0) {
+        ol->n = n_on < RV_ONLINE_REPS ? n_on : RV_ONLINE_REPS;
+        if (res) {
+            res[0] = n_on;
+            res[1] = n_pre;
+        }
+    }
 }
 
-void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint8_t* d_comm, uint8_t* d_omit, uint64_t* d_offs,
-                         OnlineList* d_ol) {
-    hipLaunchKernelGGL(k_fs_challenge, dim3(1), dim3(64), 0, st, d_h, L, d_comm, d_omit, d_offs, d_ol);
+void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint32_t rep_begin, uint32_t R, uint8_t* d_comm,
+                         uint8_t* d_omit, uint8_t* d_omit_all, uint64_t* d_offs, OnlineList* d_ol, uint32_t* d_res) {
+    hipLaunchKernelGGL(k_fs_challenge, dim3(1), dim3(64), 0, st, d_h, L, rep_begin, R, d_comm, d_omit, d_omit_all, d_offs, d_ol, d_res);
 }
 
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ,

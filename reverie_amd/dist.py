@@ -90,6 +90,21 @@ class HipShardBackend:
         _lib.check(_lib.lib().rv_shard_open_self(shard[0], C.c_void_p(tensor.data_ptr()), _ptr(comm), _ptr(omit), lens))
         return comm.tobytes(), omit, [int(x) for x in lens]
 
+    def gathered_capacity(self, count: int) -> int:
+        """bytes open_gathered may write for a shard of `count` repetitions (every one of up to 40 of them opened)"""
+        sz2, sz64 = self.circuit.record_sizes()
+        return min(40, count) * (sz2 + sz64) + 2 * count * 48
+
+    def open_gathered(self, shard, all_digests, tensor):
+        """rv_shard_open_gathered: challenge and this shard's openings on the device from the gathered digests
+        (`all_digests`: device tensor of 256 x 32 bytes) -> (comm bytes, omit[256], lens[4])"""
+        lens = (C.c_size_t * 4)()
+        comm = np.zeros(32, np.uint8)
+        omit = np.zeros(TOTAL_REPS, np.uint8)
+        _lib.check(_lib.lib().rv_shard_open_gathered(shard[0], C.c_void_p(all_digests.data_ptr()), C.c_void_p(tensor.data_ptr()),
+                                                     _ptr(comm), _ptr(omit), lens))
+        return comm.tobytes(), omit, [int(x) for x in lens]
+
     def single_shard_sizes(self) -> List[int]:
         """blob sizes of a proof whose one shard holds all 256 repetitions (40 opened, 216 not)"""
         sz2, sz64 = self.circuit.record_sizes()
@@ -193,6 +208,24 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
                 mine.copy_(torch.from_numpy(backend.digests(shard).reshape(-1)))
             allh = torch.empty(TOTAL_REPS * 32, dtype=torch.uint8, device=dev)
             dist.all_gather_into_tensor(allh, mine, group=group)
+            if on_gpu and device_resident and hasattr(backend, "open_gathered"):
+                # the gathered digests are on this GPU: commitment, challenge and this shard's openings without a
+                # host round trip (rv_shard_open_gathered); the buffer holds the worst case, `lens` what was written
+                torch.cuda.current_stream().synchronize()  # the collective ran on torch's stream, the library has its own
+                buf = torch.empty(max(backend.gathered_capacity(count), 1), dtype=torch.uint8, device="cuda")
+                comm, omit, lens = backend.open_gathered(shard, allh, buf)
+                if not gather:
+                    return comm, [buf], [lens]
+                all_lens = backend.all_open_sizes(omit, world)
+                assert all_lens[rank] == lens
+                if rank == 0:
+                    bufs = [buf] + [torch.empty(max(sum(l), 1), dtype=torch.uint8, device="cuda") for l in all_lens[1:]]
+                    reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(1, world)]
+                    for q in reqs:
+                        q.wait()
+                    return comm, bufs, all_lens
+                dist.send(buf[:max(sum(lens), 1)].contiguous(), dst=0, group=group)
+                return comm, None, None
             h = allh.cpu().numpy().reshape(TOTAL_REPS, 32)
         comm = combine_digests(h)  # every rank derives the same challenge
         omit = challenge(comm)

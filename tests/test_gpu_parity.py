@@ -532,6 +532,26 @@ def test_shards_in_one_process_bristol_circuits(rv, oracle, rule_seeds, n_shards
                 be.destroy(s)
         proof = assemble(comm, parts)
         assert proof == want
+        # the same with the challenge derived on the device from the "gathered" digests (rv_shard_open_gathered: what the
+        # RCCL path does after its all-gather), every shard into a worst-case sized buffer
+        import torch
+
+        allh = torch.from_numpy(h.reshape(-1).copy()).to("cuda")
+        shards = []
+        try:
+            parts2 = []
+            for r in range(n_shards):
+                b, n = shard_range(r, n_shards)
+                sh = be.commit(wit, [], rule_seeds[b:b + n], b, n)
+                shards.append(sh)
+                buf = torch.empty(be.gathered_capacity(n), dtype=torch.uint8, device="cuda")
+                comm2, omit2, lens2 = be.open_gathered(sh, allh, buf)
+                assert comm2 == comm and (omit2 == omit).all() and lens2 == parts[r][1]
+                parts2.append((buf.cpu().numpy().tobytes()[:sum(lens2)], lens2))
+        finally:
+            for sh in shards:
+                be.destroy(sh)
+        assert assemble(comm, parts2) == want
         # sharded verifier (rv_verify_shard over slot ranges, then rv_verify_finish)
         L = _lib.lib()
         dig = np.zeros((256, 32), np.uint8)
