@@ -16,6 +16,7 @@ GPU).  Tests inject an oracle-backed stand-in to exercise this orchestration on 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -199,7 +200,9 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
         else:
             # RCCL ("nccl") moves device tensors over xGMI; with gloo (CPU tests, or several ranks sharing one
             # GPU) the 8 KiB travel through host memory instead
-            on_gpu = backend.device_type == "cuda" and dist.get_backend(group) == "nccl"
+            # RV_DIST_DEVICE_PATH=1 takes the device-tensor branch with any backend that accepts CUDA tensors (the
+            # tests use it with gloo, several ranks on one GPU, to exercise the RCCL code path without RCCL)
+            on_gpu = backend.device_type == "cuda" and (dist.get_backend(group) == "nccl" or os.environ.get("RV_DIST_DEVICE_PATH") == "1")
             dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
             mine = torch.empty(count * 32, dtype=torch.uint8, device=dev)
             if on_gpu:

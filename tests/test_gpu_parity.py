@@ -599,14 +599,18 @@ def _two_rank_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_hip_backend_ranks_share_gpu(tmp_path, world):
-    """N>1 orchestration with the REAL HIP shard backend (R = 128 / 64 per rank: the generic-NQ kernels),
-    digests exchanged over gloo because the box has a single GPU"""
+@pytest.mark.parametrize("world,device_path", [(2, False), (4, False), (2, True), (4, True)])
+def test_sharded_hip_backend_ranks_share_gpu(tmp_path, monkeypatch, world, device_path):
+    """N>1 orchestration with the REAL HIP shard backend (R = 128 / 64 per rank: the generic-NQ kernels); the box has a
+    single GPU, so the ranks share it and talk over gloo.  device_path: the branch the RCCL run takes -- digests
+    all-gathered as device tensors, challenge on the GPU (rv_shard_open_gathered), openings sent to rank 0 as device
+    tensors -- exercised here with gloo carrying the CUDA tensors (RV_DIST_DEVICE_PATH=1)."""
     import socket
 
     import torch.multiprocessing as mp
 
+    if device_path:
+        monkeypatch.setenv("RV_DIST_DEVICE_PATH", "1")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
