@@ -342,6 +342,18 @@ def test_full_size_bit_exact_vs_oracle(rv, oracle, rule_seeds):
     assert bytes(got) == want
 
 
+def test_full_size_all_and_bit_exact_vs_oracle(rv, oracle, rule_seeds):
+    """the all-AND variant of config 4 (10 027 008 AND gates, 100 MB proof), bit-exact against the oracle, then verified"""
+    prog, wit, wc, st = circuits.layered_gf2(p_and=1.0)
+    assert st["and"] == 10027008
+    c = rv.Circuit(prog, wc)
+    got = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+    want = oracle.prove(prog, wit, [], wc, rule_seeds, threads=min(32, os.cpu_count() or 1))
+    assert bytes(got) == want
+    assert got.verify(c)
+    c.close()
+
+
 def test_full_size_properties(rv, rule_seeds):
     """BASELINE config 4 at full size (10^7 gates): size-independent properties only —
     prove -> verify accepts, a flipped transcript bit is rejected, proof length is as derived."""
