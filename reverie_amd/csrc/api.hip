@@ -711,7 +711,11 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
             continue;
         }
         if (cc.level_start[l + 1] > cc.level_start[l]) {
-            launch_interp(sb, mode, s->c->d_gates, cc.level_range[l], p);
+            // the level that follows as a launch of its own (not a narrow run) gets its first gate records prefetched
+            const LevelRange* next = (l + 1 < n_levels && s->c->run_of_level[l + 1] < 0 && cc.level_start[l + 2] > cc.level_start[l + 1])
+                                         ? &cc.level_range[l + 1]
+                                         : nullptr;
+            launch_interp(sb, mode, s->c->d_gates, cc.level_range[l], p, next);
             ctx->count();
         }
         if (has64 && cc.level_start64[l + 1] > cc.level_start64[l]) {

@@ -141,7 +141,10 @@ void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys
 struct LevelRange {
     uint32_t lo, mul11, mul, xor2, xork, hi;
 };
-void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p);
+// next: the level launched after this one by launch_interp too (nullable) -- the tail of this launch prefetches
+// its first gate records
+void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p,
+                   const LevelRange* next = nullptr);
 // levels [l0, l1) (all narrow, GF(2) only) in one launch by a single workgroup
 // tiny: plain per-gate loop (one gate per wavefront) instead of the 4-way unrolled class loops
 void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const LevelRange* d_level_range, uint32_t l0, uint32_t l1,

@@ -182,6 +182,46 @@ __host__ __device__ constexpr int interp_unroll(int NQ, bool general = true) {
     return NQ >= 64 ? (general ? RV_INTERP_UNROLL : RV_INTERP_UNROLL_FAST) : RV_INTERP_UNROLL_SMALL;
 }
 
+// Gate-record prefetch.  A wavefront of a level launch lives for three dependent memory round trips: its gate records
+// -> the operand rows they name -> the stores.  The records are static and contiguous (sorted by level, class), so
+// the wavefront that runs unrolled step t also touches the records of step t + dist (one load instruction, a lane per
+// 128-byte line, result unused), issued right behind its own row loads: by the time a later wavefront asks for them
+// they sit in L2 and the first round trip is an L2 hit instead of an HBM miss.  Steps past the end of this level map
+// onto the first steps of the next one (the gate array is contiguous across levels).  L2 is per XCD and workgroups
+// are dealt to the XCDs round-robin, so producer and consumer must agree modulo 8 workgroups = 32 wavefronts: step t
+// runs on wavefront t mod n_waves, and dist and the wrap-around are kept multiples of 32.
+struct PfPlan {
+    uint32_t dist;         // 0 = off
+    uint32_t rem;          // steps of this level modulo 32 (added back after the wrap so that t' = t + dist - 32k)
+    uint32_t n[2][4];      // [0] this level, [1] the next one: full unrolled steps of classes 0..3
+    uint32_t start[2][4];  // first gate of each class
+};
+template <uint32_t STEP>
+__device__ __forceinline__ const Gate* pf_target(const Gate* __restrict__ gates, const PfPlan& pf, uint32_t t) {
+    uint32_t tt = t + pf.dist;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (tt < pf.n[k][c]) return gates + pf.start[k][c] + tt * STEP;
+            tt -= pf.n[k][c];
+        }
+        tt += pf.rem;
+    }
+    return nullptr;
+}
+// one lane per 128-byte line of the STEP records at `g` (+ one for the unaligned tail); wave-uniform `g`.  The value
+// is a plain load that pf_sink() "uses" after the wavefront's last store, so the compiler's own vmcnt bookkeeping
+// covers it and its destination register stays reserved until it has landed.
+template <uint32_t STEP>
+__device__ __forceinline__ uint32_t pf_touch(const Gate* g, uint32_t lane) {
+    constexpr uint32_t BYTES = STEP * (uint32_t)sizeof(Gate), NL = (BYTES + 127) / 128;
+    uint32_t v = 0;
+    if (g && lane <= NL) v = *(const uint32_t*)((const char*)g + (lane < NL ? lane * 128 : BYTES - 4));
+    return v;
+}
+__device__ __forceinline__ void pf_sink(uint32_t v) { asm volatile("" ::"v"(v)); }
+
 // Fast path (NQ = 64, 32, 16 or 8, i.e. R = 256 .. 32): a wavefront covers 64/NQ gates at a time and the
 // per-class ranges run as 4-way unrolled loops that put every operand row of 4 x 64/NQ gates in flight
 // before the first use — the generic kernel above is latency-bound on the dependent
@@ -191,7 +231,7 @@ __host__ __device__ constexpr int interp_unroll(int NQ, bool general = true) {
 // the L1-hot zero row) for the rest.
 template <int MODE, int NQ, int U, int KA, int KB>
 __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
-                                     uint32_t onm) {
+                                     uint32_t onm, const Gate* pf = nullptr) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
     Gate g[U];
 #pragma unroll
@@ -228,6 +268,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
             sr[u] = p.sup_rec[(size_t)g[u].x * NQ + q];
         }
     }
+    const uint32_t pfv = pf_touch<U * GPW>(pf, sub * NQ + q);
 #pragma unroll
     for (int u = 0; u < U; u++) {
         lx[u] = ra[u][0];
@@ -264,11 +305,13 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
         store_bits(p.pre, g[u].ep, NQ, q, delta);
         store_bits(p.corr, g[u].dst, NQ, q, r ^ delta ^ (cx & cy));
     }
+    pf_sink(pfv);
 }
 
 // G_XORK: N = base rows loaded per gate (2: a[0], a[1]; 6: a[0..2], b[0..2] with zero-row padding)
 template <int NQ, int U, int N>
-__device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q) {
+__device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
+                                     const Gate* pf = nullptr) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
     Gate g[U];
 #pragma unroll
@@ -290,6 +333,7 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
             }
         }
     }
+    const uint32_t pfv = pf_touch<U * GPW>(pf, sub * NQ + q);
 #pragma unroll
     for (int u = 0; u < U; u++) {
         x[u] = 0;
@@ -305,6 +349,7 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
         p.rows[(size_t)g[u].dst * NQ + q] = x[u];
         if (q < H) p.corr[(size_t)g[u].dst * H + q] = (uint8_t)(bx[u] ^ (g_ca(g[u]) ? 0xFFu : 0u));
     }
+    pf_sink(pfv);
 }
 
 template <int MODE>
@@ -322,9 +367,10 @@ __device__ __forceinline__ void interp_one(const Gate& g, const InterpParams& p,
 // a circuit compiled with one base per wire, e.g. the wide layered workload): their unrolled loops are compiled
 // out, which keeps the kernel at 45 registers = 8 wavefronts per SIMD instead of 6; stray gates of those classes
 // take the common per-gate loop.
-template <int MODE, int NQ, bool ROTATE, bool GENERAL = true>
+template <int MODE, int NQ, bool ROTATE, bool GENERAL = true, bool PF = false>
 __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const LevelRange& r, const InterpParams& p, uint32_t wave,
-                                          uint32_t n_waves, uint32_t lane, uint32_t onm) {
+                                          uint32_t n_waves, uint32_t lane, uint32_t onm, const Gate* pf_gates = nullptr,
+                                          const PfPlan* pf = nullptr) {
     constexpr uint32_t GPW = 64 / NQ;  // gates per wavefront per step
     const uint32_t q = lane % NQ, sub = lane / NQ;
     constexpr int U = interp_unroll(NQ, GENERAL);
@@ -339,10 +385,12 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
         const uint32_t n_full = (!GENERAL && (c == 1 || c == 3)) ? 0u : (end[c] - begin[c]) / STEP;
         rest[c] = begin[c] + n_full * STEP;
         for (uint32_t g0 = begin[c] + my(slot) * STEP; g0 < rest[c]; g0 += n_waves * STEP) {
-            if (c == 0) mulU<MODE, NQ, U, 1, 1>(gates, g0, p, sub, q, onm);                  // G_MUL, one base per operand
-            if (c == 1 && GENERAL) mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K>(gates, g0, p, sub, q, onm);    // other G_MUL
-            if (c == 2) xorU<NQ, U, 2>(gates, g0, p, sub, q);                                // G_XORK of two bases
-            if (c == 3 && GENERAL) xorU<NQ, U, 2 * RV_LIN_K>(gates, g0, p, sub, q);                     // other G_XORK
+            const Gate* t = nullptr;
+            if (PF && pf->dist) t = pf_target<STEP>(pf_gates, *pf, slot + (g0 - begin[c]) / STEP);
+            if (c == 0) mulU<MODE, NQ, U, 1, 1>(gates, g0, p, sub, q, onm, t);               // G_MUL, one base per operand
+            if (c == 1 && GENERAL) mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K>(gates, g0, p, sub, q, onm, t); // other G_MUL
+            if (c == 2) xorU<NQ, U, 2>(gates, g0, p, sub, q, t);                             // G_XORK of two bases
+            if (c == 3 && GENERAL) xorU<NQ, U, 2 * RV_LIN_K>(gates, g0, p, sub, q, t);                  // other G_XORK
         }
         slot += n_full;
     }
@@ -362,7 +410,7 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
 }
 
 template <int MODE, int NQ, bool GENERAL>
-__global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p) {
+__global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p, PfPlan pf) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
@@ -370,7 +418,7 @@ __global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ ga
     // ROTATE here too: a wavefront then runs ONE step of one class instead of a Mul step followed by an Xor step
     // (two generations of short-lived wavefronts beat one generation of twice-as-long ones: 2.52 -> 2.40 ms;
     // interleaving the two classes wave by wave instead of class after class is worse again, 2.56)
-    run_level<MODE, NQ, true, GENERAL>(gates, r, p, wave, n_waves, lane, onm);
+    run_level<MODE, NQ, true, GENERAL, true>(gates, r, p, wave, n_waves, lane, onm, gates, &pf);
 }
 
 // Batched proofs of one circuit (rv_prove_batch): blockIdx.y selects the proof; its buffers come from a device array
@@ -385,12 +433,53 @@ __global__ __launch_bounds__(256) void k_interp_full_b(const Gate* __restrict__ 
     run_level<MODE, NQ, true>(gates, r, p, wave, n_waves, lane, onm);
 }
 
+// enough multi-base Mul / Xor gates in a level to be worth the variant with their unrolled loops?  (a handful
+// -- constant operands in an otherwise one-base circuit -- run through the common per-gate loop instead)
+static bool level_is_general(const LevelRange& r) { return (r.mul - r.mul11) + (r.xork - r.xor2) >= 64; }
+
+// wavefronts that prefetch gate records look this many unrolled steps ahead: half a generation of resident
+// wavefronts (8 per SIMD x 4 x 256 CUs = 8 192) measured best on full-width rows (interpreter 2.53 -> 2.42 ms on the
+// 10^7-gate circuit; 2 048: 2.47, 8 192: 2.49, 16 384: 2.52).  Narrower rows (repetition shards) read their records
+// through vector loads and gain nothing, so the default there is off.  RV_PF_DIST overrides (0 = off).
+static uint32_t pf_dist(int NQ) {
+    static const int env = [] {
+        const char* e = getenv("RV_PF_DIST");
+        return e ? atoi(e) : -1;
+    }();
+    const uint32_t v = env >= 0 ? (uint32_t)env : (NQ == 64 ? 4096u : 0u);
+    return v & ~31u;
+}
+
 template <int NQ>
-static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p) {
+static PfPlan make_pf_plan(const LevelRange& r, const LevelRange* next) {
     constexpr uint32_t GPW = 64 / NQ;
-    // enough multi-base Mul / Xor gates in this level to be worth the variant with their unrolled loops?  (a handful
-    // -- constant operands in an otherwise one-base circuit -- run through the common per-gate loop instead)
-    const bool general = (r.mul - r.mul11) + (r.xork - r.xor2) >= 64;
+    PfPlan pf{};
+    pf.dist = pf_dist(NQ);
+    if (!pf.dist) return pf;
+    const LevelRange* lr[2] = {&r, next};
+    uint32_t total = 0;
+    for (int k = 0; k < 2; k++) {
+        if (!lr[k]) break;
+        const LevelRange& x = *lr[k];
+        const bool general = level_is_general(x);
+        const uint32_t step = (uint32_t)interp_unroll(NQ, general) * GPW;
+        const uint32_t begin[4] = {x.lo, x.mul11, x.mul, x.xor2}, end[4] = {x.mul11, x.mul, x.xor2, x.xork};
+        for (int c = 0; c < 4; c++) {
+            pf.start[k][c] = begin[c];
+            pf.n[k][c] = (!general && (c == 1 || c == 3)) ? 0u : (end[c] - begin[c]) / step;
+            if (k == 0) total += pf.n[k][c];
+        }
+    }
+    pf.rem = total & 31u;
+    return pf;
+}
+
+template <int NQ>
+static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p,
+                               const LevelRange* next) {
+    constexpr uint32_t GPW = 64 / NQ;
+    const bool general = level_is_general(r);
+    const PfPlan pf = make_pf_plan<NQ>(r, next);
     const uint32_t u = (uint32_t)interp_unroll(NQ, general);
     uint64_t waves = ((uint64_t)(r.hi - r.lo) + u * GPW - 1) / (u * GPW);
     uint64_t blocks = (waves + 3) / 4;
@@ -398,14 +487,14 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
     if (blocks < 1) blocks = 1;
     if (mode == MODE_PROVE) {
         if (general)
-            hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
+            hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
         else
-            hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
+            hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
     } else {
         if (general)
-            hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
+            hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
         else
-            hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p);
+            hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
     }
 }
 
@@ -495,13 +584,13 @@ void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const L
     }
 }
 
-void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p) {
+void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p, const LevelRange* next) {
     if (r.hi <= r.lo) return;
     switch (p.NQ) {
-    case 64: return launch_interp_full<64>(st, mode, d_gates, r, p);
-    case 32: return launch_interp_full<32>(st, mode, d_gates, r, p);
-    case 16: return launch_interp_full<16>(st, mode, d_gates, r, p);
-    case 8: return launch_interp_full<8>(st, mode, d_gates, r, p);
+    case 64: return launch_interp_full<64>(st, mode, d_gates, r, p, next);
+    case 32: return launch_interp_full<32>(st, mode, d_gates, r, p, next);
+    case 16: return launch_interp_full<16>(st, mode, d_gates, r, p, next);
+    case 8: return launch_interp_full<8>(st, mode, d_gates, r, p, next);
     default: break;
     }
     const uint64_t want = (uint64_t)(r.hi - r.lo) * p.NQ;
