@@ -157,6 +157,9 @@ struct Builder {
         // keep it symbolic when that costs no more row traffic than materialising it:
         // f readers x (n - 1) extra rows  vs  n reads + 1 write
         const bool lazy = n <= 1 || (n <= lazy_k && (uint64_t)f * (uint32_t)(n - 1) <= (uint32_t)(n + 1));
+        // a linear gate nobody reads has no effect on the proof (no transcript entry, no mask consumed): drop it
+        // (13.5 % of the XOR gates of the random layered workload have fan-out zero)
+        if (f == 0) return new_ssa(Lin());
         Lin L;
         if (lazy) {
             L.n = (uint8_t)n;
