@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libreverie_amd.so")
+# RV_LIB_PATH: an alternative build of the same library (A/B measurements of kernel variants, tools/)
+LIB_PATH = os.environ.get("RV_LIB_PATH") or os.path.join(_HERE, "_build", "libreverie_amd.so")
 
 RV_OK = 0
 ERRORS = {

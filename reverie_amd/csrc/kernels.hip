@@ -173,13 +173,17 @@ __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, 
 #define RV_INTERP_UNROLL_SMALL 2
 #endif
 // gates a wavefront keeps in flight per step and gate group: narrow rows (small repetition shards, several gates per
-// wavefront already) may want fewer
+// wavefront already) want fewer -- measured per rank on the 10^7-gate circuit: 128 repetitions (NQ = 32) 1.75 ms
+// with 2, 1.64 with 4; 64 repetitions the same either way; 32 repetitions 1.02 with 2, 1.09 with 4
+#ifndef RV_INTERP_UNROLL_MID
+#define RV_INTERP_UNROLL_MID 4
+#endif
 #ifndef RV_INTERP_UNROLL_FAST
 #define RV_INTERP_UNROLL_FAST 4
 #endif
 // `general` = the kernel variant that also carries the multi-base Mul / Xor loops (more registers)
 __host__ __device__ constexpr int interp_unroll(int NQ, bool general = true) {
-    return NQ >= 64 ? (general ? RV_INTERP_UNROLL : RV_INTERP_UNROLL_FAST) : RV_INTERP_UNROLL_SMALL;
+    return NQ >= 64 ? (general ? RV_INTERP_UNROLL : RV_INTERP_UNROLL_FAST) : NQ >= 32 ? RV_INTERP_UNROLL_MID : RV_INTERP_UNROLL_SMALL;
 }
 
 // Gate-record prefetch.  A wavefront of a level launch lives for three dependent memory round trips: its gate records
