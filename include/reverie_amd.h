@@ -181,6 +181,17 @@ int rv_prove_batch(rv_ctx *ctx, const rv_circuit *c, size_t batch, const uint8_t
  * `omit` value >= 8 return RV_E_PROOF_MALFORMED (the reference panics / is UB). */
 int rv_verify(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, int *ok);
 
+/* The same with flags.  RV_VERIFY_STRICT closes the two gaps of the reference verifier and is NOT
+ * reference behaviour: *ok additionally requires
+ *   - every AssertZero of the 40 opened repetitions to reconstruct to zero -- VerifierTranscriptOnline.okay
+ *     (src/transcript/verifier/online.rs:21,117,175-177), which the reference computes and never reads, so
+ *     Proof::verify accepts a proof of an unsatisfied circuit;
+ *   - every online record's `omit` to equal the player the challenge omits -- the reference only checks which
+ *     repetitions are opened (src/proof/mod.rs:292-302: contains_key), never by whom.
+ * flags = 0 is rv_verify. */
+#define RV_VERIFY_STRICT 1u
+int rv_verify_ex(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, uint32_t flags, int *ok);
+
 void rv_free(void *p);
 
 /* ---- sharded form (one process per GPU; repetitions [rep_begin, rep_begin+rep_count),
@@ -251,6 +262,13 @@ int rv_verify_shard(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size
                     uint32_t slot_count, uint8_t *digests /* slot_count x 32 */);
 /* Final check of Proof::verify (proof/mod.rs:283-306) from all 256 slot digests */
 int rv_verify_finish(const uint8_t *proof, size_t proof_len, const uint8_t *slot_digests /* 256 x 32 */, int *ok);
+/* The sharded form of rv_verify_ex: *zero_checks_ok (nullable) = 0 when an AssertZero of one of this shard's opened
+ * repetitions did not reconstruct to zero; AND the shards' values together and hand the result to
+ * rv_verify_finish_ex, which with RV_VERIFY_STRICT also compares the records' `omit` with the challenge. */
+int rv_verify_shard_ex(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, uint32_t slot_begin,
+                       uint32_t slot_count, uint8_t *digests /* slot_count x 32 */, int *zero_checks_ok);
+int rv_verify_finish_ex(const uint8_t *proof, size_t proof_len, const uint8_t *slot_digests /* 256 x 32 */, uint32_t flags,
+                        int zero_checks_ok, int *ok);
 
 /* ---- Bristol front end (host only, no GPU) ---------------------------------------------
  * The reference's README promises Bristol-format circuits; the parser itself lives in the

@@ -1410,6 +1410,7 @@ typedef struct {
     size_t z64_wires, gf2_wires;
     proof_single gf2, z64;
     int rc[RVO_GROUPS];
+    int okay[RVO_GROUPS]; /* VerifierTranscriptOnline.okay of the group's two domains (online.rs:21,175-177) */
     u8 h[RVO_GROUPS][8][32]; /* first 5 groups online, then 27 preprocessing */
 } verify_job;
 
@@ -1519,6 +1520,7 @@ static void verify_group(job *jb, int q) {
     if (!rc && group_init_common(g, vj->z64_wires, vj->gf2_wires)) rc = RVO_E_NOMEM;
     if (!rc) rc = group_run(g, vj->ops, vj->n_ops);
     if (!rc) group_hashes(g, vj->h[q], NULL);
+    vj->okay[q] = q >= RVO_ONLINE_REPS / 8 || (g->t2.okay && g->t64.okay);
     vj->rc[q] = rc;
     group_free(g);
     free(g);
@@ -1526,6 +1528,11 @@ static void verify_group(job *jb, int q) {
 
 int rvo_verify(const rvo_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, const uint8_t *proof,
                size_t proof_len, int threads, int *ok) {
+    return rvo_verify_ex(ops, n_ops, z64_wires, gf2_wires, proof, proof_len, threads, 0, ok);
+}
+
+int rvo_verify_ex(const rvo_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, const uint8_t *proof,
+                  size_t proof_len, int threads, int strict, int *ok) {
     *ok = 0;
     reader r = {proof, proof_len, 0, 0};
     const u8 *comm = rd_bytes(&r, 32);
@@ -1559,6 +1566,18 @@ int rvo_verify(const rvo_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
             u8 c2[32];
             rvo_blake3_finalize(&hs, c2);
             *ok = memcmp(c2, comm, 32) == 0;
+            if (strict) {
+                /* the reference never reads `okay` and never compares the records' `omit` with the
+                 * challenge; the strict form enforces both */
+                for (int q = 0; q < RVO_ONLINE_REPS / 8; q++)
+                    if (!vj->okay[q]) *ok = 0;
+                size_t k = 0;
+                for (int i = 0; i < RVO_TOTAL_REPS; i++)
+                    if (omit[i] < 8) {
+                        if (vj->gf2.online[k].omit != omit[i] || vj->z64.online[k].omit != omit[i]) *ok = 0;
+                        k++;
+                    }
+            }
         }
     }
 done:

@@ -92,6 +92,13 @@ int rvo_prove(const rvo_op *ops, size_t n_ops, const uint8_t *wit_gf2, size_t n_
 int rvo_verify(const rvo_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
                const uint8_t *proof, size_t proof_len, int threads, int *ok);
 
+/* strict != 0: additionally require every AssertZero of the 40 opened repetitions to reconstruct to zero
+ * (VerifierTranscriptOnline.okay, which the reference computes but never reads -- SURVEY F9) and every online
+ * record's `omit` to equal the challenge's (the reference only checks which repetitions are opened).  This is the
+ * boundary's RV_VERIFY_STRICT, a deliberate tightening, not reference behaviour. */
+int rvo_verify_ex(const rvo_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
+                  const uint8_t *proof, size_t proof_len, int threads, int strict, int *ok);
+
 void rvo_free(void *p);
 
 /* ---- hooks used by parity tests (mirror SURVEY §8 rows a1..a18) ---- */

@@ -83,6 +83,9 @@ def build_parser():
     ap.add_argument("--proof-path")
     ap.add_argument("--program-format", default="auto", choices=["auto", "bristol", "rvops", "mcircuit-bincode"])
     ap.add_argument("--expected-outputs-path")
+    ap.add_argument("--strict", action="store_true",
+                    help="verify / oneshot-zk: RV_VERIFY_STRICT (not in the reference's CLI) -- also reject proofs whose opened "
+                         "repetitions fail an AssertZero or name another omitted player than the challenge does")
     return ap
 
 
@@ -120,7 +123,7 @@ def main(argv=None) -> int:
     else:
         proof = Proof(open(a.proof_path, "rb").read())
         print("Verifying Proof")
-    if proof.verify(circuit):
+    if proof.verify(circuit, strict=a.strict):
         print("Ok(())")
         return 0
     print('Err("Unverifiable Proof")')

@@ -1593,20 +1593,25 @@ bool format_ok(const Parsed& p) {  // ProofSingle::check_format, proof/mod.rs:11
 }  // namespace
 
 static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t slot_begin,
-                               uint32_t slot_count, uint8_t* digests);
+                               uint32_t slot_count, uint8_t* digests, int* zero_checks_ok);
 
-extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t slot_begin,
-                               uint32_t slot_count, uint8_t* digests) {
+extern "C" int rv_verify_shard_ex(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t slot_begin,
+                                  uint32_t slot_count, uint8_t* digests, int* zero_checks_ok) {
     try {  // no C++ exception may cross the C boundary
-        return rv_verify_shard_impl(ctx, c, proof, proof_len, slot_begin, slot_count, digests);
+        return rv_verify_shard_impl(ctx, c, proof, proof_len, slot_begin, slot_count, digests, zero_checks_ok);
     } catch (...) {
         g_last_error = "out of host memory";
         return RV_E_NOMEM;
     }
 }
 
-static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t slot_begin,
+extern "C" int rv_verify_shard(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t slot_begin,
                                uint32_t slot_count, uint8_t* digests) {
+    return rv_verify_shard_ex(ctx, c, proof, proof_len, slot_begin, slot_count, digests, nullptr);
+}
+
+static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t slot_begin,
+                               uint32_t slot_count, uint8_t* digests, int* zero_checks_ok) {
     if (!ctx || !c || !proof || !digests) return RV_E_ARG;
     if (slot_count == 0 || slot_count % 8 || slot_begin % 8 || slot_begin + slot_count > RV_TOTAL_REPS) return RV_E_ARG;
     Parsed P;
@@ -1802,7 +1807,10 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     launch_overlay_rows(ctx->stream, s->d_dig + 3 * DW, (const uint32_t*)d_hco64, s->d_omit, R, 8, 0);
     if ((rc = shard_join(s))) return fail(rc);
     HC(hipMemcpyAsync(digests, s->d_h, (size_t)R * 32, hipMemcpyDeviceToHost, ctx->stream));
+    int dev_flags = 0;  // RV_DEV_ZERO_CHECK: an AssertZero of an opened repetition did not reconstruct to zero
+    if (zero_checks_ok) HC(hipMemcpyAsync(&dev_flags, s->d_err, sizeof dev_flags, hipMemcpyDeviceToHost, ctx->stream));
     HC(hipStreamSynchronize(ctx->stream));
+    if (zero_checks_ok) *zero_checks_ok = !(dev_flags & RV_DEV_ZERO_CHECK);
     ctx->collect();
     ctx->prof.calls++;
 #undef HC
@@ -1810,8 +1818,9 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     return RV_OK;
 }
 
-extern "C" int rv_verify_finish(const uint8_t* proof, size_t proof_len, const uint8_t* slot_digests, int* ok) {
-    if (!proof || !slot_digests || !ok || proof_len < 32) return RV_E_ARG;
+static int rv_verify_finish_impl(const uint8_t* proof, size_t proof_len, const uint8_t* slot_digests, uint32_t flags,
+                                 int zero_checks_ok, int* ok) {
+    if (!proof || !slot_digests || !ok || proof_len < 32 || (flags & ~(uint32_t)RV_VERIFY_STRICT)) return RV_E_ARG;
     uint8_t omit[RV_TOTAL_REPS];
     rv_challenge(proof, omit);  // proof/mod.rs:290
     b3::Hasher hs;
@@ -1820,30 +1829,67 @@ extern "C" int rv_verify_finish(const uint8_t* proof, size_t proof_len, const ui
     uint8_t comm[32];
     hs.finalize(comm);
     *ok = memcmp(comm, proof, 32) == 0;
+    if (flags & RV_VERIFY_STRICT) {
+        // the reference computes `okay` without reading it (online.rs:21,175-177) and only checks WHICH
+        // repetitions are opened, never the records' omitted player (proof/mod.rs:292-302)
+        if (!zero_checks_ok) *ok = 0;
+        Parsed P;
+        int rc = parse_proof(proof, proof_len, P);
+        if (rc) return rc;
+        if (!format_ok(P)) {
+            *ok = 0;
+            return RV_OK;
+        }
+        size_t k = 0;
+        for (int i = 0; i < RV_TOTAL_REPS; i++)
+            if (omit[i] < 8) {
+                if (P.gf2.on[k].omit != omit[i] || P.z64.on[k].omit != omit[i]) *ok = 0;
+                k++;
+            }
+    }
     return RV_OK;
 }
 
-static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, int* ok);
-
-extern "C" int rv_verify(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, int* ok) {
-    try {  // no C++ exception may cross the C boundary
-        return rv_verify_impl(ctx, c, proof, proof_len, ok);
+extern "C" int rv_verify_finish_ex(const uint8_t* proof, size_t proof_len, const uint8_t* slot_digests, uint32_t flags,
+                                   int zero_checks_ok, int* ok) {
+    try {
+        return rv_verify_finish_impl(proof, proof_len, slot_digests, flags, zero_checks_ok, ok);
     } catch (...) {
         g_last_error = "out of host memory";
         return RV_E_NOMEM;
     }
 }
 
-static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, int* ok) {
-    if (!ctx || !c || !proof || !ok) return RV_E_ARG;
+extern "C" int rv_verify_finish(const uint8_t* proof, size_t proof_len, const uint8_t* slot_digests, int* ok) {
+    return rv_verify_finish_ex(proof, proof_len, slot_digests, 0, 1, ok);
+}
+
+static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t flags, int* ok);
+
+extern "C" int rv_verify_ex(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t flags, int* ok) {
+    try {  // no C++ exception may cross the C boundary
+        return rv_verify_impl(ctx, c, proof, proof_len, flags, ok);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
+}
+
+extern "C" int rv_verify(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, int* ok) {
+    return rv_verify_ex(ctx, c, proof, proof_len, 0, ok);
+}
+
+static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t flags, int* ok) {
+    if (!ctx || !c || !proof || !ok || (flags & ~(uint32_t)RV_VERIFY_STRICT)) return RV_E_ARG;
     *ok = 0;
     Parsed P;
     int rc = parse_proof(proof, proof_len, P);
     if (rc) return rc;
     if (!format_ok(P)) return RV_OK;  // wrong repetition counts: `false`, not an error (proof/mod.rs:225-230)
     std::vector<uint8_t> dig(RV_TOTAL_REPS * 32);
-    if ((rc = rv_verify_shard(ctx, c, proof, proof_len, 0, RV_TOTAL_REPS, dig.data()))) return rc;
-    return rv_verify_finish(proof, proof_len, dig.data(), ok);
+    int zc = 1;
+    if ((rc = rv_verify_shard_ex(ctx, c, proof, proof_len, 0, RV_TOTAL_REPS, dig.data(), &zc))) return rc;
+    return rv_verify_finish_ex(proof, proof_len, dig.data(), flags, zc, ok);
 }
 
 // ------------------------------------------------------------------------------------

@@ -103,6 +103,9 @@ struct Interp64Params {
 };
 
 enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1 };
+// bit set in the device error word when an AssertZero of an online-verified repetition does not reconstruct to zero
+// (VerifierTranscriptOnline.okay, online.rs:175-177; only the strict verifier looks at it)
+constexpr int RV_DEV_ZERO_CHECK = 0x100;
 
 struct InterpParams {
     uint32_t NQ;

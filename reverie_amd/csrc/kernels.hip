@@ -138,9 +138,14 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         uint32_t m = gather_rows(p.rows, g.a, NQ, q);
         if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
         p.on[(size_t)g.eo * NQ + q] = m;
-        if (MODE == MODE_PROVE) {
+        {
             const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
-            if ((recon32(m) ^ cx) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+            if (MODE == MODE_PROVE) {
+                if ((recon32(m) ^ cx) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+            } else {
+                // online.rs:175-177: okay &= recon.is_zero() -- the reference never reads it; RV_VERIFY_STRICT does
+                if (((recon32(m) ^ cx) & onm) != 0) atomicOr(p.err, RV_DEV_ZERO_CHECK);
+            }
         }
         break;
     }

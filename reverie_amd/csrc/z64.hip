@@ -117,8 +117,13 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
             uint64_t m = *am;
             if (MODE == MODE_VERIFY && online && pl == om) m += p.sup_rec[(size_t)g.x * p.R + r];
             p.on[(size_t)r * p.on_words + g.eo + pl] = m;
-            if (MODE == MODE_PROVE) {
-                if (sum8(m) + *ac != 0 && pl == 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+            {
+                const uint64_t v = sum8(m) + *ac;
+                if (MODE == MODE_PROVE) {
+                    if (v != 0 && pl == 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+                } else if (online && v != 0 && pl == 0) {
+                    atomicOr(p.err, RV_DEV_ZERO_CHECK);  // online.rs:175-177 (read by RV_VERIFY_STRICT only)
+                }
             }
             break;
         }

@@ -182,11 +182,16 @@ class Proof:
                                              C.c_size_t(z.shape[1]), _ptr(s), outs, lens))
         return [Proof(_owned=(C.c_void_p(outs[b]), int(lens[b]))) for b in range(batch)]
 
-    def verify(self, circuit, wire_counts: Optional[Tuple[int, int]] = None, ctx: Optional[Context] = None) -> bool:
+    def verify(self, circuit, wire_counts: Optional[Tuple[int, int]] = None, ctx: Optional[Context] = None,
+               strict: bool = False) -> bool:
+        """Proof::verify (/root/reference/src/proof/mod.rs:224-307).  strict=True is RV_VERIFY_STRICT: it also
+        requires the opened repetitions' AssertZero gates to hold and the records' `omit` to match the challenge,
+        both of which the reference leaves unchecked."""
         c = _as_circuit(circuit, wire_counts, ctx)
         ok = C.c_int()
         buf, n = self._buffer()
-        _lib.check(_lib.lib().rv_verify(c.ctx.handle, c.handle, buf, C.c_size_t(n), C.byref(ok)))
+        flags = _lib.RV_VERIFY_STRICT if strict else 0
+        _lib.check(_lib.lib().rv_verify_ex(c.ctx.handle, c.handle, buf, C.c_size_t(n), C.c_uint32(flags), C.byref(ok)))
         return bool(ok.value)
 
 

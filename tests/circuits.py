@@ -252,3 +252,13 @@ def random_mixed(rng: np.random.Generator, n_gates=200):
                         val |= bit << k
                 ops.append(B2A(d, 16)); v64[d] = val if ok else None
     return program(ops), w2, w64, (1, 1)
+
+
+def assert_circuits():
+    """C1 holds for the witness, C2 differs only in the constants in front of its AssertZero gates (which then
+    fail); constants touch the public value of a wire, never its masks, so both circuits produce the SAME
+    transcripts."""
+    def build(k2, k64):
+        return program([GF2.Input(0), GF2.Input(1), GF2.Mul(2, 0, 1), GF2.AddConst(3, 2, k2), GF2.AssertZero(3),
+                        Z64.Input(0), Z64.Input(1), Z64.Mul(2, 0, 1), Z64.SubConst(3, 2, k64), Z64.AssertZero(3)])
+    return build(1, 42), build(0, 41), [1, 1], [6, 7], (4, 4)

@@ -68,11 +68,11 @@ def prove(prog, wit_gf2, wit_z64, wire_counts, seeds, threads=8) -> bytes:
     return data
 
 
-def verify(prog, wire_counts, proof: bytes, threads=8) -> bool:
+def verify(prog, wire_counts, proof: bytes, threads=8, strict=False) -> bool:
     ok = C.c_int()
     buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
-    rc = lib().rvo_verify(_p(prog), C.c_size_t(len(prog)), C.c_size_t(wire_counts[0]), C.c_size_t(wire_counts[1]),
-                          buf, C.c_size_t(len(proof)), C.c_int(threads), C.byref(ok))
+    rc = lib().rvo_verify_ex(_p(prog), C.c_size_t(len(prog)), C.c_size_t(wire_counts[0]), C.c_size_t(wire_counts[1]),
+                             buf, C.c_size_t(len(proof)), C.c_int(threads), C.c_int(1 if strict else 0), C.byref(ok))
     if rc:
         raise OracleError(rc)
     return bool(ok.value)

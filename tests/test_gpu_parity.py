@@ -630,3 +630,66 @@ def test_sharded_hip_backend_ranks_share_gpu(tmp_path, monkeypatch, world, devic
     out = str(tmp_path / "r.txt")
     mp.spawn(_two_rank_worker, args=(world, port, out), nprocs=world, join=True)
     assert open(out).read() == "ok"
+
+
+# ---------------------------------------------------------------- RV_VERIFY_STRICT
+def test_strict_verify_zero_checks(rv, oracle, rule_seeds):
+    """A proof of C1 checked against C2 (same transcripts, failing AssertZero gates): the reference's verifier — and
+    rv_verify — accept it, RV_VERIFY_STRICT rejects it; every answer equals the oracle's."""
+    c1, c2, w2, w64, wc = circuits.assert_circuits()
+    pf = rv.Proof.new(c1, w2, w64, wc, seeds=rule_seeds)
+    assert bytes(pf) == oracle.prove(c1, w2, w64, wc, rule_seeds)
+    c3 = c1.copy()
+    c3[8]["imm"] = 41  # only the Z64 assertion fails
+    c4 = c1.copy()
+    c4[3]["imm"] = 0  # only the GF(2) one
+    for prog, want in ((c1, (True, True)), (c2, (True, False)), (c3, (True, False)), (c4, (True, False))):
+        got = (pf.verify(prog, wc), pf.verify(prog, wc, strict=True))
+        assert got == want
+        assert got == (oracle.verify(prog, wc, bytes(pf)), oracle.verify(prog, wc, bytes(pf), strict=True))
+    # wide levels go through the per-level kernels, deep ones through the single-workgroup kernel: a failing
+    # assertion in either must be seen
+    rng = np.random.default_rng(5)
+    prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=400)
+    seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+    pf = rv.Proof.new(prog, w2, w64, wc, seeds=seeds)
+    assert pf.verify(prog, wc, strict=True) and oracle.verify(prog, wc, bytes(pf), strict=True)
+    flipped = 0
+    for i in np.flatnonzero((prog["opcode"] == 3) | (prog["opcode"] == 5)):  # AddConst / SubConst feeding assertions
+        bad = prog.copy()
+        bad[i]["imm"] ^= 1
+        want = (oracle.verify(bad, wc, bytes(pf)), oracle.verify(bad, wc, bytes(pf), strict=True))
+        assert (pf.verify(bad, wc), pf.verify(bad, wc, strict=True)) == want
+        flipped += want == (True, False)
+        if flipped >= 3:
+            break
+
+
+def test_strict_verify_omit_must_match_challenge(rv, oracle, rule_seeds):
+    """A prover that opens the challenged repetitions but hides ANOTHER player than the challenge names: consistent
+    transcripts, so the reference accepts (proof/mod.rs:292-302 only checks which repetitions are opened);
+    RV_VERIFY_STRICT compares the records' `omit` with the challenge."""
+    from reverie_amd.dist import HipShardBackend, assemble
+    from reverie_amd.proof import challenge, combine_digests
+
+    m, prog, w2, w64, wc, gold = load_case("adder64")
+    c = rv.Circuit(prog, wc)
+    be = HipShardBackend(c)
+    shard = be.commit(w2, w64, rule_seeds, 0, 256)
+    try:
+        comm = combine_digests(be.digests(shard))
+        omit = challenge(comm)
+        blob, lens, _, _ = be.open(shard, omit)
+        honest = assemble(comm, [(blob, lens)])
+        assert honest == gold
+        forged_omit = omit.copy()
+        k = int(np.flatnonzero(omit < 8)[7])
+        forged_omit[k] = (omit[k] + 3) % 8
+        blob, lens, _, _ = be.open(shard, forged_omit)
+        forged = assemble(comm, [(blob, lens)])
+    finally:
+        be.destroy(shard)
+    assert forged != honest
+    for pf, want in ((honest, (True, True)), (forged, (True, False))):
+        assert (rv.Proof(pf).verify(c), rv.Proof(pf).verify(c, strict=True)) == want
+        assert (oracle.verify(prog, wc, pf), oracle.verify(prog, wc, pf, strict=True)) == want

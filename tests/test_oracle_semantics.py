@@ -12,6 +12,8 @@ import os
 import numpy as np
 import pytest
 
+import circuits
+
 from conftest import GOLDEN
 from reverie_amd.ops import B2A, GF2, Z64, program
 
@@ -200,3 +202,19 @@ def test_bench_circuit_small(oracle, rule_seeds):  # proof/mod.rs:318-395 shape,
     pf = oracle.prove(prog, [1, 1], [0], (128, 128), rule_seeds)
     assert oracle.verify(prog, (128, 128), pf)
     assert len(pf) == 33160 + 40 * (3000 // 8 * 2)  # recons + corrs grow by n/8 bytes each
+
+
+def test_strict_verify_closes_reference_gaps(oracle, rule_seeds):
+    """the reference's verifier computes `okay` (online.rs:175-177) without reading it, so a proof of C1
+    verifies against C2 although C2's AssertZero gates fail.  strict (RV_VERIFY_STRICT at the boundary) rejects it."""
+    c1, c2, w2, w64, wc = circuits.assert_circuits()
+    pf = oracle.prove(c1, w2, w64, wc, rule_seeds)
+    assert oracle.verify(c1, wc, pf) and oracle.verify(c1, wc, pf, strict=True)
+    assert oracle.verify(c2, wc, pf)  # the reference's behaviour
+    assert not oracle.verify(c2, wc, pf, strict=True)
+    with pytest.raises(oracle.OracleError):  # and the prover refuses C2 outright
+        oracle.prove(c2, w2, w64, wc, rule_seeds)
+    # one failing domain is enough
+    c3 = c1.copy()
+    c3[8]["imm"] = 41
+    assert oracle.verify(c3, wc, pf) and not oracle.verify(c3, wc, pf, strict=True)
