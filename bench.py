@@ -308,7 +308,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"synthetic layered AND/XOR GF(2) circuit, {st['gates']} gates ({st['and']} AND), "
                                    f"{st['inputs']} inputs, {args.layers} layers x 65536, p_and={args.p_and}, 256 reps x 8 players, 40 online",
-                       "parallelism": f"reps/{world}", "levels": info["levels"], "compile_s": compile_s},
+                       "parallelism": f"reps/{world}", "levels": info["levels"], "compile_s": compile_s,
+                       "gate_stream_upload_ms": info["upload_us"] / 1e3, "gate_stream_bytes": info["device_bytes"]},
             "roofline": roofline,
         }
     # ---- parity gate, outside the timed region (rank 0; the other ranks wait at the final barrier):
@@ -322,6 +323,15 @@ def main():
         comm, bufs, all_lens = out
         last = reverie_amd.Proof(assemble_device_parts(comm, bufs, all_lens))
         parity = {"last_timed_proof_verifies": bool(last.verify(circuit)), "proof_bytes": len(last)}
+        if world == 1:
+            # verifier rate and proof size next to the prover's.  rv_verify from host proof bytes (the upload
+            # of the proof is part of it); second call, the first one above sized the context's buffers
+            tv = time.perf_counter()
+            okv = bool(last.verify(circuit, strict=True))
+            tv = time.perf_counter() - tv
+            result["verifier"] = {"value": n_and / tv, "unit": "AND gates/s", "ms": tv * 1e3, "strict_ok": okv,
+                                  "note": "rv_verify_ex(RV_VERIFY_STRICT) on the last timed proof, host proof bytes in, one call"}
+            parity["last_timed_proof_verifies_strict"] = okv
         if world > 1:
             single = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
             parity["sharded_proof_equals_single_gpu_proof"] = bytes(single) == bytes(last)

@@ -141,6 +141,8 @@ typedef struct rv_circuit_info {
     uint64_t levels;         /* dependency levels = kernel launches of the interpreter */
     uint64_t device_bytes;   /* HBM held by the compiled circuit                       */
     uint64_t scratch_bytes;  /* HBM a full 256-repetition prove needs on top           */
+    uint64_t compile_us;     /* host time of the gate-stream compiler                  */
+    uint64_t upload_us;      /* allocation + host-to-device copy of the compiled gate stream (device_bytes), synchronised */
 } rv_circuit_info;
 int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
 

@@ -386,9 +386,11 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
         delete c;
         return rc;
     }
+    const auto t_compiled = std::chrono::steady_clock::now();
+    c->cc.info.compile_us = (uint64_t)std::chrono::duration<double, std::micro>(t_compiled - t_begin).count();
     if (getenv("RV_COMPILE_STATS"))
-        fprintf(stderr, "[rv circuit] compile_ops: %.3f s for %zu ops\n",
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), n_ops);
+        fprintf(stderr, "[rv circuit] compile_ops: %.3f s for %zu ops\n", std::chrono::duration<double>(t_compiled - t_begin).count(),
+                n_ops);
     HIPCHK(hipSetDevice(ctx->device));
     const Compiled& cc = c->cc;
     auto up = [&](const void* src, size_t bytes, void** dst) -> int {
@@ -409,6 +411,7 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
         return rc;
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    c->cc.info.upload_us = (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_compiled).count();
     {
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
         c->run_of_level.assign(n_levels, -1);
