@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "internal.h"
+#include "launch.h"
 
 namespace rv {
 
@@ -77,7 +78,8 @@ __device__ inline void ctr_block(uint64_t j, uint8_t b[16]) {
 }
 
 // expand_seed: keys[r][p] = AES_{seed[r]}(BE128(p))
-__global__ void k_expand_seeds(const uint8_t* __restrict__ seeds, uint32_t n_reps, uint8_t* __restrict__ keys) {
+struct B_k_expand_seeds {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ seeds, uint32_t n_reps, uint8_t* __restrict__ keys) const {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_reps * 8) return;
     uint32_t r = t >> 3, p = t & 7;
@@ -88,8 +90,13 @@ __global__ void k_expand_seeds(const uint8_t* __restrict__ seeds, uint32_t n_rep
     encrypt_bytes(rk, in, out);
     for (int i = 0; i < 16; i++) keys[16 * t + i] = out[i];
 }
+};
+__global__ void k_expand_seeds(const uint8_t* __restrict__ seeds, uint32_t n_reps, uint8_t* __restrict__ keys) {
+    B_k_expand_seeds{}(seeds, n_reps, keys);
+}
 
-__global__ void k_key_schedule(const uint8_t* __restrict__ keys, uint32_t n_slots, uint8_t* __restrict__ rkbytes) {
+struct B_k_key_schedule {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ keys, uint32_t n_slots, uint8_t* __restrict__ rkbytes) const {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_slots) return;
     uint8_t key[16], rk[176];
@@ -115,20 +122,35 @@ __global__ void k_key_schedule(const uint8_t* __restrict__ keys, uint32_t n_slot
     for (int i = 13; i < 16; i++) dst[176 + i] = rk[i];
     for (int i = 0; i < 16; i++) dst[192 + i] = k1[i];
 }
+};
+__global__ void k_key_schedule(const uint8_t* __restrict__ keys, uint32_t n_slots, uint8_t* __restrict__ rkbytes) {
+    B_k_key_schedule{}(keys, n_slots, rkbytes);
+}
 
 // rk[(round*128 + 8*byte + bit)*NQ + q] = bit `bit` of round-key byte `byte` of the 32
 // slots of quad q, slot (i4, p) at bit 31 - (8*i4 + p).  Slots are numbered rep*8 + p.
-__global__ void k_bitslice_rk(const uint8_t* __restrict__ rkbytes, uint32_t NQ, uint32_t* __restrict__ rk) {
+struct B_k_bitslice_rk {
+    // thread = (quad q, group of 4 key bytes): 32 dword loads (one per slot), 32 words out.  (One thread per output
+    // word re-read every byte eight times through 3.4 M byte loads per proof: 10 us per proof, 2.7 ms per batch of 256.)
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ rkbytes, uint32_t NQ, uint32_t* __restrict__ rk) const {
+    static_assert(RK_BYTES % 4 == 0, "dword loads");
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= RK_AREAS * 128u * NQ) return;
-    uint32_t q = t % NQ, idx = t / NQ;
-    uint32_t byte = idx >> 3, bit = idx & 7;  // byte in 0..RK_BYTES-1
-    uint32_t w = 0;
-    for (uint32_t s = 0; s < 32; s++) {
-        uint32_t slot = q * 32 + s;
-        w |= (uint32_t)((rkbytes[RK_BYTES * (size_t)slot + byte] >> bit) & 1) << (31 - s);
+    if (t >= (RK_BYTES / 4) * NQ) return;
+    const uint32_t q = t % NQ, bg = t / NQ;
+    uint32_t v[32];
+#pragma unroll
+    for (uint32_t s = 0; s < 32; s++) v[s] = *(const uint32_t*)(rkbytes + RK_BYTES * (size_t)(q * 32 + s) + 4 * bg);
+#pragma unroll 1
+    for (uint32_t k = 0; k < 32; k++) {  // k = 8 * (byte in the group) + bit
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t s = 0; s < 32; s++) w |= ((v[s] >> k) & 1u) << (31 - s);
+        rk[(size_t)(32 * bg + k) * NQ + q] = w;
     }
-    rk[t] = w;
+}
+};
+__global__ void k_bitslice_rk(const uint8_t* __restrict__ rkbytes, uint32_t NQ, uint32_t* __restrict__ rk) {
+    B_k_bitslice_rk{}(rkbytes, NQ, rk);
 }
 
 // test hook / Z64 path helper: plain CTR blocks, one thread per (key, block)
@@ -326,9 +348,8 @@ __device__ __forceinline__ void stage_round_keys(const uint32_t* __restrict__ rk
 // version that read them from global memory was 15x slower: every wavefront of the chip
 // requested the same 256-byte row at the same time and serialised on one L2 channel).
 template <int QW>
-__global__ __launch_bounds__(512, 2) void k_aes_gf2_masks(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep,
-                                                       uint32_t NQ, uint64_t first_block, uint64_t n_blocks,
-                                                       uint32_t blocks_per_wg, uint32_t* __restrict__ masks) {
+struct B_k_aes_gf2_masks {
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks, uint32_t blocks_per_wg, uint32_t* __restrict__ masks) const {
     __shared__ uint32_t lds_rk[11 * 128 * QW];
     constexpr uint32_t JW = 64 / QW;  // CTR blocks per wavefront per iteration
     const uint32_t n_qg = NQ / QW;
@@ -363,18 +384,23 @@ __global__ __launch_bounds__(512, 2) void k_aes_gf2_masks(const uint32_t* __rest
         }
     }
 }
+};
+template <int QW>
+__global__ __launch_bounds__(512, 2) void k_aes_gf2_masks(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks, uint32_t blocks_per_wg, uint32_t* __restrict__ masks) {
+    B_k_aes_gf2_masks<QW>{}(rk, keep, NQ, first_block, n_blocks, blocks_per_wg, masks);
+}
 
 // ---- launchers ----
 void launch_expand_seeds(hipStream_t st, const uint8_t* d_seeds, uint32_t n_reps, uint8_t* d_keys) {
     uint32_t n = n_reps * 8;
-    hipLaunchKernelGGL(k_expand_seeds, dim3((n + 63) / 64), dim3(64), 0, st, d_seeds, n_reps, d_keys);
+    launch<B_k_expand_seeds, 64>(k_expand_seeds, st, dim3((n + 63) / 64), dim3(64), d_seeds, n_reps, d_keys);
 }
 void launch_key_schedule(hipStream_t st, const uint8_t* d_keys, uint32_t n_slots, uint8_t* d_rkbytes) {
-    hipLaunchKernelGGL(k_key_schedule, dim3((n_slots + 63) / 64), dim3(64), 0, st, d_keys, n_slots, d_rkbytes);
+    launch<B_k_key_schedule, 64>(k_key_schedule, st, dim3((n_slots + 63) / 64), dim3(64), d_keys, n_slots, d_rkbytes);
 }
 void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, uint32_t* d_rk) {
-    uint32_t n = RK_AREAS * 128u * NQ;
-    hipLaunchKernelGGL(k_bitslice_rk, dim3((n + 255) / 256), dim3(256), 0, st, d_rkbytes, NQ, d_rk);
+    uint32_t n = (RK_BYTES / 4) * NQ;
+    launch<B_k_bitslice_rk, 256>(k_bitslice_rk, st, dim3((n + 255) / 256), dim3(256), d_rkbytes, NQ, d_rk);
 }
 // 32x32 bit-matrix transpose (Hacker's Delight 7-3), fully unrolled: registers only
 __device__ __forceinline__ void transpose32(uint32_t* A) {
@@ -458,10 +484,13 @@ static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t
             cus = 256;
         return (uint64_t)cus;
     }();
-    uint64_t per = (n_blocks * n_qg + target_wgs - 1) / target_wgs;
+    // recorded for a batch of proofs (rv_prove_batch): the batch supplies the parallelism, so a proof's share of the
+    // chip is one workgroup per quad group -- each workgroup fills 88 KiB of LDS with round keys before its first block
+    const uint64_t wgs = g_recorder ? (uint64_t)n_qg : target_wgs;
+    uint64_t per = (n_blocks * n_qg + wgs - 1) / wgs;
     per = ((per + 8 * JW - 1) / (8 * JW)) * (8 * JW);
     const uint64_t chunks = (n_blocks + per - 1) / per;
-    hipLaunchKernelGGL(k_aes_gf2_masks<QW>, dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_rk, d_keep, NQ, first_block,
+    launch<B_k_aes_gf2_masks<QW>, 512>(k_aes_gf2_masks<QW>, st, dim3((unsigned)(chunks * n_qg)), dim3(512), d_rk, d_keep, NQ, first_block,
                        n_blocks, (uint32_t)per, d_masks);
 }
 

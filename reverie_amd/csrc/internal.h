@@ -195,6 +195,7 @@ struct FsLayout {
                        // otherwise only base[0] = start of the output, the rest follow from the number of opened reps
     uint64_t sz2, sz64, l2r, l2c, l64r, l64c;
     uint32_t framed;
+    uint8_t* comm2;    // nullable: a second destination for comm (the head of a framed proof buffer)
 };
 // d_h: all 256 digests.  Produces for the shard (rep_begin, R): d_omit[R], d_offs[8*R], *d_ol, and d_res = {opened,
 // not opened} repetition counts; d_comm[32]; d_omit_all[256] (nullable) = the whole opening map

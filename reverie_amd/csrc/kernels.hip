@@ -19,6 +19,7 @@
 
 #include "b3.h"
 #include "internal.h"
+#include "launch.h"
 
 namespace rv {
 
@@ -641,8 +642,8 @@ void launch_interp_narrow_batched(hipStream_t st, const Gate* d_gates, const Lev
 // repetitions per lane = more, lighter wavefronts: 4 900 chunks x 64 lanes is only 1.6 rounds of the
 // chip at 3 waves/SIMD (40 % of the time is tail), RPL = 1 gives 19 600 waves at 7+ waves/SIMD.
 template <int RPL>
-__global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ,
-                                                   uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/) {
+struct B_k_b3_chunks {
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/) const {
     constexpr uint32_t SUBS = 4 / RPL;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lanes_per_chunk = NQ * SUBS;
@@ -694,11 +695,16 @@ __global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ 
         for (int k = 0; k < 8; k++) dst[k] = cv[i][k];
     }
 }
+};
+template <int RPL>
+__global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/) {
+    B_k_b3_chunks<RPL>{}(stream, n_events, NQ, n_chunks, cvs);
+}
 
 // Same for a bit-per-rep transcript (the preprocessing stream): every bit is hashed as the
 // 0x00/0xFF byte the reference feeds its hasher (gf2/recon.rs:314-321).
-__global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ,
-                                                        uint64_t n_chunks, uint32_t* __restrict__ cvs) {
+struct B_k_b3_chunks_bits {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs) const {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t c = tid / NQ;
     const uint32_t q = (uint32_t)(tid % NQ);
@@ -746,6 +752,10 @@ __global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restric
         for (int k = 0; k < 8; k++) dst[k] = cv[i4][k];
     }
 }
+};
+__global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs) {
+    B_k_b3_chunks_bits{}(stream, n_events, NQ, n_chunks, cvs);
+}
 
 // LG tree levels per launch: thread = (group of G = 2^LG consecutive nodes, repetition).  One level is
 // out[i] = parent(in[2i], in[2i+1]) with an odd last node promoted unchanged; groups are aligned to G, so
@@ -753,8 +763,8 @@ __global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restric
 // last group follows the same promote rule).  The ROOT flag belongs to the merge of the last two nodes of
 // the whole tree, which can only happen inside the only group of a launch.
 template <int LG>
-__global__ __launch_bounds__(256) void k_b3_reduce(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t R,
-                                                   uint32_t* __restrict__ out) {
+struct B_k_b3_reduce {
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t R, uint32_t* __restrict__ out) const {
     constexpr int G = 1 << LG;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t n_out = (n_in + G - 1) / G;
@@ -796,12 +806,17 @@ __global__ __launch_bounds__(256) void k_b3_reduce(const uint32_t* __restrict__ 
     d[0] = make_uint4(cv[0][0], cv[0][1], cv[0][2], cv[0][3]);
     d[1] = make_uint4(cv[0][4], cv[0][5], cv[0][6], cv[0][7]);
 }
+};
+template <int LG>
+__global__ __launch_bounds__(256) void k_b3_reduce(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t R, uint32_t* __restrict__ out) {
+    B_k_b3_reduce<LG>{}(in, n_in, R, out);
+}
 
 // The top of the tree (at most B3_TAIL nodes per repetition): one workgroup per repetition walks the
 // remaining levels through LDS, a barrier per level instead of a launch per level.
 constexpr uint32_t B3_TAIL = 512;
-__global__ __launch_bounds__(256) void k_b3_tree_tail(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R,
-                                                      uint32_t* __restrict__ digest) {
+struct B_k_b3_tree_tail {
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R, uint32_t* __restrict__ digest) const {
     __shared__ uint32_t cv[B3_TAIL][8 + 1];  // +1: odd row stride, no bank conflicts on the strided pair reads
     const uint32_t r = blockIdx.x;
     for (uint32_t i = threadIdx.x; i < n_in * 8; i += 256) cv[i >> 3][i & 7] = in[((size_t)(i >> 3) * R + r) * 8 + (i & 7)];
@@ -835,6 +850,10 @@ __global__ __launch_bounds__(256) void k_b3_tree_tail(const uint32_t* __restrict
     }
     if (threadIdx.x < 8) digest[(size_t)r * 8 + threadIdx.x] = cv[0][threadIdx.x];
 }
+};
+__global__ __launch_bounds__(256) void k_b3_tree_tail(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R, uint32_t* __restrict__ digest) {
+    B_k_b3_tree_tail{}(in, n_in, R, digest);
+}
 
 // tree reduction of n chunk chaining values per repetition; the roots land in d_digest ([R][8] words)
 uint32_t b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest) {
@@ -842,7 +861,7 @@ uint32_t b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n
     while (n > B3_TAIL) {  // two levels per launch while the level is wide
         const uint64_t n_out = (n + 3) / 4;
         const uint64_t threads = n_out * R;
-        hipLaunchKernelGGL(k_b3_reduce<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, cur, n, R, nxt);
+        launch<B_k_b3_reduce<2>, 256>(k_b3_reduce<2>, st, dim3((unsigned)((threads + 255) / 256)), dim3(256), cur, n, R, nxt);
         uint32_t* t = cur;
         cur = nxt;
         nxt = t;
@@ -850,7 +869,7 @@ uint32_t b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n
         launches++;
     }
     // a single chunk is already its own root (the chunk kernels applied the ROOT flag): cnt == 1 just copies
-    hipLaunchKernelGGL(k_b3_tree_tail, dim3(R), dim3(256), 0, st, cur, (uint32_t)n, R, d_digest);
+    launch<B_k_b3_tree_tail, 256>(k_b3_tree_tail, st, dim3(R), dim3(256), cur, (uint32_t)n, R, d_digest);
     return launches;
 }
 
@@ -865,8 +884,7 @@ uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_e
     uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
     {
         const uint64_t threads = n * NQ;
-        hipLaunchKernelGGL(k_b3_chunks<RV_B3_RPL>, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), 0, st,
-                           d_stream, n_events, NQ, n, d_cv_a);
+        launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a);
     }
     return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
 }
@@ -876,14 +894,14 @@ uint32_t launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t
     const uint32_t R = NQ * 4;
     const uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
     const uint64_t threads = n * NQ;
-    hipLaunchKernelGGL(k_b3_chunks_bits, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, n_events, NQ, n,
+    launch<B_k_b3_chunks_bits, 256>(k_b3_chunks_bits, st, dim3((unsigned)((threads + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
                        d_cv_a);
     return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
 }
 
 // Transcript::hash + CombineInstance::hash: h = B3(B3(pre2||on2) || B3(pre64||on64))
-__global__ void k_join(const uint32_t* __restrict__ pre2, const uint32_t* __restrict__ on2, const uint32_t* __restrict__ pre64,
-                       const uint32_t* __restrict__ on64, uint32_t R, uint8_t* __restrict__ h) {
+struct B_k_join {
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ pre2, const uint32_t* __restrict__ on2, const uint32_t* __restrict__ pre64, const uint32_t* __restrict__ on64, uint32_t R, uint8_t* __restrict__ h) const {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     uint32_t m[16], h2[8], h64[8], o[8];
@@ -909,6 +927,10 @@ __global__ void k_join(const uint32_t* __restrict__ pre2, const uint32_t* __rest
 #pragma unroll
     for (int k = 0; k < 8; k++) d[k] = o[k];
 }
+};
+__global__ void k_join(const uint32_t* __restrict__ pre2, const uint32_t* __restrict__ on2, const uint32_t* __restrict__ pre64, const uint32_t* __restrict__ on64, uint32_t R, uint8_t* __restrict__ h) {
+    B_k_join{}(pre2, on2, pre64, on64, R, h);
+}
 
 // verifier set-up: rows of `src` replace those of `dst` for the repetitions with (omit[r] < 8) == want_online
 // (opened player keys and carried-over online commitments arrive in ONE staging copy instead of one tiny
@@ -929,32 +951,41 @@ void launch_overlay_rows(hipStream_t st, uint32_t* d_dst, const uint32_t* d_src,
 struct Digest8 {
     uint32_t w[8];
 };
-__global__ void k_fill_digests(uint32_t* __restrict__ dst, uint32_t n_rows, Digest8 d) {
+struct B_k_fill_digests {
+    __device__ __forceinline__ void operator()(uint32_t* __restrict__ dst, uint32_t n_rows, Digest8 d) const {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_rows * 8) dst[i] = d.w[i & 7];
+}
+};
+__global__ void k_fill_digests(uint32_t* __restrict__ dst, uint32_t n_rows, Digest8 d) {
+    B_k_fill_digests{}(dst, n_rows, d);
 }
 void launch_fill_digests(hipStream_t st, uint32_t* d_dst, uint32_t n_rows, const uint32_t digest[8]) {
     Digest8 d;
     for (int k = 0; k < 8; k++) d.w[k] = digest[k];
-    hipLaunchKernelGGL(k_fill_digests, dim3((n_rows * 8 + 255) / 256), dim3(256), 0, st, d_dst, n_rows, d);
+    launch<B_k_fill_digests, 256>(k_fill_digests, st, dim3((n_rows * 8 + 255) / 256), dim3(256), d_dst, n_rows, d);
 }
 
 // start of the interpreter phase: clear the invalid-witness flag and the all-zero row (mask words, corr-bit words)
-__global__ void k_shard_init(int* __restrict__ err, uint32_t* __restrict__ zero_mask, uint32_t n_mask_words,
-                             uint8_t* __restrict__ zero_corr, uint32_t n_corr_bytes) {
+struct B_k_shard_init {
+    __device__ __forceinline__ void operator()(int* __restrict__ err, uint32_t* __restrict__ zero_mask, uint32_t n_mask_words, uint8_t* __restrict__ zero_corr, uint32_t n_corr_bytes) const {
     const uint32_t i = threadIdx.x;
     if (i == 0) *err = 0;
     if (i < n_mask_words) zero_mask[i] = 0;
     if (i < n_corr_bytes) zero_corr[i] = 0;
 }
+};
+__global__ void k_shard_init(int* __restrict__ err, uint32_t* __restrict__ zero_mask, uint32_t n_mask_words, uint8_t* __restrict__ zero_corr, uint32_t n_corr_bytes) {
+    B_k_shard_init{}(err, zero_mask, n_mask_words, zero_corr, n_corr_bytes);
+}
 void launch_shard_init(hipStream_t st, int* d_err, uint32_t* d_zero_mask, uint32_t n_mask_words, uint8_t* d_zero_corr,
                        uint32_t n_corr_bytes) {
-    hipLaunchKernelGGL(k_shard_init, dim3(1), dim3(64), 0, st, d_err, d_zero_mask, n_mask_words, d_zero_corr, n_corr_bytes);
+    launch<B_k_shard_init, 64>(k_shard_init, st, dim3(1), dim3(64), d_err, d_zero_mask, n_mask_words, d_zero_corr, n_corr_bytes);
 }
 
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
                  uint32_t R, uint8_t* d_h) {
-    hipLaunchKernelGGL(k_join, dim3((R + 63) / 64), dim3(64), 0, st, d_pre2, d_on2, d_pre64, d_on64, R, d_h);
+    launch<B_k_join, 64>(k_join, st, dim3((R + 63) / 64), dim3(64), d_pre2, d_on2, d_pre64, d_on64, R, d_h);
 }
 
 // ------------------------------------------------------------------------------------
@@ -999,10 +1030,8 @@ __device__ __forceinline__ void ex_flush(const uint8_t* s_buf, const uint64_t* s
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows,
-                                                      uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */,
-                                                      const uint8_t* __restrict__ omit /*[R]*/,
-                                                      const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out) {
+struct B_k_extract_rows {
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out) const {
     __shared__ uint8_t s_buf[RV_ONLINE_REPS * EX_TB];
     __shared__ uint32_t s_rows[8 * EX_TB];
     __shared__ uint8_t s_slot[256];
@@ -1053,13 +1082,17 @@ __global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict
     __syncthreads();
     ex_flush(s_buf, s_dst, n_slots, t0, nb, out);
 }
+};
+template <int KIND>
+__global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out) {
+    B_k_extract_rows<KIND>{}(stream, rows, n_items, NQ, tb, omit, dst_off, out);
+}
 
 // Bit-per-rep source (the preprocessing stream, [n][NQ/2] bytes; nibble bit k of quad q <-> repetition 4q+3-k):
 // the workgroup's 8*tb rows are contiguous in HBM and are copied to LDS in one coalesced pass; thread =
 // (output byte, opened repetition) then picks its 8 bits out of LDS.
-__global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ,
-                                                           uint32_t tb /* <= EX_TB */, const OnlineList* __restrict__ olp,
-                                                           uint8_t* __restrict__ out) {
+struct B_k_extract_from_bits {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const OnlineList* __restrict__ olp, uint8_t* __restrict__ out) const {
     __shared__ uint8_t s_buf[RV_ONLINE_REPS * EX_TB];
     __shared__ uint64_t s_dst[RV_ONLINE_REPS];
     __shared__ uint32_t s_pos[RV_ONLINE_REPS];  // byte in the row << 3 | bit in the byte
@@ -1100,6 +1133,10 @@ __global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __rest
     __syncthreads();
     ex_flush(s_buf, s_dst, n_ol, t0, nb, out);
 }
+};
+__global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const OnlineList* __restrict__ olp, uint8_t* __restrict__ out) {
+    B_k_extract_from_bits{}(bits, n_items, NQ, tb, olp, out);
+}
 
 static uint32_t ex_tb_for(uint64_t n_bytes) {
     // output bytes per workgroup: the full EX_TB when that still yields several workgroups per CU, fewer for
@@ -1113,7 +1150,7 @@ void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_
                               uint8_t* d_out) {
     const uint64_t n_bytes = n_items / 8 + 1;
     const uint32_t tb = ex_tb_for(n_bytes);
-    hipLaunchKernelGGL(k_extract_from_bits, dim3((unsigned)((n_bytes + tb - 1) / tb)), dim3(256), 0, st, d_bits, n_items, NQ, tb, d_ol,
+    launch<B_k_extract_from_bits, 256>(k_extract_from_bits, st, dim3((unsigned)((n_bytes + tb - 1) / tb)), dim3(256), d_bits, n_items, NQ, tb, d_ol,
                        d_out);
 }
 
@@ -1130,10 +1167,8 @@ void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_
 // How many of them are opened is only known here, so the section starts (online records, then preprocessing records,
 // per domain) are computed on the device from L.base[0] (= start of the output, 40 past it when framed) and returned
 // in res = {n_online_local, n_preprocessing_local}; omit_all (nullable) receives the full map for the host.
-__global__ __launch_bounds__(64) void k_fs_challenge(const uint8_t* __restrict__ h, FsLayout L, uint32_t rep_begin, uint32_t R,
-                                                     uint8_t* __restrict__ comm, uint8_t* __restrict__ omit,
-                                                     uint8_t* __restrict__ omit_all, uint64_t* __restrict__ offs,
-                                                     OnlineList* __restrict__ ol, uint32_t* __restrict__ res) {
+struct B_k_fs_challenge {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ h, FsLayout L, uint32_t rep_begin, uint32_t R, uint8_t* __restrict__ comm, uint8_t* __restrict__ omit, uint8_t* __restrict__ omit_all, uint64_t* __restrict__ offs, OnlineList* __restrict__ ol, uint32_t* __restrict__ res) const {
     __shared__ uint32_t s_cv[8][8], s_t1[4][8], s_t2[2][8], s_comm[8];
     __shared__ uint32_t s_msg[16];
     __shared__ uint8_t s_draw[128][2];
@@ -1173,6 +1208,12 @@ __global__ __launch_bounds__(64) void k_fs_challenge(const uint8_t* __restrict__
             comm[4 * i + 1] = blk[24 + 4 * i + 1] = (uint8_t)(s_comm[i] >> 8);
             comm[4 * i + 2] = blk[24 + 4 * i + 2] = (uint8_t)(s_comm[i] >> 16);
             comm[4 * i + 3] = blk[24 + 4 * i + 3] = (uint8_t)(s_comm[i] >> 24);
+            if (L.comm2) {
+                L.comm2[4 * i + 0] = (uint8_t)(s_comm[i]);
+                L.comm2[4 * i + 1] = (uint8_t)(s_comm[i] >> 8);
+                L.comm2[4 * i + 2] = (uint8_t)(s_comm[i] >> 16);
+                L.comm2[4 * i + 3] = (uint8_t)(s_comm[i] >> 24);
+            }
         }
         for (int i = 0; i < 16; i++)
             s_msg[i] = (uint32_t)blk[4 * i] | ((uint32_t)blk[4 * i + 1] << 8) | ((uint32_t)blk[4 * i + 2] << 16) |
@@ -1267,10 +1308,14 @@ __global__ __launch_bounds__(64) void k_fs_challenge(const uint8_t* __restrict__
         }
     }
 }
+};
+__global__ __launch_bounds__(64) void k_fs_challenge(const uint8_t* __restrict__ h, FsLayout L, uint32_t rep_begin, uint32_t R, uint8_t* __restrict__ comm, uint8_t* __restrict__ omit, uint8_t* __restrict__ omit_all, uint64_t* __restrict__ offs, OnlineList* __restrict__ ol, uint32_t* __restrict__ res) {
+    B_k_fs_challenge{}(h, L, rep_begin, R, comm, omit, omit_all, offs, ol, res);
+}
 
 void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint32_t rep_begin, uint32_t R, uint8_t* d_comm,
                          uint8_t* d_omit, uint8_t* d_omit_all, uint64_t* d_offs, OnlineList* d_ol, uint32_t* d_res) {
-    hipLaunchKernelGGL(k_fs_challenge, dim3(1), dim3(64), 0, st, d_h, L, rep_begin, R, d_comm, d_omit, d_omit_all, d_offs, d_ol, d_res);
+    launch<B_k_fs_challenge, 64>(k_fs_challenge, st, dim3(1), dim3(64), d_h, L, rep_begin, R, d_comm, d_omit, d_omit_all, d_offs, d_ol, d_res);
 }
 
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ,
@@ -1279,10 +1324,10 @@ void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d
     const uint32_t tb = ex_tb_for(n_bytes);
     const dim3 grid((unsigned)((n_bytes + tb - 1) / tb));
     if (kind == 0)
-        hipLaunchKernelGGL(k_extract_rows<0>, grid, dim3(256), 0, st, (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
+        launch<B_k_extract_rows<0>, 256>(k_extract_rows<0>, st, grid, dim3(256), (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
                            d_dst_off, d_out);
     else
-        hipLaunchKernelGGL(k_extract_rows<1>, grid, dim3(256), 0, st, (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
+        launch<B_k_extract_rows<1>, 256>(k_extract_rows<1>, st, grid, dim3(256), (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
                            d_dst_off, d_out);
 }
 
@@ -1360,11 +1405,8 @@ __device__ inline void put_u64(uint8_t* p, uint64_t v) {
     for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
 }
 
-__global__ void k_open_headers(uint32_t R, const uint8_t* __restrict__ omit, const uint8_t* __restrict__ seeds,
-                               const uint8_t* __restrict__ keys, const uint32_t* __restrict__ on2,
-                               const uint32_t* __restrict__ on64, const uint64_t* __restrict__ off2,
-                               const uint64_t* __restrict__ off64, uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r,
-                               uint64_t l64c, uint64_t l64i, uint8_t* __restrict__ out) {
+struct B_k_open_headers {
+    __device__ __forceinline__ void operator()(uint32_t R, const uint8_t* __restrict__ omit, const uint8_t* __restrict__ seeds, const uint8_t* __restrict__ keys, const uint32_t* __restrict__ on2, const uint32_t* __restrict__ on64, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ off64, uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i, uint8_t* __restrict__ out) const {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const uint32_t om = omit[r];
@@ -1386,11 +1428,15 @@ __global__ void k_open_headers(uint32_t R, const uint8_t* __restrict__ omit, con
         }
     }
 }
+};
+__global__ void k_open_headers(uint32_t R, const uint8_t* __restrict__ omit, const uint8_t* __restrict__ seeds, const uint8_t* __restrict__ keys, const uint32_t* __restrict__ on2, const uint32_t* __restrict__ on64, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ off64, uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i, uint8_t* __restrict__ out) {
+    B_k_open_headers{}(R, omit, seeds, keys, on2, on64, off2, off64, l2r, l2c, l2i, l64r, l64c, l64i, out);
+}
 
 void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys,
                          const uint32_t* d_on2, const uint32_t* d_on64, const uint64_t* d_off2, const uint64_t* d_off64,
                          uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i, uint8_t* d_out) {
-    hipLaunchKernelGGL(k_open_headers, dim3((R + 63) / 64), dim3(64), 0, st, R, d_omit, d_seeds, d_keys, d_on2, d_on64, d_off2,
+    launch<B_k_open_headers, 64>(k_open_headers, st, dim3((R + 63) / 64), dim3(64), R, d_omit, d_seeds, d_keys, d_on2, d_on64, d_off2,
                        d_off64, l2r, l2c, l2i, l64r, l64c, l64i, d_out);
 }
 
