@@ -241,6 +241,7 @@ struct PinnedPool {
         void* p;
         size_t cap;
         bool used;
+        size_t shares = 0;  // > 0: the buffer was handed out as that many slices (rv_prove_batch); put() of a slice drops one
     };
     std::mutex mu;
     std::vector<Buf> bufs;
@@ -265,14 +266,27 @@ struct PinnedPool {
         bufs.push_back(Buf{p, cap, true});
         return p;
     }
+    // the buffer `base` now belongs to `n` slices, each released on its own through put(any address inside)
+    void share(void* base, size_t n) {
+        std::lock_guard<std::mutex> g(mu);
+        for (Buf& b : bufs)
+            if (b.p == base) b.shares = n;
+    }
     bool put(void* p) {
         std::lock_guard<std::mutex> g(mu);
         bool found = false;
-        for (Buf& b : bufs)
-            if (b.p == p) {
+        for (Buf& b : bufs) {
+            if (b.shares) {
+                if ((const uint8_t*)p >= (const uint8_t*)b.p && (const uint8_t*)p < (const uint8_t*)b.p + b.cap) {
+                    found = true;
+                    if (--b.shares == 0) b.used = false;
+                    else return true;
+                }
+            } else if (b.p == p) {
                 b.used = false;
                 found = true;
             }
+        }
         if (!found) return false;
         size_t idle = 0;
         for (const Buf& b : bufs) idle += !b.used;
@@ -1548,31 +1562,30 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
         memcpy(&err, staging + slot * batch + b * sizeof(int), sizeof err);
         if (err) return cleanup(RV_E_WITNESS_INVALID);
     }
-    for (size_t b = 0; b < batch; b++) {
-        proofs[b] = (uint8_t*)out_alloc(proof_lens[b]);
-        if (!proofs[b]) return cleanup(RV_E_NOMEM);
-    }
     {
-        // staging -> the caller's buffers: tens of MB into freshly mapped pages (first-touch faults), so a few host
-        // threads share it (12 -> 3 ms for 256 SHA-256 proofs)
-        auto copy_range = [&](size_t b0, size_t b1) {
-            const uint64_t counts[4] = {RV_ONLINE_REPS, RV_PREPROCESSING_REPS, RV_ONLINE_REPS, RV_PREPROCESSING_REPS};
-            for (size_t b = b0; b < b1; b++) {
+        // The proofs are handed out where they landed: slices of the page-locked staging buffer, which returns to the
+        // pool when the last of them has been rv_free'd (no second copy into 256 freshly mapped buffers, no 256
+        // munmaps in the caller: together they cost more than the GPU work of an AES-128 batch).  RV_BATCH_COPY_OUT=1
+        // gives every proof its own malloc'ed buffer instead (callers that keep single proofs of many batches alive).
+        static const bool copy_out = getenv("RV_BATCH_COPY_OUT") != nullptr;
+        const uint64_t counts[4] = {RV_ONLINE_REPS, RV_PREPROCESSING_REPS, RV_ONLINE_REPS, RV_PREPROCESSING_REPS};
+        if (copy_out) {
+            for (size_t b = 0; b < batch; b++) {
+                proofs[b] = (uint8_t*)malloc(proof_lens[b]);
+                if (!proofs[b]) return cleanup(RV_E_NOMEM);
                 memcpy(proofs[b], staging + b * slot, proof_lens[b]);
-                size_t off = 32;
-                for (int k = 0; k < 4; k++) {
-                    put_le64(proofs[b] + off, counts[k]);
-                    off += 8 + lens[k];
-                }
             }
-        };
-        const size_t n_thr = (batch * total >= ((size_t)8 << 20)) ? std::min<size_t>({(size_t)8, batch, (size_t)std::max(1u, std::thread::hardware_concurrency())}) : 1;
-        if (n_thr <= 1) {
-            copy_range(0, batch);
         } else {
-            std::vector<std::thread> th;
-            for (size_t t = 0; t < n_thr; t++) th.emplace_back(copy_range, batch * t / n_thr, batch * (t + 1) / n_thr);
-            for (auto& x : th) x.join();
+            g_pinned.share(staging, batch);
+            for (size_t b = 0; b < batch; b++) proofs[b] = staging + b * slot;
+            staging = nullptr;  // owned by the proofs now
+        }
+        for (size_t b = 0; b < batch; b++) {
+            size_t off = 32;
+            for (int k = 0; k < 4; k++) {
+                put_le64(proofs[b] + off, counts[k]);
+                off += 8 + lens[k];
+            }
         }
     }
     ctx->prof.calls += batch;
