@@ -1371,6 +1371,27 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
         ctx->prof.calls += batch;
         return RV_OK;
     }
+    {
+        // a call keeps one proof's working set (scratch_bytes) per proof resident, and the proof index travels in
+        // gridDim.y: larger batches run as consecutive chunks that fit half of the free HBM (at most 4 096 proofs)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return RV_E_DEVICE;
+        const size_t per_proof = std::max<size_t>(cc.info.scratch_bytes, 1);
+        size_t chunk = std::min<size_t>(std::max<size_t>((free_b + ctx->cached_bytes) / 2 / per_proof, 1), 4096);
+        if (const char* e = getenv("RV_BATCH_MAX")) chunk = std::min<size_t>(chunk, (size_t)std::max(atoi(e), 1));  // tests
+        if (batch > chunk) {
+            for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+                const size_t n = std::min(chunk, batch - b0);
+                const int rcc = rv_prove_batch_impl(ctx, c, n, wit_gf2 ? wit_gf2 + b0 * n_gf2 : nullptr, n_gf2, nullptr, 0,
+                                                    seeds + b0 * RV_TOTAL_REPS * 16, proofs + b0, proof_lens + b0);
+                if (rcc) {
+                    for (size_t k = 0; k < b0; k++) rv_free(proofs[k]), proofs[k] = nullptr, proof_lens[k] = 0;
+                    return rcc;
+                }
+            }
+            return RV_OK;
+        }
+    }
     const bool was_pipelined = ctx->pipeline;
     ctx->pipeline = false;  // everything of a batch goes down ONE stream
     std::vector<rv_shard*> sh(batch, nullptr);

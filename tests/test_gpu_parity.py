@@ -369,6 +369,33 @@ def test_full_size_properties(rv, rule_seeds):
     assert not rv.Proof(bytes(bad)).verify(c)
 
 
+def test_prove_batch_chunks_and_buffer_modes(rv, oracle, monkeypatch):
+    """A batch larger than what one pass may hold runs as consecutive chunks (forced here with RV_BATCH_MAX), and the
+    proofs come out either as slices of one page-locked buffer (default) or as separate buffers
+    (RV_BATCH_COPY_OUT=1): the same bytes every time, freed in any order."""
+    rng = np.random.default_rng(31)
+    prog, wit, wc = circuits.random_gf2(rng, n_in=10, n_gates=500, n_wires=30)
+    c = rv.Circuit(prog, wc)
+    nb = 11
+    seeds = rng.integers(0, 256, (nb, 256, 16), dtype=np.uint8)
+    wits = np.tile(np.asarray(wit, np.uint8), (nb, 1))
+    want = [bytes(rv.Proof.new(c, wit, [], seeds=seeds[b])) for b in range(nb)]
+    assert want[3] == oracle.prove(prog, wit, [], wc, seeds[3], threads=2)
+    for env in ({}, {"RV_BATCH_MAX": "4"}, {"RV_BATCH_COPY_OUT": "1"}, {"RV_BATCH_MAX": "1"}):
+        for k in ("RV_BATCH_MAX", "RV_BATCH_COPY_OUT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = rv.Proof.new_batch(c, wits, seeds=seeds)
+        keep = [bytes(g) for g in got]
+        # release out of order, with a new batch in between (the shared buffer must survive until its last slice goes)
+        del got[::2]
+        again = rv.Proof.new_batch(c, wits[:3], seeds=seeds[:3])
+        assert [bytes(g) for g in got] == keep[1::2]
+        del got
+        assert keep == want and [bytes(g) for g in again] == want[:3]
+
+
 def test_prove_batch_equals_single_proofs(rv, oracle, rule_seeds):
     """rv_prove_batch: B proofs of one circuit, different witnesses and seeds, must each equal the single-proof entry
     point and the oracle — on a circuit with narrow runs of both kinds and launched levels (AES-128: valid and
