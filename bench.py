@@ -298,6 +298,9 @@ def main():
             "note": "dominant phase by HIP-event time on the library's own stream (phases of a proof run back to back on one stream); "
                     "achieved = its algorithmic HBM bytes per proof (DESIGN.md §4) / that time, both from the timed run itself; traffic = PMC-measured HBM bytes per proof for that kernel "
                     "(all its launches). The mask and hash phases are integer-VALU-bound (bitsliced AES, BLAKE3): no MFMA on this path.",
+            # the dominant phase is a chain of launches (interpreter: one per dependency level); per launch:
+            "launches_per_proof": launches[dom], "avg_launch_us": tphase[dom] * 1e3 / max(launches[dom], 1),
+            "algorithmic_bytes_per_launch": alg[dom] / max(launches[dom], 1),
             "phase_ms_isolated": tphase, "phase_ms_timed_run": phases, "phase_launches": launches,
             "algorithmic_bytes": {k: int(v) for k, v in alg.items()},
         }
