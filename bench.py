@@ -341,6 +341,25 @@ def main():
         result["parity"] = parity
         if not all(v for k, v in parity.items() if k != "proof_bytes"):
             result["value"] = 0.0
+    if world > 1:
+        # informational, outside the timed region: the same N GPUs proving N INDEPENDENT statements, one whole proof
+        # (256 repetitions) per rank and no collective -- weak scaling, what a proving service with a queue of
+        # statements would run.  `value` above stays the north-star's sharded single proof (strong scaling).
+        n_ind = max(args.steps // 2, 3)
+        whole = HipShardBackend(circuit)
+        buf = torch.empty(max(sum(whole.single_shard_sizes()), 1), dtype=torch.uint8, device="cuda")
+        whole.prove_device(wit, [], seeds, buf)
+        sync_all()
+        ti = time.perf_counter()
+        for _ in range(n_ind):
+            whole.prove_device(wit, [], seeds, buf)
+        sync_all()
+        ti = torch.tensor([time.perf_counter() - ti], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ti, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            result["independent_proofs"] = {"value": n_and * n_ind * world / float(ti.item()), "unit": "AND gates/s", "scaling": "weak",
+                                            "ms_per_proof_per_gpu": float(ti.item()) / n_ind * 1e3, "proofs": n_ind * world,
+                                            "note": "one whole proof per GPU at a time, no collective"}
     if rank == 0 and world == 1 and args.two_in_flight:
         # informational, outside the timed region: the same workload with TWO proofs in flight (two contexts, two host
         # threads) -- one proof's VALU-bound phases overlap the other's memory-bound interpreter.  `value` above stays
