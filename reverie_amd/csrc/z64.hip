@@ -6,9 +6,9 @@
 //   interpreter/combine.rs:19-36,132-219      recon_gf2_to_z64 and the Z64 half of B2A
 //   transcript/{prover,verifier/*}.rs         the same transcript rules as GF(2)
 //
-// Lane mapping: one lane = one (repetition, player) slot, 8 adjacent lanes = one
-// repetition; reconstruct = 3-step shuffle-add inside the 8-lane group.  A gate occupies
-// R*8 lanes (32 wavefronts at R = 256).
+// Lane mapping: one lane = two players of one repetition (16-byte accesses), 4 adjacent lanes = one
+// repetition; reconstruct = a local add + 2-step shuffle-add inside the 4-lane group.  A gate occupies
+// R*4 lanes (16 wavefronts at R = 256).
 #include "b3.h"
 #include "internal.h"
 
@@ -33,95 +33,133 @@ __device__ __forceinline__ uint32_t recon32_(uint32_t t) {
     return (t << 8) - t;
 }
 
+// Two players per lane: every row access is a 16-byte load/store (twice the bytes in flight per wavefront of the
+// first, one-u64-per-lane version, which ran at 2.7 TB/s), a gate occupies R*4 lanes and the player sum is one local
+// add plus two shuffle steps inside the 4-lane group of a repetition.
+struct U2 {
+    uint64_t x, y;
+};
+__device__ __forceinline__ U2 ld2(const uint64_t* p) {
+    const ulonglong2 v = *(const ulonglong2*)p;
+    return U2{v.x, v.y};
+}
+__device__ __forceinline__ void st2(uint64_t* p, U2 v) { *(ulonglong2*)p = make_ulonglong2(v.x, v.y); }
+// transcript words are only 8-byte aligned (an odd number of 8-byte events may precede a 64-byte one)
+__device__ __forceinline__ void st2_unaligned(uint64_t* p, U2 v) {
+    p[0] = v.x;
+    p[1] = v.y;
+}
+__device__ __forceinline__ uint64_t sum8(U2 v) {
+    uint64_t t = v.x + v.y;
+    t += shfl_xor64(t, 1);
+    t += shfl_xor64(t, 2);
+    return t;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gates, uint32_t lo, uint32_t hi, Interp64Params p) {
-    const uint32_t S = p.R * 8;
+    const uint32_t S = p.R * 8;   // u64 per row
+    const uint32_t S2 = p.R * 4;  // lanes per gate
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t l = tid % S;
-    const uint32_t r = l >> 3, pl = l & 7;
-    const uint32_t worker = tid / S, n_workers = (gridDim.x * blockDim.x) / S;
+    const uint32_t l = tid % S2;
+    const uint32_t r = l >> 2, pk = l & 3;  // this lane holds players 2*pk and 2*pk + 1 of repetition r
+    const uint32_t worker = tid / S2, n_workers = (gridDim.x * blockDim.x) / S2;
     const uint32_t om = (MODE == MODE_VERIFY) ? p.omit[r] : 8u;
     const bool online = om < 8;  // online-verified repetition (MODE_VERIFY only)
+    const bool mine = (om >> 1) == pk;  // the omitted player sits in this lane (slot om & 1)
     for (uint32_t gi = lo + worker; gi < hi; gi += n_workers) {
         const Gate64 g = gates[gi];
-        uint64_t* dm = p.wmask + (size_t)g.dst * S + l;
+        uint64_t* dm = p.wmask + (size_t)g.dst * S + 2 * l;
         uint64_t* dc = p.wcorr + (size_t)g.dst * p.R + r;
-        const uint64_t* am = p.wmask + (size_t)g.a * S + l;
+        const uint64_t* am = p.wmask + (size_t)g.a * S + 2 * l;
         const uint64_t* ac = p.wcorr + (size_t)g.a * p.R + r;
-        const uint64_t* bm = p.wmask + (size_t)g.b * S + l;
+        const uint64_t* bm = p.wmask + (size_t)g.b * S + 2 * l;
         const uint64_t* bc = p.wcorr + (size_t)g.b * p.R + r;
         switch (g.op) {
         case G64_INPUT: {
-            const uint64_t lam = p.masks[(size_t)g.m * S + l];
+            const U2 lam = ld2(p.masks + (size_t)g.m * S + 2 * l);
             uint64_t corr;
             if (MODE == MODE_PROVE)
                 corr = p.wit[g.x] - sum8(lam);
             else
                 corr = online ? p.sup_in[(size_t)g.x * p.R + r] : 0;
-            *dm = lam;
-            if (pl == 0) {
+            st2(dm, lam);
+            if (pk == 0) {
                 *dc = corr;
                 p.on[(size_t)r * p.on_words + g.eo] = corr;
             }
             break;
         }
-        case G64_ADD:
-            *dm = *am + *bm;
-            if (pl == 0) *dc = *ac + *bc;
+        case G64_ADD: {
+            const U2 x = ld2(am), y = ld2(bm);
+            st2(dm, U2{x.x + y.x, x.y + y.y});
+            if (pk == 0) *dc = *ac + *bc;
             break;
-        case G64_SUB:
-            *dm = *am - *bm;
-            if (pl == 0) *dc = *ac - *bc;
+        }
+        case G64_SUB: {
+            const U2 x = ld2(am), y = ld2(bm);
+            st2(dm, U2{x.x - y.x, x.y - y.y});
+            if (pk == 0) *dc = *ac - *bc;
             break;
+        }
         case G64_ADDC:
-            *dm = *am;
-            if (pl == 0) *dc = *ac + g.imm;
+            st2(dm, ld2(am));
+            if (pk == 0) *dc = *ac + g.imm;
             break;
         case G64_SUBC:
-            *dm = *am;
-            if (pl == 0) *dc = *ac - g.imm;
+            st2(dm, ld2(am));
+            if (pk == 0) *dc = *ac - g.imm;
             break;
-        case G64_MULC:
-            *dm = *am * g.imm;
-            if (pl == 0) *dc = *ac * g.imm;
+        case G64_MULC: {
+            const U2 x = ld2(am);
+            st2(dm, U2{x.x * g.imm, x.y * g.imm});
+            if (pk == 0) *dc = *ac * g.imm;
             break;
+        }
         case G64_CONST:
-            *dm = 0;
-            if (pl == 0) *dc = g.imm;
+            st2(dm, U2{0, 0});
+            if (pk == 0) *dc = g.imm;
             break;
         case G64_RANDOM:
-            *dm = p.masks[(size_t)g.m * S + l];
-            if (pl == 0) *dc = 0;
+            st2(dm, ld2(p.masks + (size_t)g.m * S + 2 * l));
+            if (pk == 0) *dc = 0;
             break;
         case G64_MUL: {
-            const uint64_t lx = *am, cx = *ac, ly = *bm, cy = *bc;
-            const uint64_t lab = p.masks[(size_t)g.m * S + l], lnew = p.masks[(size_t)(g.m + 1) * S + l];
+            const U2 lx = ld2(am), ly = ld2(bm);
+            const U2 lab = ld2(p.masks + (size_t)g.m * S + 2 * l), lnew = ld2(p.masks + (size_t)(g.m + 1) * S + 2 * l);
+            const uint64_t cx = *ac, cy = *bc;
             const uint64_t a = sum8(lx), b = sum8(ly), c = sum8(lab);
             uint64_t delta = a * b - c;
-            uint64_t s = ly * cx + lx * cy + lab - lnew;
+            U2 s{ly.x * cx + lx.x * cy + lab.x - lnew.x, ly.y * cx + lx.y * cy + lab.y - lnew.y};
             if (MODE == MODE_VERIFY && online) {
                 delta = p.sup_corr[(size_t)g.xc * p.R + r];
-                if (pl == om) s += p.sup_rec[(size_t)g.x * p.R + r];
+                if (mine) {
+                    const uint64_t sup = p.sup_rec[(size_t)g.x * p.R + r];
+                    if (om & 1) s.y += sup; else s.x += sup;
+                }
             }
-            p.on[(size_t)r * p.on_words + g.eo + pl] = s;
+            st2_unaligned(p.on + (size_t)r * p.on_words + g.eo + 2 * pk, s);
             uint64_t rec = sum8(s);
             if (MODE == MODE_VERIFY && !online) rec = 0;
-            *dm = lnew;
-            if (pl == 0) {
+            st2(dm, lnew);
+            if (pk == 0) {
                 p.pre[(size_t)r * p.pre_words + g.ep] = delta;
                 *dc = rec + delta + cx * cy;
             }
             break;
         }
         case G64_ASSERT: {
-            uint64_t m = *am;
-            if (MODE == MODE_VERIFY && online && pl == om) m += p.sup_rec[(size_t)g.x * p.R + r];
-            p.on[(size_t)r * p.on_words + g.eo + pl] = m;
+            U2 m = ld2(am);
+            if (MODE == MODE_VERIFY && online && mine) {
+                const uint64_t sup = p.sup_rec[(size_t)g.x * p.R + r];
+                if (om & 1) m.y += sup; else m.x += sup;
+            }
+            st2_unaligned(p.on + (size_t)r * p.on_words + g.eo + 2 * pk, m);
             {
                 const uint64_t v = sum8(m) + *ac;
                 if (MODE == MODE_PROVE) {
-                    if (v != 0 && pl == 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
-                } else if (online && v != 0 && pl == 0) {
+                    if (v != 0 && pk == 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+                } else if (online && v != 0 && pk == 0) {
                     atomicOr(p.err, RV_DEV_ZERO_CHECK);  // online.rs:175-177 (read by RV_VERIFY_STRICT only)
                 }
             }
@@ -138,11 +176,11 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
                 const uint32_t v = p.corr2[(size_t)(g.a + k) * (p.NQ >> 1) + (qw >> 1)];
                 zrec |= (uint64_t)((v >> (4 * (qw & 1) + 3 - (r & 3))) & 1u) << k;
             }
-            const uint64_t mu = p.masks[(size_t)g.m * S + l];
+            const U2 mu = ld2(p.masks + (size_t)g.m * S + 2 * l);
             uint64_t kappa = zval - sum8(mu);
             if (MODE == MODE_VERIFY && online) kappa = p.sup_corr[(size_t)g.xc * p.R + r];
-            *dm = 0 - mu;
-            if (pl == 0) {
+            st2(dm, U2{0 - mu.x, 0 - mu.y});
+            if (pk == 0) {
                 p.pre[(size_t)r * p.pre_words + g.ep] = kappa;
                 *dc = zrec - kappa;
             }
@@ -156,10 +194,10 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
 
 void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t lo, uint32_t hi, const Interp64Params& p) {
     if (hi <= lo) return;
-    const uint64_t S = (uint64_t)p.R * 8;
-    const uint64_t want = (uint64_t)(hi - lo) * S;
+    const uint64_t S2 = (uint64_t)p.R * 4;  // lanes per gate
+    const uint64_t want = (uint64_t)(hi - lo) * S2;
     uint64_t blocks = (want + 255) / 256;
-    const uint64_t cap = ((uint64_t)8192 * 256 / S) * S / 256;  // whole workers only
+    const uint64_t cap = ((uint64_t)8192 * 256 / S2) * S2 / 256;  // whole workers only
     if (blocks > cap) blocks = cap;
     if (mode == MODE_PROVE)
         hipLaunchKernelGGL(k_interp64<MODE_PROVE>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, lo, hi, p);
