@@ -18,13 +18,6 @@ __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
     const uint32_t lo = __shfl_xor((uint32_t)v, m), hi = __shfl_xor((uint32_t)(v >> 32), m);
     return ((uint64_t)hi << 32) | lo;
 }
-// DomainZ64::reconstruct (z64/domain.rs:53-61): wrapping sum over the 8 players
-__device__ __forceinline__ uint64_t sum8(uint64_t v) {
-    v += shfl_xor64(v, 1);
-    v += shfl_xor64(v, 2);
-    v += shfl_xor64(v, 4);
-    return v;
-}
 __device__ __forceinline__ uint32_t recon32_(uint32_t t) {
     t ^= t >> 4;
     t ^= t >> 2;
@@ -49,6 +42,7 @@ __device__ __forceinline__ void st2_unaligned(uint64_t* p, U2 v) {
     p[0] = v.x;
     p[1] = v.y;
 }
+// DomainZ64::reconstruct (z64/domain.rs:53-61): wrapping sum over the 8 players
 __device__ __forceinline__ uint64_t sum8(U2 v) {
     uint64_t t = v.x + v.y;
     t += shfl_xor64(t, 1);
