@@ -720,3 +720,34 @@ def test_strict_verify_omit_must_match_challenge(rv, oracle, rule_seeds):
     for pf, want in ((honest, (True, True)), (forged, (True, False))):
         assert (rv.Proof(pf).verify(c), rv.Proof(pf).verify(c, strict=True)) == want
         assert (oracle.verify(prog, wc, pf), oracle.verify(prog, wc, pf, strict=True)) == want
+
+
+# ---------------------------------------------------------------- boundary shapes
+@pytest.mark.parametrize("n_in,width,layers,p_and", [
+    (1, 1, 40, 0.5), (127, 63, 9, 0.5), (128, 64, 9, 1.0), (129, 65, 9, 0.5), (5, 255, 12, 0.5), (64, 256, 12, 0.7),
+    (300, 257, 12, 0.5), (2, 513, 5, 0.5), (1000, 1025, 4, 0.3), (16, 4097, 3, 0.5), (4096, 8192, 2, 0.0)])
+def test_level_width_boundaries_vs_oracle(rv, oracle, n_in, width, layers, p_and):
+    """Level widths around the kernels' switch points (one gate per wavefront <-> unrolled class loops at 32 gates, the
+    single-workgroup narrow runs <-> one launch per level at 256, the 1 024-record LDS window, the 4 096-workgroup cap)
+    and input counts around the 128-mask AES block; an all-XOR circuit has no Mul at all.  Whole proofs against the
+    oracle, as one shard and as 32-repetition shards."""
+    from reverie_amd.dist import HipShardBackend, assemble
+    from reverie_amd.proof import challenge, combine_digests
+
+    prog, wit, wc, st = circuits.layered_gf2(n_in=n_in, width=width, layers=layers, p_and=p_and, seed=n_in * 7919 + width, fold_to=width)
+    seeds = np.random.default_rng(width).integers(0, 256, (256, 16), dtype=np.uint8)
+    want = oracle.prove(prog, wit, [], wc, seeds, threads=4)
+    c = rv.Circuit(prog, wc)
+    got = rv.Proof.new(c, wit, [], seeds=seeds)
+    assert bytes(got) == want
+    assert got.verify(c, strict=True)
+    be = HipShardBackend(c)
+    shards = [be.commit(wit, [], seeds[b:b + 32], b, 32) for b in range(0, 256, 32)]
+    try:
+        comm = combine_digests(np.concatenate([be.digests(s) for s in shards]))
+        omit = challenge(comm)
+        parts = [be.open(s, omit)[:2] for s in shards]
+    finally:
+        for s in shards:
+            be.destroy(s)
+    assert assemble(comm, parts) == want
