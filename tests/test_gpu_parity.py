@@ -751,3 +751,46 @@ def test_level_width_boundaries_vs_oracle(rv, oracle, n_in, width, layers, p_and
         for s in shards:
             be.destroy(s)
     assert assemble(comm, parts) == want
+
+
+@pytest.mark.parametrize("n_shards", [2, 8])
+def test_mixed_circuit_shards_vs_oracle(rv, oracle, n_shards):
+    """GF(2) + Z64 + B2A circuits as repetition shards (the Z64 interpreter keeps two players per lane, four lanes per
+    repetition, whatever the shard width): prover shards against the oracle's proof, verifier shards against
+    rv_verify, odd numbers of Z64 inputs in front of the 64-byte transcript events included."""
+    from reverie_amd import _lib
+    from reverie_amd.dist import HipShardBackend, assemble
+    from reverie_amd.proof import challenge, combine_digests
+
+    L = _lib.lib()
+    for seed in (11, 12, 13):
+        rng = np.random.default_rng(seed)
+        prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=250)
+        seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+        want = oracle.prove(prog, w2, w64, wc, seeds, threads=4)
+        c = rv.Circuit(prog, wc)
+        be = HipShardBackend(c)
+        n = 256 // n_shards
+        shards = [be.commit(w2, w64, seeds[b:b + n], b, n) for b in range(0, 256, n)]
+        try:
+            comm = combine_digests(np.concatenate([be.digests(s) for s in shards]))
+            omit = challenge(comm)
+            parts = [be.open(s, omit)[:2] for s in shards]
+        finally:
+            for s in shards:
+                be.destroy(s)
+        assert assemble(comm, parts) == want
+        # sharded verifier: slot ranges of 256 / n_shards, then the final check
+        buf = np.frombuffer(want, np.uint8)
+        dig = np.zeros((256, 32), np.uint8)
+        zc_all = 1
+        for b in range(0, 256, n):
+            zc = C.c_int(1)
+            part = np.zeros((n, 32), np.uint8)
+            _lib.check(L.rv_verify_shard_ex(c.ctx.handle, c.handle, _p(buf), C.c_size_t(len(buf)), C.c_uint32(b), C.c_uint32(n), _p(part),
+                                            C.byref(zc)))
+            dig[b:b + n] = part
+            zc_all &= zc.value
+        ok = C.c_int()
+        _lib.check(L.rv_verify_finish_ex(_p(buf), C.c_size_t(len(buf)), _p(dig), C.c_uint32(1), C.c_int(zc_all), C.byref(ok)))
+        assert ok.value == 1 and zc_all == 1
