@@ -1423,6 +1423,9 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
     // circuit.  Each proof's string is RECORDED (launch.h) instead of launched, then every step is issued once for the
     // whole batch (gridDim.y = proof, arguments from a device array): 35 launches per batch instead of 35 per proof.
     std::vector<LaunchRecorder> recs(batch);
+    struct RecorderOff {  // whatever way this function is left (an exception included), launches go to the stream again
+        ~RecorderOff() { g_recorder = nullptr; }
+    } recorder_off;
     static const bool stats = getenv("RV_BATCH_STATS") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
