@@ -485,8 +485,9 @@ static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t
         return (uint64_t)cus;
     }();
     // recorded for a batch of proofs (rv_prove_batch): the batch supplies the parallelism, so a proof's share of the
-    // chip is one workgroup per quad group -- each workgroup fills 88 KiB of LDS with round keys before its first block
-    const uint64_t wgs = g_recorder ? (uint64_t)n_qg : target_wgs;
+    // chip is its 1/batch of the workgroups, at least one per quad group -- each workgroup fills 88 KiB of LDS with
+    // round keys before its first block
+    const uint64_t wgs = g_recorder ? std::max<uint64_t>(n_qg, target_wgs / std::max(g_recorder->batch, 1u)) : target_wgs;
     uint64_t per = (n_blocks * n_qg + wgs - 1) / wgs;
     per = ((per + 8 * JW - 1) / (8 * JW)) * (8 * JW);
     const uint64_t chunks = (n_blocks + per - 1) / per;

@@ -1333,7 +1333,11 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
     };
     if (batch == 1 || !cc.gates64.empty()) return one_by_one();
     HIPCHK(hipSetDevice(ctx->device));
-    if (cc.gates.size() >= (size_t)1 << 20) {
+    static const size_t big_gates = [] {
+        const char* e = getenv("RV_BATCH_BIG_GATES");  // circuits from this many gates on take the two-proofs-in-flight path
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 20;
+    }();
+    if (cc.gates.size() >= big_gates) {
         // Large circuits fill the GPU on their own; what is left to gain is overlapping one proof's VALU-bound phases
         // (masks, digests) with another's memory-bound interpreter.  Two host threads, each with its own worker
         // context (stream + arena; the circuit's device arrays are shared read-only), prove alternate statements
@@ -1423,6 +1427,7 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
     // circuit.  Each proof's string is RECORDED (launch.h) instead of launched, then every step is issued once for the
     // whole batch (gridDim.y = proof, arguments from a device array): 35 launches per batch instead of 35 per proof.
     std::vector<LaunchRecorder> recs(batch);
+    for (auto& r : recs) r.batch = (unsigned)batch;
     struct RecorderOff {  // whatever way this function is left (an exception included), launches go to the stream again
         ~RecorderOff() { g_recorder = nullptr; }
     } recorder_off;

@@ -70,6 +70,7 @@ struct LaunchRecorder {
         std::vector<uint8_t> args;
     };
     std::vector<Call> calls;
+    unsigned batch = 1;  // proofs the recorded calls will be replayed for (launchers may size their grids by it)
 };
 // the recorder of the calling thread (null: launches go straight to the stream)
 inline thread_local LaunchRecorder* g_recorder = nullptr;
