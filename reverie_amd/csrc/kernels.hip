@@ -1119,16 +1119,27 @@ struct B_k_extract_from_bits {
         s_pos[threadIdx.x] = ((r >> 3) << 3) | (4 * ((r >> 2) & 1) + 3 - (r & 3));
     }
     __syncthreads();
-    for (uint32_t idx = threadIdx.x; idx < nb * n_ol; idx += 256) {
-        const uint32_t k = idx % n_ol, tl = idx / n_ol;
-        const uint32_t pos = s_pos[k], byte = pos >> 3, bit = pos & 7;
-        uint32_t acc = 0;
+    // thread = (opened repetition k, output-byte lane): k, and with it the byte / bit it picks out of a row, stay in
+    // registers for the whole loop (an index split per output byte cost 4x the instructions: 123 -> 45 us per proof)
+    {
+        const uint32_t lanes = 256 / n_ol;  // output bytes in flight per repetition
+        const uint32_t k = threadIdx.x % n_ol, tlane = threadIdx.x / n_ol;
+        if (tlane < lanes) {
+            const uint32_t pos = s_pos[k], bit = pos & 7;
+            const uint8_t* col = s_pre + (pos >> 3);
+            const uint32_t full = n_rows / 8;  // output bytes whose eight rows all exist
+            for (uint32_t tl = tlane; tl < nb; tl += lanes) {
+                uint32_t acc = 0;
+                if (tl < full) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t row = 8 * tl + j;
-            if (row < n_rows) acc |= (((uint32_t)s_pre[row * h + byte] >> bit) & 1u) << (7 - j);
+                    for (int j = 0; j < 8; j++) acc |= (((uint32_t)col[(8 * tl + j) * h] >> bit) & 1u) << (7 - j);
+                } else {
+                    for (uint32_t j = 0; j < 8; j++)
+                        if (8 * tl + j < n_rows) acc |= (((uint32_t)col[(8 * tl + j) * h] >> bit) & 1u) << (7 - j);
+                }
+                s_buf[k * EX_TB + tl] = (uint8_t)acc;
+            }
         }
-        s_buf[k * EX_TB + tl] = (uint8_t)acc;
     }
     __syncthreads();
     ex_flush(s_buf, s_dst, n_ol, t0, nb, out);
