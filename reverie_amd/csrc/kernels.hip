@@ -271,7 +271,10 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
                 cb[u][i] = p.corr[(size_t)g[u].b[i] * H + (q >> 1)];
             }
         }
-        lab[u] = p.rows[(size_t)g[u].m * NQ + q];
+        // lambda_ab is read exactly once and the online row is not read again before the hash phase: nontemporal, so
+        // they do not displace operand rows from L2 (interpreter 2.35 -> 2.30 ms; lambda_new -- the output wire's mask,
+        // an operand of the next level -- and the XOR outputs are better left as plain accesses: 2.35 / 2.38)
+        lab[u] = __builtin_nontemporal_load(&p.rows[(size_t)g[u].m * NQ + q]);
         lnew[u] = p.rows[(size_t)(g[u].m + 1) * NQ + q];
         if (MODE == MODE_VERIFY) {
             sc[u] = p.sup_corr[(size_t)g[u].ep * NQ + q];
@@ -311,7 +314,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
             s ^= sr[u];
             r = recon32(s) & onm;
         }
-        p.on[(size_t)g[u].eo * NQ + q] = s;
+        __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
         store_bits(p.pre, g[u].ep, NQ, q, delta);
         store_bits(p.corr, g[u].dst, NQ, q, r ^ delta ^ (cx & cy));
     }
