@@ -1065,8 +1065,9 @@ struct B_k_extract_rows {
         if (!any) continue;
         const uint64_t it0 = 8 * (t0 + tl);
         uint32_t w[8];
+        // (read once: nontemporal, 0.43 -> 0.41 ms for the opening phase)
 #pragma unroll
-        for (int j = 0; j < 8; j++) w[j] = n_items ? stream[(size_t)s_rows[8 * tl + j] * NQ + q] : 0u;
+        for (int j = 0; j < 8; j++) w[j] = n_items ? __builtin_nontemporal_load(&stream[(size_t)s_rows[8 * tl + j] * NQ + q]) : 0u;
         // rows past the end contribute zero bits (their loads were clamped to the last item)
 #pragma unroll
         for (int j = 0; j < 8; j++)
