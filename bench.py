@@ -163,9 +163,10 @@ def main():
     ap.add_argument("--fused-batch", type=int, default=0,
                     help="secondary GF(2) workloads: proofs per rv_prove_batch call (every level launched once for the whole batch)")
     ap.add_argument("--z64-muls", type=int, default=1_000_000)
-    ap.add_argument("--two-in-flight", action="store_true",
-                    help="also measure the workload with two proofs in flight (reported as two_proofs_in_flight; off by default so "
-                         "that a rocprofv3 summary of the default command only contains the timed configuration)")
+    ap.add_argument("--two-in-flight", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-two-in-flight", action="store_true",
+                    help="skip the extra measurement with two proofs in flight (reported as two_proofs_in_flight next to the "
+                         "one-at-a-time `value`): for rocprofv3 runs whose summary should only contain the timed configuration")
     ap.add_argument("--cpu-sample-layers", type=int, default=0,
                     help="layers of the workload the CPU oracle proves (0 = all of them: the whole timed workload)")
     args = ap.parse_args()
@@ -360,7 +361,7 @@ def main():
             result["independent_proofs"] = {"value": n_and * n_ind * world / float(ti.item()), "unit": "AND gates/s", "scaling": "weak",
                                             "ms_per_proof_per_gpu": float(ti.item()) / n_ind * 1e3, "proofs": n_ind * world,
                                             "note": "one whole proof per GPU at a time, no collective"}
-    if rank == 0 and world == 1 and args.two_in_flight:
+    if rank == 0 and world == 1 and not args.no_two_in_flight:
         # informational, outside the timed region: the same workload with TWO proofs in flight (two contexts, two host
         # threads) -- one proof's VALU-bound phases overlap the other's memory-bound interpreter.  `value` above stays
         # the one-proof-at-a-time number.
@@ -386,7 +387,7 @@ def main():
             return time.perf_counter() - t
 
         run_pair(2)
-        n2 = max(args.steps // 2, 4)
+        n2 = max(args.steps, 8)
         dt2 = run_pair(n2)
         result["two_proofs_in_flight"] = {"value": n_and * 2 * n2 / dt2, "unit": "AND gates/s", "ms_per_proof": dt2 / (2 * n2) * 1e3,
                                           "proofs": 2 * n2}
