@@ -333,9 +333,20 @@ def main():
             tv = time.perf_counter()
             okv = bool(last.verify(circuit, strict=True))
             tv = time.perf_counter() - tv
-            result["verifier"] = {"value": n_and / tv, "unit": "AND gates/s", "ms": tv * 1e3, "strict_ok": okv,
-                                  "note": "rv_verify_ex(RV_VERIFY_STRICT) on the last timed proof, host proof bytes in, one call"}
-            parity["last_timed_proof_verifies_strict"] = okv
+            # the same proof as rv_prove returns it (host bytes in the library's page-locked buffer, which the Proof
+            # object hands back to rv_verify in place): the 50 MB upload then runs at PCIe speed
+            host_proof = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
+            same_bytes = bytes(host_proof) == bytes(last)
+            host_proof.verify(circuit, strict=True)
+            tp = time.perf_counter()
+            okp = bool(host_proof.verify(circuit, strict=True))
+            tp = time.perf_counter() - tp
+            result["verifier"] = {"value": n_and / tp, "unit": "AND gates/s", "ms": tp * 1e3, "ms_pageable_input": tv * 1e3,
+                                  "strict_ok": okv and okp,
+                                  "note": "rv_verify_ex(RV_VERIFY_STRICT), host proof bytes in, one call: `ms` on the buffer rv_prove "
+                                          "returned (page-locked), `ms_pageable_input` on a copy in ordinary host memory"}
+            parity["last_timed_proof_verifies_strict"] = okv and okp
+            parity["rv_prove_bytes_equal_device_resident_proof"] = same_bytes
         if world > 1:
             single = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
             parity["sharded_proof_equals_single_gpu_proof"] = bytes(single) == bytes(last)
