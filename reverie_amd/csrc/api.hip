@@ -540,6 +540,8 @@ struct rv_shard {
     rv_ctx* ctx = nullptr;
     const rv_circuit* c = nullptr;
     uint32_t rep_begin = 0, R = 0, NQ = 0;
+    const uint32_t* d_on_quads = nullptr;  // verifier: the quad words that hold an opened repetition (not owned)
+    uint32_t n_on_quads = 0;
     uint8_t* d_seeds = nullptr;
     uint8_t* d_keys = nullptr;
     uint8_t* d_rkbytes = nullptr;
@@ -758,7 +760,7 @@ static int shard_run_hash(rv_shard* s) {
     uint32_t* dig = s->d_dig;
     const size_t DW = (size_t)s->R * 8;
     uint32_t n_launch = launch_b3_stream_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
-    n_launch += launch_b3_stream(ctx->stream, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 1 * DW);
+    n_launch += launch_b3_stream(ctx->stream, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 1 * DW, s->d_on_quads, s->n_on_quads);
     // Z64 transcripts; for a pure GF(2) circuit both are empty and every digest is BLAKE3("") (one fill, not four launches)
     if (cc.pre_words64 == 0 && cc.on_words64 == 0) {
         static const std::vector<uint32_t> empty = [] {
@@ -1818,6 +1820,12 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     track(d_keep);
     if ((rc = dalloc(ctx, NQ, &d_onm))) return fail(rc);
     track(d_onm);
+    std::vector<uint32_t> on_quads;
+    for (uint32_t q = 0; q < NQ; q++)
+        if (onm[q]) on_quads.push_back(q);
+    uint32_t* d_on_quads = nullptr;
+    if ((rc = dalloc(ctx, std::max<size_t>(on_quads.size(), 1), &d_on_quads))) return fail(rc);
+    track(d_on_quads);
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_in, 1) * NQ, &d_sup_in))) return fail(rc);
     track(d_sup_in);
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * NQ, &d_sup_corr))) return fail(rc);
@@ -1880,6 +1888,9 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     HC(hipMemcpyAsync(s->d_omit, omit.data(), omit.size(), hipMemcpyHostToDevice, ctx->stream));
     HC(hipMemcpyAsync(d_keep, keep.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
     HC(hipMemcpyAsync(d_onm, onm.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!on_quads.empty()) HC(hipMemcpyAsync(d_on_quads, on_quads.data(), on_quads.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    s->d_on_quads = d_on_quads;
+    s->n_on_quads = (uint32_t)on_quads.size();
     HC(hipMemcpyAsync(d_hkeys, hkeys.data(), hkeys.size(), hipMemcpyHostToDevice, ctx->stream));
     HC(hipMemcpyAsync(d_hco, hco.data(), hco.size(), hipMemcpyHostToDevice, ctx->stream));
     HC(hipMemcpyAsync(d_hco64, hco64.data(), hco64.size(), hipMemcpyHostToDevice, ctx->stream));

@@ -169,8 +169,9 @@ void launch_extract64(hipStream_t st, const uint64_t* d_stream, uint64_t stride_
 void launch_unpack64(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
                      const uint8_t* d_omit, uint64_t n_items, uint32_t R, uint64_t* d_out);
 // BLAKE3 over a row-format transcript: digests[R][8] words
+// d_quads / n_quads (nullable): hash only the listed quad words (the verifier's opened repetitions)
 uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
-                      uint32_t* d_cv_b, uint32_t* d_digest /*[R][8]*/);
+                      uint32_t* d_cv_b, uint32_t* d_digest /*[R][8]*/, const uint32_t* d_quads = nullptr, uint32_t n_quads = 0);
 // same for a bit-per-rep transcript [n_events][NQ/2] (each bit hashed as a 0x00/0xFF byte)
 uint32_t launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
                            uint32_t* d_cv_b, uint32_t* d_digest);

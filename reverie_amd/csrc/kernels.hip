@@ -646,13 +646,15 @@ void launch_interp_narrow_batched(hipStream_t st, const Gate* d_gates, const Lev
 // chip at 3 waves/SIMD (40 % of the time is tail), RPL = 1 gives 19 600 waves at 7+ waves/SIMD.
 template <int RPL>
 struct B_k_b3_chunks {
-    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/) const {
+    // quads (nullable) / n_quads: only these quad words are hashed -- the verifier needs the online digest of the 40
+    // opened repetitions alone (the other 216 carry theirs in the proof), i.e. of at most 40 of the 64 quads
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/, const uint32_t* __restrict__ quads, uint32_t n_quads) const {
     constexpr uint32_t SUBS = 4 / RPL;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lanes_per_chunk = NQ * SUBS;
+    const uint32_t lanes_per_chunk = (quads ? n_quads : NQ) * SUBS;
     const uint64_t c = tid / lanes_per_chunk;
     const uint32_t ql = (uint32_t)(tid % lanes_per_chunk);
-    const uint32_t q = ql / SUBS, sub = ql % SUBS;
+    const uint32_t q = quads ? quads[ql / SUBS] : ql / SUBS, sub = ql % SUBS;
     if (c >= n_chunks) return;
     const uint64_t ev0 = c * 1024;
     const uint64_t len = (n_events - ev0 < 1024) ? (n_events - ev0) : 1024;
@@ -700,8 +702,8 @@ struct B_k_b3_chunks {
 }
 };
 template <int RPL>
-__global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/) {
-    B_k_b3_chunks<RPL>{}(stream, n_events, NQ, n_chunks, cvs);
+__global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/, const uint32_t* __restrict__ quads, uint32_t n_quads) {
+    B_k_b3_chunks<RPL>{}(stream, n_events, NQ, n_chunks, cvs, quads, n_quads);
 }
 
 // Same for a bit-per-rep transcript (the preprocessing stream): every bit is hashed as the
@@ -882,12 +884,15 @@ size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R) {
 }
 
 uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
-                      uint32_t* d_cv_b, uint32_t* d_digest) {
+                      uint32_t* d_cv_b, uint32_t* d_digest, const uint32_t* d_quads, uint32_t n_quads) {
     const uint32_t R = NQ * 4;
     uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
+    if (d_quads && !n_quads) return 0;  // a verifier shard without opened repetitions: every online digest comes from the proof
     {
-        const uint64_t threads = n * NQ;
-        launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a);
+        // (the chaining values of skipped quads stay whatever the scratch buffer held: the tree above them runs on
+        // garbage and the caller replaces those digests)
+        const uint64_t threads = n * (d_quads ? n_quads : NQ);
+        launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a, d_quads, n_quads);
     }
     return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
 }
