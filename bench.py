@@ -152,8 +152,8 @@ def secondary(args, local):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--layers", type=int, default=153, help="circuit depth (153 = the BASELINE workload)")
     ap.add_argument("--p-and", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
