@@ -168,14 +168,16 @@ int rv_prove_device(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, si
 
 /* ---- many proofs of one circuit ------------------------------------------------------------
  * `batch` independent Proof::new calls (witness b at wit_gf2 + b*n_gf2 / wit_z64 + b*n_z64, seeds b at
- * seeds + b*256*16, NULL => OS randomness) executed together: every dependency level of the circuit is
- * launched once for the whole batch.  This is what makes deep, narrow circuits (AES, SHA-256: thousands of
- * levels of a few gates, latency-bound) use the GPU; the reference reaches the same goal with one rayon task per
- * proof, and so are the per-proof phases (keys, masks, digests, Fiat-Shamir, openings: one launch per step with
- * gridDim.y = proof).  proofs[b] / proof_lens[b] as rv_prove (rv_free each, exactly once).  The proofs of a batch
- * are slices of one page-locked buffer that goes back to the library's pool when the last of them has been freed;
- * RV_BATCH_COPY_OUT=1 returns separately malloc'ed buffers instead.  Each proof is byte-identical to what rv_prove
- * returns for the same witness and seeds.  Mixed / Z64 circuits fall back to one rv_prove per proof. */
+ * seeds + b*256*16, NULL => OS randomness) executed together; the reference reaches the same goal with one rayon
+ * task per proof.  Small and medium circuits: every dependency level of the circuit AND every per-proof phase (keys,
+ * masks, digests, Fiat-Shamir, openings) is launched once for the whole batch (gridDim.y = proof) -- this is what
+ * makes deep, narrow circuits (AES, SHA-256: thousands of levels of a few gates, latency-bound for one proof) use the
+ * GPU.  Circuits of 2^20 gates and more fill the GPU on their own: there a few host threads keep several proofs in
+ * flight so that one proof's VALU-bound phases, another's memory-bound interpreter and a third one's PCIe copy overlap.
+ * proofs[b] / proof_lens[b] as rv_prove (rv_free each, exactly once).  The proofs of a call are slices of one
+ * page-locked buffer that goes back to the library's pool when the last of them has been freed (RV_BATCH_COPY_OUT=1:
+ * separately malloc'ed buffers, small-circuit path only).  Each proof is byte-identical to what rv_prove returns for
+ * the same witness and seeds.  Mixed / Z64 circuits fall back to one rv_prove per proof. */
 int rv_prove_batch(rv_ctx *ctx, const rv_circuit *c, size_t batch, const uint8_t *wit_gf2, size_t n_gf2,
                    const uint64_t *wit_z64, size_t n_z64, const uint8_t *seeds, uint8_t **proofs, size_t *proof_lens);
 

@@ -1184,8 +1184,11 @@ extern "C" int rv_assemble_proof(const uint8_t comm[RV_HASH_SIZE], const rv_shar
     return RV_OK;
 }
 
+// dst (nullable): page-locked destination of at least dst_cap bytes supplied by the caller (rv_prove_batch hands every
+// proof a slice of one buffer); otherwise the proof gets a buffer of its own
 static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
-                        size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len);
+                        size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len, uint8_t* dst = nullptr,
+                        size_t dst_cap = 0);
 
 extern "C" int rv_prove(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
                         size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len) {
@@ -1198,7 +1201,7 @@ extern "C" int rv_prove(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2
 }
 
 static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
-                        size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len) {
+                        size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len, uint8_t* dst, size_t dst_cap) {
     if (!ctx || !c || !proof || !proof_len) return RV_E_ARG;
     *proof = nullptr;
     *proof_len = 0;
@@ -1223,7 +1226,11 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         size_t lens[4];
         if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, nullptr, nullptr, /*no_sync=*/true))) break;
         const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
-        out = (uint8_t*)out_alloc(total);
+        if (dst && total > dst_cap) {
+            rc = RV_E_ARG;
+            break;
+        }
+        out = dst ? dst : (uint8_t*)out_alloc(total);
         if (!out) {
             rc = RV_E_NOMEM;
             break;
@@ -1250,7 +1257,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         *proof_len = total;
         out = nullptr;
     } while (0);
-    rv_free(out);
+    if (!dst) rv_free(out);
     rv_shard_destroy(s);
     return rc;
 }
@@ -1341,18 +1348,27 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
     }();
     if (cc.gates.size() >= big_gates) {
         // Large circuits fill the GPU on their own; what is left to gain is overlapping one proof's VALU-bound phases
-        // (masks, digests) with another's memory-bound interpreter.  Two host threads, each with its own worker
-        // context (stream + arena; the circuit's device arrays are shared read-only), prove alternate statements
-        // through the ordinary single-proof path: two proofs in flight, 5.1 instead of 5.9 ms per proof on the
-        // 10^7-gate circuit.  (A third proof in flight does not help.)
-        constexpr size_t T = 2;
+        // (masks, digests) with another's memory-bound interpreter, and a third one's 50 MB trip over PCIe.  A few host
+        // threads, each with its own worker context (stream + arena; the circuit's device arrays are shared read-only),
+        // prove alternate statements through the ordinary single-proof path.  Host bytes in, host proof bytes out on the
+        // 10^7-gate circuit: 6.7 ms for a single rv_prove, 5.9 per proof with two threads, 5.4 with three, 5.5 with four
+        // (device-resident proofs: 4.9 with two in flight, no gain from a third).
+        constexpr size_t T = 3;
         while (ctx->workers.size() < T) {
             rv_ctx* w = nullptr;
             int rcw = rv_ctx_create(ctx->device, &w);
             if (rcw) return rcw;
             ctx->workers.push_back(w);
         }
-        int rcs[T] = {RV_OK, RV_OK};
+        // every proof of the batch lands in a slice of ONE page-locked buffer (released when the last proof has been
+        // rv_free'd): a buffer per proof meant a hipHostMalloc of tens of MB per proof as soon as the caller held more
+        // proofs than the pool keeps idle -- 7.7 ms per proof at 16 proofs per call instead of 6.2 at 2
+        uint8_t canon[RV_TOTAL_REPS];
+        for (uint32_t r = 0; r < RV_TOTAL_REPS; r++) canon[r] = r < RV_ONLINE_REPS ? 0 : RV_PLAYERS;
+        const size_t stride = (open_layout(cc, canon, RV_TOTAL_REPS, true).total + 4095) & ~(size_t)4095;
+        uint8_t* slab = (uint8_t*)g_pinned.get(std::max<size_t>(stride * batch, PinnedPool::MIN_BYTES));
+        if (!slab) return RV_E_NOMEM;
+        int rcs[T] = {};
         std::thread th[T];
         for (size_t t = 0; t < T; t++)
             th[t] = std::thread([&, t] {
@@ -1362,8 +1378,8 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
                         return;
                     }
                     for (size_t b = t; b < batch && rcs[t] == RV_OK; b += T)
-                        rcs[t] = rv_prove(ctx->workers[t], c, wit_gf2 ? wit_gf2 + b * n_gf2 : nullptr, n_gf2, nullptr, 0,
-                                          seeds + b * RV_TOTAL_REPS * 16, &proofs[b], &proof_lens[b]);
+                        rcs[t] = rv_prove_impl(ctx->workers[t], c, wit_gf2 ? wit_gf2 + b * n_gf2 : nullptr, n_gf2, nullptr, 0,
+                                               seeds + b * RV_TOTAL_REPS * 16, &proofs[b], &proof_lens[b], slab + b * stride, stride);
                 } catch (...) {
                     rcs[t] = RV_E_NOMEM;
                 }
@@ -1371,32 +1387,13 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
         for (auto& x : th) x.join();
         for (int r : rcs)
             if (r) {
-                for (size_t b = 0; b < batch; b++) rv_free(proofs[b]), proofs[b] = nullptr, proof_lens[b] = 0;
+                for (size_t b = 0; b < batch; b++) proofs[b] = nullptr, proof_lens[b] = 0;
+                g_pinned.put(slab);
                 return r;
             }
+        g_pinned.share(slab, batch);  // from here on the proofs own it
         ctx->prof.calls += batch;
         return RV_OK;
-    }
-    {
-        // a call keeps one proof's working set (scratch_bytes) per proof resident, and the proof index travels in
-        // gridDim.y: larger batches run as consecutive chunks that fit half of the free HBM (at most 4 096 proofs)
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return RV_E_DEVICE;
-        const size_t per_proof = std::max<size_t>(cc.info.scratch_bytes, 1);
-        size_t chunk = std::min<size_t>(std::max<size_t>((free_b + ctx->cached_bytes) / 2 / per_proof, 1), 4096);
-        if (const char* e = getenv("RV_BATCH_MAX")) chunk = std::min<size_t>(chunk, (size_t)std::max(atoi(e), 1));  // tests
-        if (batch > chunk) {
-            for (size_t b0 = 0; b0 < batch; b0 += chunk) {
-                const size_t n = std::min(chunk, batch - b0);
-                const int rcc = rv_prove_batch_impl(ctx, c, n, wit_gf2 ? wit_gf2 + b0 * n_gf2 : nullptr, n_gf2, nullptr, 0,
-                                                    seeds + b0 * RV_TOTAL_REPS * 16, proofs + b0, proof_lens + b0);
-                if (rcc) {
-                    for (size_t k = 0; k < b0; k++) rv_free(proofs[k]), proofs[k] = nullptr, proof_lens[k] = 0;
-                    return rcc;
-                }
-            }
-            return RV_OK;
-        }
     }
     const bool was_pipelined = ctx->pipeline;
     ctx->pipeline = false;  // everything of a batch goes down ONE stream
