@@ -70,6 +70,17 @@ def test_cli_prove_verify_roundtrip(tmp_path, capsys, oracle):
     assert main(["--operation", "oneshot-zk", "--witness-path", str(w)] + common) == 0
     txt = capsys.readouterr().out
     assert txt.count("Ok(())") == 3 and "Verifying Proof" in txt
+    # the statement checked against OTHER expected outputs: the output assertions fail, which the reference's verifier
+    # does not notice -- the plain CLI says Ok like speed-reverie would, --strict reports it
+    e2 = tmp_path / "exp2.txt"
+    e2.write_text("".join(str((((a + b + 1) & (2**64 - 1)) >> i) & 1) for i in range(64)))
+    other = ["--program-path", str(p), "--expected-outputs-path", str(e2), "--operation", "verify", "--proof-path", str(out)]
+    main(other)
+    assert "Ok(())" in capsys.readouterr().out
+    main(other + ["--strict"])
+    assert 'Err("Unverifiable Proof")' in capsys.readouterr().out
+    assert main(["--operation", "verify", "--proof-path", str(out), "--strict"] + common) == 0
+    assert "Ok(())" in capsys.readouterr().out
     # the oracle accepts the CLI's proof file; a tampered file is reported like the reference does
     prog, wc = load_program(str(p), "auto", str(e))
     assert oracle.verify(prog, wc, out.read_bytes())
