@@ -81,9 +81,9 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
             const uint32_t w = p.wit[g.x] ? 0xFFFFFFFFu : 0u;
             corr = w ^ recon32(lam);
         } else {
-            corr = p.sup_in[(size_t)g.x * NQ + q] & onm;
+            corr = onm ? (p.sup_in[(size_t)g.x * NQ + q] & onm) : 0u;  // (rows of quads without an opened repetition are never written)
         }
-        p.on[(size_t)g.eo * NQ + q] = corr;
+        if (MODE == MODE_PROVE || onm) p.on[(size_t)g.eo * NQ + q] = corr;
         store_bits(p.corr, g.dst, NQ, q, corr);
         break;
     }
@@ -114,11 +114,16 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
             r = recon32(s);
         } else {
             // online-verified reps: supplied correction, add the unopened player's broadcast
-            delta = (p.sup_corr[(size_t)g.ep * NQ + q] & onm) | (delta & ~onm);
-            s ^= p.sup_rec[(size_t)g.x * NQ + q];
+            if (onm) {
+                delta = (p.sup_corr[(size_t)g.ep * NQ + q] & onm) | (delta & ~onm);
+                s ^= p.sup_rec[(size_t)g.x * NQ + q];
+            }
             r = recon32(s) & onm;  // preprocessing-verified reps: reconstruct() returns zero
         }
-        p.on[(size_t)g.eo * NQ + q] = s;
+        // verifier: the online transcript is only hashed for quads that hold an opened repetition (the other
+        // repetitions' online digests come from the proof), so only those lanes store -- in the verifier's slot order
+        // they are the first ten quads of a row, two 32-byte sectors instead of eight
+        if (MODE == MODE_PROVE || onm) p.on[(size_t)g.eo * NQ + q] = s;
         store_bits(p.pre, g.ep, NQ, q, delta);
         store_bits(p.corr, g.dst, NQ, q, r ^ delta ^ (cx & cy));
         break;
@@ -126,8 +131,8 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     case G_RECON: {
         // B2A's recorded reconstruction (combine.rs:181-183): value = reconstruct(mask) + corr
         uint32_t m = gather_rows(p.rows, g.a, NQ, q);
-        if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
-        p.on[(size_t)g.eo * NQ + q] = m;
+        if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * NQ + q];
+        if (MODE == MODE_PROVE || onm) p.on[(size_t)g.eo * NQ + q] = m;
         uint32_t r = recon32(m);
         if (MODE == MODE_VERIFY) r &= onm;
         const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
@@ -137,8 +142,8 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     }
     case G_ASSERT: {
         uint32_t m = gather_rows(p.rows, g.a, NQ, q);
-        if (MODE == MODE_VERIFY) m ^= p.sup_rec[(size_t)g.x * NQ + q];
-        p.on[(size_t)g.eo * NQ + q] = m;
+        if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * NQ + q];
+        if (MODE == MODE_PROVE || onm) p.on[(size_t)g.eo * NQ + q] = m;
         {
             const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
             if (MODE == MODE_PROVE) {
@@ -277,8 +282,11 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
         lab[u] = __builtin_nontemporal_load(&p.rows[(size_t)g[u].m * NQ + q]);
         lnew[u] = p.rows[(size_t)(g[u].m + 1) * NQ + q];
         if (MODE == MODE_VERIFY) {
-            sc[u] = p.sup_corr[(size_t)g[u].ep * NQ + q];
-            sr[u] = p.sup_rec[(size_t)g[u].x * NQ + q];
+            sc[u] = sr[u] = 0;
+            if (onm) {  // supplied values exist (and are stored) only for quads with an opened repetition
+                sc[u] = p.sup_corr[(size_t)g[u].ep * NQ + q];
+                sr[u] = p.sup_rec[(size_t)g[u].x * NQ + q];
+            }
         }
     }
     const uint32_t pfv = pf_touch<U * GPW>(pf, sub * NQ + q);
@@ -314,7 +322,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
             s ^= sr[u];
             r = recon32(s) & onm;
         }
-        __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
+        if (MODE == MODE_PROVE || onm) __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
         store_bits(p.pre, g[u].ep, NQ, q, delta);
         store_bits(p.corr, g[u].dst, NQ, q, r ^ delta ^ (cx & cy));
     }
@@ -892,7 +900,10 @@ uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_e
         // (the chaining values of skipped quads stay whatever the scratch buffer held: the tree above them runs on
         // garbage and the caller replaces those digests)
         const uint64_t threads = n * (d_quads ? n_quads : NQ);
-        launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a, d_quads, n_quads);
+        if (d_quads && n_quads * 4 <= NQ)  // a quarter of the row or less: one repetition per lane keeps the chip busy
+            launch<B_k_b3_chunks<1>, 256>(k_b3_chunks<1>, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a, d_quads, n_quads);
+        else
+            launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a, d_quads, n_quads);
     }
     return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
 }
@@ -1396,23 +1407,32 @@ __global__ __launch_bounds__(256) void k_unpack_bits(const uint8_t* __restrict__
     const uint64_t n_here = (n_items - it0 < 8ull * UNP_TB) ? n_items - it0 : 8ull * UNP_TB;
     if (256 % NQ == 0) {
         // a thread keeps its quad for the whole loop: which of its four repetitions are opened, their slots and the
-        // word each contributes stay in registers, and the (majority of) quads without an opened repetition only
-        // store zeros (per-word slot lookups made this write-bound kernel compute-bound: 483 us per 1.28 GB vector)
-        const uint32_t q = tid % NQ, step = 256 / NQ;
+        // word each contributes stay in registers (per-word slot lookups made this kernel compute-bound: 483 us per
+        // vector); only the quads that hold an opened repetition are written at all -- the interpreter reads no others
+        // -- and the threads are dealt over exactly those quads (in the verifier's slot order: the first ten)
+        __shared__ uint8_t s_quads[64];
+        __shared__ uint32_t s_nq;
+        if (tid == 0) {
+            uint32_t n = 0;
+            for (uint32_t qq = 0; qq < NQ; qq++)
+                if ((s_slot[4 * qq] & s_slot[4 * qq + 1] & s_slot[4 * qq + 2] & s_slot[4 * qq + 3]) != 0xFF) s_quads[n++] = (uint8_t)qq;
+            s_nq = n;
+        }
+        __syncthreads();
+        const uint32_t nq = s_nq;
+        if (!nq || tid >= nq * (256 / nq)) return;
+        const uint32_t q = s_quads[tid % nq], step = 256 / nq;
         uint32_t sl[4], val[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             sl[i] = s_slot[4 * q + i];
             val[i] = (kind == 0) ? (1u << (31u - 8u * i - (omit[4 * q + i] & 7u))) : (0xFFu << (24 - 8 * i));
         }
-        const bool any = (sl[0] & sl[1] & sl[2] & sl[3]) != 0xFF;
-        for (uint32_t il = tid / NQ; il < n_here; il += step) {
+        for (uint32_t il = tid / nq; il < n_here; il += step) {
             uint32_t w = 0;
-            if (any) {
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (sl[i] != 0xFF && (((uint32_t)s_bytes[sl[i] * UNP_TB + (il >> 3)] >> (7 - (il & 7))) & 1u)) w |= val[i];
-            }
+            for (int i = 0; i < 4; i++)
+                if (sl[i] != 0xFF && (((uint32_t)s_bytes[sl[i] * UNP_TB + (il >> 3)] >> (7 - (il & 7))) & 1u)) w |= val[i];
             rows_out[(it0 + il) * NQ + q] = w;
         }
         return;
