@@ -430,8 +430,10 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
     }
 }
 
+// (the full-width variant without the multi-base loops must fit eight wavefronts per SIMD: its verify-mode instance
+// took 70 registers = seven; with the bound it is 61, without scratch.  Narrower rows keep the default: they would spill)
 template <int MODE, int NQ, bool GENERAL>
-__global__ __launch_bounds__(256) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p, PfPlan pf) {
+__global__ __launch_bounds__(256, (GENERAL || NQ != 64) ? 1 : 8) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p, PfPlan pf) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
