@@ -902,7 +902,9 @@ uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_e
         // (the chaining values of skipped quads stay whatever the scratch buffer held: the tree above them runs on
         // garbage and the caller replaces those digests)
         const uint64_t threads = n * (d_quads ? n_quads : NQ);
-        if (d_quads && n_quads * 4 <= NQ)  // a quarter of the row or less: one repetition per lane keeps the chip busy
+        // few lanes (a quarter of the row or less in the verifier; a transcript of a few chunks, i.e. a small circuit):
+        // one repetition per lane gives four times the wavefronts, each a quarter as long
+        if ((d_quads && n_quads * 4 <= NQ) || threads < 64 * 1024)
             launch<B_k_b3_chunks<1>, 256>(k_b3_chunks<1>, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a, d_quads, n_quads);
         else
             launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a, d_quads, n_quads);
