@@ -396,6 +396,32 @@ def test_prove_batch_chunks_and_buffer_modes(rv, oracle, monkeypatch):
         assert keep == want and [bytes(g) for g in again] == want[:3]
 
 
+def test_prove_batch_witness_strides_and_no_inputs(rv, oracle):
+    """Witness rows wider than the circuit's input count (the batch upload is a strided 2-D copy) and a circuit
+    without any Input gate (constants only): each proof still equals the single-proof path."""
+    rng = np.random.default_rng(41)
+    prog, wit, wc = circuits.random_gf2(rng, n_in=9, n_gates=300, n_wires=30)
+    c = rv.Circuit(prog, wc)
+    nb = 6
+    seeds = rng.integers(0, 256, (nb, 256, 16), dtype=np.uint8)
+    wide = np.zeros((nb, len(wit) + 7), np.uint8)
+    wide[:, :len(wit)] = np.asarray(wit, np.uint8)
+    wide[:, len(wit):] = 1  # never read
+    got = rv.Proof.new_batch(c, wide, seeds=seeds)
+    for b in range(nb):
+        assert bytes(got[b]) == bytes(rv.Proof.new(c, wit, [], seeds=seeds[b]))
+    assert bytes(got[2]) == oracle.prove(prog, wit, [], wc, seeds[2], threads=2)
+    # no inputs at all
+    ops = [GF2.Const(0, 1), GF2.Const(1, 1), GF2.Mul(2, 0, 1), GF2.AddConst(3, 2, 1), GF2.AssertZero(3), GF2.Random(4),
+           GF2.Mul(5, 4, 2), GF2.Add(6, 5, 5), GF2.AssertZero(6)]
+    p0 = program(ops)
+    c0 = rv.Circuit(p0, (0, 7))
+    g0 = rv.Proof.new_batch(c0, np.zeros((3, 0), np.uint8), seeds=seeds[:3])
+    for b in range(3):
+        assert bytes(g0[b]) == oracle.prove(p0, [], [], (0, 7), seeds[b], threads=2)
+        assert g0[b].verify(c0, strict=True)
+
+
 def test_prove_batch_equals_single_proofs(rv, oracle, rule_seeds):
     """rv_prove_batch: B proofs of one circuit, different witnesses and seeds, must each equal the single-proof entry
     point and the oracle — on a circuit with narrow runs of both kinds and launched levels (AES-128: valid and
