@@ -277,6 +277,13 @@ int rv_verify_shard_ex(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, s
 int rv_verify_finish_ex(const uint8_t *proof, size_t proof_len, const uint8_t *slot_digests /* 256 x 32 */, uint32_t flags,
                         int zero_checks_ok, int *ok);
 
+/* Many proofs of one circuit in one pass (the verifier's counterpart of rv_prove_batch; pure GF(2) circuits below the
+ * large-circuit threshold -- everything else verifies proof after proof): ok[b] as rv_verify_ex would set it for
+ * proofs[b] with the same flags.  A proof whose bytes cannot be parsed fails the whole call with RV_E_PROOF_MALFORMED,
+ * like the panic of one rayon task would. */
+int rv_verify_batch(rv_ctx *ctx, const rv_circuit *c, size_t batch, const uint8_t *const *proofs, const size_t *proof_lens,
+                    uint32_t flags, int *ok /* [batch] */);
+
 /* ---- Bristol front end (host only, no GPU) ---------------------------------------------
  * The reference's README promises Bristol-format circuits; the parser itself lives in the
  * un-vendored `mcircuit` crate.  This turns Bristol text into the rv_op stream:

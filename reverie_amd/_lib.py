@@ -62,7 +62,7 @@ SYMBOLS = [
     "rv_verify_finish", "rv_hook_prg_blocks", "rv_hook_expand_seed", "rv_hook_sharegen_gf2", "rv_hook_sharegen_z64",
     "rv_hook_blake3", "rv_hook_shard_stream_digests", "rv_ctx_profile", "rv_shard_digests_to_device", "rv_shard_open_size", "rv_shard_open_into", "rv_shard_open_self", "rv_shard_open_gathered",
     "rv_bristol_parse", "rv_circuit_record_sizes", "rv_program_from_bincode", "rv_program_to_bincode", "rv_prove_batch", "rv_prove_device",
-    "rv_verify_ex", "rv_verify_shard_ex", "rv_verify_finish_ex",
+    "rv_verify_ex", "rv_verify_shard_ex", "rv_verify_finish_ex", "rv_verify_batch",
 ]
 RV_VERIFY_STRICT = 1
 

@@ -665,7 +665,7 @@ static int shard_run_alloc(rv_shard* s, InterpParams& p, Interp64Params& p64) {
     const size_t cvw = b3_stream_scratch_words(std::max({cc.n_on, cc.n_pre, cc.on_words64 * 8, cc.pre_words64 * 8}), s->R);
     if ((rc = dalloc(ctx, cvw, &s->d_cv[0])) || (rc = dalloc(ctx, cvw, &s->d_cv[1]))) return rc;
     if ((rc = dalloc(ctx, (size_t)4 * s->R * 8, &s->d_dig))) return rc;
-    if ((rc = dalloc(ctx, (size_t)s->R * 32, &s->d_h))) return rc;
+    if (!s->d_h && (rc = dalloc(ctx, (size_t)s->R * 32, &s->d_h))) return rc;  // (rv_verify_batch: a slot of one array)
     const bool has64 = !cc.gates64.empty();
     if (has64) {
         if ((rc = dalloc(ctx, (size_t)cc.n_ssa64 * s->R * 8, &s->d_wmask64))) return rc;
@@ -2020,6 +2020,328 @@ static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof
     int zc = 1;
     if ((rc = rv_verify_shard_ex(ctx, c, proof, proof_len, 0, RV_TOTAL_REPS, dig.data(), &zc))) return rc;
     return rv_verify_finish_ex(proof, proof_len, dig.data(), flags, zc, ok);
+}
+
+// ------------------------------------------------------------------------------------
+// rv_verify_batch: many proofs of one circuit in one pass -- the verifier's counterpart of rv_prove_batch's fused path
+// (pure GF(2) circuits below the large-circuit threshold; everything else verifies proof after proof).  Per proof the
+// host only parses the bincode framing and fills its slot of ONE page-locked staging slab (seeds, omitted players,
+// masks, opened keys, carried-over commitments, source offsets and the proof bytes themselves), which goes to the
+// device in one copy; the per-proof kernel strings are recorded and replayed once per batch (launch.h), the levels run
+// through the batched interpreter kernels in verify mode, and the slot digests plus the zero-check flags come back in
+// one copy each.  The final check (rv_verify_finish_ex) is host work per proof.
+// ------------------------------------------------------------------------------------
+static int replay_recorded(rv_ctx* ctx, std::vector<LaunchRecorder>& recs, std::vector<void*>& pinned_tmp, std::vector<void*>& device_tmp) {
+    const size_t batch = recs.size(), n = recs[0].calls.size();
+    for (size_t b = 1; b < batch; b++)
+        if (recs[b].calls.size() != n) return RV_E_DEVICE;
+    size_t total = 0;
+    std::vector<size_t> off(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const auto& c0 = recs[0].calls[i];
+        for (size_t b = 1; b < batch; b++) {
+            const auto& c = recs[b].calls[i];
+            if (c.replay != c0.replay || c.grid.x != c0.grid.x || c.block.x != c0.block.x || c.arg_bytes != c0.arg_bytes) return RV_E_DEVICE;
+        }
+        if (!c0.replay) continue;
+        if (c0.grid.y != 1 || c0.grid.z != 1) return RV_E_DEVICE;
+        off[i] = total;
+        total += ((size_t)c0.arg_bytes * batch + 15) & ~(size_t)15;
+    }
+    uint8_t* d_args = nullptr;
+    if (total) {
+        uint8_t* h = (uint8_t*)g_pinned.get(std::max<size_t>(total, PinnedPool::MIN_BYTES));
+        if (!h) return RV_E_NOMEM;
+        pinned_tmp.push_back(h);
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t ab = recs[0].calls[i].arg_bytes;
+            if (!recs[0].calls[i].replay) continue;
+            for (size_t b = 0; b < batch; b++) memcpy(h + off[i] + b * ab, recs[b].calls[i].args.data(), ab);
+        }
+        int r = dalloc(ctx, total, &d_args);
+        if (r) return r;
+        device_tmp.push_back(d_args);
+        if (hipMemcpyAsync(d_args, h, total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return RV_E_DEVICE;
+    }
+    for (size_t i = 0; i < n; i++) {
+        const auto& c0 = recs[0].calls[i];
+        if (c0.replay) {
+            c0.replay(ctx->stream, c0.grid, c0.block, d_args + off[i], (unsigned)batch);
+        } else {
+            for (size_t b = 0; b < batch; b++) {
+                const auto& c = recs[b].calls[i];
+                if (hipMemcpyAsync(c.dst, c.src, c.n, c.kind, ctx->stream) != hipSuccess) return RV_E_DEVICE;
+            }
+        }
+    }
+    if (hipGetLastError() != hipSuccess) return RV_E_DEVICE;
+    for (auto& r : recs) r.calls.clear();
+    return RV_OK;
+}
+
+static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, const uint8_t* const* proofs, const size_t* proof_lens,
+                                uint32_t flags, int* ok) {
+    if (!ctx || !c || !batch || !proofs || !proof_lens || !ok || (flags & ~(uint32_t)RV_VERIFY_STRICT)) return RV_E_ARG;
+    for (size_t b = 0; b < batch; b++) {
+        ok[b] = 0;
+        if (!proofs[b]) return RV_E_ARG;
+    }
+    const Compiled& cc = c->cc;
+    auto one_by_one = [&]() -> int {
+        for (size_t b = 0; b < batch; b++) {
+            const int rc = rv_verify_ex(ctx, c, proofs[b], proof_lens[b], flags, &ok[b]);
+            if (rc) return rc;
+        }
+        return RV_OK;
+    };
+    static const size_t big_gates = [] {
+        const char* e = getenv("RV_BATCH_BIG_GATES");
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 20;
+    }();
+    if (batch == 1 || !cc.gates64.empty() || cc.gates.size() >= big_gates) return one_by_one();
+    // ---- parse; proofs with the wrong repetition counts are `false` (proof/mod.rs:225-230) and take no further part
+    std::vector<Parsed> P(batch);
+    std::vector<size_t> live;  // indices of the proofs that go to the GPU
+    size_t max_len = 0;
+    for (size_t b = 0; b < batch; b++) {
+        const int rc = parse_proof(proofs[b], proof_lens[b], P[b]);
+        if (rc) return rc;
+        if (!format_ok(P[b])) continue;
+        live.push_back(b);
+        max_len = std::max(max_len, proof_lens[b]);
+    }
+    if (live.size() < 2) {
+        for (size_t b : live) {
+            const int rc = rv_verify_ex(ctx, c, proofs[b], proof_lens[b], flags, &ok[b]);
+            if (rc) return rc;
+        }
+        return RV_OK;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    {  // a pass keeps one proof's working set resident per proof: larger batches run as consecutive chunks
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return RV_E_DEVICE;
+        const size_t per_proof = std::max<size_t>(cc.info.scratch_bytes + 3 * (size_t)std::max<uint64_t>({cc.n_in, cc.n_pre, cc.n_rec, 1}) * 256, 1);
+        size_t chunk = std::min<size_t>(std::max<size_t>((free_b + ctx->cached_bytes) / 2 / per_proof, 2), 4096);
+        if (const char* e = getenv("RV_BATCH_MAX")) chunk = std::min<size_t>(chunk, (size_t)std::max(atoi(e), 2));
+        if (batch > chunk) {
+            for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+                const int rc = rv_verify_batch_impl(ctx, c, std::min(chunk, batch - b0), proofs + b0, proof_lens + b0, flags, ok + b0);
+                if (rc) return rc;
+            }
+            return RV_OK;
+        }
+    }
+    const size_t B = live.size();
+    const uint32_t R = RV_TOTAL_REPS, NQ = R / 4;
+    // ---- the staging slab: one slot per proof
+    struct Slot {
+        size_t seeds, omit, keep, onm, quads, hkeys, hco, hco64, src, proof, stride;
+    } L{};
+    {
+        size_t o = 0;
+        auto take = [&](size_t n) {
+            const size_t at = o;
+            o += (n + 255) & ~(size_t)255;
+            return at;
+        };
+        L.seeds = take((size_t)R * 16);
+        L.omit = take(R);
+        L.keep = take((size_t)NQ * 4);
+        L.onm = take((size_t)NQ * 4);
+        L.quads = take((size_t)NQ * 4);
+        L.hkeys = take((size_t)R * 128);
+        L.hco = take((size_t)R * 32);
+        L.hco64 = take((size_t)R * 32);
+        L.src = take((size_t)6 * R * 8);
+        L.proof = take(max_len);
+        L.stride = o;
+    }
+    std::vector<rv_shard*> sh(B, nullptr);
+    std::vector<void*> pinned_tmp, device_tmp;
+    std::vector<LaunchRecorder> recs(B);
+    for (auto& r : recs) r.batch = (unsigned)B;
+    struct RecorderOff {
+        ~RecorderOff() { g_recorder = nullptr; }
+    } recorder_off;
+    const bool was_pipelined = ctx->pipeline;
+    ctx->pipeline = false;
+    InterpParams* d_pp = nullptr;
+    auto cleanup = [&](int code) {
+        g_recorder = nullptr;
+        (void)hipStreamSynchronize(ctx->stream);
+        for (rv_shard* s : sh)
+            if (s) {
+                s->destroy();
+                delete s;
+            }
+        ctx->release(d_pp);
+        for (void* q : device_tmp) ctx->release(q);
+        for (void* q : pinned_tmp) g_pinned.put(q);
+        ctx->pipeline = was_pipelined;
+        return code;
+    };
+    constexpr size_t HEAD = 256;  // (no slot pointer equals an arena block: the slabs are released exactly once)
+    uint8_t* h_slab = (uint8_t*)g_pinned.get(std::max<size_t>(L.stride * B, PinnedPool::MIN_BYTES));
+    if (!h_slab) return cleanup(RV_E_NOMEM);
+    pinned_tmp.push_back(h_slab);
+    uint8_t* d_slab = nullptr;
+    int rc;
+    if ((rc = dalloc(ctx, HEAD + L.stride * B, &d_slab))) return cleanup(rc);
+    device_tmp.push_back(d_slab);
+    uint8_t* d_out = nullptr;  // per proof: 256 x 32 digest bytes, then the device flag word
+    const size_t out_stride = (size_t)R * 32 + 256;
+    if ((rc = dalloc(ctx, HEAD + out_stride * B, &d_out))) return cleanup(rc);
+    device_tmp.push_back(d_out);
+    std::vector<uint32_t> n_quads(B, 0);
+    for (size_t k = 0; k < B; k++) {
+        const size_t b = live[k];
+        const Parsed& Q = P[b];
+        uint8_t* h = h_slab + k * L.stride;
+        memset(h, 0, L.proof);  // everything in front of the proof bytes
+        uint8_t* omit = h + L.omit;
+        memset(omit, 8, R);
+        uint32_t* keep = (uint32_t*)(h + L.keep);
+        uint32_t* onm = (uint32_t*)(h + L.onm);
+        for (uint32_t q = 0; q < NQ; q++) keep[q] = 0xFFFFFFFFu;
+        uint64_t* src = (uint64_t*)(h + L.src);
+        // VerifierTranscriptOnline::new (online.rs:25-119) / VerifierTranscriptPreprocess::new (preprocess.rs:17-43),
+        // as in rv_verify_shard: slots 0..39 are the online records in proof order, 40..255 the preprocessing ones
+        for (uint32_t g0 = 0; g0 < R; g0 += 8) {
+            if (g0 < RV_ONLINE_REPS) {
+                const OnRec* o = &Q.gf2.on[g0];
+                const OnRec* z = &Q.z64.on[g0];
+                for (int i = 0; i < 8; i++) {
+                    if (o[i].omit >= 8 || z[i].omit >= 8) return cleanup(RV_E_PROOF_MALFORMED);
+                    if (o[i].n_corr < o[0].n_corr || o[i].n_in < o[0].n_in || o[i].n_rec != o[0].n_rec) return cleanup(RV_E_PROOF_MALFORMED);
+                    const uint32_t r = g0 + i;
+                    omit[r] = o[i].omit;
+                    src[0 * R + r] = L.proof + o[i].rec;  // offsets into this proof's slot
+                    src[1 * R + r] = o[0].n_rec;
+                    src[2 * R + r] = L.proof + o[i].corr;
+                    src[3 * R + r] = o[0].n_corr;
+                    src[4 * R + r] = L.proof + o[i].in;
+                    src[5 * R + r] = o[0].n_in;
+                    keep[r / 4] &= ~(1u << (31 - 8 * (r % 4) - o[i].omit));
+                    onm[r / 4] |= 0xFFu << (24 - 8 * (r % 4));
+                    memcpy(h + L.hkeys + (size_t)r * 128, proofs[b] + o[i].keys, 128);
+                }
+            } else {
+                const PreRec* q = &Q.gf2.pre[g0 - RV_ONLINE_REPS];
+                const PreRec* q64 = &Q.z64.pre[g0 - RV_ONLINE_REPS];
+                for (int i = 0; i < 8; i++) {
+                    memcpy(h + L.seeds + (size_t)(g0 + i) * 16, proofs[b] + q[i].seed, 16);
+                    memcpy(h + L.hco + (size_t)(g0 + i) * 32, proofs[b] + q[i].comm_online, 32);
+                    memcpy(h + L.hco64 + (size_t)(g0 + i) * 32, proofs[b] + q64[i].comm_online, 32);
+                }
+            }
+        }
+        uint32_t* quads = (uint32_t*)(h + L.quads);
+        for (uint32_t q = 0; q < NQ; q++)
+            if (onm[q]) quads[n_quads[k]++] = q;
+        memcpy(h + L.proof, proofs[b], proof_lens[b]);
+    }
+    if (hipMemcpyAsync(d_slab + HEAD, h_slab, L.stride * B, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return cleanup(RV_E_DEVICE);
+    // ---- per proof (recorded): keys, masks, supplied-value rows, buffers
+    std::vector<InterpParams> pp(B);
+    for (size_t k = 0; k < B && !rc; k++) {
+        uint8_t* d = d_slab + HEAD + k * L.stride;
+        rv_shard* s = sh[k] = new rv_shard();
+        s->ctx = ctx;
+        s->c = c;
+        s->rep_begin = 0;
+        s->R = R;
+        s->NQ = NQ;
+        s->d_seeds = d + L.seeds;  // slab slots: not arena blocks, destroy() ignores them
+        s->d_omit = d + L.omit;
+        s->d_h = d_out + HEAD + k * out_stride;
+        s->d_err = (int*)(d_out + HEAD + k * out_stride + (size_t)R * 32);
+        s->d_on_quads = (const uint32_t*)(d + L.quads);
+        s->n_on_quads = n_quads[k];
+        if ((rc = dalloc(ctx, (size_t)R * 128, &s->d_keys))) break;
+        uint32_t *d_sup_in = nullptr, *d_sup_corr = nullptr, *d_sup_rec = nullptr;
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_in, 1) * NQ, &d_sup_in))) break;
+        s->extra.push_back(d_sup_in);
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * NQ, &d_sup_corr))) break;
+        s->extra.push_back(d_sup_corr);
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_rec, 1) * NQ, &d_sup_rec))) break;
+        s->extra.push_back(d_sup_rec);
+        g_recorder = &recs[k];
+        launch_expand_seeds(ctx->stream, s->d_seeds, R, s->d_keys);
+        launch_overlay_rows(ctx->stream, (uint32_t*)s->d_keys, (const uint32_t*)(d + L.hkeys), s->d_omit, R, 32, 1);
+        if (!(rc = shard_setup_prg(s, (const uint32_t*)(d + L.keep)))) {
+            const uint64_t* d_src = (const uint64_t*)(d + L.src);
+            launch_unpack_bits(ctx->stream, d, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
+            launch_unpack_bits(ctx->stream, d, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr);
+            launch_unpack_bits(ctx->stream, d, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec);
+            Interp64Params p64{};
+            pp[k] = InterpParams{};
+            pp[k].on_mask = (const uint32_t*)(d + L.onm);
+            pp[k].sup_in = d_sup_in;
+            pp[k].sup_corr = d_sup_corr;
+            pp[k].sup_rec = d_sup_rec;
+            rc = shard_run_alloc(s, pp[k], p64);
+        }
+        g_recorder = nullptr;
+    }
+    if (rc) return cleanup(rc);
+    if ((rc = replay_recorded(ctx, recs, pinned_tmp, device_tmp))) return cleanup(rc);
+    // ---- all proofs level by level, verify mode
+    if ((rc = dalloc(ctx, B, &d_pp))) return cleanup(rc);
+    if (hipMemcpyAsync(d_pp, pp.data(), B * sizeof(InterpParams), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return cleanup(RV_E_DEVICE);
+    {
+        const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+        for (size_t l = 0; l < n_levels; l++) {
+            if (c->run_of_level[l] >= 0) {
+                const auto& run = c->narrow_runs[(size_t)c->run_of_level[l]];
+                if (l == run.first)
+                    launch_interp_narrow_batched(ctx->stream, c->d_gates, c->d_level_range, run.first, run.second, run.tiny, d_pp, (uint32_t)B, MODE_VERIFY);
+                continue;
+            }
+            launch_interp_batched(ctx->stream, c->d_gates, cc.level_range[l], d_pp, (uint32_t)B, MODE_VERIFY);
+        }
+    }
+    // ---- per proof (recorded): digests, the commitments the preprocessing slots carry over, join
+    for (size_t k = 0; k < B && !rc; k++) {
+        uint8_t* d = d_slab + HEAD + k * L.stride;
+        rv_shard* s = sh[k];
+        const size_t DW = (size_t)R * 8;
+        g_recorder = &recs[k];
+        if (!(rc = shard_run_hash(s))) {
+            launch_overlay_rows(ctx->stream, s->d_dig + 1 * DW, (const uint32_t*)(d + L.hco), s->d_omit, R, 8, 0);
+            launch_overlay_rows(ctx->stream, s->d_dig + 3 * DW, (const uint32_t*)(d + L.hco64), s->d_omit, R, 8, 0);
+            rc = shard_join(s);
+        }
+        g_recorder = nullptr;
+    }
+    if (rc) return cleanup(rc);
+    if ((rc = replay_recorded(ctx, recs, pinned_tmp, device_tmp))) return cleanup(rc);
+    uint8_t* h_out = (uint8_t*)g_pinned.get(std::max<size_t>(out_stride * B, PinnedPool::MIN_BYTES));
+    if (!h_out) return cleanup(RV_E_NOMEM);
+    pinned_tmp.push_back(h_out);
+    if (hipMemcpyAsync(h_out, d_out + HEAD, out_stride * B, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return cleanup(hip_fail(hipGetLastError(), "verify batch sync", __FILE__, __LINE__));
+    // ---- the final check per proof (proof/mod.rs:283-306)
+    for (size_t k = 0; k < B; k++) {
+        const size_t b = live[k];
+        int dev_flags = 0;
+        memcpy(&dev_flags, h_out + k * out_stride + (size_t)R * 32, sizeof dev_flags);
+        if ((rc = rv_verify_finish_ex(proofs[b], proof_lens[b], h_out + k * out_stride, flags, !(dev_flags & RV_DEV_ZERO_CHECK), &ok[b])))
+            return cleanup(rc);
+    }
+    ctx->prof.calls += B;
+    return cleanup(RV_OK);
+}
+
+extern "C" int rv_verify_batch(rv_ctx* ctx, const rv_circuit* c, size_t batch, const uint8_t* const* proofs, const size_t* proof_lens,
+                               uint32_t flags, int* ok) {
+    try {  // no C++ exception may cross the C boundary
+        return rv_verify_batch_impl(ctx, c, batch, proofs, proof_lens, flags, ok);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
 }
 
 // ------------------------------------------------------------------------------------

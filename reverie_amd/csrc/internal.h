@@ -154,9 +154,10 @@ void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const L
                           int tiny, const InterpParams& p);
 // rv_prove_batch: the same level / narrow-run launches for `batch` proofs at once (prover, NQ = 64); d_pp = device
 // array of one InterpParams per proof
-void launch_interp_batched(hipStream_t st, const Gate* d_gates, const LevelRange& r, const InterpParams* d_pp, uint32_t batch);
+void launch_interp_batched(hipStream_t st, const Gate* d_gates, const LevelRange& r, const InterpParams* d_pp, uint32_t batch,
+                           int mode = MODE_PROVE);
 void launch_interp_narrow_batched(hipStream_t st, const Gate* d_gates, const LevelRange* d_level_range, uint32_t l0, uint32_t l1,
-                                  int tiny, const InterpParams* d_pp, uint32_t batch);
+                                  int tiny, const InterpParams* d_pp, uint32_t batch, int mode = MODE_PROVE);
 void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t lo, uint32_t hi, const Interp64Params& p);
 // Z64 masks: masks64[m][slot] = LE64(keystream[slot][8m..8m+8)), blocks [first, first+n_blocks) -> masks 2*first..
 void launch_aes_z64_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t n_blocks,

@@ -625,24 +625,34 @@ void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRan
         hipLaunchKernelGGL(k_interp<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);
 }
 
-// rv_prove_batch: `batch` full proofs (256 repetitions, NQ = 64) of one circuit, prover side only
-void launch_interp_batched(hipStream_t st, const Gate* d_gates, const LevelRange& r, const InterpParams* d_pp, uint32_t batch) {
+// rv_prove_batch / rv_verify_batch: `batch` full proofs (256 repetitions, NQ = 64) of one circuit
+void launch_interp_batched(hipStream_t st, const Gate* d_gates, const LevelRange& r, const InterpParams* d_pp, uint32_t batch, int mode) {
     if (r.hi <= r.lo || !batch) return;
     uint64_t waves = ((uint64_t)(r.hi - r.lo) + RV_INTERP_UNROLL - 1) / RV_INTERP_UNROLL;
     uint64_t blocks = (waves + 3) / 4;
     const uint64_t cap = std::max<uint64_t>(4096 / batch, 1);
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_interp_full_b<MODE_PROVE, 64>), dim3((unsigned)blocks, batch), dim3(256), 0, st, d_gates, r, d_pp);
+    if (mode == MODE_PROVE)
+        hipLaunchKernelGGL((k_interp_full_b<MODE_PROVE, 64>), dim3((unsigned)blocks, batch), dim3(256), 0, st, d_gates, r, d_pp);
+    else
+        hipLaunchKernelGGL((k_interp_full_b<MODE_VERIFY, 64>), dim3((unsigned)blocks, batch), dim3(256), 0, st, d_gates, r, d_pp);
 }
 
 void launch_interp_narrow_batched(hipStream_t st, const Gate* d_gates, const LevelRange* d_level_range, uint32_t l0, uint32_t l1,
-                                  int tiny, const InterpParams* d_pp, uint32_t batch) {
+                                  int tiny, const InterpParams* d_pp, uint32_t batch, int mode) {
     for (uint32_t a = l0; a < l1 && batch; a += NARROW_MAX_LEVELS) {
         const uint32_t b = (a + NARROW_MAX_LEVELS < l1) ? a + NARROW_MAX_LEVELS : l1;
-        if (tiny)
-            hipLaunchKernelGGL((k_interp_narrow_b<MODE_PROVE, 0>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
-        else
-            hipLaunchKernelGGL((k_interp_narrow_b<MODE_PROVE, 64>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
+        if (mode == MODE_PROVE) {
+            if (tiny)
+                hipLaunchKernelGGL((k_interp_narrow_b<MODE_PROVE, 0>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
+            else
+                hipLaunchKernelGGL((k_interp_narrow_b<MODE_PROVE, 64>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
+        } else {
+            if (tiny)
+                hipLaunchKernelGGL((k_interp_narrow_b<MODE_VERIFY, 0>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
+            else
+                hipLaunchKernelGGL((k_interp_narrow_b<MODE_VERIFY, 64>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
+        }
     }
 }
 
@@ -958,16 +968,20 @@ __global__ void k_join(const uint32_t* __restrict__ pre2, const uint32_t* __rest
 // verifier set-up: rows of `src` replace those of `dst` for the repetitions with (omit[r] < 8) == want_online
 // (opened player keys and carried-over online commitments arrive in ONE staging copy instead of one tiny
 // host-to-device copy per repetition)
-__global__ void k_overlay_rows(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, const uint8_t* __restrict__ omit,
-                               uint32_t R, uint32_t row_words, int want_online) {
+struct B_k_overlay_rows {
+    __device__ __forceinline__ void operator()(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, const uint8_t* __restrict__ omit, uint32_t R, uint32_t row_words, int want_online) const {
     const uint32_t r = blockIdx.x;
     if (r >= R || (int)(omit[r] < RV_PLAYERS) != want_online) return;
     for (uint32_t t = threadIdx.x; t < row_words; t += blockDim.x) dst[(size_t)r * row_words + t] = src[(size_t)r * row_words + t];
 }
+};
+__global__ void k_overlay_rows(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, const uint8_t* __restrict__ omit, uint32_t R, uint32_t row_words, int want_online) {
+    B_k_overlay_rows{}(dst, src, omit, R, row_words, want_online);
+}
 
 void launch_overlay_rows(hipStream_t st, uint32_t* d_dst, const uint32_t* d_src, const uint8_t* d_omit, uint32_t R,
                          uint32_t row_words, int want_online) {
-    hipLaunchKernelGGL(k_overlay_rows, dim3(R), dim3(32), 0, st, d_dst, d_src, d_omit, R, row_words, want_online);
+    launch<B_k_overlay_rows, 32>(k_overlay_rows, st, dim3(R), dim3(32), d_dst, d_src, d_omit, R, row_words, want_online);
 }
 
 // n_rows copies of one 32-byte digest (the Z64 transcripts of a pure GF(2) circuit are empty: BLAKE3(""))
@@ -1375,9 +1389,8 @@ void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d
 // and the rows leave as full-width coalesced stores.  (One thread per word with four scattered byte loads from the
 // proof took 2.0 ms per vector on the headline circuit; this takes 0.3: the 1.28 GB of rows written are the cost.)
 constexpr uint32_t UNP_TB = 64;
-__global__ __launch_bounds__(256) void k_unpack_bits(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off,
-                                                     const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit,
-                                                     uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out) {
+struct B_k_unpack_bits {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out) const {
     __shared__ uint8_t s_bytes[RV_ONLINE_REPS * UNP_TB];
     __shared__ uint8_t s_slot[256];
     __shared__ uint64_t s_off[RV_ONLINE_REPS], s_len[RV_ONLINE_REPS];
@@ -1455,13 +1468,17 @@ __global__ __launch_bounds__(256) void k_unpack_bits(const uint8_t* __restrict__
         rows_out[(it0 + il) * NQ + q] = w;
     }
 }
+};
+__global__ __launch_bounds__(256) void k_unpack_bits(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out) {
+    B_k_unpack_bits{}(blob, src_off, src_len, omit, n_items, NQ, kind, rows_out);
+}
 
 void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
                         const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out) {
     if (!n_items) return;
     const uint64_t n_bytes = (n_items + 7) / 8;
-    hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((n_bytes + UNP_TB - 1) / UNP_TB)), dim3(256), 0, st, d_blob, d_src_off, d_src_len,
-                       d_omit, n_items, NQ, kind, d_rows_out);
+    launch<B_k_unpack_bits, 256>(k_unpack_bits, st, dim3((unsigned)((n_bytes + UNP_TB - 1) / UNP_TB)), dim3(256), d_blob, d_src_off, d_src_len,
+                                 d_omit, n_items, NQ, kind, d_rows_out);
 }
 
 // Fixed-size parts of the openings, one thread per repetition of the shard.

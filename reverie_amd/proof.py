@@ -195,6 +195,36 @@ class Proof:
         return bool(ok.value)
 
 
+def verify_batch(circuit, proofs, wire_counts: Optional[Tuple[int, int]] = None, ctx: Optional[Context] = None,
+                 strict: bool = False) -> "list[bool]":
+    """rv_verify_batch: Proof.verify for many proofs of one circuit in one pass (`proofs`: Proof objects or bytes);
+    -> one bool per proof, each what Proof.verify(circuit, strict=strict) would return.  A proof whose bytes cannot be
+    parsed raises, like it would on its own."""
+    c = _as_circuit(circuit, wire_counts, ctx)
+    n = len(proofs)
+    if n == 0:
+        return []
+    keep = []
+    ptrs = (C.c_void_p * n)()
+    lens = (C.c_size_t * n)()
+    for i, p in enumerate(proofs):
+        if isinstance(p, Proof):
+            buf, ln = p._buffer()
+            ptrs[i] = C.cast(buf, C.c_void_p).value
+            keep.append(p)
+        else:
+            b = bytes(p)
+            buf = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0")
+            ptrs[i] = C.addressof(buf)
+            ln = len(b)
+        keep.append(buf)
+        lens[i] = ln
+    ok = (C.c_int * n)()
+    flags = _lib.RV_VERIFY_STRICT if strict else 0
+    _lib.check(_lib.lib().rv_verify_batch(c.ctx.handle, c.handle, C.c_size_t(n), ptrs, lens, C.c_uint32(flags), ok))
+    return [bool(x) for x in ok]
+
+
 # ---- Fiat-Shamir helpers (host) ----
 def combine_digests(h) -> bytes:
     h = np.ascontiguousarray(np.asarray(h, dtype=np.uint8)).reshape(TOTAL_REPS, 32)

@@ -820,3 +820,67 @@ def test_mixed_circuit_shards_vs_oracle(rv, oracle, n_shards):
         ok = C.c_int()
         _lib.check(L.rv_verify_finish_ex(_p(buf), C.c_size_t(len(buf)), _p(dig), C.c_uint32(1), C.c_int(zc_all), C.byref(ok)))
         assert ok.value == 1 and zc_all == 1
+
+
+# ---------------------------------------------------------------- rv_verify_batch
+def test_verify_batch_matches_single_verifier(rv, oracle, monkeypatch):
+    """rv_verify_batch answers, proof by proof, what rv_verify_ex answers (and the oracle): valid proofs, flipped payload
+    and commitment bytes, wrong repetition counts (`false`), the assertion gap with and without RV_VERIFY_STRICT, a
+    mixed circuit (proof-after-proof fallback), chunked batches; unparsable bytes fail the call like they do alone."""
+    from reverie_amd._lib import ReverieError
+
+    for seed in range(3):
+        rng = np.random.default_rng(100 + seed)
+        prog, wit, wc = circuits.random_gf2(rng, n_in=12, n_gates=700, n_wires=40)
+        c = rv.Circuit(prog, wc)
+        nb = 9
+        seeds = rng.integers(0, 256, (nb, 256, 16), dtype=np.uint8)
+        proofs = rv.Proof.new_batch(c, np.tile(np.asarray(wit, np.uint8), (nb, 1)), seeds=seeds)
+        assert rv.verify_batch(c, proofs, strict=True) == [True] * nb  # Proof objects, in place
+        blobs = [bytes(p) for p in proofs]
+        for k in (1, 4, 7):  # a payload byte of an online record
+            b = bytearray(blobs[k])
+            b[200 + 37 * k] ^= 1 << (k % 8)
+            blobs[k] = bytes(b)
+        b = bytearray(blobs[5]); b[3] ^= 1; blobs[5] = bytes(b)  # a commitment byte
+        short = blobs[8]
+        off = len(short) - 216 * 48 - 8
+        blobs[8] = short[:off] + (215).to_bytes(8, "little") + short[off + 8:-48]  # 215 preprocessing records: `false`
+        for env in ({}, {"RV_BATCH_MAX": "4"}):
+            monkeypatch.delenv("RV_BATCH_MAX", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for strict in (False, True):
+                want, err = [], 0
+                for bl in blobs:
+                    try:
+                        want.append(rv.Proof(bl).verify(c, strict=strict))
+                    except ReverieError as e:
+                        err = err or e.code
+                        want.append(None)
+                if err:
+                    with pytest.raises(ReverieError) as e:
+                        rv.verify_batch(c, blobs, strict=strict)
+                    assert e.value.code == err
+                    good = [bl for bl, w in zip(blobs, want) if w is not None]
+                    assert rv.verify_batch(c, good, strict=strict) == [w for w in want if w is not None]
+                else:
+                    assert rv.verify_batch(c, blobs, strict=strict) == want
+                assert want[8] is False and want[0] is True
+                assert [oracle.verify(prog, wc, bl, strict=strict) for bl, w in zip(blobs, want) if w is not None] == [w for w in want if w is not None]
+        monkeypatch.delenv("RV_BATCH_MAX", raising=False)
+    # the reference's assertion gap, batched: a pure GF(2) statement checked against other constants
+    prog1 = program([GF2.Input(0), GF2.Input(1), GF2.Mul(2, 0, 1), GF2.AddConst(3, 2, 1), GF2.AssertZero(3)] +
+                    [GF2.Mul(4 + i, 2, i % 2) for i in range(40)])
+    prog2 = prog1.copy()
+    prog2[3]["imm"] = 0
+    seeds = np.random.default_rng(9).integers(0, 256, (5, 256, 16), dtype=np.uint8)
+    c1, c2 = rv.Circuit(prog1, (0, 44)), rv.Circuit(prog2, (0, 44))
+    proofs = rv.Proof.new_batch(c1, np.ones((5, 2), np.uint8), seeds=seeds)
+    assert rv.verify_batch(c1, proofs) == [True] * 5 and rv.verify_batch(c1, proofs, strict=True) == [True] * 5
+    assert rv.verify_batch(c2, proofs) == [True] * 5 and rv.verify_batch(c2, proofs, strict=True) == [False] * 5
+    # a mixed circuit falls back to one proof after the other
+    cm1, cm2, w2, w64, wcm = circuits.assert_circuits()
+    pm = rv.Proof.new(cm1, w2, w64, wcm, seeds=seeds[0])
+    assert rv.verify_batch(cm2, [pm, pm], wcm) == [True, True] and rv.verify_batch(cm2, [pm, pm], wcm, strict=True) == [False, False]
+    assert rv.verify_batch(c1, []) == []
