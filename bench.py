@@ -94,6 +94,7 @@ def secondary(args, local):
     proofs = [None] * args.batch
 
     fused = args.fused_batch
+    last_batch = [None] * args.batch
     if fused:
         rng = np.random.default_rng(99)
         fused_seeds = rng.integers(0, 256, (fused, 256, 16), dtype=np.uint8)
@@ -103,7 +104,8 @@ def secondary(args, local):
     def worker(i, n):
         for _ in range(n):
             if fused:
-                proofs[i] = reverie_amd.Proof.new_batch(circs[i], fused_w2, seeds=fused_seeds)[0]
+                last_batch[i] = reverie_amd.Proof.new_batch(circs[i], fused_w2, seeds=fused_seeds)
+                proofs[i] = last_batch[i][0]
             else:
                 proofs[i] = reverie_amd.Proof.new(circs[i], w2, w64, seeds=seeds)
 
@@ -129,6 +131,15 @@ def secondary(args, local):
     t0 = time.perf_counter()
     ok = proofs[0].verify(circs[0])
     verify_s = time.perf_counter() - t0
+    vb = None
+    if fused and last_batch[0] is not None:
+        # rv_verify_batch on the proofs of the last rv_prove_batch call (strict), second call timed
+        reverie_amd.verify_batch(circs[0], last_batch[0], strict=True)
+        t0 = time.perf_counter()
+        oks = reverie_amd.verify_batch(circs[0], last_batch[0], strict=True)
+        tvb = time.perf_counter() - t0
+        vb = {"proofs": len(oks), "all_ok": all(oks), "ms": tvb * 1e3, "us_per_proof": tvb / len(oks) * 1e6,
+              "value": unit_n * len(oks) / tvb, "unit": unit}
     res = {
         "metric": f"prover {unit} ({args.workload}); secondary config", "value": unit_n * args.steps * args.batch * max(args.fused_batch, 1) / dt, "unit": unit,
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -139,6 +150,8 @@ def secondary(args, local):
                    "phase_ms_ctx0": phases,
                    "boundary": "host bytes in / host proof bytes out (rv_prove), PCIe included"},
     }
+    if vb:
+        res["verify_batch"] = vb
     if not args.no_cpu_baseline and args.workload != "z64":
         t0 = time.perf_counter()
         want = oracle_lib.prove(prog, w2, w64, wc, seeds, threads=min(32, os.cpu_count() or 1))
