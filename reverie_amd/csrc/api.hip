@@ -1311,6 +1311,56 @@ extern "C" int rv_prove_device(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
 // chain is paid once per batch; the per-proof phases around it (keys, masks, digests, openings) are queued proof
 // after proof on the same stream with a single synchronisation at the end.
 // ------------------------------------------------------------------------------------
+// Issues the calls recorded for the proofs of a batch (launch.h): every kernel step once, with gridDim.y = proof and
+// the argument blocks in a device array; recorded copies one by one.  The staging buffers go to the caller's lists.
+static int replay_recorded(rv_ctx* ctx, std::vector<LaunchRecorder>& recs, std::vector<void*>& pinned_tmp, std::vector<void*>& device_tmp) {
+    const size_t batch = recs.size(), n = recs[0].calls.size();
+    for (size_t b = 1; b < batch; b++)
+        if (recs[b].calls.size() != n) return RV_E_DEVICE;
+    size_t total = 0;
+    std::vector<size_t> off(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const auto& c0 = recs[0].calls[i];
+        for (size_t b = 1; b < batch; b++) {
+            const auto& c = recs[b].calls[i];
+            if (c.replay != c0.replay || c.grid.x != c0.grid.x || c.block.x != c0.block.x || c.arg_bytes != c0.arg_bytes) return RV_E_DEVICE;
+        }
+        if (!c0.replay) continue;
+        if (c0.grid.y != 1 || c0.grid.z != 1) return RV_E_DEVICE;
+        off[i] = total;
+        total += ((size_t)c0.arg_bytes * batch + 15) & ~(size_t)15;
+    }
+    uint8_t* d_args = nullptr;
+    if (total) {
+        uint8_t* h = (uint8_t*)g_pinned.get(std::max<size_t>(total, PinnedPool::MIN_BYTES));
+        if (!h) return RV_E_NOMEM;
+        pinned_tmp.push_back(h);
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t ab = recs[0].calls[i].arg_bytes;
+            if (!recs[0].calls[i].replay) continue;
+            for (size_t b = 0; b < batch; b++) memcpy(h + off[i] + b * ab, recs[b].calls[i].args.data(), ab);
+        }
+        int r = dalloc(ctx, total, &d_args);
+        if (r) return r;
+        device_tmp.push_back(d_args);
+        if (hipMemcpyAsync(d_args, h, total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return RV_E_DEVICE;
+    }
+    for (size_t i = 0; i < n; i++) {
+        const auto& c0 = recs[0].calls[i];
+        if (c0.replay) {
+            c0.replay(ctx->stream, c0.grid, c0.block, d_args + off[i], (unsigned)batch);
+        } else {
+            for (size_t b = 0; b < batch; b++) {
+                const auto& c = recs[b].calls[i];
+                if (hipMemcpyAsync(c.dst, c.src, c.n, c.kind, ctx->stream) != hipSuccess) return RV_E_DEVICE;
+            }
+        }
+    }
+    if (hipGetLastError() != hipSuccess) return RV_E_DEVICE;
+    for (auto& r : recs) r.calls.clear();
+    return RV_OK;
+}
+
 static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, const uint8_t* wit_gf2, size_t n_gf2,
                                const uint64_t* wit_z64, size_t n_z64, const uint8_t* seeds, uint8_t** proofs, size_t* proof_lens) {
     if (!ctx || !c || !proofs || !proof_lens || !batch) return RV_E_ARG;
@@ -1438,54 +1488,7 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
         fprintf(stderr, "[rv batch] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
         t_last = t;
     };
-    auto replay = [&]() -> int {
-        const size_t n = recs[0].calls.size();
-        for (size_t b = 1; b < batch; b++)
-            if (recs[b].calls.size() != n) return RV_E_DEVICE;
-        size_t total = 0;
-        std::vector<size_t> off(n, 0);
-        for (size_t i = 0; i < n; i++) {
-            const auto& c0 = recs[0].calls[i];
-            for (size_t b = 1; b < batch; b++) {
-                const auto& c = recs[b].calls[i];
-                if (c.replay != c0.replay || c.grid.x != c0.grid.x || c.block.x != c0.block.x || c.arg_bytes != c0.arg_bytes)
-                    return RV_E_DEVICE;  // cannot happen: one circuit, one code path
-            }
-            if (!c0.replay) continue;
-            if (c0.grid.y != 1 || c0.grid.z != 1) return RV_E_DEVICE;
-            off[i] = total;
-            total += ((size_t)c0.arg_bytes * batch + 15) & ~(size_t)15;
-        }
-        uint8_t* d_args = nullptr;
-        if (total) {
-            uint8_t* h = (uint8_t*)g_pinned.get(std::max<size_t>(total, PinnedPool::MIN_BYTES));
-            if (!h) return RV_E_NOMEM;
-            pinned_tmp.push_back(h);
-            for (size_t i = 0; i < n; i++) {
-                const uint32_t ab = recs[0].calls[i].arg_bytes;
-                if (!recs[0].calls[i].replay) continue;
-                for (size_t b = 0; b < batch; b++) memcpy(h + off[i] + b * ab, recs[b].calls[i].args.data(), ab);
-            }
-            int r = dalloc(ctx, total, &d_args);
-            if (r) return r;
-            device_tmp.push_back(d_args);
-            if (hipMemcpyAsync(d_args, h, total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return RV_E_DEVICE;
-        }
-        for (size_t i = 0; i < n; i++) {
-            const auto& c0 = recs[0].calls[i];
-            if (c0.replay) {
-                c0.replay(ctx->stream, c0.grid, c0.block, d_args + off[i], (unsigned)batch);
-            } else {
-                for (size_t b = 0; b < batch; b++) {
-                    const auto& c = recs[b].calls[i];
-                    if (hipMemcpyAsync(c.dst, c.src, c.n, c.kind, ctx->stream) != hipSuccess) return RV_E_DEVICE;
-                }
-            }
-        }
-        if (hipGetLastError() != hipSuccess) return RV_E_DEVICE;
-        for (auto& r : recs) r.calls.clear();
-        return RV_OK;
-    };
+    auto replay = [&]() -> int { return replay_recorded(ctx, recs, pinned_tmp, device_tmp); };
     // ---- per proof: seeds, witness, keys, masks, buffers.  What the host sends or fetches per proof (seeds, witness,
     // error flag, the proof itself) lives in ONE allocation per kind, a slot per proof, so that it moves in one copy
     // per batch instead of one per proof (1 280 small copies were a fifth of a batch's GPU time).  The slots start
@@ -2031,54 +2034,6 @@ static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof
 // through the batched interpreter kernels in verify mode, and the slot digests plus the zero-check flags come back in
 // one copy each.  The final check (rv_verify_finish_ex) is host work per proof.
 // ------------------------------------------------------------------------------------
-static int replay_recorded(rv_ctx* ctx, std::vector<LaunchRecorder>& recs, std::vector<void*>& pinned_tmp, std::vector<void*>& device_tmp) {
-    const size_t batch = recs.size(), n = recs[0].calls.size();
-    for (size_t b = 1; b < batch; b++)
-        if (recs[b].calls.size() != n) return RV_E_DEVICE;
-    size_t total = 0;
-    std::vector<size_t> off(n, 0);
-    for (size_t i = 0; i < n; i++) {
-        const auto& c0 = recs[0].calls[i];
-        for (size_t b = 1; b < batch; b++) {
-            const auto& c = recs[b].calls[i];
-            if (c.replay != c0.replay || c.grid.x != c0.grid.x || c.block.x != c0.block.x || c.arg_bytes != c0.arg_bytes) return RV_E_DEVICE;
-        }
-        if (!c0.replay) continue;
-        if (c0.grid.y != 1 || c0.grid.z != 1) return RV_E_DEVICE;
-        off[i] = total;
-        total += ((size_t)c0.arg_bytes * batch + 15) & ~(size_t)15;
-    }
-    uint8_t* d_args = nullptr;
-    if (total) {
-        uint8_t* h = (uint8_t*)g_pinned.get(std::max<size_t>(total, PinnedPool::MIN_BYTES));
-        if (!h) return RV_E_NOMEM;
-        pinned_tmp.push_back(h);
-        for (size_t i = 0; i < n; i++) {
-            const uint32_t ab = recs[0].calls[i].arg_bytes;
-            if (!recs[0].calls[i].replay) continue;
-            for (size_t b = 0; b < batch; b++) memcpy(h + off[i] + b * ab, recs[b].calls[i].args.data(), ab);
-        }
-        int r = dalloc(ctx, total, &d_args);
-        if (r) return r;
-        device_tmp.push_back(d_args);
-        if (hipMemcpyAsync(d_args, h, total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return RV_E_DEVICE;
-    }
-    for (size_t i = 0; i < n; i++) {
-        const auto& c0 = recs[0].calls[i];
-        if (c0.replay) {
-            c0.replay(ctx->stream, c0.grid, c0.block, d_args + off[i], (unsigned)batch);
-        } else {
-            for (size_t b = 0; b < batch; b++) {
-                const auto& c = recs[b].calls[i];
-                if (hipMemcpyAsync(c.dst, c.src, c.n, c.kind, ctx->stream) != hipSuccess) return RV_E_DEVICE;
-            }
-        }
-    }
-    if (hipGetLastError() != hipSuccess) return RV_E_DEVICE;
-    for (auto& r : recs) r.calls.clear();
-    return RV_OK;
-}
-
 static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, const uint8_t* const* proofs, const size_t* proof_lens,
                                 uint32_t flags, int* ok) {
     if (!ctx || !c || !batch || !proofs || !proof_lens || !ok || (flags & ~(uint32_t)RV_VERIFY_STRICT)) return RV_E_ARG;
