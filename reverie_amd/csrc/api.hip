@@ -2149,7 +2149,7 @@ static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, 
     if ((rc = dalloc(ctx, HEAD + out_stride * B, &d_out))) return cleanup(rc);
     device_tmp.push_back(d_out);
     std::vector<uint32_t> n_quads(B, 0);
-    for (size_t k = 0; k < B; k++) {
+    auto fill = [&](size_t k) -> int {
         const size_t b = live[k];
         const Parsed& Q = P[b];
         uint8_t* h = h_slab + k * L.stride;
@@ -2167,8 +2167,8 @@ static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, 
                 const OnRec* o = &Q.gf2.on[g0];
                 const OnRec* z = &Q.z64.on[g0];
                 for (int i = 0; i < 8; i++) {
-                    if (o[i].omit >= 8 || z[i].omit >= 8) return cleanup(RV_E_PROOF_MALFORMED);
-                    if (o[i].n_corr < o[0].n_corr || o[i].n_in < o[0].n_in || o[i].n_rec != o[0].n_rec) return cleanup(RV_E_PROOF_MALFORMED);
+                    if (o[i].omit >= 8 || z[i].omit >= 8) return RV_E_PROOF_MALFORMED;
+                    if (o[i].n_corr < o[0].n_corr || o[i].n_in < o[0].n_in || o[i].n_rec != o[0].n_rec) return RV_E_PROOF_MALFORMED;
                     const uint32_t r = g0 + i;
                     omit[r] = o[i].omit;
                     src[0 * R + r] = L.proof + o[i].rec;  // offsets into this proof's slot
@@ -2195,6 +2195,24 @@ static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, 
         for (uint32_t q = 0; q < NQ; q++)
             if (onm[q]) quads[n_quads[k]++] = q;
         memcpy(h + L.proof, proofs[b], proof_lens[b]);
+        return RV_OK;
+    };
+    {
+        // host work per proof (a few hundred KB of copies each): shared by a few threads for large batches
+        const size_t n_thr = B >= 32 ? std::min<size_t>({(size_t)8, B / 8, (size_t)std::max(1u, std::thread::hardware_concurrency())}) : 1;
+        std::vector<int> rcs(std::max<size_t>(n_thr, 1), RV_OK);
+        auto range = [&](size_t t, size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1 && rcs[t] == RV_OK; k++) rcs[t] = fill(k);
+        };
+        if (n_thr <= 1) {
+            range(0, 0, B);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < n_thr; t++) th.emplace_back(range, t, B * t / n_thr, B * (t + 1) / n_thr);
+            for (auto& x : th) x.join();
+        }
+        for (int r : rcs)
+            if (r) return cleanup(r);
     }
     if (hipMemcpyAsync(d_slab + HEAD, h_slab, L.stride * B, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return cleanup(RV_E_DEVICE);
     // ---- per proof (recorded): keys, masks, supplied-value rows, buffers
