@@ -40,6 +40,13 @@ class HipShardBackend:
 
     def __init__(self, circuit: Circuit):
         self.circuit = circuit
+        self._sizes = None      # record sizes of the circuit (constant)
+        self._gather_bufs = {}  # (count, device) -> (own digests, all digests): reused from proof to proof
+
+    def _record_sizes(self):
+        if self._sizes is None:
+            self._sizes = self.circuit.record_sizes()
+        return self._sizes
 
     def commit(self, wit_gf2, wit_z64, seeds, rep_begin, rep_count):
         g = np.ascontiguousarray(np.asarray(wit_gf2, dtype=np.uint8))
@@ -64,7 +71,7 @@ class HipShardBackend:
     def all_open_sizes(self, omit: np.ndarray, world: int) -> List[List[int]]:
         """blob sizes of every rank's shard for this challenge — a pure function of the challenge and the
         circuit, so no collective is needed to learn them"""
-        sz2, sz64 = self.circuit.record_sizes()
+        sz2, sz64 = self._record_sizes()
         out = []
         for r in range(world):
             b, n = shard_range(r, world)
@@ -93,7 +100,7 @@ class HipShardBackend:
 
     def gathered_capacity(self, count: int) -> int:
         """bytes open_gathered may write for a shard of `count` repetitions (every one of up to 40 of them opened)"""
-        sz2, sz64 = self.circuit.record_sizes()
+        sz2, sz64 = self._record_sizes()
         return min(40, count) * (sz2 + sz64) + 2 * count * 48
 
     def open_gathered(self, shard, all_digests, tensor):
@@ -108,7 +115,7 @@ class HipShardBackend:
 
     def single_shard_sizes(self) -> List[int]:
         """blob sizes of a proof whose one shard holds all 256 repetitions (40 opened, 216 not)"""
-        sz2, sz64 = self.circuit.record_sizes()
+        sz2, sz64 = self._record_sizes()
         return [40 * sz2, 216 * 48, 40 * sz64, 216 * 48]
 
     def prove_device(self, wit_gf2, wit_z64, seeds, tensor):
@@ -204,12 +211,19 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
             # tests use it with gloo, several ranks on one GPU, to exercise the RCCL code path without RCCL)
             on_gpu = backend.device_type == "cuda" and (dist.get_backend(group) == "nccl" or os.environ.get("RV_DIST_DEVICE_PATH") == "1")
             dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-            mine = torch.empty(count * 32, dtype=torch.uint8, device=dev)
+            cache = getattr(backend, "_gather_bufs", None)
+            key = (count, str(dev))
+            if cache is not None and key in cache:
+                mine, allh = cache[key]  # both are consumed before this function returns
+            else:
+                mine = torch.empty(count * 32, dtype=torch.uint8, device=dev)
+                allh = torch.empty(TOTAL_REPS * 32, dtype=torch.uint8, device=dev)
+                if cache is not None:
+                    cache[key] = (mine, allh)
             if on_gpu:
                 backend.digests_into(shard, mine)
             else:
                 mine.copy_(torch.from_numpy(backend.digests(shard).reshape(-1)))
-            allh = torch.empty(TOTAL_REPS * 32, dtype=torch.uint8, device=dev)
             dist.all_gather_into_tensor(allh, mine, group=group)
             if on_gpu and device_resident and hasattr(backend, "open_gathered"):
                 # the gathered digests are on this GPU: commitment, challenge and this shard's openings without a
