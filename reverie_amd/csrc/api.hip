@@ -37,7 +37,7 @@ static int hip_fail(hipError_t e, const char* what, const char* file, int line) 
     } while (0)
 
 extern "C" const char* rv_last_error(void) { return g_last_error.c_str(); }
-extern "C" uint32_t rv_abi_version(void) { return 1; }
+extern "C" uint32_t rv_abi_version(void) { return 2; }  // 2: rv_circuit_info grew (compile_us, upload_us); rv_verify_ex / _batch, strict flag
 
 extern "C" const char* rv_strerror(int code) {
     switch (code) {
