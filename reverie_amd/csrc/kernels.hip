@@ -728,26 +728,30 @@ __global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ 
 
 // Same for a bit-per-rep transcript (the preprocessing stream): every bit is hashed as the
 // 0x00/0xFF byte the reference feeds its hasher (gf2/recon.rs:314-321).
+// RPL as in k_b3_chunks: 4 = one lane per quad word, 1 = four lanes share it (short transcripts: more, lighter wavefronts)
+template <int RPL>
 struct B_k_b3_chunks_bits {
     __device__ __forceinline__ void operator()(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs) const {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t c = tid / NQ;
-    const uint32_t q = (uint32_t)(tid % NQ);
+    constexpr uint32_t SUBS = 4 / RPL;
+    const uint64_t c = tid / (NQ * SUBS);
+    const uint32_t ql = (uint32_t)(tid % (NQ * SUBS));
+    const uint32_t q = ql / SUBS, sub = ql % SUBS;
     if (c >= n_chunks) return;
     const uint64_t ev0 = c * 1024;
     const uint64_t len = (n_events - ev0 < 1024) ? (n_events - ev0) : 1024;
     const uint32_t nblk = len == 0 ? 1 : (uint32_t)((len + 63) / 64);
     const uint32_t h = NQ >> 1, o = q >> 1, sh = 4 * (q & 1);
-    uint32_t cv[4][8];
+    uint32_t cv[RPL][8];
 #pragma unroll
-    for (int i = 0; i < 4; i++) b3::iv(cv[i]);
+    for (int i = 0; i < RPL; i++) b3::iv(cv[i]);
     for (uint32_t b = 0; b < nblk; b++) {
         const uint64_t e0 = ev0 + 64ull * b;
         const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
         uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
         if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
         // P = the nibbles of events 4k..4k+3, one per byte; repetition i4 owns nibble bit 3-i4
-        uint32_t m[4][16];
+        uint32_t m[RPL][16];
         uint32_t nbs[64];
         if (blen == 64) {
 #pragma unroll
@@ -762,24 +766,28 @@ struct B_k_b3_chunks_bits {
 #pragma unroll
             for (int j = 0; j < 4; j++) P |= ((nbs[4 * k + j] >> sh) & 0xFu) << (8 * j);
 #pragma unroll
-            for (int i4 = 0; i4 < 4; i4++) {
+            for (int i = 0; i < RPL; i++) {
+                const uint32_t i4 = sub * RPL + i;
                 const uint32_t t = (P >> (3 - i4)) & 0x01010101u;
-                m[i4][k] = (t << 8) - t;
+                m[i][k] = (t << 8) - t;
             }
         }
-        b3::compress_n<4>(cv, m, c, blen, flags);
+        b3::compress_n<RPL>(cv, m, c, blen, flags);
     }
     const uint32_t R = NQ * 4;
 #pragma unroll
-    for (int i4 = 0; i4 < 4; i4++) {
-        uint32_t* dst = cvs + ((size_t)c * R + 4 * q + i4) * 8;
+    for (int i = 0; i < RPL; i++) {
+        uint32_t* dst = cvs + ((size_t)c * R + 4 * q + sub * RPL + i) * 8;
 #pragma unroll
-        for (int k = 0; k < 8; k++) dst[k] = cv[i4][k];
+        for (int k = 0; k < 8; k++) dst[k] = cv[i][k];
     }
 }
 };
 __global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs) {
-    B_k_b3_chunks_bits{}(stream, n_events, NQ, n_chunks, cvs);
+    B_k_b3_chunks_bits<4>{}(stream, n_events, NQ, n_chunks, cvs);
+}
+__global__ __launch_bounds__(256) void k_b3_chunks_bits1(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs) {
+    B_k_b3_chunks_bits<1>{}(stream, n_events, NQ, n_chunks, cvs);
 }
 
 // LG tree levels per launch: thread = (group of G = 2^LG consecutive nodes, repetition).  One level is
@@ -927,8 +935,12 @@ uint32_t launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t
     const uint32_t R = NQ * 4;
     const uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
     const uint64_t threads = n * NQ;
-    launch<B_k_b3_chunks_bits, 256>(k_b3_chunks_bits, st, dim3((unsigned)((threads + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
-                       d_cv_a);
+    if (threads < 64 * 1024)  // a transcript of a few chunks (small circuit): one repetition per lane, as in launch_b3_stream
+        launch<B_k_b3_chunks_bits<1>, 256>(k_b3_chunks_bits1, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
+                                           d_cv_a);
+    else
+        launch<B_k_b3_chunks_bits<4>, 256>(k_b3_chunks_bits, st, dim3((unsigned)((threads + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
+                                           d_cv_a);
     return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
 }
 
