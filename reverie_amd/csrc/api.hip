@@ -355,7 +355,7 @@ struct rv_circuit {
     // maximal runs [first, last) of consecutive narrow GF(2)-only levels, executed by one workgroup each
     struct NarrowRun {
         uint32_t first, second;  // levels [first, second)
-        int tiny;                // 1: the plain per-gate kernel, 0: the class-loop kernel (every level > 32 gates)
+        int tiny;                // 1: the plain per-gate kernel, 0: the class-loop kernel (every level > 32 gates), 2: its lean variant
     };
     std::vector<NarrowRun> narrow_runs;
     std::vector<int32_t> run_of_level;  // index into narrow_runs or -1
@@ -454,8 +454,16 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
                     size_t b = a;
                     const bool w = wide(a);
                     while (b < e && wide(b) == w) b++;
-                    const int tiny = (w && b - a >= 8) ? 0 : 1;
-                    if (tiny && a > l && !c->narrow_runs.empty() && c->narrow_runs.back().second == a && c->narrow_runs.back().tiny) {
+                    int tiny = (w && b - a >= 8) ? 0 : 1;
+                    if (!tiny) {  // a class-loop stretch without multi-base gates takes the lean variant (8-gate Xor steps)
+                        bool lean = true;
+                        for (size_t i = a; i < b; i++) {
+                            const LevelRange& lr = cc.level_range[i];
+                            lean = lean && lr.mul == lr.mul11 && lr.xork == lr.xor2;
+                        }
+                        if (lean) tiny = 2;
+                    }
+                    if (tiny == 1 && a > l && !c->narrow_runs.empty() && c->narrow_runs.back().second == a && c->narrow_runs.back().tiny == 1) {
                         c->narrow_runs.back().second = (uint32_t)b;  // merge with the preceding per-gate piece
                     } else {
                         c->narrow_runs.push_back(rv_circuit::NarrowRun{(uint32_t)a, (uint32_t)b, tiny});
@@ -469,7 +477,7 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
     }
     if (getenv("RV_COMPILE_STATS")) {
         size_t n_tiny = 0, n_med = 0, lv_tiny = 0, lv_med = 0;
-        for (const auto& r : c->narrow_runs) (r.tiny ? n_tiny : n_med)++, (r.tiny ? lv_tiny : lv_med) += r.second - r.first;
+        for (const auto& r : c->narrow_runs) (r.tiny == 1 ? n_tiny : n_med)++, (r.tiny == 1 ? lv_tiny : lv_med) += r.second - r.first;
         fprintf(stderr, "[rv circuit] narrow runs: %zu per-gate (%zu levels), %zu class-loop (%zu levels), %zu levels launched one by one\n",
                 n_tiny, lv_tiny, n_med, lv_med, c->run_of_level.size() - lv_tiny - lv_med);
     }

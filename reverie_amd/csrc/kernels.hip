@@ -388,14 +388,17 @@ __device__ __forceinline__ void interp_one(const Gate& g, const InterpParams& p,
 // a circuit compiled with one base per wire, e.g. the wide layered workload): their unrolled loops are compiled
 // out, which keeps the kernel at 45 registers = 8 wavefronts per SIMD instead of 6; stray gates of those classes
 // take the common per-gate loop.
-template <int MODE, int NQ, bool ROTATE, bool GENERAL = true, bool PF = false>
+// UXOR: unroll depth of the Xor classes when it differs from the Mul classes' (0 = the same) -- the single-workgroup
+// kernel runs 8-gate Xor steps on circuits without multi-base gates
+template <int MODE, int NQ, bool ROTATE, bool GENERAL = true, bool PF = false, int UXOR = 0>
 __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const LevelRange& r, const InterpParams& p, uint32_t wave,
                                           uint32_t n_waves, uint32_t lane, uint32_t onm, const Gate* pf_gates = nullptr,
                                           const PfPlan* pf = nullptr) {
     constexpr uint32_t GPW = 64 / NQ;  // gates per wavefront per step
     const uint32_t q = lane % NQ, sub = lane / NQ;
     constexpr int U = interp_unroll(NQ, GENERAL);
-    constexpr uint32_t STEP = U * GPW;
+    constexpr int UX = UXOR ? UXOR : U;
+    static_assert(!PF || UX == U, "the prefetch plan assumes one step size");
     uint32_t slot = 0;
     auto my = [&](uint32_t used) { return ROTATE ? (wave + n_waves - used % n_waves) % n_waves : wave; };
     const uint32_t begin[5] = {r.lo, r.mul11, r.mul, r.xor2, r.xork}, end[5] = {r.mul11, r.mul, r.xor2, r.xork, r.hi};
@@ -403,15 +406,16 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         // without the multi-base loops (GENERAL = false) the few gates of those classes all go to the common loop
+        const uint32_t STEP = (uint32_t)(c >= 2 ? UX : U) * GPW;
         const uint32_t n_full = (!GENERAL && (c == 1 || c == 3)) ? 0u : (end[c] - begin[c]) / STEP;
         rest[c] = begin[c] + n_full * STEP;
         for (uint32_t g0 = begin[c] + my(slot) * STEP; g0 < rest[c]; g0 += n_waves * STEP) {
             const Gate* t = nullptr;
-            if (PF && pf->dist) t = pf_target<STEP>(pf_gates, *pf, slot + (g0 - begin[c]) / STEP);
+            if (PF && pf->dist) t = pf_target<U * GPW>(pf_gates, *pf, slot + (g0 - begin[c]) / STEP);
             if (c == 0) mulU<MODE, NQ, U, 1, 1>(gates, g0, p, sub, q, onm, t);               // G_MUL, one base per operand
             if (c == 1 && GENERAL) mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K>(gates, g0, p, sub, q, onm, t); // other G_MUL
-            if (c == 2) xorU<NQ, U, 2>(gates, g0, p, sub, q, t);                             // G_XORK of two bases
-            if (c == 3 && GENERAL) xorU<NQ, U, 2 * RV_LIN_K>(gates, g0, p, sub, q, t);                  // other G_XORK
+            if (c == 2) xorU<NQ, UX, 2>(gates, g0, p, sub, q, t);                            // G_XORK of two bases
+            if (c == 3 && GENERAL) xorU<NQ, UX, 2 * RV_LIN_K>(gates, g0, p, sub, q, t);                 // other G_XORK
         }
         slot += n_full;
     }
@@ -532,7 +536,11 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
 // NQ = 0: generic row width (one gate per NQ lanes, no unrolling).
 constexpr uint32_t NARROW_MAX_LEVELS = 1024;  // levels per launch (longer runs are split)
 constexpr uint32_t NARROW_WIN = 1024;         // gate records resident in LDS (48 KiB) >= 2 x the widest narrow level
-template <int MODE, int NQT>
+// LEAN: the run holds no multi-base Mul / Xor gates (a circuit compiled with one base per wire, e.g. AES-128): their
+// unrolled loops are left out and the Xor steps take 8 gates -- a level of ~20 Mul + ~75 Xor gates is then 5 + 10 steps,
+// one round of the 16 wavefronts instead of two (AES-128: 2.7 -> 2.6 us per level; a level moves ~100 KB through ONE CU,
+// which at 64 B/clk is 0.7 us of the 2.6)
+template <int MODE, int NQT, bool LEAN = false>
 __device__ __forceinline__ void interp_narrow_body(const Gate* __restrict__ gates, const LevelRange* __restrict__ level_range,
                                                    uint32_t l0, uint32_t l1, const InterpParams& p) {
     __shared__ LevelRange s_lr[NARROW_MAX_LEVELS];
@@ -561,7 +569,10 @@ __device__ __forceinline__ void interp_narrow_body(const Gate* __restrict__ gate
         }
         const Gate* g = s_g - win_lo;  // indexed by absolute gate number
         if (NQT) {
-            run_level<MODE, NQT ? NQT : 64, true>(g, r, p, wave, 16, lane, onm);
+            if (LEAN)
+                run_level<MODE, NQT ? NQT : 64, true, false, false, 8>(g, r, p, wave, 16, lane, onm);
+            else
+                run_level<MODE, NQT ? NQT : 64, true>(g, r, p, wave, 16, lane, onm);
         } else {
             const uint32_t q = threadIdx.x % NQ, worker = threadIdx.x / NQ, n_workers = 1024 / NQ;
             for (uint32_t gi = r.lo + worker; gi < r.hi; gi += n_workers) interp_one_impl<MODE>(g[gi], p, NQ, q, onm);
@@ -570,10 +581,10 @@ __device__ __forceinline__ void interp_narrow_body(const Gate* __restrict__ gate
     }
 }
 
-template <int MODE, int NQT>
+template <int MODE, int NQT, bool LEAN = false>
 __global__ __launch_bounds__(1024) void k_interp_narrow(const Gate* __restrict__ gates, const LevelRange* __restrict__ level_range,
                                                         uint32_t l0, uint32_t l1, InterpParams p) {
-    interp_narrow_body<MODE, NQT>(gates, level_range, l0, l1, p);
+    interp_narrow_body<MODE, NQT, LEAN>(gates, level_range, l0, l1, p);
 }
 // batched proofs: one workgroup per proof (blockIdx.x), see k_interp_full_b
 template <int MODE, int NQT>
@@ -583,13 +594,13 @@ __global__ __launch_bounds__(1024) void k_interp_narrow_b(const Gate* __restrict
     interp_narrow_body<MODE, NQT>(gates, level_range, l0, l1, p);
 }
 
-template <int NQT>
+template <int NQT, bool LEAN = false>
 static void launch_narrow_nq(hipStream_t st, int mode, const Gate* d_gates, const LevelRange* d_lr, uint32_t a, uint32_t b,
                              const InterpParams& p) {
     if (mode == MODE_PROVE)
-        hipLaunchKernelGGL((k_interp_narrow<MODE_PROVE, NQT>), dim3(1), dim3(1024), 0, st, d_gates, d_lr, a, b, p);
+        hipLaunchKernelGGL((k_interp_narrow<MODE_PROVE, NQT, LEAN>), dim3(1), dim3(1024), 0, st, d_gates, d_lr, a, b, p);
     else
-        hipLaunchKernelGGL((k_interp_narrow<MODE_VERIFY, NQT>), dim3(1), dim3(1024), 0, st, d_gates, d_lr, a, b, p);
+        hipLaunchKernelGGL((k_interp_narrow<MODE_VERIFY, NQT, LEAN>), dim3(1), dim3(1024), 0, st, d_gates, d_lr, a, b, p);
 }
 
 void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const LevelRange* d_level_range, uint32_t l0, uint32_t l1,
@@ -597,8 +608,13 @@ void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const L
     for (uint32_t a = l0; a < l1; a += NARROW_MAX_LEVELS) {
         const uint32_t b = (a + NARROW_MAX_LEVELS < l1) ? a + NARROW_MAX_LEVELS : l1;
         // NQT = 0 is the plain per-gate loop (also the fallback for row widths without a class-loop instantiation)
-        switch (tiny ? 0u : p.NQ) {
-        case 64: launch_narrow_nq<64>(st, mode, d_gates, d_level_range, a, b, p); break;
+        switch (tiny == 1 ? 0u : p.NQ) {
+        case 64:
+            if (tiny == 2)
+                launch_narrow_nq<64, true>(st, mode, d_gates, d_level_range, a, b, p);
+            else
+                launch_narrow_nq<64>(st, mode, d_gates, d_level_range, a, b, p);
+            break;
         case 32: launch_narrow_nq<32>(st, mode, d_gates, d_level_range, a, b, p); break;
         case 16: launch_narrow_nq<16>(st, mode, d_gates, d_level_range, a, b, p); break;
         case 8: launch_narrow_nq<8>(st, mode, d_gates, d_level_range, a, b, p); break;
@@ -643,12 +659,12 @@ void launch_interp_narrow_batched(hipStream_t st, const Gate* d_gates, const Lev
     for (uint32_t a = l0; a < l1 && batch; a += NARROW_MAX_LEVELS) {
         const uint32_t b = (a + NARROW_MAX_LEVELS < l1) ? a + NARROW_MAX_LEVELS : l1;
         if (mode == MODE_PROVE) {
-            if (tiny)
+            if (tiny == 1)
                 hipLaunchKernelGGL((k_interp_narrow_b<MODE_PROVE, 0>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
             else
                 hipLaunchKernelGGL((k_interp_narrow_b<MODE_PROVE, 64>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
         } else {
-            if (tiny)
+            if (tiny == 1)
                 hipLaunchKernelGGL((k_interp_narrow_b<MODE_VERIFY, 0>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
             else
                 hipLaunchKernelGGL((k_interp_narrow_b<MODE_VERIFY, 64>), dim3(batch), dim3(1024), 0, st, d_gates, d_level_range, a, b, d_pp);
