@@ -938,7 +938,7 @@ uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_e
         const uint64_t threads = n * (d_quads ? n_quads : NQ);
         // few lanes (a quarter of the row or less in the verifier; a transcript of a few chunks, i.e. a small circuit):
         // one repetition per lane gives four times the wavefronts, each a quarter as long
-        if ((d_quads && n_quads * 4 <= NQ) || threads < 64 * 1024)
+        if ((d_quads && n_quads * 4 <= NQ) || threads * (g_recorder ? g_recorder->batch : 1u) < 64 * 1024)
             launch<B_k_b3_chunks<1>, 256>(k_b3_chunks<1>, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a, d_quads, n_quads);
         else
             launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a, d_quads, n_quads);
@@ -951,7 +951,8 @@ uint32_t launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t
     const uint32_t R = NQ * 4;
     const uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
     const uint64_t threads = n * NQ;
-    if (threads < 64 * 1024)  // a transcript of a few chunks (small circuit): one repetition per lane, as in launch_b3_stream
+    // a transcript of a few chunks (small circuit, and no batch to supply the wavefronts): one repetition per lane
+    if (threads * (g_recorder ? g_recorder->batch : 1u) < 64 * 1024)
         launch<B_k_b3_chunks_bits<1>, 256>(k_b3_chunks_bits1, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
                                            d_cv_a);
     else
