@@ -864,11 +864,15 @@ __global__ __launch_bounds__(256) void k_b3_reduce(const uint32_t* __restrict__ 
 // The top of the tree (at most B3_TAIL nodes per repetition): one workgroup per repetition walks the
 // remaining levels through LDS, a barrier per level instead of a launch per level.
 constexpr uint32_t B3_TAIL = 512;
+// CAP = most nodes the workgroup takes (its LDS footprint): B3_TAIL with 256 threads, or 64 with one wavefront for the
+// short transcripts of small circuits -- 2.3 KB instead of 18 KB of LDS, so a batch of proofs gets four times the
+// workgroups per CU
+template <int CAP>
 struct B_k_b3_tree_tail {
     __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R, uint32_t* __restrict__ digest) const {
-    __shared__ uint32_t cv[B3_TAIL][8 + 1];  // +1: odd row stride, no bank conflicts on the strided pair reads
+    __shared__ uint32_t cv[CAP][8 + 1];  // +1: odd row stride, no bank conflicts on the strided pair reads
     const uint32_t r = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < n_in * 8; i += 256) cv[i >> 3][i & 7] = in[((size_t)(i >> 3) * R + r) * 8 + (i & 7)];
+    for (uint32_t i = threadIdx.x; i < n_in * 8; i += blockDim.x) cv[i >> 3][i & 7] = in[((size_t)(i >> 3) * R + r) * 8 + (i & 7)];
     __syncthreads();
     uint32_t cnt = n_in;
     while (cnt > 1) {
@@ -901,7 +905,10 @@ struct B_k_b3_tree_tail {
 }
 };
 __global__ __launch_bounds__(256) void k_b3_tree_tail(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R, uint32_t* __restrict__ digest) {
-    B_k_b3_tree_tail{}(in, n_in, R, digest);
+    B_k_b3_tree_tail<(int)B3_TAIL>{}(in, n_in, R, digest);
+}
+__global__ __launch_bounds__(64) void k_b3_tree_tail_small(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R, uint32_t* __restrict__ digest) {
+    B_k_b3_tree_tail<64>{}(in, n_in, R, digest);
 }
 
 // tree reduction of n chunk chaining values per repetition; the roots land in d_digest ([R][8] words)
@@ -918,7 +925,10 @@ uint32_t b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n
         launches++;
     }
     // a single chunk is already its own root (the chunk kernels applied the ROOT flag): cnt == 1 just copies
-    launch<B_k_b3_tree_tail, 256>(k_b3_tree_tail, st, dim3(R), dim3(256), cur, (uint32_t)n, R, d_digest);
+    if (n <= 64)
+        launch<B_k_b3_tree_tail<64>, 64>(k_b3_tree_tail_small, st, dim3(R), dim3(64), cur, (uint32_t)n, R, d_digest);
+    else
+        launch<B_k_b3_tree_tail<(int)B3_TAIL>, 256>(k_b3_tree_tail, st, dim3(R), dim3(256), cur, (uint32_t)n, R, d_digest);
     return launches;
 }
 
