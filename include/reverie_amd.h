@@ -107,10 +107,10 @@ int rv_ctx_sync(rv_ctx *ctx);
 enum {
     RV_PH_SETUP = 0,  /* seed expansion, key schedules, round-key bitslicing          */
     RV_PH_MASKS = 1,  /* k_aes_gf2_masks: bitsliced AES-128-CTR mask generator         */
-    RV_PH_INTERP = 2, /* k_interp: one launch per dependency level                     */
-    RV_PH_HASH = 3,   /* k_b3_chunks + k_b3_parents: transcript BLAKE3                 */
+    RV_PH_INTERP = 2, /* k_interp_full / k_interp_narrow / k_interp64: one launch per dependency level or narrow run */
+    RV_PH_HASH = 3,   /* k_b3_chunks(_bits,_contig) + k_b3_reduce + k_b3_tree_tail: transcript BLAKE3 */
     RV_PH_JOIN = 4,   /* k_join                                                        */
-    RV_PH_OPEN = 5,   /* k_open_headers + k_extract_bits                               */
+    RV_PH_OPEN = 5,   /* k_fs_challenge + k_open_headers + k_extract_rows / k_extract_from_bits / k_extract64 */
     RV_PH_COUNT = 8
 };
 typedef struct rv_profile {
@@ -182,21 +182,22 @@ int rv_prove_batch(rv_ctx *ctx, const rv_circuit *c, size_t batch, const uint8_t
                    const uint64_t *wit_z64, size_t n_z64, const uint8_t *seeds, uint8_t **proofs, size_t *proof_lens);
 
 /* ---- Proof::verify ----------------------------------------------------------------
- * *ok follows the reference exactly: 0 when a ProofSingle has the wrong number of
- * repetitions or the recomputed commitment differs, 1 otherwise.  Bytes that cannot be
- * parsed as a Proof, unequal GF(2) opening lengths inside a verifier group, or an
- * `omit` value >= 8 return RV_E_PROOF_MALFORMED (the reference panics / is UB). */
-int rv_verify(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, int *ok);
-
-/* The same with flags.  RV_VERIFY_STRICT closes the two gaps of the reference verifier and is NOT
- * reference behaviour: *ok additionally requires
- *   - every AssertZero of the 40 opened repetitions to reconstruct to zero -- VerifierTranscriptOnline.okay
+ * Verification is STRICT by default (flags 0, rv_verify): on top of the reference's check (*ok = 0 when a ProofSingle
+ * has the wrong number of repetitions or the recomputed commitment differs) it closes the two soundness gaps of the
+ * reference verifier:
+ *   - every AssertZero of the 40 opened repetitions must reconstruct to zero -- VerifierTranscriptOnline.okay
  *     (src/transcript/verifier/online.rs:21,117,175-177), which the reference computes and never reads, so
- *     Proof::verify accepts a proof of an unsatisfied circuit;
- *   - every online record's `omit` to equal the player the challenge omits -- the reference only checks which
+ *     its Proof::verify accepts a proof of an unsatisfied circuit;
+ *   - every online record's `omit` must equal the player the challenge omits -- the reference only checks which
  *     repetitions are opened (src/proof/mod.rs:292-302: contains_key), never by whom.
- * flags = 0 is rv_verify. */
+ * RV_VERIFY_REFERENCE_COMPAT switches both extra checks off: *ok is then exactly what the reference's Proof::verify
+ * returns (byte-compatibility tests; never for untrusted proofs).  RV_VERIFY_STRICT is accepted and means flags 0;
+ * both bits together are RV_E_ARG.
+ * Bytes that cannot be parsed as a Proof, unequal GF(2) opening lengths inside a verifier group, or an
+ * `omit` value >= 8 return RV_E_PROOF_MALFORMED (the reference panics / is UB). */
 #define RV_VERIFY_STRICT 1u
+#define RV_VERIFY_REFERENCE_COMPAT 2u
+int rv_verify(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, int *ok);
 int rv_verify_ex(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, uint32_t flags, int *ok);
 
 void rv_free(void *p);
@@ -267,11 +268,13 @@ int rv_assemble_proof(const uint8_t comm[RV_HASH_SIZE], const rv_shard_parts *pa
  * proof order, 40..255 = preprocessing openings; proof/mod.rs:234-281), multiples of 8. */
 int rv_verify_shard(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, uint32_t slot_begin,
                     uint32_t slot_count, uint8_t *digests /* slot_count x 32 */);
-/* Final check of Proof::verify (proof/mod.rs:283-306) from all 256 slot digests */
+/* Final check of Proof::verify (proof/mod.rs:283-306) from all 256 slot digests: the reference's check and nothing
+ * else (this form has no zero-check input, so it cannot be strict; use the _ex pair below for untrusted proofs). */
 int rv_verify_finish(const uint8_t *proof, size_t proof_len, const uint8_t *slot_digests /* 256 x 32 */, int *ok);
 /* The sharded form of rv_verify_ex: *zero_checks_ok (nullable) = 0 when an AssertZero of one of this shard's opened
  * repetitions did not reconstruct to zero; AND the shards' values together and hand the result to
- * rv_verify_finish_ex, which with RV_VERIFY_STRICT also compares the records' `omit` with the challenge. */
+ * rv_verify_finish_ex, which (unless RV_VERIFY_REFERENCE_COMPAT) requires it and also compares the records' `omit`
+ * with the challenge. */
 int rv_verify_shard_ex(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, uint32_t slot_begin,
                        uint32_t slot_count, uint8_t *digests /* slot_count x 32 */, int *zero_checks_ok);
 int rv_verify_finish_ex(const uint8_t *proof, size_t proof_len, const uint8_t *slot_digests /* 256 x 32 */, uint32_t flags,
@@ -279,8 +282,9 @@ int rv_verify_finish_ex(const uint8_t *proof, size_t proof_len, const uint8_t *s
 
 /* Many proofs of one circuit in one pass (the verifier's counterpart of rv_prove_batch; pure GF(2) circuits below the
  * large-circuit threshold -- everything else verifies proof after proof): ok[b] as rv_verify_ex would set it for
- * proofs[b] with the same flags.  A proof whose bytes cannot be parsed fails the whole call with RV_E_PROOF_MALFORMED,
- * like the panic of one rayon task would. */
+ * proofs[b] with the same flags.  A proof whose bytes cannot be parsed (or whose records rv_verify_ex would answer with
+ * RV_E_PROOF_MALFORMED) is a REJECTED proof, ok[b] = 0, and the others are verified all the same; a non-zero return
+ * code means an argument or device error. */
 int rv_verify_batch(rv_ctx *ctx, const rv_circuit *c, size_t batch, const uint8_t *const *proofs, const size_t *proof_lens,
                     uint32_t flags, int *ok /* [batch] */);
 
@@ -292,7 +296,8 @@ int rv_verify_batch(rv_ctx *ctx, const rv_circuit *c, size_t batch, const uint8_
  *   MAND -> one Mul per lane
  *   if expected_outputs != NULL: for each output wire (the last n_out wires, in order)
  *   AddConst(tmp, w, expected) + AssertZero(tmp)  — the statement "the circuit maps the witness
- *   to these outputs" (SURVEY §8d configs 1-3).
+ *   to these outputs" (SURVEY §8d configs 1-3); n_expected must equal the circuit's output count (RV_E_ARG otherwise,
+ *   before anything is read from expected_outputs).
  * format: 0 = auto, 1 = Bristol Fashion ("ngates nwires / niv n.. / nov n.."), 2 = old Bristol
  * ("ngates nwires / n1 n2 n3").  ops is library-allocated (rv_free). */
 typedef struct rv_bristol_info {
@@ -300,8 +305,8 @@ typedef struct rv_bristol_info {
     uint64_t n_and, n_xor, n_inv, n_other;
     uint64_t gf2_wires; /* wire count to pass to rv_circuit_compile (includes assertion temporaries) */
 } rv_bristol_info;
-int rv_bristol_parse(const char *text, size_t len, int format, const uint8_t *expected_outputs, rv_op **ops, size_t *n_ops,
-                     rv_bristol_info *info);
+int rv_bristol_parse(const char *text, size_t len, int format, const uint8_t *expected_outputs, size_t n_expected, rv_op **ops,
+                     size_t *n_ops, rv_bristol_info *info);
 
 /* ---- program files (host only, no GPU) ---------------------------------------------------
  * The reference CLI reads its gate stream as bincode 1.3 of Vec<mcircuit::CombineOperation>
@@ -326,6 +331,11 @@ int rv_hook_expand_seed(rv_ctx *ctx, const uint8_t *seeds, size_t n, uint8_t *ke
 int rv_hook_sharegen_gf2(rv_ctx *ctx, const uint8_t *keys, const uint32_t omit[8], size_t n, uint64_t *out);
 /* ShareGen<Z64>::next() x n -> n x 8 x 8 u64 */
 int rv_hook_sharegen_z64(rv_ctx *ctx, const uint8_t *keys, const uint32_t omit[8], size_t n, uint64_t *out);
+/* DomainGF2::reconstruct (gf2/domain.rs:47-63) on n packed u64 shares (bit 63 - (8*rep + player)) -> n ReconGF2 words
+ * (one 0x00/0xFF byte per repetition), through the interpreter's own device function */
+int rv_hook_gf2_reconstruct(rv_ctx *ctx, const uint64_t *shares, size_t n, uint64_t *out);
+/* DomainZ64::reconstruct (z64/domain.rs:53-61) on n ShareZ64 values ([8 reps][8 players] u64) -> n x 8 wrapping sums */
+int rv_hook_z64_reconstruct(rv_ctx *ctx, const uint64_t *shares /* n x 64 */, size_t n, uint64_t *out /* n x 8 */);
 /* BLAKE3 of n_streams independent byte strings of equal length len (row-major), on the GPU
  * tree-hash kernels used for the transcripts (crypto/hash.rs:17-57) */
 int rv_hook_blake3(rv_ctx *ctx, const uint8_t *data, size_t n_streams, size_t len, uint8_t *out /* n x 32 */);

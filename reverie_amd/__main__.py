@@ -11,6 +11,9 @@ same `Ok(())` / `Err("Unverifiable Proof")` result lines.  Differences, stated p
   little-endian array of 24-byte `rv_op` records (`--program-format rvops`).  `--expected-outputs-path` (text of 0/1) appends the output
   assertions to a Bristol circuit (see rv_bristol_parse).
 * proofs are the same bincode bytes.
+* verification is strict by default (`--reference-compat` restores the reference verifier's two unchecked
+  conditions), and a rejected proof exits with status 1 (the reference prints the same
+  `Err("Unverifiable Proof")` line but exits 0).
 """
 from __future__ import annotations
 
@@ -83,9 +86,11 @@ def build_parser():
     ap.add_argument("--proof-path")
     ap.add_argument("--program-format", default="auto", choices=["auto", "bristol", "rvops", "mcircuit-bincode"])
     ap.add_argument("--expected-outputs-path")
-    ap.add_argument("--strict", action="store_true",
-                    help="verify / oneshot-zk: RV_VERIFY_STRICT (not in the reference's CLI) -- also reject proofs whose opened "
-                         "repetitions fail an AssertZero or name another omitted player than the challenge does")
+    ap.add_argument("--strict", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--reference-compat", action="store_true",
+                    help="verify / oneshot-zk: RV_VERIFY_REFERENCE_COMPAT -- answer exactly like the reference's verifier, which "
+                         "accepts proofs whose opened repetitions fail an AssertZero or name another omitted player than the "
+                         "challenge does (SURVEY F9); never for untrusted proofs")
     return ap
 
 
@@ -123,11 +128,15 @@ def main(argv=None) -> int:
     else:
         proof = Proof(open(a.proof_path, "rb").read())
         print("Verifying Proof")
-    if proof.verify(circuit, strict=a.strict):
+    if a.strict and a.reference_compat:
+        ap.error("--strict and --reference-compat exclude each other")
+    if proof.verify(circuit, strict=not a.reference_compat):
         print("Ok(())")
         return 0
+    # the reference prints this line and exits 0 (main.rs:108-111,160-163); a script gating on the exit status would
+    # then accept a rejected proof, so this front end keeps the line and returns 1
     print('Err("Unverifiable Proof")')
-    return 0
+    return 1
 
 
 if __name__ == "__main__":

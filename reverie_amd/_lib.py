@@ -63,8 +63,10 @@ SYMBOLS = [
     "rv_hook_blake3", "rv_hook_shard_stream_digests", "rv_ctx_profile", "rv_shard_digests_to_device", "rv_shard_open_size", "rv_shard_open_into", "rv_shard_open_self", "rv_shard_open_gathered",
     "rv_bristol_parse", "rv_circuit_record_sizes", "rv_program_from_bincode", "rv_program_to_bincode", "rv_prove_batch", "rv_prove_device",
     "rv_verify_ex", "rv_verify_shard_ex", "rv_verify_finish_ex", "rv_verify_batch",
+    "rv_hook_gf2_reconstruct", "rv_hook_z64_reconstruct",
 ]
 RV_VERIFY_STRICT = 1
+RV_VERIFY_REFERENCE_COMPAT = 2  # the reference verifier's two unchecked conditions stay unchecked
 
 _lib = None
 

@@ -19,7 +19,8 @@ from .ops import OP_DTYPE
 def parse(text: str | bytes, expected_outputs: Optional[Sequence[int]] = None, fmt: int = 0) -> Tuple[np.ndarray, dict]:
     """-> (program, info).  With expected_outputs the program ends with one AddConst+AssertZero
     per output wire, i.e. it states "this witness drives the circuit to these outputs".
-    info["wire_counts"] is the (z64, gf2) tuple Proof.new / Proof.verify take."""
+    info["wire_counts"] is the (z64, gf2) tuple Proof.new / Proof.verify take.  A wrong number of expected outputs
+    is RV_E_ARG (checked by the parser before it reads any of them)."""
     data = text.encode() if isinstance(text, str) else bytes(text)
     exp = None
     if expected_outputs is not None:
@@ -29,10 +30,8 @@ def parse(text: str | bytes, expected_outputs: Optional[Sequence[int]] = None, f
     info = _lib.BristolInfo()
     _lib.check(_lib.lib().rv_bristol_parse(data, C.c_size_t(len(data)), C.c_int(fmt),
                                            exp.ctypes.data_as(C.c_void_p) if exp is not None else None,
+                                           C.c_size_t(len(exp) if exp is not None else 0),
                                            C.byref(ops), C.byref(n), C.byref(info)))
-    if exp is not None and len(exp) != info.n_outputs:
-        _lib.lib().rv_free(ops)
-        raise ValueError(f"expected_outputs has {len(exp)} bits, circuit has {info.n_outputs} outputs")
     prog = np.frombuffer(C.string_at(ops, n.value * OP_DTYPE.itemsize), dtype=OP_DTYPE).copy()
     _lib.lib().rv_free(ops)
     d = {k: int(getattr(info, k)) for k, _ in info._fields_}

@@ -37,7 +37,8 @@ static int hip_fail(hipError_t e, const char* what, const char* file, int line) 
     } while (0)
 
 extern "C" const char* rv_last_error(void) { return g_last_error.c_str(); }
-extern "C" uint32_t rv_abi_version(void) { return 2; }  // 2: rv_circuit_info grew (compile_us, upload_us); rv_verify_ex / _batch, strict flag
+extern "C" uint32_t rv_abi_version(void) { return 3; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
+                                                        //    streaming prover, rv_prove_multi, reconstruct hooks
 
 extern "C" const char* rv_strerror(int code) {
     switch (code) {
@@ -1959,9 +1960,17 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     return RV_OK;
 }
 
+// Verification is STRICT unless the caller asks for the reference's behaviour (RV_VERIFY_REFERENCE_COMPAT): flags 0 and
+// RV_VERIFY_STRICT mean the same thing; both bits together are a contradiction
+static bool verify_flags_ok(uint32_t flags) {
+    return !(flags & ~(uint32_t)(RV_VERIFY_STRICT | RV_VERIFY_REFERENCE_COMPAT)) &&
+           (flags & (RV_VERIFY_STRICT | RV_VERIFY_REFERENCE_COMPAT)) != (RV_VERIFY_STRICT | RV_VERIFY_REFERENCE_COMPAT);
+}
+static bool verify_is_strict(uint32_t flags) { return !(flags & RV_VERIFY_REFERENCE_COMPAT); }
+
 static int rv_verify_finish_impl(const uint8_t* proof, size_t proof_len, const uint8_t* slot_digests, uint32_t flags,
                                  int zero_checks_ok, int* ok) {
-    if (!proof || !slot_digests || !ok || proof_len < 32 || (flags & ~(uint32_t)RV_VERIFY_STRICT)) return RV_E_ARG;
+    if (!proof || !slot_digests || !ok || proof_len < 32 || !verify_flags_ok(flags)) return RV_E_ARG;
     uint8_t omit[RV_TOTAL_REPS];
     rv_challenge(proof, omit);  // proof/mod.rs:290
     b3::Hasher hs;
@@ -1970,7 +1979,7 @@ static int rv_verify_finish_impl(const uint8_t* proof, size_t proof_len, const u
     uint8_t comm[32];
     hs.finalize(comm);
     *ok = memcmp(comm, proof, 32) == 0;
-    if (flags & RV_VERIFY_STRICT) {
+    if (verify_is_strict(flags)) {
         // the reference computes `okay` without reading it (online.rs:21,175-177) and only checks WHICH
         // repetitions are opened, never the records' omitted player (proof/mod.rs:292-302)
         if (!zero_checks_ok) *ok = 0;
@@ -2002,7 +2011,8 @@ extern "C" int rv_verify_finish_ex(const uint8_t* proof, size_t proof_len, const
 }
 
 extern "C" int rv_verify_finish(const uint8_t* proof, size_t proof_len, const uint8_t* slot_digests, int* ok) {
-    return rv_verify_finish_ex(proof, proof_len, slot_digests, 0, 1, ok);
+    // no zero-check input here: this entry point is the reference's final check and nothing more (see the header)
+    return rv_verify_finish_ex(proof, proof_len, slot_digests, RV_VERIFY_REFERENCE_COMPAT, 1, ok);
 }
 
 static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t flags, int* ok);
@@ -2017,11 +2027,11 @@ extern "C" int rv_verify_ex(rv_ctx* ctx, const rv_circuit* c, const uint8_t* pro
 }
 
 extern "C" int rv_verify(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, int* ok) {
-    return rv_verify_ex(ctx, c, proof, proof_len, 0, ok);
+    return rv_verify_ex(ctx, c, proof, proof_len, 0, ok);  // flags 0 = strict
 }
 
 static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, uint32_t flags, int* ok) {
-    if (!ctx || !c || !proof || !ok || (flags & ~(uint32_t)RV_VERIFY_STRICT)) return RV_E_ARG;
+    if (!ctx || !c || !proof || !ok || !verify_flags_ok(flags)) return RV_E_ARG;
     *ok = 0;
     Parsed P;
     int rc = parse_proof(proof, proof_len, P);
@@ -2044,15 +2054,21 @@ static int rv_verify_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof
 // ------------------------------------------------------------------------------------
 static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, const uint8_t* const* proofs, const size_t* proof_lens,
                                 uint32_t flags, int* ok) {
-    if (!ctx || !c || !batch || !proofs || !proof_lens || !ok || (flags & ~(uint32_t)RV_VERIFY_STRICT)) return RV_E_ARG;
+    if (!ctx || !c || !batch || !proofs || !proof_lens || !ok || !verify_flags_ok(flags)) return RV_E_ARG;
     for (size_t b = 0; b < batch; b++) {
         ok[b] = 0;
         if (!proofs[b]) return RV_E_ARG;
     }
     const Compiled& cc = c->cc;
+    // A proof that cannot be parsed is a rejected proof (ok[b] = 0), not a failed call: one bad proof from an untrusted
+    // peer must not keep the others from being verified.  Non-zero return codes are left to argument / device errors.
     auto one_by_one = [&]() -> int {
         for (size_t b = 0; b < batch; b++) {
             const int rc = rv_verify_ex(ctx, c, proofs[b], proof_lens[b], flags, &ok[b]);
+            if (rc == RV_E_PROOF_MALFORMED) {
+                ok[b] = 0;
+                continue;
+            }
             if (rc) return rc;
         }
         return RV_OK;
@@ -2066,16 +2082,32 @@ static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, 
     std::vector<Parsed> P(batch);
     std::vector<size_t> live;  // indices of the proofs that go to the GPU
     size_t max_len = 0;
+    // what the verifier groups require of the online records (the checks of fill() below, made before anything is
+    // staged so that a malformed proof simply drops out of the batch)
+    auto records_ok = [](const Parsed& Q) {
+        for (uint32_t g0 = 0; g0 < RV_ONLINE_REPS; g0 += 8) {
+            const OnRec* o = &Q.gf2.on[g0];
+            const OnRec* z = &Q.z64.on[g0];
+            for (int i = 0; i < 8; i++) {
+                if (o[i].omit >= 8 || z[i].omit >= 8) return false;
+                if (o[i].n_corr < o[0].n_corr || o[i].n_in < o[0].n_in || o[i].n_rec != o[0].n_rec) return false;
+            }
+        }
+        return true;
+    };
     for (size_t b = 0; b < batch; b++) {
-        const int rc = parse_proof(proofs[b], proof_lens[b], P[b]);
-        if (rc) return rc;
-        if (!format_ok(P[b])) continue;
+        if (parse_proof(proofs[b], proof_lens[b], P[b]) != RV_OK) continue;  // ok[b] stays 0
+        if (!format_ok(P[b]) || !records_ok(P[b])) continue;
         live.push_back(b);
         max_len = std::max(max_len, proof_lens[b]);
     }
     if (live.size() < 2) {
         for (size_t b : live) {
             const int rc = rv_verify_ex(ctx, c, proofs[b], proof_lens[b], flags, &ok[b]);
+            if (rc == RV_E_PROOF_MALFORMED) {
+                ok[b] = 0;
+                continue;
+            }
             if (rc) return rc;
         }
         return RV_OK;
@@ -2453,5 +2485,39 @@ extern "C" int rv_hook_blake3(rv_ctx* ctx, const uint8_t* data, size_t n_streams
     ctx->release(cva);
     ctx->release(cvb);
     ctx->release(dig);
+    return RV_OK;
+}
+
+// DomainGF2::reconstruct / DomainZ64::reconstruct (gf2/domain.rs:47-63, z64/domain.rs:53-61) through the device
+// functions the interpreters use (recon32 on the two quad words of a packed share; the 4-lane shuffle sum)
+extern "C" int rv_hook_gf2_reconstruct(rv_ctx* ctx, const uint64_t* shares, size_t n, uint64_t* out) {
+    if (!ctx || (n && (!shares || !out))) return RV_E_ARG;
+    if (!n) return RV_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    uint64_t *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = dalloc(ctx, n, &d_in)) || (rc = dalloc(ctx, n, &d_out))) return rc;
+    HIPCHK(hipMemcpyAsync(d_in, shares, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    launch_hook_recon_gf2(ctx->stream, d_in, n, d_out);
+    HIPCHK(hipMemcpyAsync(out, d_out, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->release(d_in);
+    ctx->release(d_out);
+    return RV_OK;
+}
+
+extern "C" int rv_hook_z64_reconstruct(rv_ctx* ctx, const uint64_t* shares, size_t n, uint64_t* out) {
+    if (!ctx || (n && (!shares || !out))) return RV_E_ARG;
+    if (!n) return RV_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    uint64_t *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    if ((rc = dalloc(ctx, n * 64, &d_in)) || (rc = dalloc(ctx, n * 8, &d_out))) return rc;
+    HIPCHK(hipMemcpyAsync(d_in, shares, n * 64 * 8, hipMemcpyHostToDevice, ctx->stream));
+    launch_hook_recon_z64(ctx->stream, d_in, n, d_out);
+    HIPCHK(hipMemcpyAsync(out, d_out, n * 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->release(d_in);
+    ctx->release(d_out);
     return RV_OK;
 }

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -58,20 +59,20 @@ rv_op mk(uint8_t opcode, uint32_t dst, uint32_t a, uint32_t b, uint64_t imm) {
 
 }  // namespace
 
-static int parse_impl(const char* text, size_t len, int format, const uint8_t* expected_outputs, rv_op** ops, size_t* n_ops,
-                      rv_bristol_info* info);
+static int parse_impl(const char* text, size_t len, int format, const uint8_t* expected_outputs, size_t n_expected, rv_op** ops,
+                      size_t* n_ops, rv_bristol_info* info);
 
-extern "C" int rv_bristol_parse(const char* text, size_t len, int format, const uint8_t* expected_outputs, rv_op** ops,
-                                size_t* n_ops, rv_bristol_info* info) {
+extern "C" int rv_bristol_parse(const char* text, size_t len, int format, const uint8_t* expected_outputs, size_t n_expected,
+                                rv_op** ops, size_t* n_ops, rv_bristol_info* info) {
     try {  // no C++ exception may cross the C boundary
-        return parse_impl(text, len, format, expected_outputs, ops, n_ops, info);
+        return parse_impl(text, len, format, expected_outputs, n_expected, ops, n_ops, info);
     } catch (...) {
         return RV_E_NOMEM;
     }
 }
 
-static int parse_impl(const char* text, size_t len, int format, const uint8_t* expected_outputs, rv_op** ops, size_t* n_ops,
-                      rv_bristol_info* info) {
+static int parse_impl(const char* text, size_t len, int format, const uint8_t* expected_outputs, size_t n_expected, rv_op** ops,
+                      size_t* n_ops, rv_bristol_info* info) {
     if (!text || !ops || !n_ops) return RV_E_ARG;
     *ops = nullptr;
     *n_ops = 0;
@@ -112,6 +113,8 @@ static int parse_impl(const char* text, size_t len, int format, const uint8_t* e
         n_out = c;
     }
     if (n_in > n_wires || n_out > n_wires) return RV_E_WIRE_OOB;
+    // the assertions read expected_outputs[0 .. n_out): the caller states how many it passed, checked before any is read
+    if (expected_outputs && n_expected != n_out) return RV_E_ARG;
 
     rv_bristol_info bi;
     memset(&bi, 0, sizeof bi);
@@ -121,7 +124,9 @@ static int parse_impl(const char* text, size_t len, int format, const uint8_t* e
     bi.n_outputs = n_out;
     std::vector<rv_op> out;
     if (n_gates > len / 8 + 1) return RV_E_BAD_OP;  // every gate line needs at least 8 characters
-    out.reserve((size_t)(n_in + n_gates + 2 * n_out));
+    // (a header may claim billions of input wires in a few bytes of text: reserve what the TEXT can justify, let the
+    // vector grow for the rest -- a failed allocation is caught by the caller and reported as RV_E_NOMEM)
+    out.reserve((size_t)std::min<uint64_t>(n_in + n_gates + 2 * n_out, (uint64_t)len + 4096));
     for (uint64_t w = 0; w < n_in; w++) out.push_back(mk(RV_OP_INPUT, (uint32_t)w, 0, 0, 0));
     std::vector<std::string> g;
     std::vector<uint64_t> v;

@@ -213,6 +213,8 @@ void launch_shard_init(hipStream_t st, int* d_err, uint32_t* d_zero_mask, uint32
 void launch_fill_digests(hipStream_t st, uint32_t* d_dst, uint32_t n_rows, const uint32_t digest[8]);
 void launch_overlay_rows(hipStream_t st, uint32_t* d_dst, const uint32_t* d_src, const uint8_t* d_omit, uint32_t R,
                          uint32_t row_words, int want_online);
+void launch_hook_recon_gf2(hipStream_t st, const uint64_t* d_shares, uint64_t n, uint64_t* d_out);
+void launch_hook_recon_z64(hipStream_t st, const uint64_t* d_shares /*[n][8][8]*/, uint64_t n, uint64_t* d_out /*[n][8]*/);
 void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys,
                          const uint32_t* d_on2, const uint32_t* d_on64, const uint64_t* d_off2, const uint64_t* d_off64,
                          uint64_t lens2_rec, uint64_t lens2_corr, uint64_t lens2_in, uint64_t lens64_rec, uint64_t lens64_corr,

@@ -1018,6 +1018,17 @@ __global__ void k_overlay_rows(uint32_t* __restrict__ dst, const uint32_t* __res
     B_k_overlay_rows{}(dst, src, omit, R, row_words, want_online);
 }
 
+// parity hook for DomainGF2::reconstruct (gf2/domain.rs:47-63): the reference's packed u64 share is two quad words (hi, lo)
+__global__ void k_hook_recon_gf2(const uint64_t* __restrict__ shares, uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t v = shares[i];
+    out[i] = ((uint64_t)recon32((uint32_t)(v >> 32)) << 32) | recon32((uint32_t)v);
+}
+void launch_hook_recon_gf2(hipStream_t st, const uint64_t* d_shares, uint64_t n, uint64_t* d_out) {
+    if (n) hipLaunchKernelGGL(k_hook_recon_gf2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_shares, n, d_out);
+}
+
 void launch_overlay_rows(hipStream_t st, uint32_t* d_dst, const uint32_t* d_src, const uint8_t* d_omit, uint32_t R,
                          uint32_t row_words, int want_online) {
     launch<B_k_overlay_rows, 32>(k_overlay_rows, st, dim3(R), dim3(32), d_dst, d_src, d_omit, R, row_words, want_online);

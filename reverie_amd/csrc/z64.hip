@@ -50,6 +50,20 @@ __device__ __forceinline__ uint64_t sum8(U2 v) {
     return t;
 }
 
+// parity hook for DomainZ64::reconstruct (z64/domain.rs:53-61) on ShareZ64 values ([8 reps][8 players] u64 each): the
+// interpreter's own lane mapping (two players per lane, four lanes per repetition) and its sum8
+__global__ void k_hook_recon_z64(const uint64_t* __restrict__ shares, uint64_t n_reps_total, uint64_t* __restrict__ out) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = tid >> 2;
+    const U2 v = r < n_reps_total ? ld2(shares + 2 * tid) : U2{0, 0};
+    const uint64_t s = sum8(v);
+    if (r < n_reps_total && (tid & 3) == 0) out[r] = s;
+}
+void launch_hook_recon_z64(hipStream_t st, const uint64_t* d_shares, uint64_t n, uint64_t* d_out) {
+    const uint64_t lanes = n * 8 * 4;
+    if (n) hipLaunchKernelGGL(k_hook_recon_z64, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, d_shares, n * 8, d_out);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gates, uint32_t lo, uint32_t hi, Interp64Params p) {
     const uint32_t S = p.R * 8;   // u64 per row

@@ -189,6 +189,11 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
+
+    def g_rank(r: int) -> int:
+        # `rank` / `r` are ranks INSIDE `group`; the point-to-point calls and gather_object(dst=) take global ranks
+        return dist.get_global_rank(group, r) if (group is not None and world > 1) else r
+
     begin, count = shard_range(rank, world)
     seeds = np.asarray(seeds, dtype=np.uint8).reshape(TOTAL_REPS, 16)
     if world == 1 and device_resident and backend.device_type == "cuda" and hasattr(backend, "prove_device"):
@@ -237,11 +242,11 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
                 assert all_lens[rank] == lens
                 if rank == 0:
                     bufs = [buf] + [torch.empty(max(sum(l), 1), dtype=torch.uint8, device="cuda") for l in all_lens[1:]]
-                    reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(1, world)]
+                    reqs = [dist.irecv(bufs[r], src=g_rank(r), group=group) for r in range(1, world)]
                     for q in reqs:
                         q.wait()
                     return comm, bufs, all_lens
-                dist.send(buf[:max(sum(lens), 1)].contiguous(), dst=0, group=group)
+                dist.send(buf[:max(sum(lens), 1)].contiguous(), dst=g_rank(0), group=group)
                 return comm, None, None
             h = allh.cpu().numpy().reshape(TOTAL_REPS, 32)
         comm = combine_digests(h)  # every rank derives the same challenge
@@ -260,24 +265,24 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
                     if rank == 0:
                         bufs = [buf.cpu()] + [torch.empty(max(sum(l), 1), dtype=torch.uint8) for l in all_lens[1:]]
                         for r in range(1, world):
-                            dist.recv(bufs[r], src=r, group=group)
+                            dist.recv(bufs[r], src=g_rank(r), group=group)
                         return comm, bufs, all_lens
-                    dist.send(buf.cpu(), dst=0, group=group)
+                    dist.send(buf.cpu(), dst=g_rank(0), group=group)
                     return comm, None, None
                 if rank == 0:
                     bufs = [buf] + [torch.empty(max(sum(l), 1), dtype=torch.uint8, device="cuda") for l in all_lens[1:]]
-                    reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(1, world)]
+                    reqs = [dist.irecv(bufs[r], src=g_rank(r), group=group) for r in range(1, world)]
                     for q in reqs:
                         q.wait()
                     return comm, bufs, all_lens
-                dist.send(buf, dst=0, group=group)
+                dist.send(buf, dst=g_rank(0), group=group)
                 return comm, None, None
             return comm, [buf], [lens]
         blob, lens, _, _ = backend.open(shard, omit)
         if world == 1:
             return assemble(comm, [(blob, lens)])
         gathered = [None] * world if rank == 0 else None
-        dist.gather_object((blob, lens), gathered, dst=0, group=group)
+        dist.gather_object((blob, lens), gathered, dst=g_rank(0), group=group)
         return assemble(comm, gathered) if rank == 0 else None
     finally:
         backend.destroy(shard)

@@ -183,23 +183,25 @@ class Proof:
         return [Proof(_owned=(C.c_void_p(outs[b]), int(lens[b]))) for b in range(batch)]
 
     def verify(self, circuit, wire_counts: Optional[Tuple[int, int]] = None, ctx: Optional[Context] = None,
-               strict: bool = False) -> bool:
-        """Proof::verify (/root/reference/src/proof/mod.rs:224-307).  strict=True is RV_VERIFY_STRICT: it also
-        requires the opened repetitions' AssertZero gates to hold and the records' `omit` to match the challenge,
-        both of which the reference leaves unchecked."""
+               strict: bool = True) -> bool:
+        """Proof::verify (/root/reference/src/proof/mod.rs:224-307), strict by default: the opened repetitions'
+        AssertZero gates must hold and the records' `omit` must match the challenge -- both of which the reference
+        leaves unchecked, so that it accepts proofs of false statements.  strict=False is
+        RV_VERIFY_REFERENCE_COMPAT: exactly the reference's answer (compatibility tests only)."""
         c = _as_circuit(circuit, wire_counts, ctx)
         ok = C.c_int()
         buf, n = self._buffer()
-        flags = _lib.RV_VERIFY_STRICT if strict else 0
+        flags = 0 if strict else _lib.RV_VERIFY_REFERENCE_COMPAT
         _lib.check(_lib.lib().rv_verify_ex(c.ctx.handle, c.handle, buf, C.c_size_t(n), C.c_uint32(flags), C.byref(ok)))
         return bool(ok.value)
 
 
 def verify_batch(circuit, proofs, wire_counts: Optional[Tuple[int, int]] = None, ctx: Optional[Context] = None,
-                 strict: bool = False) -> "list[bool]":
+                 strict: bool = True) -> "list[bool]":
     """rv_verify_batch: Proof.verify for many proofs of one circuit in one pass (`proofs`: Proof objects or bytes);
-    -> one bool per proof, each what Proof.verify(circuit, strict=strict) would return.  A proof whose bytes cannot be
-    parsed raises, like it would on its own."""
+    -> one bool per proof, each what Proof.verify(circuit, strict=strict) would return -- except that a proof whose
+    bytes cannot be parsed is simply False here (on its own it raises): one malformed proof does not keep the others
+    from being verified."""
     c = _as_circuit(circuit, wire_counts, ctx)
     n = len(proofs)
     if n == 0:
@@ -220,7 +222,7 @@ def verify_batch(circuit, proofs, wire_counts: Optional[Tuple[int, int]] = None,
         keep.append(buf)
         lens[i] = ln
     ok = (C.c_int * n)()
-    flags = _lib.RV_VERIFY_STRICT if strict else 0
+    flags = 0 if strict else _lib.RV_VERIFY_REFERENCE_COMPAT
     _lib.check(_lib.lib().rv_verify_batch(c.ctx.handle, c.handle, C.c_size_t(n), ptrs, lens, C.c_uint32(flags), ok))
     return [bool(x) for x in ok]
 

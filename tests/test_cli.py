@@ -71,13 +71,16 @@ def test_cli_prove_verify_roundtrip(tmp_path, capsys, oracle):
     txt = capsys.readouterr().out
     assert txt.count("Ok(())") == 3 and "Verifying Proof" in txt
     # the statement checked against OTHER expected outputs: the output assertions fail, which the reference's verifier
-    # does not notice -- the plain CLI says Ok like speed-reverie would, --strict reports it
+    # does not notice -- --reference-compat says Ok like speed-reverie would, the default (strict) reports it
+    # and exits with status 1
     e2 = tmp_path / "exp2.txt"
     e2.write_text("".join(str((((a + b + 1) & (2**64 - 1)) >> i) & 1) for i in range(64)))
     other = ["--program-path", str(p), "--expected-outputs-path", str(e2), "--operation", "verify", "--proof-path", str(out)]
-    main(other)
+    assert main(other + ["--reference-compat"]) == 0
     assert "Ok(())" in capsys.readouterr().out
-    main(other + ["--strict"])
+    assert main(other) == 1
+    assert 'Err("Unverifiable Proof")' in capsys.readouterr().out
+    assert main(other + ["--strict"]) == 1
     assert 'Err("Unverifiable Proof")' in capsys.readouterr().out
     assert main(["--operation", "verify", "--proof-path", str(out), "--strict"] + common) == 0
     assert "Ok(())" in capsys.readouterr().out
@@ -87,5 +90,5 @@ def test_cli_prove_verify_roundtrip(tmp_path, capsys, oracle):
     bad = bytearray(out.read_bytes())
     bad[5] ^= 1
     out.write_bytes(bytes(bad))
-    main(["--operation", "verify", "--proof-path", str(out)] + common)
+    assert main(["--operation", "verify", "--proof-path", str(out)] + common) == 1
     assert 'Err("Unverifiable Proof")' in capsys.readouterr().out
