@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: prover AND-gates/sec on a GF(2) circuit (BASELINE.json metric).
+"""Headline benchmark: prover AND-gates/sec on a GF(2) circuit (BASELINE.json metric), on the boundary SURVEY §8(d)
+defines: `rv_prove` from "compiled gate stream resident on the GPU + witness bytes on the host" to "bincode(Proof)
+bytes on the host" -- seeds, AES-CTR masks, interpreter, BLAKE3 commitments, Fiat-Shamir challenge, openings AND the
+device-to-host copy of the proof (what the reference's bench_prover times around Proof::new,
+/root/reference/src/proof/mod.rs:346-353, plus the PCIe leg a GPU prover has to pay).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): BASELINE configs[3] — the synthetic 10^7-gate layered random
-AND/XOR GF(2) circuit of SURVEY §8d (SplitMix64 seed 0x5EED000000000004, 4096 inputs,
-153 layers x 65536 gates, p(AND)=1/2, folded + asserted tail), full KKW parameters
-(256 repetitions, 8 players, 40 opened).  It fits one GPU, and it is the configuration the
-metric (and the north-star 10^9 AND/s target) is quoted on.  One step = one complete proof:
-seeds -> AES-CTR masks -> interpreter -> BLAKE3 commitments -> digest all-gather ->
-Fiat-Shamir challenge -> openings.  The compiled gate stream and the witness are resident
-in HBM before the timed region; the timed region ends with the proof's openings resident
-in HBM (PCIe-inclusive numbers are in DESIGN.md).  With N GPUs the 256 repetitions are
-split N ways (strong scaling of ONE proof), one RCCL all-gather of digests per proof.
+Workload (config.workload): BASELINE configs[3] — the synthetic 10^7-gate layered random AND/XOR GF(2) circuit of
+SURVEY §8d (SplitMix64 seed 0x5EED000000000004, 4096 inputs, 153 layers x 65536 gates, p(AND)=1/2, folded + asserted
+tail), full KKW parameters (256 repetitions, 8 players, 40 opened).  It fits one GPU, and it is the configuration the
+metric (and the north-star 10^9 AND/s target) is quoted on.  One step = one complete proof, host to host.  With N GPUs
+the 256 repetitions are split N ways (strong scaling of ONE proof), one RCCL all-gather of digests per proof, and the
+step ends with the assembled proof bytes on rank 0's host.
+
+Next to `value` the line carries, all outside the timed region and each with its own parity flag: `device_resident`
+(round 1's headline: the same proof left in HBM), `prove_batch_host` (rv_prove_batch, host to host), `all_and`
+(the 10^7-AND variant), `secondary` (AES-128 / SHA-256 Bristol circuits, single proof and 64 / 256 proofs per call;
+the 10^6-MUL Z64 circuit), `streaming` (the bounded-memory prover), `verifier`, and `cpu_baseline` (the CPU oracle,
+median of five proofs of the same workload, CPU model and core counts stated).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,137 +36,186 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+PROFILE_TAG = "r02"    # profiles/<tag>_pmc_traffic.json feeds roofline.traffic
 
 
 def rule_seeds():
-    """seed[r] = BLAKE3("rv-seed" || LE32(r))[0..16] via the product's host BLAKE3 (rv_combine_digests
-    is a plain BLAKE3 of 8 KiB, so use a tiny local derivation instead: any fixed seeds do)."""
     rng = np.random.default_rng(0x5EED)
     return rng.integers(0, 256, (256, 16), dtype=np.uint8)
 
 
-def cpu_baseline(sample_layers: int, p_and: float = 0.5):
-    """Times the CPU oracle (a C port of the reference algorithm: packed u64 groups, AES-NI CTR,
-    scalar BLAKE3, one thread per packed group) on the same workload (by default ALL of it: one proof of the
-    10^7-gate circuit is a few seconds of 32 threads) or on its first `sample_layers` layers."""
-    import circuits
+def host_info():
+    """CPU model, logical CPUs, physical cores (distinct (physical id, core id) pairs) of this host"""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return {"cpu_model": model, "logical_cpus": logical, "physical_cores": len(cores) or logical}
+
+
+def cpu_baseline(prog, w2, w64, wc, seeds, units, unit, what, runs=5):
+    """The CPU oracle (a C port of the reference algorithm: packed u64 groups, AES-NI CTR, AVX2 movemask transpose,
+    eight-chunk AVX2 BLAKE3 behind a 64 KiB staged hasher, one thread per packed group like rayon at
+    proof/mod.rs:128) timed on this host: median of `runs` proofs.  -> (record, proof bytes)"""
     import oracle_lib
 
-    cores = os.cpu_count() or 1
-    threads = max(1, min(32, cores))
-    prog, wit, wc, st = circuits.layered_gf2(layers=sample_layers, p_and=p_and)
-    seeds = rule_seeds()
-    t0 = time.perf_counter()
-    proof = oracle_lib.prove(prog, wit, [], wc, seeds, threads=threads)
-    dt = time.perf_counter() - t0
+    hi = host_info()
+    threads = max(1, min(32, hi["physical_cores"]))
+    times, proof = [], None
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        proof = oracle_lib.prove(prog, w2, w64, wc, seeds, threads=threads)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
     return {
-        "value": st["and"] / dt, "unit": "AND gates/s", "cores": threads, "kind": "port",
-        "sample": f"same generator, {sample_layers} layers ({st['gates']} gates, {st['and']} AND), "
-                  f"1 proof, {dt:.2f}s wall, host has {cores} logical CPUs",
-        "proof_bytes": len(proof),
-    }, (prog, wit, wc, seeds, proof)
+        "value": units / med, "unit": unit, "cores": threads, "kind": "port",
+        "sample": f"{what}: {runs} proofs, median {med:.3f} s (min {min(times):.3f}, max {max(times):.3f}); "
+                  f"{threads} threads = one per packed group (32 groups), capped by the physical cores",
+        "cpu_model": hi["cpu_model"], "physical_cores": hi["physical_cores"], "logical_cpus": hi["logical_cpus"],
+        "simd": "AES-NI, AVX2 (movemask bit transpose, 8-way BLAKE3)", "proof_bytes": len(proof),
+    }, proof
 
 
-def secondary(args, local):
-    """Configs 2, 3, 5: single-proof latency and batched throughput through the plain
-    rv_prove / rv_verify entry points (host bytes in, host bytes out), checked against the oracle."""
+class HostProver:
+    """rv_prove through ctypes with as little Python in the loop as the FFI allows: witness and seeds are numpy arrays
+    made once, every call returns the library's page-locked proof buffer, which is handed back with rv_free"""
+
+    def __init__(self, circuit, w2, w64, seeds):
+        from reverie_amd import _lib
+
+        self.L = _lib.lib()
+        self.check = _lib.check
+        self.circuit = circuit
+        self.g = np.ascontiguousarray(np.asarray(w2, dtype=np.uint8))
+        self.z = np.ascontiguousarray(np.asarray(w64, dtype=np.uint64))
+        self.s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint8)).reshape(256, 16)
+        self.args = (circuit.ctx.handle, circuit.handle, self.g.ctypes.data_as(C.c_void_p) if self.g.size else None, C.c_size_t(len(self.g)),
+                     self.z.ctypes.data_as(C.c_void_p) if self.z.size else None, C.c_size_t(len(self.z)), self.s.ctypes.data_as(C.c_void_p))
+
+    def prove(self):
+        out, n = C.c_void_p(), C.c_size_t()
+        self.check(self.L.rv_prove(*self.args, C.byref(out), C.byref(n)))
+        return out, n.value
+
+    def free(self, p):
+        self.L.rv_free(p)
+
+    def run(self, steps):
+        """-> (seconds, bytes of the last proof)"""
+        last = None
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p, n = self.prove()
+            if last is not None:
+                self.free(last[0])
+            last = (p, n)
+        dt = time.perf_counter() - t0
+        data = C.string_at(last[0], last[1])
+        self.free(last[0])
+        return dt, data
+
+
+def bristol_case(name):
     import hashlib
-    import threading
 
     import bristol_gen
+    from reverie_amd import bristol
+
+    bits = lambda d: [(b >> (7 - k)) & 1 for b in d for k in range(8)]  # noqa: E731
+    if name == "aes128":
+        key = bytes(range(16)); pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+        prog, info = bristol.parse(bristol_gen.aes128(), expected_outputs=bits(bytes.fromhex("69c4e0d86a7b0430d8cdb78070b4c55a")))
+        return prog, bits(key) + bits(pt), info["wire_counts"], info["n_and"]
+    block = b"abc" + b"\x80" + bytes(52) + (24).to_bytes(8, "big")
+    prog, info = bristol.parse(bristol_gen.sha256_block(), expected_outputs=bits(hashlib.sha256(b"abc").digest()))
+    return prog, bits(block), info["wire_counts"], info["n_and"]
+
+
+def secondary_records(ctx, seeds, quick):
+    """Configs 2, 3 and 5 through the host-bytes entry points; every record carries its parity flag"""
     import circuits
     import oracle_lib
     import reverie_amd
-    from reverie_amd import bristol
 
-    seeds = rule_seeds()
-    if args.workload == "aes128":
-        key = bytes(range(16)); pt = bytes.fromhex("00112233445566778899aabbccddeeff")
-        bits = lambda d: [(b >> (7 - k)) & 1 for b in d for k in range(8)]  # noqa: E731
-        prog, info = bristol.parse(bristol_gen.aes128(), expected_outputs=bits(bytes.fromhex("69c4e0d86a7b0430d8cdb78070b4c55a")))
-        w2, w64, wc, unit_n, unit = bits(key) + bits(pt), [], info["wire_counts"], info["n_and"], "AND gates/s"
-    elif args.workload == "sha256":
-        block = b"abc" + b"\x80" + bytes(52) + (24).to_bytes(8, "big")
-        bits = lambda d: [(b >> (7 - k)) & 1 for b in d for k in range(8)]  # noqa: E731
-        prog, info = bristol.parse(bristol_gen.sha256_block(), expected_outputs=bits(hashlib.sha256(b"abc").digest()))
-        w2, w64, wc, unit_n, unit = bits(block), [], info["wire_counts"], info["n_and"], "AND gates/s"
-    else:
-        prog, w64, wc, st = circuits.layered_z64(n_mul=args.z64_muls)
-        w2, unit_n, unit = [], st["mul"], "Z64 MUL gates/s"
-    ctxs = [reverie_amd.Context(local) for _ in range(args.batch)]
-    t0 = time.perf_counter()
-    circs = [reverie_amd.Circuit(prog, wc, c) for c in ctxs]
-    compile_s = (time.perf_counter() - t0) / args.batch
-    info = circs[0].info
-    proofs = [None] * args.batch
-
-    fused = args.fused_batch
-    last_batch = [None] * args.batch
-    if fused:
-        rng = np.random.default_rng(99)
-        fused_seeds = rng.integers(0, 256, (fused, 256, 16), dtype=np.uint8)
-        fused_seeds[0] = seeds
-        fused_w2 = np.tile(np.asarray(w2, np.uint8), (fused, 1))
-
-    def worker(i, n):
-        for _ in range(n):
-            if fused:
-                last_batch[i] = reverie_amd.Proof.new_batch(circs[i], fused_w2, seeds=fused_seeds)
-                proofs[i] = last_batch[i][0]
-            else:
-                proofs[i] = reverie_amd.Proof.new(circs[i], w2, w64, seeds=seeds)
-
-    def run(n):
-        th = [threading.Thread(target=worker, args=(i, n)) for i in range(args.batch)]
-        t = time.perf_counter()
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        return time.perf_counter() - t
-
-    import ctypes as C2
-
-    from reverie_amd import _lib as L2
-
-    run(args.warmup)
-    L2.lib().rv_ctx_profile(ctxs[0].handle, 1, 1, None)
-    dt = run(args.steps)
-    prof = L2.Profile()
-    L2.lib().rv_ctx_profile(ctxs[0].handle, 0, 0, C2.byref(prof))
-    phases = {n: prof.ms[i] / max(args.steps, 1) for i, n in enumerate(L2.PHASES)}
-    t0 = time.perf_counter()
-    ok = proofs[0].verify(circs[0])
-    verify_s = time.perf_counter() - t0
-    vb = None
-    if fused and last_batch[0] is not None:
-        # rv_verify_batch on the proofs of the last rv_prove_batch call (strict), second call timed
-        reverie_amd.verify_batch(circs[0], last_batch[0], strict=True)
+    out = {}
+    for name in ("aes128", "sha256"):
+        prog, w2, wc, n_and = bristol_case(name)
+        circ = reverie_amd.Circuit(prog, wc, ctx)
+        hp = HostProver(circ, w2, [], seeds)
+        hp.run(3)
+        lat = []
+        for _ in range(10 if quick else 30):
+            dt, data = hp.run(1)
+            lat.append(dt)
+        want = oracle_lib.prove(prog, w2, [], wc, seeds, threads=8)
+        rec = {"and_gates": n_and, "levels": circ.info["levels"], "proof_bytes": len(data),
+               "single_proof_ms": statistics.median(lat) * 1e3, "single_proof_and_per_s": n_and / statistics.median(lat),
+               "bit_exact_vs_cpu": data == want, "verifies_strict": bool(reverie_amd.Proof(data).verify(circ))}
+        for B in (64, 256):
+            rng = np.random.default_rng(B)
+            bs = rng.integers(0, 256, (B, 256, 16), dtype=np.uint8)
+            bs[0] = seeds
+            bw = np.tile(np.asarray(w2, np.uint8), (B, 1))
+            reverie_amd.Proof.new_batch(circ, bw, seeds=bs)
+            t0 = time.perf_counter()
+            n_calls = 2 if quick else 4
+            for _ in range(n_calls):
+                proofs = reverie_amd.Proof.new_batch(circ, bw, seeds=bs)
+            dt = (time.perf_counter() - t0) / n_calls
+            reverie_amd.verify_batch(circ, proofs)
+            t0 = time.perf_counter()
+            oks = reverie_amd.verify_batch(circ, proofs)
+            tv = time.perf_counter() - t0
+            rec[f"batch{B}"] = {"ms_per_call": dt * 1e3, "us_per_proof": dt / B * 1e6, "and_per_s": n_and * B / dt,
+                                "first_proof_bit_exact_vs_cpu": bytes(proofs[0]) == want,
+                                "verify_batch_all_ok": all(oks), "verify_us_per_proof": tv / B * 1e6}
+            del proofs
         t0 = time.perf_counter()
-        oks = reverie_amd.verify_batch(circs[0], last_batch[0], strict=True)
-        tvb = time.perf_counter() - t0
-        vb = {"proofs": len(oks), "all_ok": all(oks), "ms": tvb * 1e3, "us_per_proof": tvb / len(oks) * 1e6,
-              "value": unit_n * len(oks) / tvb, "unit": unit}
-    res = {
-        "metric": f"prover {unit} ({args.workload}); secondary config", "value": unit_n * args.steps * args.batch * max(args.fused_batch, 1) / dt, "unit": unit,
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u64" if args.workload == "z64" else "u32", "data": "synthetic",
-        "config": {"workload": args.workload, "batch_in_flight": args.batch, "proofs_per_rv_prove_batch": args.fused_batch, "levels": info["levels"], "n_ops": info["n_ops"],
-                   "units_per_proof": unit_n, "compile_s": compile_s, "proof_bytes": len(proofs[0]),
-                   "latency_ms_per_proof": dt / args.steps * 1e3, "verify_ms": verify_s * 1e3, "verify_ok": ok,
-                   "phase_ms_ctx0": phases,
-                   "boundary": "host bytes in / host proof bytes out (rv_prove), PCIe included"},
-    }
-    if vb:
-        res["verify_batch"] = vb
-    if not args.no_cpu_baseline and args.workload != "z64":
-        t0 = time.perf_counter()
-        want = oracle_lib.prove(prog, w2, w64, wc, seeds, threads=min(32, os.cpu_count() or 1))
-        cdt = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": unit_n / cdt, "unit": unit, "cores": min(32, os.cpu_count() or 1), "kind": "port",
-                               "sample": f"the same circuit, 1 proof, {cdt * 1e3:.1f} ms"}
-        res["parity"] = {"proof_bit_exact_vs_cpu": bytes(proofs[0]) == want}
-    print(json.dumps(res))
+        for _ in range(3):
+            oracle_lib.prove(prog, w2, [], wc, seeds, threads=32)
+        rec["cpu_oracle_and_per_s"] = n_and * 3 / (time.perf_counter() - t0)
+        out[name] = rec
+        circ.close()
+    # config 5: Z64, 10^6 MUL (the full size on the GPU; the CPU oracle proves a 10^5-MUL sample of the same generator,
+    # which is also the bit-exactness check -- the full circuit needs ~20 GB and minutes on the host)
+    n_mul = 100_000 if quick else 1_000_000
+    prog, w64, wc, st = circuits.layered_z64(n_mul=n_mul)
+    circ = reverie_amd.Circuit(prog, wc, ctx)
+    hp = HostProver(circ, [], w64, seeds)
+    hp.run(1)
+    steps = 3
+    dt, data = hp.run(steps)
+    p = reverie_amd.Proof(data)
+    t0 = time.perf_counter()
+    ok = bool(p.verify(circ))
+    tv = time.perf_counter() - t0
+    rec = {"mul_gates": st["mul"], "levels": circ.info["levels"], "proof_bytes": len(data), "ms_per_proof": dt / steps * 1e3,
+           "mul_per_s": st["mul"] * steps / dt, "verifies_strict": ok, "verify_ms": tv * 1e3}
+    circ.close()
+    del p, data
+    sprog, sw64, swc, sst = circuits.layered_z64(n_mul=100_000)
+    scirc = reverie_amd.Circuit(sprog, swc, ctx)
+    dts, sdata = HostProver(scirc, [], sw64, seeds).run(1)
+    base, sproof = cpu_baseline(sprog, [], sw64, swc, seeds, sst["mul"], "Z64 MUL gates/s", "10^5-MUL sample of the same generator", runs=3)
+    rec["sample_1e5_bit_exact_vs_cpu"] = sdata == sproof
+    rec["cpu_baseline"] = base
+    scirc.close()
+    out["z64"] = rec
+    return out
 
 
 def main():
@@ -170,18 +226,12 @@ def main():
     ap.add_argument("--layers", type=int, default=153, help="circuit depth (153 = the BASELINE workload)")
     ap.add_argument("--p-and", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="layered", choices=["layered", "aes128", "sha256", "z64"],
-                    help="layered = the headline BASELINE config 4; the others are the secondary configs 2, 3 and 5")
-    ap.add_argument("--batch", type=int, default=1, help="secondary workloads: independent proofs in flight (one context each)")
-    ap.add_argument("--fused-batch", type=int, default=0,
-                    help="secondary GF(2) workloads: proofs per rv_prove_batch call (every level launched once for the whole batch)")
-    ap.add_argument("--z64-muls", type=int, default=1_000_000)
-    ap.add_argument("--two-in-flight", action="store_true", help="(default now; kept for old command lines)")
-    ap.add_argument("--no-two-in-flight", action="store_true",
-                    help="skip the extra measurement with two proofs in flight (reported as two_proofs_in_flight next to the "
-                         "one-at-a-time `value`): for rocprofv3 runs whose summary should only contain the timed configuration")
-    ap.add_argument("--cpu-sample-layers", type=int, default=0,
-                    help="layers of the workload the CPU oracle proves (0 = all of them: the whole timed workload)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="only the timed configuration (rocprofv3 runs whose summary should contain nothing else)")
+    ap.add_argument("--quick", action="store_true", help="fewer repetitions in the secondary records, Z64 at 10^5 MUL")
+    ap.add_argument("--device-resident", action="store_true",
+                    help="time rv_prove_device (openings left in HBM: round 1's headline) instead of the host-to-host rv_prove")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="(accepted for old command lines; implied by --no-secondary)")
     args = ap.parse_args()
 
     import torch
@@ -208,10 +258,8 @@ def main():
     import circuits
     import reverie_amd
     from reverie_amd import _lib
-    from reverie_amd.dist import HipShardBackend, prove_sharded
+    from reverie_amd.dist import HipShardBackend, assemble_device_parts, prove_sharded
 
-    if args.workload != "layered":
-        return secondary(args, local)
     ctx = reverie_amd.Context(local)
     prog, wit, wc, st = circuits.layered_gf2(layers=args.layers, p_and=args.p_and)
     t0 = time.perf_counter()
@@ -221,6 +269,7 @@ def main():
     backend = HipShardBackend(circuit)
     seeds = rule_seeds()
     n_and = info["gf2_muls"]
+    L = _lib.lib()
 
     def sync_all():
         if world > 1:
@@ -228,63 +277,54 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    def step(gather=False):
-        # timed steps leave every rank's openings in that rank's HBM (with one GPU: the whole proof in HBM); the
-        # gather to rank 0 and the bincode assembly belong to the parity gate below, outside the timed region
-        return prove_sharded(backend, wit, [], seeds, device_resident=True, gather=gather)
+    hp = HostProver(circuit, wit, [], seeds)
+    dev_buf = torch.empty(max(sum(backend.single_shard_sizes()), 1), dtype=torch.uint8, device="cuda")
+    last_bytes = [None]
+
+    def step():
+        if world > 1:
+            # sharded proof; rank 0 ends the step with the assembled bincode(Proof) bytes in host memory
+            out = prove_sharded(backend, wit, [], seeds, device_resident=True, gather=True)
+            if rank == 0:
+                comm, bufs, all_lens = out
+                last_bytes[0] = assemble_device_parts(comm, bufs, all_lens)
+        elif args.device_resident:
+            backend.prove_device(wit, [], seeds, dev_buf)
+        else:
+            p, n = hp.prove()
+            if last_bytes[0] is not None:
+                hp.free(last_bytes[0][0])
+            last_bytes[0] = (p, n)
 
     for _ in range(args.warmup):
         step()
-    L = _lib.lib()
     L.rv_ctx_profile(ctx.handle, 1, 1, None)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        step()
     sync_all()
     dt = time.perf_counter() - t0
     prof = _lib.Profile()
     L.rv_ctx_profile(ctx.handle, 0, 0, C.byref(prof))
-    # Kernel-quality numbers (roofline) need per-phase times that do not include another phase's stalls.  By default the
-    # library runs a proof's phases back to back on ONE stream, so the HIP-event times of the timed run are exactly
-    # that.  Only with RV_PIPELINE=1 (mask generator and interpreter on two streams) a short second single-stream pass
-    # provides them.
-    iso = None
-    if world == 1 and os.environ.get("RV_PIPELINE") == "1":
-        os.environ["RV_PIPELINE"] = "0"
-        ctx2 = reverie_amd.Context(local)
-        os.environ["RV_PIPELINE"] = "1"
-        c2 = reverie_amd.Circuit(prog, wc, ctx2)
-        b2 = HipShardBackend(c2)
-        prove_sharded(b2, wit, [], seeds, device_resident=True)
-        L.rv_ctx_profile(ctx2.handle, 1, 1, None)
-        n_iso = 3
-        for _ in range(n_iso):
-            prove_sharded(b2, wit, [], seeds, device_resident=True)
-        iso = _lib.Profile()
-        L.rv_ctx_profile(ctx2.handle, 0, 0, C.byref(iso))
-        iso = {n: iso.ms[i] / n_iso for i, n in enumerate(_lib.PHASES)}
-        c2.close()
-        ctx2.close()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if world == 1 and not args.device_resident:
+        p, n = last_bytes[0]
+        last_bytes[0] = C.string_at(p, n)
+        hp.free(p)
 
-    # ---- parity gate on rank 0, outside the timed region: the full proof must verify, and a
-    # short prefix of the workload must be byte-identical to the CPU oracle
     result = None
     if rank == 0:
         phases = {n: prof.ms[i] / max(args.steps, 1) for i, n in enumerate(_lib.PHASES)}
         launches = {n: int(prof.launches[i] // max(args.steps, 1)) for i, n in enumerate(_lib.PHASES)}
-        tphase = iso if iso is not None else phases
-        dom = max(("masks", "interp", "hash"), key=lambda k: tphase[k])
-        reps_here = 256 // world
-        row = reps_here  # bytes per transcript/mask row on this rank
-        # algorithmic HBM bytes per launch of each phase, materialised variant
-        n_masks, n_ssa = info["gf2_masks"], None
+        dom = max(("masks", "interp", "hash"), key=lambda k: phases[k])
+        row = 256 // world  # bytes per transcript / mask row on this rank
+        # algorithmic HBM bytes per proof of each phase, materialised variant
         alg = {
-            "masks": n_masks * row,  # writes every mask row once
+            "masks": info["gf2_masks"] * row,  # writes every mask row once
             # AND: 48 B gate + 4 share rows in + 2 corr-bit rows in + 1 out + online row + pre bits
             # XOR: 48 B gate + 2 share rows in + 1 out + 3 corr-bit rows
             # (XOR gates the device executes: the compiler drops linear gates nobody reads, 13.5 % of this circuit's)
@@ -292,32 +332,33 @@ def main():
                        + min(st["xor"], info["gf2_linear"]) * (48 + 3 * row + 3 * row // 8)),
             "hash": (info["gf2_muls"] + info["gf2_inputs"] + info["gf2_asserts"]) * row + info["gf2_muls"] * row // 8,
         }
-        # names as rocprofv3 prints them (profiles/r01_k_bench_kernel_stats.txt); <0, 64, false> = prover mode, 64 quad
-        # words per row (256 repetitions), the variant without the multi-base gate loops
         kname = {"masks": "rv::k_aes_gf2_masks<16>", "interp": "rv::k_interp_full<0, 64, false>", "hash": "rv::k_b3_chunks<4>"}[dom]
-        ach = alg[dom] / (tphase[dom] * 1e-3) / 1e9 if tphase[dom] > 0 else 0.0
-        # measured HBM traffic of the same workload (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
-        # tools/pmc_summary.py, committed under profiles/); only valid for the default workload on 1 GPU
+        ach = alg[dom] / (phases[dom] * 1e-3) / 1e9 if phases[dom] > 0 else 0.0
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")
         if world == 1 and args.layers == 153 and args.p_and == 0.5 and os.path.exists(pmc_path):
             pk = json.load(open(pmc_path))["kernels"]
             prefix = {"masks": "rv::k_aes_gf2_masks<", "interp": "rv::k_interp_full<0", "hash": "rv::k_b3_chunks<"}[dom]
             hits = [v["hbm_bytes_per_proof"] for k, v in pk.items() if k.startswith(prefix)]
             if hits:
-                traffic = sum(hits)
+                traffic = sum(hits) / max(launches[dom], 1)
+        n_l = max(launches[dom], 1)
         roofline = {
             "bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-            "note": "dominant phase by HIP-event time on the library's own stream (phases of a proof run back to back on one stream); "
-                    "achieved = its algorithmic HBM bytes per proof (DESIGN.md §4) / that time, both from the timed run itself; traffic = PMC-measured HBM bytes per proof for that kernel "
-                    "(all its launches). The mask and hash phases are integer-VALU-bound (bitsliced AES, BLAKE3): no MFMA on this path.",
-            # the dominant phase is a chain of launches (interpreter: one per dependency level); per launch:
-            "launches_per_proof": launches[dom], "avg_launch_us": tphase[dom] * 1e3 / max(launches[dom], 1),
-            "algorithmic_bytes_per_launch": alg[dom] / max(launches[dom], 1),
-            "phase_ms_isolated": tphase, "phase_ms_timed_run": phases, "phase_launches": launches,
-            "algorithmic_bytes": {k: int(v) for k, v in alg.items()},
+            "note": "dominant phase by HIP-event time on the library's own stream (a proof's phases run back to back on one "
+                    "stream); achieved = algorithmic HBM bytes per launch (DESIGN.md §4) / average launch duration, both from the "
+                    "timed run itself; traffic = PMC-measured HBM bytes per launch of that kernel "
+                    f"(profiles/{PROFILE_TAG}_pmc_traffic.json). The mask and hash phases are integer-VALU-bound (bitsliced AES, "
+                    "BLAKE3): no MFMA on this path.",
+            "launches_per_proof": launches[dom], "avg_launch_us": phases[dom] * 1e3 / n_l,
+            "algorithmic_bytes_per_launch": alg[dom] / n_l,
+            "phase_ms": phases, "phase_launches": launches, "algorithmic_bytes_per_proof": {k: int(v) for k, v in alg.items()},
+            "gpu_ms_per_proof": sum(phases.values()),
         }
+        boundary = ("sharded rv_shard_* + RCCL all-gather; rank 0 ends with bincode(Proof) bytes in host memory" if world > 1 else
+                    "rv_prove_device: openings left in HBM (NOT the SURVEY 8(d) boundary)" if args.device_resident else
+                    "rv_prove: witness bytes on the host -> bincode(Proof) bytes on the host (page-locked), D2H of the proof included")
         result = {
             "metric": "prover AND-gates/sec on GF(2) Bristol circuit; 1/2/4/8-GPU; proof bit-exact",
             "value": n_and * args.steps / dt, "unit": "AND gates/s", "n_gpus": world, "steps": args.steps,
@@ -325,114 +366,125 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"synthetic layered AND/XOR GF(2) circuit, {st['gates']} gates ({st['and']} AND), "
                                    f"{st['inputs']} inputs, {args.layers} layers x 65536, p_and={args.p_and}, 256 reps x 8 players, 40 online",
-                       "parallelism": f"reps/{world}", "levels": info["levels"], "compile_s": compile_s,
+                       "boundary": boundary, "parallelism": f"reps/{world}", "levels": info["levels"], "compile_s": compile_s,
                        "gate_stream_upload_ms": info["upload_us"] / 1e3, "gate_stream_bytes": info["device_bytes"]},
             "roofline": roofline,
         }
-    # ---- parity gate, outside the timed region (rank 0; the other ranks wait at the final barrier):
-    # the last timed proof must verify; with N > 1 the sharded proof must equal, byte for byte, the proof one GPU
-    # produces from the same seeds; and (N = 1) a prefix of the workload must equal the CPU oracle's proof
-    if world > 1:
-        out = step(gather=True)  # same seeds, same proof: rank 0 now holds every rank's openings
-    if rank == 0:
-        from reverie_amd.dist import assemble_device_parts
 
-        comm, bufs, all_lens = out
-        last = reverie_amd.Proof(assemble_device_parts(comm, bufs, all_lens))
-        parity = {"last_timed_proof_verifies": bool(last.verify(circuit)), "proof_bytes": len(last)}
-        if world == 1:
-            # verifier rate and proof size next to the prover's.  rv_verify from host proof bytes (the upload
-            # of the proof is part of it); second call, the first one above sized the context's buffers
-            tv = time.perf_counter()
-            okv = bool(last.verify(circuit, strict=True))
-            tv = time.perf_counter() - tv
-            # the same proof as rv_prove returns it (host bytes in the library's page-locked buffer, which the Proof
-            # object hands back to rv_verify in place): the 50 MB upload then runs at PCIe speed
-            host_proof = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
-            same_bytes = bytes(host_proof) == bytes(last)
-            host_proof.verify(circuit, strict=True)
-            tp = time.perf_counter()
-            okp = bool(host_proof.verify(circuit, strict=True))
-            tp = time.perf_counter() - tp
-            result["verifier"] = {"value": n_and / tp, "unit": "AND gates/s", "ms": tp * 1e3, "ms_pageable_input": tv * 1e3,
-                                  "strict_ok": okv and okp,
-                                  "note": "rv_verify_ex(RV_VERIFY_STRICT), host proof bytes in, one call: `ms` on the buffer rv_prove "
-                                          "returned (page-locked), `ms_pageable_input` on a copy in ordinary host memory"}
-            parity["last_timed_proof_verifies_strict"] = okv and okp
-            parity["rv_prove_bytes_equal_device_resident_proof"] = same_bytes
+    # ---- parity gate and the secondary records, outside the timed region (rank 0; the other ranks wait at the barrier)
+    if rank == 0:
+        if world == 1 and args.device_resident:
+            last = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
+        else:
+            last = reverie_amd.Proof(last_bytes[0])
+        parity = {"last_timed_proof_verifies_strict": bool(last.verify(circuit)), "proof_bytes": len(last)}
         if world > 1:
             single = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
             parity["sharded_proof_equals_single_gpu_proof"] = bytes(single) == bytes(last)
         result["parity"] = parity
-        if not all(v for k, v in parity.items() if k != "proof_bytes"):
-            result["value"] = 0.0
+        if world == 1 and not args.no_secondary:
+            # verifier: rv_verify (strict) from host proof bytes, second call timed
+            host_proof = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
+            host_proof.verify(circuit)
+            tp = time.perf_counter()
+            okp = bool(host_proof.verify(circuit))
+            tp = time.perf_counter() - tp
+            result["verifier"] = {"value": n_and / tp, "unit": "AND gates/s", "ms": tp * 1e3, "strict_ok": okp,
+                                  "note": "rv_verify (strict), host proof bytes (page-locked, as rv_prove returned them) in, one call"}
+            parity["rv_prove_is_deterministic"] = bytes(host_proof) == bytes(last)
+            del host_proof
+            # the same proof left in HBM (round 1's headline) -- or, with --device-resident, the host-to-host one
+            n2 = max(args.steps // 2, 5)
+            if args.device_resident:
+                hp.run(2)
+                d2, data2 = hp.run(n2)
+                result["host_to_host"] = {"value": n_and * n2 / d2, "unit": "AND gates/s", "ms_per_proof": d2 / n2 * 1e3,
+                                          "bit_exact_vs_timed_proof": data2 == bytes(last)}
+            else:
+                backend.prove_device(wit, [], seeds, dev_buf)
+                sync_all()
+                t0 = time.perf_counter()
+                for _ in range(n2):
+                    comm, omit, lens = backend.prove_device(wit, [], seeds, dev_buf)
+                sync_all()
+                d2 = time.perf_counter() - t0
+                dev_proof = assemble_device_parts(comm, [dev_buf], [lens])
+                result["device_resident"] = {"value": n_and * n2 / d2, "unit": "AND gates/s", "ms_per_proof": d2 / n2 * 1e3,
+                                             "bit_exact_vs_timed_proof": dev_proof == bytes(last),
+                                             "note": "rv_prove_device: the proof's openings stay in HBM (no D2H, no framing)"}
+            # rv_prove_batch, host to host: several proofs of the circuit per call
+            B = 8
+            rng = np.random.default_rng(7)
+            bs = rng.integers(0, 256, (B, 256, 16), dtype=np.uint8)
+            bs[0] = seeds
+            bw = np.tile(np.asarray(wit, np.uint8), (B, 1))
+            reverie_amd.Proof.new_batch(circuit, bw, seeds=bs)
+            t0 = time.perf_counter()
+            proofs = reverie_amd.Proof.new_batch(circuit, bw, seeds=bs)
+            d3 = time.perf_counter() - t0
+            result["prove_batch_host"] = {"value": n_and * B / d3, "unit": "AND gates/s", "ms_per_proof": d3 / B * 1e3, "proofs_per_call": B,
+                                          "first_proof_bit_exact_vs_timed_proof": bytes(proofs[0]) == bytes(last),
+                                          "last_proof_verifies_strict": bool(proofs[-1].verify(circuit)),
+                                          "note": "rv_prove_batch: witness bytes on the host -> B proofs' bytes on the host, one call"}
+            del proofs
     if world > 1:
         # informational, outside the timed region: the same N GPUs proving N INDEPENDENT statements, one whole proof
         # (256 repetitions) per rank and no collective -- weak scaling, what a proving service with a queue of
         # statements would run.  `value` above stays the north-star's sharded single proof (strong scaling).
         n_ind = max(args.steps // 2, 3)
-        whole = HipShardBackend(circuit)
-        buf = torch.empty(max(sum(whole.single_shard_sizes()), 1), dtype=torch.uint8, device="cuda")
-        whole.prove_device(wit, [], seeds, buf)
+        hp.run(1)
         sync_all()
         ti = time.perf_counter()
-        for _ in range(n_ind):
-            whole.prove_device(wit, [], seeds, buf)
+        hp.run(n_ind)
         sync_all()
         ti = torch.tensor([time.perf_counter() - ti], dtype=torch.float64, device="cuda")
         dist.all_reduce(ti, op=dist.ReduceOp.MAX)
         if rank == 0:
             result["independent_proofs"] = {"value": n_and * n_ind * world / float(ti.item()), "unit": "AND gates/s", "scaling": "weak",
                                             "ms_per_proof_per_gpu": float(ti.item()) / n_ind * 1e3, "proofs": n_ind * world,
-                                            "note": "one whole proof per GPU at a time, no collective"}
-    if rank == 0 and world == 1 and not args.no_two_in_flight:
-        # informational, outside the timed region: the same workload with TWO proofs in flight (two contexts, two host
-        # threads) -- one proof's VALU-bound phases overlap the other's memory-bound interpreter.  `value` above stays
-        # the one-proof-at-a-time number.
-        import threading
-
-        ctx_b = reverie_amd.Context(local)
-        circ_b = reverie_amd.Circuit(prog, wc, ctx_b)
-        pair = [backend, HipShardBackend(circ_b)]
-
-        def fly(i, n):
-            torch.cuda.set_device(local)
-            for _ in range(n):
-                prove_sharded(pair[i], wit, [], seeds, device_resident=True)
-
-        def run_pair(n):
-            th = [threading.Thread(target=fly, args=(i, n)) for i in range(2)]
-            t = time.perf_counter()
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            torch.cuda.synchronize()
-            return time.perf_counter() - t
-
-        run_pair(2)
-        n2 = max(args.steps, 8)
-        dt2 = run_pair(n2)
-        result["two_proofs_in_flight"] = {"value": n_and * 2 * n2 / dt2, "unit": "AND gates/s", "ms_per_proof": dt2 / (2 * n2) * 1e3,
-                                          "proofs": 2 * n2}
-        circ_b.close()
-        ctx_b.close()
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
-        n_layers = args.cpu_sample_layers or args.layers
-        base, (sprog, swit, swc, sseeds, sproof) = cpu_baseline(n_layers, args.p_and)
+                                            "note": "one whole rv_prove (host to host) per GPU at a time, no collective"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        what = f"the whole timed workload ({st['gates']} gates, {st['and']} AND), same seeds"
+        base, cproof = cpu_baseline(prog, wit, [], wc, seeds, st["and"], "AND gates/s", what, runs=5)
         result["cpu_baseline"] = base
-        if n_layers == args.layers:
-            # the oracle proved the very workload that was timed, with the same seeds: the last timed proof must be
-            # its proof, byte for byte
-            same = bytes(last) == sproof
-            result["parity"]["timed_proof_bit_exact_vs_cpu"] = same
-        else:
-            got = reverie_amd.Proof.new(reverie_amd.Circuit(sprog, swc, ctx), swit, [], seeds=sseeds)
-            same = bytes(got) == sproof
-            result["parity"]["sample_proof_bit_exact_vs_cpu"] = same
-        if not same:
-            result["value"] = 0.0
+        # the oracle proved the very workload that was timed, with the same seeds: the last timed proof must be its
+        # proof, byte for byte
+        result["parity"]["timed_proof_bit_exact_vs_cpu"] = bytes(last) == cproof
+        del cproof
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # the all-AND variant (the north-star's "10^7-gate" phrasing read as 10^7 AND gates)
+        circuit.close()
+        aprog, awit, awc, ast = circuits.layered_gf2(layers=args.layers, p_and=1.0)
+        acirc = reverie_amd.Circuit(aprog, awc, ctx)
+        ahp = HostProver(acirc, awit, [], seeds)
+        ahp.run(2)
+        na = 5
+        da, adata = ahp.run(na)
+        rec = {"value": ast["and"] * na / da, "unit": "AND gates/s", "ms_per_proof": da / na * 1e3, "and_gates": ast["and"],
+               "proof_bytes": len(adata), "verifies_strict": bool(reverie_amd.Proof(adata).verify(acirc)),
+               "note": "rv_prove host to host on the p_and = 1 variant of the workload"}
+        if not args.no_cpu_baseline:
+            import oracle_lib
+
+            t0 = time.perf_counter()
+            want = oracle_lib.prove(aprog, awit, [], awc, seeds, threads=32)
+            rec["cpu_oracle_and_per_s"] = ast["and"] / (time.perf_counter() - t0)
+            rec["bit_exact_vs_cpu"] = adata == want
+            del want
+        result["all_and"] = rec
+        acirc.close()
+        del aprog, adata
+        result["secondary"] = secondary_records(ctx, seeds, args.quick)
+        try:
+            from tools.stream_bench import streaming_record
+
+            result["streaming"] = streaming_record(ctx, prog, wit, wc, st, seeds, bytes(last))
+        except ImportError:
+            pass
     if rank == 0:
+        flags = [v for k, v in result["parity"].items() if k != "proof_bytes"]
+        if not all(flags):
+            result["value"] = 0.0
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

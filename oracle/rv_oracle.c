@@ -51,9 +51,11 @@ static void bvec_free(bvec *v) {
 }
 
 /* ------------------------------------------------------------------ BufferedHasher
- * crypto/hash.rs:17-58.  The reference stages 64 KiB before each blake3 update; the
- * staging size does not change the digest, so a 4 KiB stage is used here. */
-#define STAGE 4096
+ * crypto/hash.rs:17-58.  The reference stages 64 KiB before each blake3 update, which lets the blake3 crate hash many
+ * chunks per call with its SIMD back ends; the staging size does not change the digest.  Here the stage is 65 KiB: a
+ * flush then hands rvo_blake3_update 64 KiB that are KNOWN not to be the end of the stream (one more KiB follows), so
+ * all 64 chunks take the eight-chunks-at-a-time AVX2 path (rv_blake3.c). */
+#define STAGE (65 * 1024)
 typedef struct {
     rvo_blake3 h;
     u8 buf[STAGE];

@@ -420,7 +420,7 @@ def main():
         "blake3": [{"len": n, "hash": blake3(bytes(i % 251 for i in range(n))).hex(),
                     "xof_seek7_len131": blake3(bytes(i % 251 for i in range(n)), 131, 7).hex()} for n in
                    (0, 1, 2, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 2048, 2049, 3072, 3073, 4096, 4097, 5120, 6144,
-                    7168, 8192, 8193, 16384, 31744, 102400)],
+                    7168, 8192, 8193, 9216, 9217, 16384, 17409, 31744, 66560, 66561, 102400, 133120, 205825)],
         "rep_seed": {"0": seeds[0].hex(), "1": seeds[1].hex(), "255": seeds[255].hex()},
         "expand_seed": [{"seed": s.hex(), "keys": aes_ctr(s, 128).hex()} for s in (bytes(16), seeds[3])],
         "challenge": [],
