@@ -88,6 +88,7 @@ enum {
 typedef struct rv_ctx rv_ctx;         /* one GPU: stream, scratch arena                    */
 typedef struct rv_circuit rv_circuit; /* a gate stream levelised and resident in HBM       */
 typedef struct rv_shard rv_shard;     /* committed repetitions awaiting the challenge      */
+typedef struct rv_stream rv_stream;   /* a bounded-memory proof in progress (two passes over a chunked gate stream) */
 
 const char *rv_strerror(int code);
 /* last HIP/driver error text for this thread ("" if none) */
@@ -201,6 +202,51 @@ int rv_verify(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t pro
 int rv_verify_ex(rv_ctx *ctx, const rv_circuit *c, const uint8_t *proof, size_t proof_len, uint32_t flags, int *ok);
 
 void rv_free(void *p);
+
+/* ---- streaming prover --------------------------------------------------------
+ * The reference's README promises "a streaming interface" over its single-pass just-in-time preprocessing
+ * (/root/reference/README.md:14,38; src/generator/share.rs:54-65), while the surveyed source keeps every
+ * reconstruction and correction of all repetitions until the challenge (src/transcript/prover.rs:29-31,211,217).
+ * Here the gate stream is fed in pieces and device memory is bounded by
+ *     the wire store (one share row per GF(2) wire INDEX, one slot per Z64 wire index -- the reference's own
+ *     `wires` vectors, sized by wire_counts) + one chunk's working set + the proof itself,
+ * independent of the number of gates: transcripts are hashed chunk by chunk into incremental BLAKE3 trees and
+ * dropped.  Because the omitted players are only known after the commitment, the SAME ops are fed twice:
+ *
+ *     rv_stream_begin(ctx, z64_wires, gf2_wires, seeds, max_chunk_ops, &s)
+ *     rv_stream_feed(s, ops_0, ...) ... rv_stream_feed(s, ops_k, ...)      pass 1: commitments
+ *     rv_stream_commit(s, comm)                                            Fiat-Shamir challenge
+ *     rv_stream_feed(s, ops_0, ...) ... rv_stream_feed(s, ops_k, ...)      pass 2: openings of the 40 challenged reps
+ *     rv_stream_finish(s, &proof, &len)        bincode(Proof), byte-identical to rv_prove's for the same seeds
+ *     rv_stream_abort(s)                       releases the stream (also after a finish or an error)
+ *
+ * The pieces of pass 2 need not be cut where those of pass 1 were, but their concatenation must be the same op
+ * list (checked at finish: RV_E_ARG).  wit_gf2 / wit_z64 of a feed are the witness elements its Input gates
+ * consume, in order (more may be passed; RV_E_WITNESS_SHORT if fewer).  A feed longer than max_chunk_ops
+ * (0 = 2^20) is cut into device chunks of that size.  SizeHint ops may not grow the wire counts given at begin
+ * (RV_E_UNSUPPORTED).  After an error the stream only accepts rv_stream_abort. */
+int rv_stream_begin(rv_ctx *ctx, size_t z64_wires, size_t gf2_wires, const uint8_t *seeds /* 256 x 16 or NULL */,
+                    size_t max_chunk_ops, rv_stream **out);
+int rv_stream_feed(rv_stream *s, const rv_op *ops, size_t n_ops, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64,
+                   size_t n_z64);
+int rv_stream_commit(rv_stream *s, uint8_t comm[RV_HASH_SIZE] /* nullable */);
+int rv_stream_finish(rv_stream *s, uint8_t **proof, size_t *proof_len);
+void rv_stream_abort(rv_stream *s);
+typedef struct rv_stream_info {
+    uint64_t n_ops, chunks, levels; /* of pass 1 (running totals while it is in progress) */
+    uint64_t gf2_masks, z64_masks, gf2_muls, z64_muls;
+    uint64_t wire_store_bytes;  /* HBM held by the carried wires + the largest chunk's rows */
+    uint64_t peak_chunk_bytes;  /* largest single chunk's working set (rows, transcripts, gate records) */
+    uint64_t hash_state_bytes;  /* incremental BLAKE3 trees + unhashed stream tails */
+    uint64_t proof_bytes;       /* 0 before rv_stream_commit */
+    uint32_t pass, reserved;
+} rv_stream_info;
+int rv_stream_get_info(const rv_stream *s, rv_stream_info *info);
+/* Both passes over an op array that already sits in host memory: Proof::new with bounded DEVICE memory.
+ * info (nullable) receives the stream's final figures. */
+int rv_prove_streaming(rv_ctx *ctx, const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, const uint8_t *wit_gf2,
+                       size_t n_gf2, const uint64_t *wit_z64, size_t n_z64, const uint8_t *seeds, size_t max_chunk_ops,
+                       uint8_t **proof, size_t *proof_len, rv_stream_info *info);
 
 /* ---- sharded form (one process per GPU; repetitions [rep_begin, rep_begin+rep_count),
  * both multiples of 8).  rv_prove == commit(0,256) -> combine -> challenge -> open ->

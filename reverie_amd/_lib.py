@@ -46,6 +46,11 @@ class BristolInfo(C.Structure):
                                           "n_other", "gf2_wires")]
 
 
+class StreamInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_ops", "chunks", "levels", "gf2_masks", "z64_masks", "gf2_muls", "z64_muls", "wire_store_bytes",
+                                          "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")] + [("pass_", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("calls", C.c_uint64)]
 
@@ -64,6 +69,8 @@ SYMBOLS = [
     "rv_bristol_parse", "rv_circuit_record_sizes", "rv_program_from_bincode", "rv_program_to_bincode", "rv_prove_batch", "rv_prove_device",
     "rv_verify_ex", "rv_verify_shard_ex", "rv_verify_finish_ex", "rv_verify_batch",
     "rv_hook_gf2_reconstruct", "rv_hook_z64_reconstruct",
+    "rv_stream_begin", "rv_stream_feed", "rv_stream_commit", "rv_stream_finish", "rv_stream_abort", "rv_stream_get_info",
+    "rv_prove_streaming",
 ]
 RV_VERIFY_STRICT = 1
 RV_VERIFY_REFERENCE_COMPAT = 2  # the reference verifier's two unchecked conditions stay unchecked
@@ -109,7 +116,7 @@ def lib():
         L.rv_abi_version.restype = C.c_uint32
         for name in SYMBOLS:
             fn = getattr(L, name)
-            if name in ("rv_ctx_destroy", "rv_circuit_destroy", "rv_shard_destroy", "rv_free"):
+            if name in ("rv_ctx_destroy", "rv_circuit_destroy", "rv_shard_destroy", "rv_free", "rv_stream_abort"):
                 fn.restype = None
             elif name not in ("rv_strerror", "rv_last_error", "rv_abi_version"):
                 fn.restype = C.c_int

@@ -423,7 +423,7 @@ __device__ __forceinline__ void transpose32(uint32_t* A) {
 // slot.  masks64[(2j+h)*S + slot] with S = NQ*32 slots, slot = rep*8 + player.
 template <int QW>
 __global__ __launch_bounds__(512, 2) void k_aes_z64_masks(const uint32_t* __restrict__ rk, const uint32_t* __restrict__ keep,
-                                                       uint32_t NQ, uint64_t n_blocks, uint32_t blocks_per_wg,
+                                                       uint32_t NQ, uint64_t first_block, uint64_t n_blocks, uint32_t blocks_per_wg,
                                                        uint64_t* __restrict__ masks64) {
     __shared__ uint32_t lds_rk[11 * 128 * QW];
     constexpr uint32_t JW = 64 / QW;
@@ -440,10 +440,10 @@ __global__ __launch_bounds__(512, 2) void k_aes_z64_masks(const uint32_t* __rest
     const uint64_t j_lo = chunk * blocks_per_wg;
     const uint64_t j_hi = (j_lo + blocks_per_wg < n_blocks) ? j_lo + blocks_per_wg : n_blocks;
     for (uint64_t jb = j_lo + (uint64_t)wave * JW; jb < j_hi; jb += 8 * JW) {
-        const uint64_t j = jb + jsub;
+        const uint64_t j = jb + jsub;  // block inside this launch: its output slot; CTR index first_block + j
         if (j >= j_hi) continue;
         uint32_t s[128], t[128];
-        rounds_0_to_9<QW>(j, s, t, rkl);
+        rounds_0_to_9<QW>(first_block + j, s, t, rkl);
         sub_shift(s, t);
         const uint32_t* rk10 = rkl + 10 * 128 * QW;
 #pragma unroll
@@ -506,26 +506,26 @@ void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* 
         launch_masks_qw<2>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
 }
 template <int QW>
-static void launch_z64_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t n_blocks,
+static void launch_z64_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks,
                           uint64_t* d_masks64) {
     const uint32_t n_qg = NQ / QW;
     constexpr uint32_t JW = 64 / QW;
     uint64_t per = (n_blocks * n_qg + 511) / 512;
     per = ((per + 8 * JW - 1) / (8 * JW)) * (8 * JW);
     const uint64_t chunks = (n_blocks + per - 1) / per;
-    hipLaunchKernelGGL(k_aes_z64_masks<QW>, dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_rk, d_keep, NQ, n_blocks,
+    hipLaunchKernelGGL(k_aes_z64_masks<QW>, dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_rk, d_keep, NQ, first_block, n_blocks,
                        (uint32_t)per, d_masks64);
 }
 
 void launch_aes_z64_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t n_blocks,
-                          uint64_t* d_masks64) {
+                          uint64_t* d_masks64, uint64_t first_block) {
     if (!n_blocks) return;
     if (NQ % 16 == 0)
-        launch_z64_qw<16>(st, d_rk, d_keep, NQ, n_blocks, d_masks64);
+        launch_z64_qw<16>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks64);
     else if (NQ % 8 == 0)
-        launch_z64_qw<8>(st, d_rk, d_keep, NQ, n_blocks, d_masks64);
+        launch_z64_qw<8>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks64);
     else
-        launch_z64_qw<2>(st, d_rk, d_keep, NQ, n_blocks, d_masks64);
+        launch_z64_qw<2>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks64);
 }
 
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,

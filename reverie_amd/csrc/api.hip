@@ -379,6 +379,7 @@ static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
 
 static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
                                   rv_circuit** out);
+static int circuit_upload(rv_ctx* ctx, rv_circuit* c);
 
 extern "C" int rv_circuit_compile(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
                                   rv_circuit** out) {
@@ -407,6 +408,15 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
     if (getenv("RV_COMPILE_STATS"))
         fprintf(stderr, "[rv circuit] compile_ops: %.3f s for %zu ops\n", std::chrono::duration<double>(t_compiled - t_begin).count(),
                 n_ops);
+    if ((rc = circuit_upload(ctx, c))) return rc;  // (destroys c on failure)
+    *out = c;
+    return RV_OK;
+}
+
+// the compiled gate stream (c->cc) to HBM + the narrow-run plan; c is destroyed on failure
+static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
+    const auto t_compiled = std::chrono::steady_clock::now();
+    int rc;
     HIPCHK(hipSetDevice(ctx->device));
     const Compiled& cc = c->cc;
     auto up = [&](const void* src, size_t bytes, void** dst) -> int {
@@ -485,7 +495,6 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
     c->cc.info.device_bytes = cc.gates.size() * sizeof(Gate) + (cc.rec_rows.size() + cc.in_rows.size()) * 4 +
                               cc.gates64.size() * sizeof(Gate64) + (cc.rec_offs64.size() + cc.in_offs64.size()) * 8;
     c->cc.info.scratch_bytes = scratch_bytes_for(cc, RV_TOTAL_REPS);
-    *out = c;
     return RV_OK;
 }
 
@@ -687,8 +696,8 @@ static int shard_run_alloc(rv_shard* s, InterpParams& p, Interp64Params& p64) {
     hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
     if (s->ev_setup && ctx->pipeline) HIPCHK(hipStreamWaitEvent(sb, s->ev_setup, 0));
     // error flag and the zero row (first computed row: mask 0, corr 0), one launch
-    launch_shard_init(sb, s->d_err, s->d_masks + (size_t)cc.n_masks_pad * s->NQ, s->NQ,
-                      s->d_wires + (size_t)cc.n_masks_pad * (s->NQ / 2), s->NQ / 2);
+    launch_shard_init(sb, s->d_err, s->d_masks + (size_t)cc.zero_row * s->NQ, s->NQ,
+                      s->d_wires + (size_t)cc.zero_row * (s->NQ / 2), s->NQ / 2);
     p.NQ = s->NQ;
     p.rows = s->d_masks;
     p.corr = s->d_wires;
@@ -2521,3 +2530,5 @@ extern "C" int rv_hook_z64_reconstruct(rv_ctx* ctx, const uint64_t* shares, size
     ctx->release(d_out);
     return RV_OK;
 }
+
+#include "stream.inc"

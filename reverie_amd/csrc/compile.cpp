@@ -14,6 +14,7 @@ namespace {
 
 constexpr int K = RV_LIN_K;
 constexpr uint32_t COMP = 0x80000000u;  // computed-row flag (resolved to n_masks_pad + index at the end)
+constexpr uint32_t CARRY = 0x40000000u; // carried wire row of a streaming chunk (resolved to the wire index)
 constexpr uint32_t ZERO_ROW = COMP | 0;
 
 // a wire as a linear form over base rows: XOR of b[0..n) (sorted, distinct) plus the constant c
@@ -60,7 +61,7 @@ struct Builder {
         if (counting) uses.assign(1, 0);
     }
 
-    int32_t row_level(uint32_t r) const { return (r & COMP) ? lvl_comp[r & ~COMP] : lvl_prg[r]; }
+    int32_t row_level(uint32_t r) const { return (r & COMP) ? lvl_comp[r & ~COMP] : (r & CARRY) ? -1 : lvl_prg[r]; }
     int32_t lin_level(const Lin& L) const {
         int32_t l = -1;
         for (int i = 0; i < L.n; i++) l = std::max(l, row_level(L.b[i]));
@@ -132,6 +133,20 @@ struct Builder {
         emit(g, (uint32_t)lvl);
         out.info.gf2_linear++;
         return g.dst;
+    }
+
+    // streaming chunk: the chunk's last level writes a wire's final value (a linear form) into its carried row
+    void write_back(uint32_t wire, const Lin& L, uint32_t lvl) {
+        Gate g{};
+        g.op = G_XORK;
+        for (int i = 0; i < K; i++) {
+            g.a[i] = i < L.n ? L.b[i] : ZERO_ROW;
+            g.b[i] = ZERO_ROW;
+        }
+        g.op |= (uint32_t)L.n << 8 | (uint32_t)L.c << 16;
+        g.dst = CARRY | wire;
+        emit(g, lvl);
+        out.info.gf2_linear++;
     }
 
     // ---- GF(2) primitives on SSA ids (used by plain ops and by the B2A expansion) ----
@@ -276,10 +291,21 @@ void sort_by_level(const std::vector<T>& in, const std::vector<uint32_t>& lvl, u
 
 }  // namespace
 
-static int run_pass(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Builder& b) {
+static int run_pass(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Builder& b, const ChunkStart* chunk) {
     Compiled& out = b.out;
     b.cur.assign(gf2_wires, 0);
     b.cur64.assign(z64_wires, 0);
+    if (chunk) {
+        // every wire starts as its carried row / slot (SSA 1 + w), available before level 0
+        for (size_t w = 0; w < gf2_wires; w++) b.cur[w] = b.new_ssa(Builder::base(CARRY | (uint32_t)w));
+        for (size_t w = 0; w < z64_wires; w++) b.cur64[w] = b.new_ssa64(-1);
+        out.n_masks = chunk->mask_phase;
+        out.n_masks64 = chunk->mask64_phase;
+        out.n_on = chunk->on0;
+        out.n_pre = chunk->pre0;
+        out.on_words64 = chunk->on_words64_0;
+        out.pre_words64 = chunk->pre_words64_0;
+    }
     rv_circuit_info& info = out.info;
     const uint64_t LIM = std::numeric_limits<uint32_t>::max() - 512;
 
@@ -288,6 +314,8 @@ static int run_pass(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
         if (op.reserved != 0) return RV_E_BAD_OP;
         switch (op.domain) {
         case RV_DOM_SIZEHINT:  // interpreter/combine.rs:122-129
+            // (a streaming chunk's wire store was sized when the stream began: growing it mid-stream is not supported)
+            if (chunk && (op.b > b.cur.size() || op.a > b.cur64.size())) return RV_E_UNSUPPORTED;
             if (op.b > b.cur.size()) b.cur.resize(op.b, 0);
             if (op.a > b.cur64.size()) b.cur64.resize(op.a, 0);
             break;
@@ -479,10 +507,39 @@ static int run_pass(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
             out.n_on > LIM)
             return RV_E_UNSUPPORTED;
     }
+    if (chunk) {
+        // Write-back level.  A final form that still reads carried rows is materialised first: its write-back would
+        // otherwise race with the write-back of the rows it reads (two wires swapped by the chunk).
+        std::vector<std::pair<uint32_t, Lin>> wb;
+        for (size_t w = 0; w < gf2_wires; w++) {
+            const uint32_t ssa = b.cur[w];
+            if (ssa == 1 + (uint32_t)w) continue;  // never written in this chunk
+            b.use(ssa);                            // (pass 1: a wire that is live out is not dead)
+            if (b.counting) continue;
+            Lin L = b.lin[ssa];
+            bool reads_carry = false;
+            for (int i = 0; i < L.n; i++) reads_carry |= (L.b[i] & CARRY) != 0;
+            if (reads_carry) L = Builder::base(b.materialise(L.b, L.n, L.c));
+            wb.emplace_back((uint32_t)w, L);
+        }
+        if (!b.counting) {
+            const uint32_t last = b.any ? b.max_level + 1 : 0;
+            for (const auto& e : wb) b.write_back(e.first, e.second, last);
+            for (size_t w = 0; w < z64_wires; w++) {
+                if (b.cur64[w] == 1 + (uint32_t)w) continue;
+                Gate64 g{};
+                g.op = G64_ADDC;  // a copy: dst slot = the wire's carried slot
+                g.dst = 1 + (uint32_t)w;
+                g.a = b.cur64[w];
+                b.emit64(g, last);
+                info.z64_linear++;
+            }
+        }
+    }
     return RV_OK;
 }
 
-int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out) {
+int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk) {
     const auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (getenv("RV_COMPILE_STATS"))
@@ -493,7 +550,7 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
         // pass 1: SSA numbering + read counts (the materialisation rule needs each wire's fan-out)
         Compiled scratch;
         Builder b1(scratch, true, uses);
-        int rc = run_pass(ops, n_ops, z64_wires, gf2_wires, b1);
+        int rc = run_pass(ops, n_ops, z64_wires, gf2_wires, b1, chunk);
         if (rc) return rc;
     }
     lap("pass 1 (SSA, read counts) done");
@@ -513,7 +570,7 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
         delete bp;
         bp = new Builder(out, false, uses);
         bp->lazy_k = lazy_k;
-        int rc = run_pass(ops, n_ops, z64_wires, gf2_wires, *bp);
+        int rc = run_pass(ops, n_ops, z64_wires, gf2_wires, *bp, chunk);
         if (rc) {
             delete bp;
             return rc;
@@ -521,6 +578,7 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
         const uint64_t n_levels_now = bp->any ? (uint64_t)bp->max_level + 1 : 0;
         const bool deep_narrow = n_levels_now > 256 && bp->gates.size() / n_levels_now < 64 && bp->gates.size() < 5000000;
         if (forced || lazy_k != 1 || !deep_narrow) break;
+        if (chunk) break;  // (a chunk's counters were seeded from ChunkStart; one attempt)
         lazy_k = K;
     }
     lap("pass 2 (gates) done");
@@ -602,12 +660,20 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
     out.n_ssa64 = b.ssa_level64.size();
     // resolve share rows: PRG masks first (padded to whole AES blocks), computed rows after
     out.n_masks_pad = (out.n_masks + 127) / 128 * 128;
-    out.n_rows = out.n_masks_pad + b.n_comp;
+    out.row_prg_base = chunk ? gf2_wires : 0;
+    out.zero_row = out.row_prg_base + out.n_masks_pad;
+    out.n_rows = out.row_prg_base + out.n_masks_pad + b.n_comp;
     if (out.n_rows > LIM) return RV_E_UNSUPPORTED;
     // the mask kernels take CTR block indices below 2^24 (first-round constants, internal.h); more would not fit HBM anyway
     if (out.n_masks_pad / 128 > RV_MAX_CTR_BLOCKS || (out.n_masks64 + 1) / 2 > RV_MAX_CTR_BLOCKS) return RV_E_UNSUPPORTED;
+    const uint32_t base = (uint32_t)out.row_prg_base;
     auto fix = [&](uint32_t& r) {
-        if (r & COMP) r = (uint32_t)(out.n_masks_pad + (r & ~COMP));
+        if (r & COMP)
+            r = (uint32_t)(base + out.n_masks_pad + (r & ~COMP));
+        else if (r & CARRY)
+            r &= ~CARRY;
+        else
+            r += base;  // a PRG mask row
     };
     for (Gate& g : out.gates) {
         fix(g.dst);
@@ -615,9 +681,13 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
             fix(g.a[i]);
             fix(g.b[i]);
         }
+        g.m += base;  // the kernels address a gate's fresh masks as share rows m, m + 1
     }
     for (Gate64& g : out.gates64)
-        if (g.op == G64_B2A) fix(g.a);
+        if (g.op == G64_B2A) {
+            fix(g.a);
+            g.m2 += base;
+        }
     info.gf2_masks = out.n_masks;
     info.z64_masks = out.n_masks64;
     info.levels = n_levels;

@@ -45,10 +45,24 @@ struct Compiled {
     std::vector<uint64_t> in_offs64;    // input ordinal -> word offset in the online transcript
     uint64_t n_ssa64 = 1;
     uint64_t n_masks64 = 0, on_words64 = 0, pre_words64 = 0, n_in64 = 0, n_rec64 = 0, n_corr64 = 0;
+    // row numbering: [0, row_prg_base) carried wire rows (streaming chunks only), then the PRG mask rows, then the
+    // computed rows; zero_row = the all-zero row (first computed row)
+    uint64_t row_prg_base = 0, zero_row = 0;
     rv_circuit_info info{};
 };
 
+// Streaming (rv_stream_*): a chunk of a longer gate stream.  The chunk starts with every wire holding the value the
+// previous chunks left in it -- GF(2) wire w in share row w ("carried rows", ahead of the PRG rows), Z64 wire w in SSA
+// slot 1 + w -- and ends with one extra level that writes the final value of every wire the chunk wrote back there.
+// The transcript / mask counters continue where the previous chunk stopped:
+struct ChunkStart {
+    uint32_t mask_phase = 0;    // ShareGen<GF2>::next() calls so far, modulo 128 (the chunk's first AES block is shared)
+    uint32_t mask64_phase = 0;  // ShareGen<Z64>::next() calls so far, modulo 2
+    uint64_t on0 = 0, pre0 = 0;              // transcript rows reserved in front of the chunk's own (carried events)
+    uint64_t on_words64_0 = 0, pre_words64_0 = 0;
+};
+
 // returns RV_OK or RV_E_*
-int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out);
+int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr);
 
 }  // namespace rv

@@ -161,7 +161,7 @@ void launch_interp_narrow_batched(hipStream_t st, const Gate* d_gates, const Lev
 void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t lo, uint32_t hi, const Interp64Params& p);
 // Z64 masks: masks64[m][slot] = LE64(keystream[slot][8m..8m+8)), blocks [first, first+n_blocks) -> masks 2*first..
 void launch_aes_z64_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t n_blocks,
-                          uint64_t* d_masks64);
+                          uint64_t* d_masks64, uint64_t first_block = 0);
 // BLAKE3 of R contiguous streams of n_words u64 each -> digests[R][8]
 uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
                       uint32_t* d_digest);
@@ -177,6 +177,21 @@ uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_e
 uint32_t launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
                            uint32_t* d_cv_b, uint32_t* d_digest);
 size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R);
+// streaming prover: chunk chaining values of a PIECE of a stream (first chunk counter chunk_base; a lone chunk is
+// the root only if root_ok), one level of the incremental tree, and the final fold
+void launch_b3_stream_chunks(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv, const uint32_t* d_quads,
+                             uint32_t n_quads, uint64_t chunk_base, uint32_t root_ok);
+void launch_b3_stream_bits_chunks(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv, uint64_t chunk_base,
+                                  uint32_t root_ok);
+// streams [R][stride_words] u64, the first n_words of each hashed
+void launch_b3_contig_chunks(hipStream_t st, const uint64_t* d_streams, uint64_t stride_words, uint64_t n_words, uint32_t R, uint32_t* d_cv,
+                             uint64_t chunk_base, uint32_t root_ok);
+void launch_b3_pairs(hipStream_t st, const uint32_t* d_pending, const uint32_t* d_in, uint64_t n_pairs, uint32_t R, uint32_t* d_out);
+struct B3FoldList {
+    uint32_t n;
+    const uint32_t* p[48];  // pending subtree roots, smallest subtree first ([R][8] each)
+};
+void launch_b3_fold(hipStream_t st, const B3FoldList& L, const uint32_t* d_last, uint32_t R, uint32_t* d_digest);
 uint32_t b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest);
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
                  uint32_t R, uint8_t* d_h /*[R][32]*/);

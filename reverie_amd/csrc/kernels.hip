@@ -684,7 +684,9 @@ template <int RPL>
 struct B_k_b3_chunks {
     // quads (nullable) / n_quads: only these quad words are hashed -- the verifier needs the online digest of the 40
     // opened repetitions alone (the other 216 carry theirs in the proof), i.e. of at most 40 of the 64 quads
-    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/, const uint32_t* __restrict__ quads, uint32_t n_quads) const {
+    // chunk_base / root_ok (streaming prover): the stream handed in is a piece of a longer one -- its first chunk has
+    // BLAKE3 chunk counter chunk_base, and a lone chunk only takes the ROOT flag when the caller knows it is the whole stream
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/, const uint32_t* __restrict__ quads, uint32_t n_quads, uint64_t chunk_base, uint32_t root_ok) const {
     constexpr uint32_t SUBS = 4 / RPL;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lanes_per_chunk = (quads ? n_quads : NQ) * SUBS;
@@ -702,7 +704,7 @@ struct B_k_b3_chunks {
         const uint64_t e0 = ev0 + 64ull * b;
         const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
         uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
-        if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
+        if (b + 1 == nblk && n_chunks == 1 && root_ok) flags |= b3::ROOT;
         uint32_t w[64];
         if (blen == 64) {
             // unguarded: a per-element "load or zero" select makes hipcc branch around every load and
@@ -726,7 +728,7 @@ struct B_k_b3_chunks {
                 m[i][k] = lo | (hi << 16);
             }
         }
-        b3::compress_n<RPL>(cv, m, c, blen, flags);  // the lane's repetitions in lockstep
+        b3::compress_n<RPL>(cv, m, c + chunk_base, blen, flags);  // the lane's repetitions in lockstep
     }
     const uint32_t R = NQ * 4;
 #pragma unroll
@@ -738,8 +740,8 @@ struct B_k_b3_chunks {
 }
 };
 template <int RPL>
-__global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/, const uint32_t* __restrict__ quads, uint32_t n_quads) {
-    B_k_b3_chunks<RPL>{}(stream, n_events, NQ, n_chunks, cvs, quads, n_quads);
+__global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/, const uint32_t* __restrict__ quads, uint32_t n_quads, uint64_t chunk_base, uint32_t root_ok) {
+    B_k_b3_chunks<RPL>{}(stream, n_events, NQ, n_chunks, cvs, quads, n_quads, chunk_base, root_ok);
 }
 
 // Same for a bit-per-rep transcript (the preprocessing stream): every bit is hashed as the
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ 
 // RPL as in k_b3_chunks: 4 = one lane per quad word, 1 = four lanes share it (short transcripts: more, lighter wavefronts)
 template <int RPL>
 struct B_k_b3_chunks_bits {
-    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs) const {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) const {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     constexpr uint32_t SUBS = 4 / RPL;
     const uint64_t c = tid / (NQ * SUBS);
@@ -765,7 +767,7 @@ struct B_k_b3_chunks_bits {
         const uint64_t e0 = ev0 + 64ull * b;
         const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
         uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
-        if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
+        if (b + 1 == nblk && n_chunks == 1 && root_ok) flags |= b3::ROOT;
         // P = the nibbles of events 4k..4k+3, one per byte; repetition i4 owns nibble bit 3-i4
         uint32_t m[RPL][16];
         uint32_t nbs[64];
@@ -788,7 +790,7 @@ struct B_k_b3_chunks_bits {
                 m[i][k] = (t << 8) - t;
             }
         }
-        b3::compress_n<RPL>(cv, m, c, blen, flags);
+        b3::compress_n<RPL>(cv, m, c + chunk_base, blen, flags);
     }
     const uint32_t R = NQ * 4;
 #pragma unroll
@@ -799,11 +801,11 @@ struct B_k_b3_chunks_bits {
     }
 }
 };
-__global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs) {
-    B_k_b3_chunks_bits<4>{}(stream, n_events, NQ, n_chunks, cvs);
+__global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) {
+    B_k_b3_chunks_bits<4>{}(stream, n_events, NQ, n_chunks, cvs, chunk_base, root_ok);
 }
-__global__ __launch_bounds__(256) void k_b3_chunks_bits1(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs) {
-    B_k_b3_chunks_bits<1>{}(stream, n_events, NQ, n_chunks, cvs);
+__global__ __launch_bounds__(256) void k_b3_chunks_bits1(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) {
+    B_k_b3_chunks_bits<1>{}(stream, n_events, NQ, n_chunks, cvs, chunk_base, root_ok);
 }
 
 // LG tree levels per launch: thread = (group of G = 2^LG consecutive nodes, repetition).  One level is
@@ -937,38 +939,100 @@ size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R) {
     return (size_t)n_chunks * R * 8;  // per ping-pong buffer
 }
 
+// chunk chaining values only ([n_chunks][R][8] into d_cv); chunk_base / root_ok: see B_k_b3_chunks
+void launch_b3_stream_chunks(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv, const uint32_t* d_quads,
+                             uint32_t n_quads, uint64_t chunk_base, uint32_t root_ok) {
+    const uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
+    // (the chaining values of skipped quads stay whatever the scratch buffer held: the tree above them runs on
+    // garbage and the caller replaces those digests)
+    const uint64_t threads = n * (d_quads ? n_quads : NQ);
+    // few lanes (a quarter of the row or less in the verifier; a transcript of a few chunks, i.e. a small circuit):
+    // one repetition per lane gives four times the wavefronts, each a quarter as long
+    if ((d_quads && n_quads * 4 <= NQ) || threads * (g_recorder ? g_recorder->batch : 1u) < 64 * 1024)
+        launch<B_k_b3_chunks<1>, 256>(k_b3_chunks<1>, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv, d_quads, n_quads, chunk_base, root_ok);
+    else
+        launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv, d_quads, n_quads, chunk_base, root_ok);
+}
+
 uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
                       uint32_t* d_cv_b, uint32_t* d_digest, const uint32_t* d_quads, uint32_t n_quads) {
     const uint32_t R = NQ * 4;
     uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
     if (d_quads && !n_quads) return 0;  // a verifier shard without opened repetitions: every online digest comes from the proof
-    {
-        // (the chaining values of skipped quads stay whatever the scratch buffer held: the tree above them runs on
-        // garbage and the caller replaces those digests)
-        const uint64_t threads = n * (d_quads ? n_quads : NQ);
-        // few lanes (a quarter of the row or less in the verifier; a transcript of a few chunks, i.e. a small circuit):
-        // one repetition per lane gives four times the wavefronts, each a quarter as long
-        if ((d_quads && n_quads * 4 <= NQ) || threads * (g_recorder ? g_recorder->batch : 1u) < 64 * 1024)
-            launch<B_k_b3_chunks<1>, 256>(k_b3_chunks<1>, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a, d_quads, n_quads);
-        else
-            launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv_a, d_quads, n_quads);
-    }
+    launch_b3_stream_chunks(st, d_stream, n_events, NQ, d_cv_a, d_quads, n_quads, 0, 1);
     return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
+}
+
+void launch_b3_stream_bits_chunks(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv, uint64_t chunk_base,
+                                  uint32_t root_ok) {
+    const uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
+    const uint64_t threads = n * NQ;
+    // a transcript of a few chunks (small circuit, and no batch to supply the wavefronts): one repetition per lane
+    if (threads * (g_recorder ? g_recorder->batch : 1u) < 64 * 1024)
+        launch<B_k_b3_chunks_bits<1>, 256>(k_b3_chunks_bits1, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
+                                           d_cv, chunk_base, root_ok);
+    else
+        launch<B_k_b3_chunks_bits<4>, 256>(k_b3_chunks_bits, st, dim3((unsigned)((threads + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
+                                           d_cv, chunk_base, root_ok);
 }
 
 uint32_t launch_b3_stream_bits(hipStream_t st, const uint8_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,
                            uint32_t* d_cv_b, uint32_t* d_digest) {
     const uint32_t R = NQ * 4;
     const uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
-    const uint64_t threads = n * NQ;
-    // a transcript of a few chunks (small circuit, and no batch to supply the wavefronts): one repetition per lane
-    if (threads * (g_recorder ? g_recorder->batch : 1u) < 64 * 1024)
-        launch<B_k_b3_chunks_bits<1>, 256>(k_b3_chunks_bits1, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
-                                           d_cv_a);
-    else
-        launch<B_k_b3_chunks_bits<4>, 256>(k_b3_chunks_bits, st, dim3((unsigned)((threads + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
-                                           d_cv_a);
+    launch_b3_stream_bits_chunks(st, d_stream, n_events, NQ, d_cv_a, 0, 1);
     return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
+}
+
+// ---- incremental BLAKE3 tree (streaming prover): the chunk chaining values of a stream arrive in batches ----
+// one tree level over a batch: seq = [pending?] ++ in[0 .. n_in); out[i] = parent(seq[2i], seq[2i+1]) for i < n_pairs
+// (never ROOT: whether a merge is the root is only known when the stream ends, see k_b3_fold)
+__global__ __launch_bounds__(256) void k_b3_pairs(const uint32_t* __restrict__ pending /* [R][8] or null */, const uint32_t* __restrict__ in,
+                                                  uint64_t n_pairs, uint32_t R, uint32_t* __restrict__ out) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = tid / R;
+    const uint32_t r = (uint32_t)(tid % R);
+    if (i >= n_pairs) return;
+    const uint64_t shift = pending ? 1 : 0;
+    const uint32_t* lp = (pending && i == 0) ? pending + (size_t)r * 8 : in + ((size_t)(2 * i - shift) * R + r) * 8;
+    const uint32_t* rp = in + ((size_t)(2 * i + 1 - shift) * R + r) * 8;
+    uint32_t l[8], rr[8], o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        l[k] = lp[k];
+        rr[k] = rp[k];
+    }
+    b3::parent(l, rr, 0, o);
+    uint32_t* d = out + ((size_t)i * R + r) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = o[k];
+}
+void launch_b3_pairs(hipStream_t st, const uint32_t* d_pending, const uint32_t* d_in, uint64_t n_pairs, uint32_t R, uint32_t* d_out) {
+    if (!n_pairs) return;
+    const uint64_t threads = n_pairs * R;
+    hipLaunchKernelGGL(k_b3_pairs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_pending, d_in, n_pairs, R, d_out);
+}
+// end of a stream: the last chunk's chaining value folded into the pending subtree roots, smallest first; the last
+// merge is the root (a lone last chunk was hashed with ROOT already and n = 0 just copies it)
+__global__ void k_b3_fold(B3FoldList L, const uint32_t* __restrict__ last, uint32_t R, uint32_t* __restrict__ digest) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    uint32_t cv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) cv[k] = last[(size_t)r * 8 + k];
+    for (uint32_t i = 0; i < L.n; i++) {
+        uint32_t l[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) l[k] = L.p[i][(size_t)r * 8 + k];
+        b3::parent(l, cv, i + 1 == L.n ? b3::ROOT : 0u, o);
+#pragma unroll
+        for (int k = 0; k < 8; k++) cv[k] = o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) digest[(size_t)r * 8 + k] = cv[k];
+}
+void launch_b3_fold(hipStream_t st, const B3FoldList& L, const uint32_t* d_last, uint32_t R, uint32_t* d_digest) {
+    hipLaunchKernelGGL(k_b3_fold, dim3((R + 63) / 64), dim3(64), 0, st, L, d_last, R, d_digest);
 }
 
 // Transcript::hash + CombineInstance::hash: h = B3(B3(pre2||on2) || B3(pre64||on64))

@@ -218,8 +218,10 @@ void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t l
 // (the first version put the repetitions of one chunk in adjacent lanes: 64 MB apart, every 16-byte load a different
 // DRAM page, 1.2 TB/s).  A lane fetches a whole 128-byte line (two blocks, eight 16-byte loads issued together) and
 // then runs the two dependent compressions, so each line crosses L2 -> L1 once instead of eight times.
-__global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __restrict__ streams, uint64_t n_bytes, uint32_t R,
-                                                          uint64_t n_chunks, uint32_t* __restrict__ cvs) {
+// stride_bytes: distance between two repetitions' streams (>= n_bytes; the streaming prover hashes a prefix of each);
+// chunk_base / root_ok: see B_k_b3_chunks
+__global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __restrict__ streams, uint64_t stride_bytes, uint64_t n_bytes, uint32_t R,
+                                                          uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t c = tid % n_chunks;
     const uint32_t r = (uint32_t)(tid / n_chunks);
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __rest
     const uint64_t b0 = c * 1024;
     const uint64_t len = (n_bytes - b0 < 1024) ? (n_bytes - b0) : 1024;  // multiple of 8
     const uint32_t nblk = len == 0 ? 1 : (uint32_t)((len + 63) / 64);
-    const uint32_t* src = streams + ((size_t)r * n_bytes + b0) / 4;
+    const uint32_t* src = streams + ((size_t)r * stride_bytes + b0) / 4;
     uint32_t cv[8];
     b3::iv(cv);
     uint32_t b = 0;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __rest
                     m[4 * k + 3] = v[4 * h + k].w;
                 }
                 const uint32_t flags = (b + h == 0 ? b3::CHUNK_START : 0u) | (b + h == 15 ? b3::CHUNK_END : 0u);
-                b3::compress<false>(cv, m, c, 64, flags, o);
+                b3::compress<false>(cv, m, c + chunk_base, 64, flags, o);
 #pragma unroll
                 for (int k = 0; k < 8; k++) cv[k] = o[k];
             }
@@ -257,12 +259,12 @@ __global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __rest
     for (; b < nblk; b++) {
         const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
         uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
-        if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
+        if (b + 1 == nblk && n_chunks == 1 && root_ok) flags |= b3::ROOT;
         uint32_t m[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) m[k] = (4u * k < blen) ? src[16 * b + k] : 0u;
         uint32_t o[8];
-        b3::compress<false>(cv, m, c, blen, flags, o);
+        b3::compress<false>(cv, m, c + chunk_base, blen, flags, o);
 #pragma unroll
         for (int k = 0; k < 8; k++) cv[k] = o[k];
     }
@@ -271,15 +273,20 @@ __global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __rest
     for (int k = 0; k < 8; k++) dst[k] = cv[k];
 }
 
+void launch_b3_contig_chunks(hipStream_t st, const uint64_t* d_streams, uint64_t stride_words, uint64_t n_words, uint32_t R, uint32_t* d_cv,
+                             uint64_t chunk_base, uint32_t root_ok) {
+    const uint64_t n_bytes = n_words * 8;
+    const uint64_t n = n_bytes == 0 ? 1 : (n_bytes + 1023) / 1024;
+    const uint64_t threads = n * R;
+    hipLaunchKernelGGL(k_b3_chunks_contig, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_streams,
+                       stride_words * 8, n_bytes, R, n, d_cv, chunk_base, root_ok);
+}
+
 uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
                       uint32_t* d_digest) {
     const uint64_t n_bytes = n_words * 8;
-    uint64_t n = n_bytes == 0 ? 1 : (n_bytes + 1023) / 1024;
-    {
-        const uint64_t threads = n * R;
-        hipLaunchKernelGGL(k_b3_chunks_contig, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
-                           (const uint32_t*)d_streams, n_bytes, R, n, d_cv_a);
-    }
+    const uint64_t n = n_bytes == 0 ? 1 : (n_bytes + 1023) / 1024;
+    launch_b3_contig_chunks(st, d_streams, n_words, n_words, R, d_cv_a, 0, 1);
     return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);  // launches
 }
 

@@ -32,14 +32,17 @@ def _splitmix_array(seed: int, n: int) -> np.ndarray:
     return z
 
 
-def layered_gf2(n_in=4096, width=65536, layers=153, p_and=0.5, seed=0x5EED000000000004, fold_to=128):
+def layered_gf2(n_in=4096, width=65536, layers=153, p_and=0.5, seed=0x5EED000000000004, fold_to=128, recycle=False):
     """Config 4: layered random AND/XOR circuit in SSA form.
 
     n_in Inputs (witness bits from the PRNG); `layers` layers of `width` gates; gate type AND
     with probability p_and else XOR; operands uniform over the previous layer (layer 0 reads
     the inputs); tail: XOR-fold the last layer to `fold_to` wires, then AddConst(clear value)
     + AssertZero on each.  Returns (prog, witness_bits, (z64_wires, gf2_wires), stats).
-    The clear evaluation is done here with numpy so the asserted constants are correct."""
+    The clear evaluation is done here with numpy so the asserted constants are correct.
+    recycle=True: the same gates with wire indices reused every other layer (layer l writes wires
+    n_in + (l % 2) * width + g), the way a circuit written for a streaming prover numbers them -- the proof does not
+    depend on wire numbering, the wire store does (2 * width + n_in + tail instead of one wire per gate)."""
     n_gates = width * layers
     r = _splitmix_array(seed, n_in + 3 * n_gates)
     wit = (r[:n_in] & np.uint64(1)).astype(np.uint8)
@@ -60,14 +63,17 @@ def layered_gf2(n_in=4096, width=65536, layers=153, p_and=0.5, seed=0x5EED000000
         a = (rr[l, :, 1] % np.uint64(prev_n)).astype(np.uint32)
         b = (rr[l, :, 2] % np.uint64(prev_n)).astype(np.uint32)
         sl = slice(pos, pos + width)
+        base = n_in + (l % 2) * width if recycle else pos
         ops["opcode"][sl] = np.where(is_and[l], OP_MUL, OP_ADD)
-        ops["dst"][sl] = np.arange(pos, pos + width, dtype=np.uint32)
+        ops["dst"][sl] = np.arange(base, base + width, dtype=np.uint32)
         ops["a"][sl] = prev_base + a
         ops["b"][sl] = prev_base + b
         va, vb = vals[a], vals[b]
         vals = np.where(is_and[l], va & vb, va ^ vb).astype(np.uint8)
-        prev_base, prev_n = pos, width
+        prev_base, prev_n = base, width
         pos += width
+    if recycle:
+        pos = n_in + 2 * width
     # tail: XOR-fold to fold_to wires
     tail = []
     cur = list(range(prev_base, prev_base + prev_n))
@@ -153,9 +159,10 @@ def random_gf2(rng: np.random.Generator, n_in=12, n_gates=300, n_wires=40, p_ass
     return program(ops), wit, (0, n_wires)
 
 
-def layered_z64(n_in=1024, width=16384, n_mul=1_000_000, seed=0x5EED000000000005, fold_to=16):
+def layered_z64(n_in=1024, width=16384, n_mul=1_000_000, seed=0x5EED000000000005, fold_to=16, recycle=False):
     """Config 5: layered Z64 circuit, Mul/Add with p=1/2 until n_mul Mul gates, operands
-    uniform over the previous layer, tail SubConst(clear value) + AssertZero on `fold_to` wires."""
+    uniform over the previous layer, tail SubConst(clear value) + AssertZero on `fold_to` wires.
+    recycle=True: the same gates with wire indices reused every other layer (see layered_gf2)."""
     rng = SplitMix64(seed)
     wit = [rng.next() for _ in range(n_in)]
     vals = np.array(wit, dtype=np.uint64)
@@ -164,6 +171,7 @@ def layered_z64(n_in=1024, width=16384, n_mul=1_000_000, seed=0x5EED000000000005
     pos = n_in
     muls = 0
     gates = 0
+    layer = 0
     with np.errstate(over="ignore"):
         while muls < n_mul:
             r = _splitmix_array(rng.next(), 3 * width).reshape(width, 3)
@@ -173,15 +181,19 @@ def layered_z64(n_in=1024, width=16384, n_mul=1_000_000, seed=0x5EED000000000005
             left = n_mul - muls
             cs = np.cumsum(is_mul)
             w = width if cs[-1] <= left else int(np.searchsorted(cs, left) + 1)
+            base = n_in + (layer % 2) * width if recycle else pos
             for g in range(w):
-                ops.append(Z64.Mul(pos + g, prev_base + int(a[g]), prev_base + int(b[g])) if is_mul[g]
-                           else Z64.Add(pos + g, prev_base + int(a[g]), prev_base + int(b[g])))
+                ops.append(Z64.Mul(base + g, prev_base + int(a[g]), prev_base + int(b[g])) if is_mul[g]
+                           else Z64.Add(base + g, prev_base + int(a[g]), prev_base + int(b[g])))
             va, vb = vals[a[:w]], vals[b[:w]]
             vals = np.where(is_mul[:w], va * vb, va + vb)
             muls += int(is_mul[:w].sum())
             gates += w
-            prev_base, prev_n = pos, w
+            prev_base, prev_n = base, w
             pos += w
+            layer += 1
+    if recycle:
+        pos = n_in + 2 * width
     k = min(fold_to, prev_n)
     for i in range(k):
         ops.append(Z64.SubConst(pos, prev_base + i, int(vals[i])))

@@ -1,0 +1,195 @@
+"""Streaming prover (rv_stream_*): byte-identical to rv_prove / the oracle whatever the pieces are, with
+device memory that does not grow with the number of gates."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import circuits
+from conftest import GOLDEN
+from reverie_amd.ops import GF2, OP_DTYPE, Z64, program
+
+pytestmark = pytest.mark.gpu
+
+META = json.load(open(os.path.join(GOLDEN, "proofs.json")))
+
+
+@pytest.fixture(scope="module")
+def rv():
+    import reverie_amd
+
+    reverie_amd.Context.default()
+    return reverie_amd
+
+
+def _pieces(prog, w2, w64, cuts):
+    """split (prog, witness) at the op indices `cuts`: every piece gets the witness elements its Input gates consume"""
+    out = []
+    i2 = i64 = 0
+    edges = [0] + sorted(set(int(c) for c in cuts if 0 < c < len(prog))) + [len(prog)]
+    for a, b in zip(edges[:-1], edges[1:]):
+        part = prog[a:b]
+        n2 = int(((part["domain"] == 0) & (part["opcode"] == 0)).sum())
+        n64 = int(((part["domain"] == 1) & (part["opcode"] == 0)).sum())
+        out.append((part, list(w2[i2:i2 + n2]), list(w64[i64:i64 + n64])))
+        i2 += n2
+        i64 += n64
+    return out
+
+
+def _stream(rv, prog, w2, w64, wc, seeds, cuts1, cuts2=None):
+    from reverie_amd.stream import StreamingProver
+
+    sp = StreamingProver(wc, seeds=seeds)
+    for part, a, b in _pieces(prog, w2, w64, cuts1):
+        sp.feed(part, a, b)
+    comm = sp.commit()
+    for part, a, b in _pieces(prog, w2, w64, cuts1 if cuts2 is None else cuts2):
+        sp.feed(part, a, b)
+    proof = sp.finish()
+    info = sp.info
+    sp.close()
+    assert proof.comm == comm
+    return proof, info
+
+
+@pytest.mark.parametrize("name", sorted(META))
+def test_stream_golden(rv, rule_seeds, name):
+    m = META[name]
+    prog = program([tuple(o) for o in m["ops"]]) if m["ops"] else np.zeros(0, OP_DTYPE)
+    gold = open(os.path.join(GOLDEN, f"proof_{name}.bin"), "rb").read()
+    w2, w64, wc = m["wit_gf2"], [int(x) for x in m["wit_z64"]], tuple(m["wire_counts"])
+    hint = prog[prog["domain"] == 3]  # a stream's wire store is sized at begin: SizeHint ops must fit in it
+    wc = (max([wc[0]] + [int(x) for x in hint["a"]]), max([wc[1]] + [int(x) for x in hint["b"]]))
+    seeds = rule_seeds
+    n = len(prog)
+    for cuts in ([], [n // 2], list(range(1, n, 3)), list(range(7, n, 50))):
+        proof, _ = _stream(rv, prog, w2, w64, wc, seeds, cuts)
+        assert bytes(proof) == gold, (name, cuts[:4])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_stream_random_mixed(rv, oracle, seed):
+    """GF(2) + Z64 + B2A with wire reuse, cut at random places (different cuts in the two passes): every carry path
+    (transcript tails across BLAKE3 chunks, items across opening bytes, the shared AES block, Z64 mask parity)"""
+    rng = np.random.default_rng(4200 + seed)
+    prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=int(rng.integers(150, 700)))
+    # SizeHint may only appear where it does not grow the stream's wire store: give the stream the hinted sizes
+    hint = prog[prog["domain"] == 3]
+    wc = (max([wc[0]] + [int(x) for x in hint["a"]]), max([wc[1]] + [int(x) for x in hint["b"]]))
+    seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+    want = oracle.prove(prog, w2, w64, wc, seeds)
+    assert bytes(rv.Proof.new(prog, w2, w64, wc, seeds=seeds)) == want
+    n = len(prog)
+    for k in (1, 2, 9):
+        c1 = rng.integers(1, n, k)
+        c2 = rng.integers(1, n, k + 1)
+        proof, info = _stream(rv, prog, w2, w64, wc, seeds, c1, c2)
+        assert bytes(proof) == want, (seed, k)
+        assert proof.verify(prog, wc)
+        assert info["chunks"] >= 1 and info["n_ops"] == n
+
+
+def test_stream_long_transcripts(rv, oracle, rule_seeds):
+    """transcripts of several BLAKE3 chunks and superblocks, cut so that chunk boundaries fall before, at and after
+    the 1024-event marks; Z64 transcripts (72 bytes per Mul) next to them"""
+    rng = np.random.default_rng(5)
+    ops = [GF2.Input(i) for i in range(8)] + [Z64.Input(i) for i in range(3)]
+    for i in range(5000):
+        a, b = int(rng.integers(0, 24)), int(rng.integers(0, 24))
+        d = int(rng.integers(8, 24))
+        ops.append(GF2.Mul(d, a, b) if i % 3 else GF2.Add(d, a, b))
+        if i % 11 == 0:
+            ops.append(Z64.Mul(int(rng.integers(3, 8)), int(rng.integers(0, 8)), int(rng.integers(0, 8))))
+    prog = program(ops)
+    w2 = rng.integers(0, 2, 8).tolist()
+    w64 = [int(x) for x in rng.integers(0, 1 << 63, 3, dtype=np.uint64)]
+    wc = (8, 24)
+    want = oracle.prove(prog, w2, w64, wc, rule_seeds)
+    n = len(prog)
+    for cuts in ([1536 + 11], [1023, 1024, 1025, 2048, 3071], list(range(100, n, 137))):
+        proof, info = _stream(rv, prog, w2, w64, wc, rule_seeds, cuts)
+        assert bytes(proof) == want, cuts[:3]
+    # the one-call form
+    from reverie_amd.stream import prove_streaming
+
+    proof, info = prove_streaming(prog, w2, w64, wc, seeds=rule_seeds, max_chunk_ops=1024)
+    assert bytes(proof) == want and info["chunks"] == (n + 1023) // 1024
+
+
+def test_stream_errors(rv, rule_seeds):
+    from reverie_amd.stream import StreamingProver
+
+    prog = program([GF2.Input(0), GF2.Input(1), GF2.Mul(2, 0, 1), GF2.AddConst(3, 2, 1), GF2.AssertZero(3)])
+    sp = StreamingProver((0, 4), seeds=rule_seeds)
+    with pytest.raises(rv.ReverieError) as e:
+        sp.feed(prog, [1], [])
+    assert e.value.code == 2  # witness too short
+    with pytest.raises(rv.ReverieError):
+        sp.feed(prog, [1, 1], [])  # a failed stream stays failed
+    sp.close()
+    sp = StreamingProver((0, 4), seeds=rule_seeds)
+    with pytest.raises(rv.ReverieError) as e:
+        sp.feed(prog, [1, 0], [])
+    assert e.value.code == 1  # AssertZero fails
+    sp.close()
+    sp = StreamingProver((0, 4), seeds=rule_seeds)
+    sp.feed(prog, [1, 1], [])
+    sp.commit()
+    sp.feed(prog[:3], [1, 1], [])
+    with pytest.raises(rv.ReverieError) as e:
+        sp.finish()  # pass 2 saw fewer ops than pass 1
+    assert e.value.code == 9
+    sp.close()
+    sp = StreamingProver((0, 3), seeds=rule_seeds)
+    with pytest.raises(rv.ReverieError) as e:
+        sp.feed(prog, [1, 1], [])
+    assert e.value.code == 3  # wire out of range
+    sp.close()
+
+
+def test_stream_layered_bounded_memory(rv, oracle, rule_seeds):
+    """the layered workload at two depths with recycled wire indices: the same proof as rv_prove / the oracle, and a
+    device footprint that does not move when the circuit gets four times longer"""
+    from reverie_amd.stream import prove_streaming
+
+    infos = []
+    for layers in (6, 24):
+        prog, wit, wc, st = circuits.layered_gf2(layers=layers, width=16384, n_in=512, recycle=True)
+        ssa_prog, _, ssa_wc, _ = circuits.layered_gf2(layers=layers, width=16384, n_in=512)
+        want = oracle.prove(ssa_prog, wit, [], ssa_wc, rule_seeds)
+        assert oracle.prove(prog, wit, [], wc, rule_seeds) == want  # wire numbering does not reach the proof
+        proof, info = prove_streaming(prog, wit, [], wc, seeds=rule_seeds, max_chunk_ops=40000)
+        assert bytes(proof) == want
+        assert bytes(rv.Proof.new(prog, wit, [], wc, seeds=rule_seeds)) == want
+        infos.append(info)
+    a, b = infos
+    assert b["n_ops"] > 3 * a["n_ops"] and b["chunks"] > 3 * a["chunks"]
+    assert b["peak_chunk_bytes"] <= 1.1 * a["peak_chunk_bytes"] and b["wire_store_bytes"] <= 1.1 * a["wire_store_bytes"]
+    assert b["hash_state_bytes"] <= a["hash_state_bytes"] + 4 * 4 * 256 * 32  # a few more tree levels, nothing else
+
+
+def test_stream_full_size_configs(rv, rule_seeds):
+    """BASELINE configs 4 and 5 at full size through the streaming prover: byte-identical to rv_prove's proofs, with
+    a device footprint of well under 1 GB (config 4; the resident prover keeps ~6.4 GB) and under 10 GB (config 5, 10^6
+    Z64 MUL; the resident prover keeps ~88 GB)"""
+    from reverie_amd.stream import prove_streaming
+
+    prog, wit, wc, st = circuits.layered_gf2(recycle=True)
+    assert st["gates"] == 10027008
+    c = rv.Circuit(prog, wc)
+    want = bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds))
+    c.close()
+    proof, info = prove_streaming(prog, wit, [], wc, seeds=rule_seeds, max_chunk_ops=1 << 18)
+    assert bytes(proof) == want
+    assert info["wire_store_bytes"] + info["peak_chunk_bytes"] + info["hash_state_bytes"] + info["proof_bytes"] < 1 << 30
+    del proof, want
+    prog, w64, wc, st = circuits.layered_z64(n_mul=1_000_000, recycle=True)
+    proof, info = prove_streaming(prog, [], w64, wc, seeds=rule_seeds, max_chunk_ops=1 << 16)
+    assert info["wire_store_bytes"] + info["peak_chunk_bytes"] + info["hash_state_bytes"] + info["proof_bytes"] < 10 * (1 << 30)
+    c = rv.Circuit(prog, wc)
+    want = rv.Proof.new(c, [], w64, seeds=rule_seeds)
+    assert bytes(proof) == bytes(want)
+    assert proof.verify(c)
+    c.close()

@@ -1,0 +1,68 @@
+"""Streaming prover on the benchmark workloads: time, device footprint, byte equality with rv_prove.
+
+    python tools/stream_bench.py            # config 4 (recycled wire indices) and config 5
+bench.py imports streaming_record() for its `streaming` record."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+def streaming_record(ctx, prog, wit, wc, st, seeds, want: bytes, chunk_ops: int = 1 << 20, layers: int = 153, p_and: float = 0.5):
+    """config 4 through rv_prove_streaming.  The circuit is regenerated with recycled wire indices (the proof does not
+    depend on wire numbering, the streaming prover's wire store does); `want` = rv_prove's proof of the same statement."""
+    import circuits
+    from reverie_amd.stream import prove_streaming
+
+    rprog, rwit, rwc, rst = circuits.layered_gf2(layers=layers, p_and=p_and, recycle=True)
+    t0 = time.perf_counter()
+    proof, info = prove_streaming(rprog, rwit, [], rwc, seeds=seeds, max_chunk_ops=chunk_ops, ctx=ctx)
+    dt = time.perf_counter() - t0
+    rec = {"value": rst["and"] / dt, "unit": "AND gates/s", "ms": dt * 1e3, "chunk_ops": chunk_ops, "chunks": info["chunks"],
+           "gf2_wires": rwc[1], "bit_exact_vs_rv_prove": bytes(proof) == want,
+           "device_bytes": {k: info[k] for k in ("wire_store_bytes", "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")},
+           "note": "rv_prove_streaming, host ops in -> host proof bytes out, two passes over the op array; every chunk is compiled "
+                   "(levelised) on the host in each pass, which is most of the time; the resident prover keeps ~6.4 GB for this circuit"}
+    del proof
+    return rec
+
+
+def z64_record(ctx, seeds, n_mul=1_000_000, chunk_ops=1 << 16):
+    import circuits
+    import reverie_amd
+    from reverie_amd.stream import prove_streaming
+
+    prog, w64, wc, st = circuits.layered_z64(n_mul=n_mul, recycle=True)  # (wire numbering does not reach the proof)
+    t0 = time.perf_counter()
+    proof, info = prove_streaming(prog, [], w64, wc, seeds=seeds, max_chunk_ops=chunk_ops, ctx=ctx)
+    dt = time.perf_counter() - t0
+    circ = reverie_amd.Circuit(prog, wc, ctx)
+    want = reverie_amd.Proof.new(circ, [], w64, seeds=seeds)
+    rec = {"value": st["mul"] / dt, "unit": "Z64 MUL gates/s", "ms": dt * 1e3, "chunk_ops": chunk_ops, "chunks": info["chunks"],
+           "z64_wires": wc[0], "bit_exact_vs_rv_prove": bytes(proof) == bytes(want), "resident_prover_scratch_bytes": circ.info["scratch_bytes"],
+           "device_bytes": {k: info[k] for k in ("wire_store_bytes", "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")}}
+    circ.close()
+    return rec
+
+
+if __name__ == "__main__":
+    import json
+
+    import circuits
+    import reverie_amd
+
+    ctx = reverie_amd.Context(0)
+    seeds = np.random.default_rng(0x5EED).integers(0, 256, (256, 16), dtype=np.uint8)
+    layers = int(os.environ.get("LAYERS", "153"))
+    prog, wit, wc, st = circuits.layered_gf2(layers=layers)
+    circ = reverie_amd.Circuit(prog, wc, ctx)
+    want = bytes(reverie_amd.Proof.new(circ, wit, [], seeds=seeds))
+    circ.close()
+    for chunk in (1 << 20, 1 << 18):
+        print(json.dumps(streaming_record(ctx, prog, wit, wc, st, seeds, want, chunk_ops=chunk, layers=layers)))
+    print(json.dumps(z64_record(ctx, seeds, n_mul=int(os.environ.get("Z64_MULS", "1000000")))))
