@@ -258,7 +258,7 @@ def main():
     import circuits
     import reverie_amd
     from reverie_amd import _lib
-    from reverie_amd.dist import HipShardBackend, assemble_device_parts, prove_sharded
+    from reverie_amd.dist import HipShardBackend, LibComm, assemble_device_parts, prove_sharded
 
     ctx = reverie_amd.Context(local)
     prog, wit, wc, st = circuits.layered_gf2(layers=args.layers, p_and=args.p_and)
@@ -281,8 +281,35 @@ def main():
     dev_buf = torch.empty(max(sum(backend.single_shard_sizes()), 1), dtype=torch.uint8, device="cuda")
     last_bytes = [None]
 
+    # N > 1: the library's own communicator (rv_comm_* / rv_prove_sharded: RCCL all-gather on the library's stream,
+    # openings to rank 0 by ncclSend/ncclRecv, one D2H).  If it cannot be set up, or its first proof fails, on ANY rank,
+    # all ranks fall back to the torch.distributed orchestration of reverie_amd/dist.py (RV_BENCH_COMM=torch forces it).
+    lib_comm, comm_note = None, None
+    if world > 1:
+        ok = 1
+        if os.environ.get("RV_BENCH_COMM", "lib") == "lib":
+            try:
+                lib_comm = LibComm(circuit)
+                r = lib_comm.prove(wit, [], seeds)
+                if r:
+                    L.rv_free(r[0])
+            except Exception as e:  # noqa: BLE001
+                ok, comm_note = 0, f"library communicator failed ({e}); torch.distributed path used"
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            lib_comm = None
+
     def step():
-        if world > 1:
+        if world > 1 and lib_comm is not None:
+            r = lib_comm.prove(wit, [], seeds)
+            if r:
+                if isinstance(last_bytes[0], tuple):
+                    hp.free(last_bytes[0][0])
+                last_bytes[0] = r
+        elif world > 1:
             # sharded proof; rank 0 ends the step with the assembled bincode(Proof) bytes in host memory
             out = prove_sharded(backend, wit, [], seeds, device_resident=True, gather=True)
             if rank == 0:
@@ -311,7 +338,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if world == 1 and not args.device_resident:
+    if isinstance(last_bytes[0], tuple):
         p, n = last_bytes[0]
         last_bytes[0] = C.string_at(p, n)
         hp.free(p)
@@ -356,7 +383,10 @@ def main():
             "phase_ms": phases, "phase_launches": launches, "algorithmic_bytes_per_proof": {k: int(v) for k, v in alg.items()},
             "gpu_ms_per_proof": sum(phases.values()),
         }
-        boundary = ("sharded rv_shard_* + RCCL all-gather; rank 0 ends with bincode(Proof) bytes in host memory" if world > 1 else
+        boundary = (("rv_prove_sharded (library communicator: RCCL all-gather of digests on the library's stream, ncclSend/ncclRecv of "
+                     "the openings); rank 0 ends with bincode(Proof) bytes in host memory" if lib_comm is not None else
+                     "sharded rv_shard_* + torch.distributed all-gather; rank 0 ends with bincode(Proof) bytes in host memory"
+                     + (f" [{comm_note}]" if comm_note else "")) if world > 1 else
                     "rv_prove_device: openings left in HBM (NOT the SURVEY 8(d) boundary)" if args.device_resident else
                     "rv_prove: witness bytes on the host -> bincode(Proof) bytes on the host (page-locked), D2H of the proof included")
         result = {

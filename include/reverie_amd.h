@@ -89,6 +89,7 @@ typedef struct rv_ctx rv_ctx;         /* one GPU: stream, scratch arena         
 typedef struct rv_circuit rv_circuit; /* a gate stream levelised and resident in HBM       */
 typedef struct rv_shard rv_shard;     /* committed repetitions awaiting the challenge      */
 typedef struct rv_stream rv_stream;   /* a bounded-memory proof in progress (two passes over a chunked gate stream) */
+typedef struct rv_comm rv_comm;       /* this GPU's rank in a group of GPUs proving together (RCCL communicator)   */
 
 const char *rv_strerror(int code);
 /* last HIP/driver error text for this thread ("" if none) */
@@ -301,6 +302,32 @@ int rv_shard_open_self(rv_shard *s, void *dst_device, uint8_t comm[RV_HASH_SIZE]
  * lens[4] reports what was written: [gf2 online | gf2 preprocessing | z64 online | z64 preprocessing], contiguous. */
 int rv_shard_open_gathered(rv_shard *s, const void *all_digests_device, void *dst_device, uint8_t comm[RV_HASH_SIZE],
                            uint8_t omit[RV_TOTAL_REPS], size_t lens[4]);
+
+/* ---- multi-GPU inside the library ---------------------------------------------------------------
+ * The reference fans its 32 packed groups out over a rayon pool INSIDE Proof::new (proof/mod.rs:127-157) and meets
+ * again at one point, combine_hashes over the 256 digests (:160-172).  A communicator does the same over GPUs: rank r
+ * of `world` (1, 2, 4, 8, 16 or 32) proves repetitions [r*256/world, (r+1)*256/world); the one data-path collective
+ * is an ncclAllGather of the 32-byte digests over RCCL/xGMI on the library's own stream; every rank derives the
+ * challenge on its GPU and opens its own repetitions; the openings go to rank 0 with ncclSend/ncclRecv straight into
+ * their place in the proof.  RCCL is bound at run time (dlopen; RV_RCCL_PATH overrides the search): the library
+ * loads without it and reuses a copy the process already has (PyTorch's).
+ *   one process per GPU : rank 0 calls rv_comm_unique_id and hands the 128 bytes to the others out of band (MPI,
+ *                         torch.distributed, a file); every rank calls rv_comm_create with its own context
+ *   one process, n GPUs : rv_comm_create_all(ctxs, n, comms), then rv_prove_multi (a host thread per GPU)
+ * rv_prove_sharded is a COLLECTIVE call: every rank calls it with the same statement and the same 256 seeds (all of
+ * them, not only its share; NULL is not allowed -- the ranks could not agree on OS randomness); *proof is set on rank
+ * 0 only (NULL / 0 elsewhere) and is byte-identical to rv_prove's.  If one rank fails before the collective the
+ * others wait for it: destroy the communicator.  circuits[i] / c must have been compiled on the rank's own context. */
+#define RV_COMM_ID_BYTES 128
+int rv_comm_unique_id(uint8_t id[RV_COMM_ID_BYTES]);
+int rv_comm_create(rv_ctx *ctx, int world, int rank, const uint8_t id[RV_COMM_ID_BYTES], rv_comm **out);
+int rv_comm_create_all(rv_ctx *const *ctxs, int n, rv_comm **comms /* [n] */);
+void rv_comm_destroy(rv_comm *comm);
+int rv_prove_sharded(rv_comm *comm, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64, size_t n_z64,
+                     const uint8_t *seeds /* 256 x 16 */, uint8_t **proof, size_t *proof_len);
+/* seeds NULL => drawn once from the OS and shared by the ranks */
+int rv_prove_multi(rv_comm *const *comms, const rv_circuit *const *circuits, int n, const uint8_t *wit_gf2, size_t n_gf2,
+                   const uint64_t *wit_z64, size_t n_z64, const uint8_t *seeds, uint8_t **proof, size_t *proof_len);
 
 /* combine_hashes (proof/mod.rs:102-108): comm = BLAKE3(h[0] || ... || h[255]) */
 int rv_combine_digests(const uint8_t *h /* 256 x 32 */, uint8_t comm[RV_HASH_SIZE]);

@@ -71,6 +71,7 @@ SYMBOLS = [
     "rv_hook_gf2_reconstruct", "rv_hook_z64_reconstruct",
     "rv_stream_begin", "rv_stream_feed", "rv_stream_commit", "rv_stream_finish", "rv_stream_abort", "rv_stream_get_info",
     "rv_prove_streaming",
+    "rv_comm_unique_id", "rv_comm_create", "rv_comm_create_all", "rv_comm_destroy", "rv_prove_sharded", "rv_prove_multi",
 ]
 RV_VERIFY_STRICT = 1
 RV_VERIFY_REFERENCE_COMPAT = 2  # the reference verifier's two unchecked conditions stay unchecked
@@ -116,7 +117,7 @@ def lib():
         L.rv_abi_version.restype = C.c_uint32
         for name in SYMBOLS:
             fn = getattr(L, name)
-            if name in ("rv_ctx_destroy", "rv_circuit_destroy", "rv_shard_destroy", "rv_free", "rv_stream_abort"):
+            if name in ("rv_ctx_destroy", "rv_circuit_destroy", "rv_shard_destroy", "rv_free", "rv_stream_abort", "rv_comm_destroy"):
                 fn.restype = None
             elif name not in ("rv_strerror", "rv_last_error", "rv_abi_version"):
                 fn.restype = C.c_int

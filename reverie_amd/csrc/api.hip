@@ -7,6 +7,7 @@
 #include <sys/random.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <map>
 #include <string>
@@ -2532,3 +2533,4 @@ extern "C" int rv_hook_z64_reconstruct(rv_ctx* ctx, const uint64_t* shares, size
 }
 
 #include "stream.inc"
+#include "comm.inc"

@@ -286,3 +286,52 @@ def prove_sharded(backend, wit_gf2, wit_z64, seeds, group=None, device_resident:
         return assemble(comm, gathered) if rank == 0 else None
     finally:
         backend.destroy(shard)
+
+
+class LibComm:
+    """This rank's place in a group of GPUs proving together INSIDE the library (rv_comm_*, rv_prove_sharded): the
+    library owns the RCCL communicator, the digests' all-gather runs on its own stream and the openings go to rank 0
+    with ncclSend/ncclRecv.  torch.distributed (any backend) is only used once, to hand rank 0's communicator id to
+    the other ranks; with world == 1 nothing is exchanged."""
+
+    def __init__(self, circuit: Circuit, group=None):
+        import torch.distributed as dist
+
+        self.circuit = circuit
+        if dist.is_available() and dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            self.rank, self.world = 0, 1
+        uid = np.zeros(128, np.uint8)
+        if self.rank == 0:
+            _lib.check(_lib.lib().rv_comm_unique_id(_ptr(uid)))
+        if self.world > 1:
+            box = [uid.tobytes()]
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            uid = np.frombuffer(box[0], np.uint8).copy()
+        self.handle = C.c_void_p()
+        _lib.check(_lib.lib().rv_comm_create(circuit.ctx.handle, C.c_int(self.world), C.c_int(self.rank), _ptr(uid), C.byref(self.handle)))
+
+    def prove(self, wit_gf2, wit_z64, seeds):
+        """rv_prove_sharded (collective).  -> (pointer, length) of the library's proof buffer on rank 0 (hand it to
+        Proof(_owned=...) or rv_free), None on the other ranks"""
+        g = np.ascontiguousarray(np.asarray(wit_gf2, dtype=np.uint8))
+        z = np.ascontiguousarray(np.asarray(wit_z64, dtype=np.uint64))
+        s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint8)).reshape(TOTAL_REPS, 16)
+        out, n = C.c_void_p(), C.c_size_t()
+        _lib.check(_lib.lib().rv_prove_sharded(self.handle, self.circuit.handle, _ptr(g), C.c_size_t(len(g)), _ptr(z), C.c_size_t(len(z)),
+                                               _ptr(s), C.byref(out), C.byref(n)))
+        return (C.c_void_p(out.value), n.value) if out.value else None
+
+    def close(self):
+        if self.handle:
+            if self.circuit.ctx.handle:
+                _lib.lib().rv_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -915,3 +915,49 @@ def test_verify_batch_matches_single_verifier(rv, oracle, monkeypatch):
     pm = rv.Proof.new(cm1, w2, w64, wcm, seeds=seeds[0])
     assert rv.verify_batch(cm2, [pm, pm], wcm, strict=False) == [True, True] and rv.verify_batch(cm2, [pm, pm], wcm) == [False, False]
     assert rv.verify_batch(c1, []) == []
+
+
+def test_library_communicator_world1(rv, oracle, rule_seeds):
+    """rv_comm_* / rv_prove_sharded / rv_prove_multi with a communicator of one rank (all this box has): RCCL is found
+    and initialised, the collective entry point produces rv_prove's bytes.  (More ranks need more GPUs: RCCL refuses two
+    ranks on one device; the shard kernels themselves are covered by the sharded tests above.)"""
+    from reverie_amd import _lib
+    from reverie_amd.dist import LibComm
+
+    rng = np.random.default_rng(31)
+    prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=300)
+    c = rv.Circuit(prog, wc)
+    want = oracle.prove(prog, w2, w64, wc, rule_seeds)
+    lc = LibComm(c)
+    assert (lc.rank, lc.world) == (0, 1)
+    for _ in range(2):
+        p = rv.Proof(_owned=lc.prove(w2, w64, rule_seeds))
+        assert bytes(p) == want
+    # rv_prove_multi over the same communicator (one host thread per rank; here one)
+    g = np.ascontiguousarray(np.asarray(w2, np.uint8))
+    z = np.ascontiguousarray(np.asarray(w64, np.uint64))
+    comms = (C.c_void_p * 1)(lc.handle)
+    circs = (C.c_void_p * 1)(c.handle)
+    out, n = C.c_void_p(), C.c_size_t()
+    _lib.check(_lib.lib().rv_prove_multi(comms, circs, C.c_int(1), _p(g), C.c_size_t(len(g)), _p(z), C.c_size_t(len(z)), _p(rule_seeds),
+                                         C.byref(out), C.byref(n)))
+    assert bytes(rv.Proof(_owned=(C.c_void_p(out.value), n.value))) == want
+    # an invalid witness is reported, not hung on
+    bad = list(w2)
+    bad[0] ^= 1
+    try:
+        r = lc.prove(bad, w64, rule_seeds)
+        if r:
+            _lib.lib().rv_free(r[0])
+    except rv.ReverieError as e:
+        assert e.code == 1
+    lc.close()
+    # rv_comm_create_all: the single-process form
+    ctxs = (C.c_void_p * 1)(c.ctx.handle)
+    cm = (C.c_void_p * 1)()
+    _lib.check(_lib.lib().rv_comm_create_all(ctxs, C.c_int(1), cm))
+    out, n = C.c_void_p(), C.c_size_t()
+    _lib.check(_lib.lib().rv_prove_sharded(C.c_void_p(cm[0]), c.handle, _p(g), C.c_size_t(len(g)), _p(z), C.c_size_t(len(z)), _p(rule_seeds),
+                                           C.byref(out), C.byref(n)))
+    assert bytes(rv.Proof(_owned=(C.c_void_p(out.value), n.value))) == want
+    _lib.lib().rv_comm_destroy(C.c_void_p(cm[0]))
