@@ -19,6 +19,7 @@
 #include "compile.h"
 #include "internal.h"
 #include "launch.h"
+#include "repprog.h"
 
 using namespace rv;
 
@@ -361,7 +362,30 @@ struct rv_circuit {
     };
     std::vector<NarrowRun> narrow_runs;
     std::vector<int32_t> run_of_level;  // index into narrow_runs or -1
+    // rep-sliced prover path (repprog.h): present when the circuit is eligible
+    bool rep_ok = false;
+    RepProgram rp;  // host copy without the big vectors (only counts are read after the upload)
+    RepLevel* d_rep_levels = nullptr;
+    RepSeg* d_rep_segs = nullptr;
+    RepRec* d_rep_recs = nullptr;
 };
+
+// LDS the rep-sliced interpreter may use for wire slots (a workgroup owns the CU: 160 KiB minus a little headroom)
+static uint32_t rep_lds_budget() {
+    static const uint32_t v = [] {
+        const char* e = getenv("RV_REP_LDS");
+        return e ? (uint32_t)atoi(e) : 156u * 1024u;
+    }();
+    return v;
+}
+// RV_REP: 0 = never take the rep-sliced path, 1 (default) = whole proofs (all 256 repetitions on this GPU), 2 = shards too
+static int rep_mode() {
+    static const int v = [] {
+        const char* e = getenv("RV_REP");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
 
 static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
     const size_t NQ = R / 4;
@@ -409,6 +433,19 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
     if (getenv("RV_COMPILE_STATS"))
         fprintf(stderr, "[rv circuit] compile_ops: %.3f s for %zu ops\n", std::chrono::duration<double>(t_compiled - t_begin).count(),
                 n_ops);
+    // the rep-sliced program of the prover (pure GF(2) circuits whose live wires fit the LDS): from this compile when it
+    // keeps one base row per wire, else from a second compile that does
+    if (rep_mode() && c->cc.gates64.empty() && !c->cc.gates.empty()) {
+        const char* why = "";
+        c->rep_ok = build_rep_program(c->cc, rep_lds_budget(), c->rp, &why);
+        if (!c->rep_ok && strstr(why, "base")) {
+            Compiled one;
+            if (compile_ops(ops, n_ops, z64_wires, gf2_wires, one, nullptr, 1) == RV_OK) c->rep_ok = build_rep_program(one, rep_lds_budget(), c->rp, &why);
+        }
+        if (getenv("RV_COMPILE_STATS"))
+            fprintf(stderr, "[rv circuit] rep-sliced path: %s%s (%u levels, %zu segments, %u LDS slots) at %.3f s\n", c->rep_ok ? "yes" : "no: ", why,
+                    c->rp.n_levels, c->rp.segs.size(), c->rp.lds_slots, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+    }
     if ((rc = circuit_upload(ctx, c))) return rc;  // (destroys c on failure)
     *out = c;
     return RV_OK;
@@ -437,7 +474,20 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         rv_circuit_destroy(c);
         return rc;
     }
+    if (c->rep_ok) {
+        if ((rc = up(c->rp.levels.data(), c->rp.levels.size() * sizeof(RepLevel), (void**)&c->d_rep_levels)) ||
+            (rc = up(c->rp.segs.data(), c->rp.segs.size() * sizeof(RepSeg), (void**)&c->d_rep_segs)) ||
+            (rc = up(c->rp.recs.data(), c->rp.recs.size() * sizeof(RepRec), (void**)&c->d_rep_recs))) {
+            rv_circuit_destroy(c);
+            return rc;
+        }
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (c->rep_ok) {  // the device holds them now
+        std::vector<RepRec>().swap(c->rp.recs);
+        std::vector<RepSeg>().swap(c->rp.segs);
+        std::vector<RepLevel>().swap(c->rp.levels);
+    }
     c->cc.info.upload_us = (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_compiled).count();
     {
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
@@ -509,6 +559,9 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     c->ctx->release(c->d_in_offs64);
     c->ctx->release(c->d_level_start);
     c->ctx->release(c->d_level_range);
+    c->ctx->release(c->d_rep_levels);
+    c->ctx->release(c->d_rep_segs);
+    c->ctx->release(c->d_rep_recs);
     delete c;
 }
 
@@ -570,6 +623,11 @@ struct rv_shard {
     uint32_t* d_on = nullptr;
     uint8_t* d_pre = nullptr;     // [n_pre][NQ/2]
     uint8_t* d_wit = nullptr;
+    // rep-sliced prover path (rep.hip): rep-major masks / transcripts instead of the row arrays above
+    bool rep = false;
+    uint8_t *d_masks_rep = nullptr, *d_on_rep = nullptr, *d_pre_rep = nullptr, *d_vbits = nullptr;
+    uint32_t* d_rk_rep = nullptr;
+    uint64_t mask_stride = 0, on_stride = 0, pre_stride = 0;
     // Z64 domain
     uint64_t* d_masks64 = nullptr;
     uint64_t* d_wmask64 = nullptr;
@@ -604,7 +662,7 @@ struct rv_shard {
         ev_setup = nullptr;
         void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk,    d_masks,  d_wires,   d_on,     d_pre,    d_wit,  d_cv[0],
                       d_cv[1], d_dig,  d_h,       d_err,   d_omit,   d_offs,    d_out,    d_masks64, d_wmask64,
-                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64};
+                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep};
         for (void* p : ps) ctx->release(p);
         for (void* p : extra) ctx->release(p);
     }
@@ -817,6 +875,77 @@ static int shard_join(rv_shard* s) {
     return RV_OK;
 }
 
+// The rep-sliced prover (rep.hip): a workgroup per repetition, live wires in LDS, rep-major masks and transcripts.
+// Same digests as shard_setup_prg + shard_run, for the circuits build_rep_program accepts.
+static int shard_commit_rep(rv_shard* s) {
+    rv_ctx* ctx = s->ctx;
+    const rv_circuit* c = s->c;
+    const Compiled& cc = c->cc;
+    hipStream_t st = ctx->stream;
+    const uint32_t R = s->R;
+    int rc;
+    s->rep = true;
+    const uint64_t n_blocks = cc.n_masks_pad / 128, n4 = (n_blocks + 3) / 4;
+    auto pad = [](uint64_t n) { return (n + 64 + 1023) & ~(uint64_t)1023; };
+    s->mask_stride = pad(512 * n4);
+    s->on_stride = pad(cc.n_on);
+    s->pre_stride = pad(cc.n_pre);
+    const size_t cvw = b3_stream_scratch_words(std::max(cc.n_on, cc.n_pre), R);
+    if ((rc = dalloc(ctx, (size_t)R * 8 * RK_BYTES, &s->d_rkbytes)) || (rc = dalloc(ctx, (size_t)RK_AREAS * 128 * R, &s->d_rk_rep)) ||
+        (rc = dalloc(ctx, (size_t)R * s->mask_stride, &s->d_masks_rep)) || (rc = dalloc(ctx, (size_t)R * s->on_stride, &s->d_on_rep)) ||
+        (rc = dalloc(ctx, (size_t)R * s->pre_stride, &s->d_pre_rep)) || (rc = dalloc(ctx, std::max<size_t>(c->rp.n_vb_bytes, 1), &s->d_vbits)) ||
+        (rc = dalloc(ctx, cvw, &s->d_cv[0])) || (rc = dalloc(ctx, cvw, &s->d_cv[1])) || (rc = dalloc(ctx, (size_t)4 * R * 8, &s->d_dig)))
+        return rc;
+    if (!s->d_err && (rc = dalloc(ctx, 1, &s->d_err))) return rc;
+    if (!s->d_h && (rc = dalloc(ctx, (size_t)R * 32, &s->d_h))) return rc;
+    launch_key_schedule(st, s->d_keys, R * 8, s->d_rkbytes);
+    launch_bitslice_rk_rep(st, s->d_rkbytes, R, s->d_rk_rep);
+    ctx->count(2);
+    ctx->phase(RV_PH_MASKS);
+    launch_aes_rep_masks(st, s->d_rk_rep, R, n_blocks, s->d_masks_rep, s->mask_stride);
+    ctx->count();
+    ctx->phase(RV_PH_INTERP);
+    HIPCHK(hipMemsetAsync(s->d_err, 0, 8 * sizeof(int), st));
+    launch_rep_clear(st, c->d_rep_levels, c->rp.n_levels, c->d_rep_segs, c->d_rep_recs, s->d_wit, s->d_vbits, s->d_err, c->rp.lds_slots);
+    RepParams P{};
+    P.levels = c->d_rep_levels;
+    P.segs = c->d_rep_segs;
+    P.recs = c->d_rep_recs;
+    P.vbits = s->d_vbits;
+    P.wit = s->d_wit;
+    P.masks = s->d_masks_rep;
+    P.on = s->d_on_rep;
+    P.pre = s->d_pre_rep;
+    P.mask_stride = s->mask_stride;
+    P.on_stride = s->on_stride;
+    P.pre_stride = s->pre_stride;
+    P.n_levels = c->rp.n_levels;
+    if (getenv("RV_REP_DEBUG")) {
+        int dbg[8];
+        (void)hipMemcpyAsync(dbg, s->d_err, sizeof dbg, hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        fprintf(stderr, "[rep debug] err=%d n=%d level=%d seg=%d k=%d a=%08x v=%d\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], (unsigned)dbg[5], dbg[6]);
+    }
+    launch_rep_interp(st, P, R, c->rp.lds_slots);
+    ctx->count(2);
+    ctx->phase(RV_PH_HASH);
+    const size_t DW = (size_t)R * 8;
+    uint32_t n_launch = launch_b3_bytes(st, s->d_pre_rep, s->pre_stride, cc.n_pre, R, s->d_cv[0], s->d_cv[1], s->d_dig + 0 * DW);
+    n_launch += launch_b3_bytes(st, s->d_on_rep, s->on_stride, cc.n_on, R, s->d_cv[0], s->d_cv[1], s->d_dig + 1 * DW);
+    {  // the Z64 transcripts of a pure GF(2) circuit are empty: BLAKE3("")
+        b3::Hasher hs;
+        uint8_t e[32];
+        hs.finalize(e);
+        uint32_t w[8];
+        for (int k = 0; k < 8; k++) w[k] = (uint32_t)e[4 * k] | ((uint32_t)e[4 * k + 1] << 8) | ((uint32_t)e[4 * k + 2] << 16) | ((uint32_t)e[4 * k + 3] << 24);
+        launch_fill_digests(st, s->d_dig + 2 * DW, 2 * R, w);
+    }
+    ctx->count(n_launch + 1);
+    ctx->phase(-1);
+    HIPCHK(hipGetLastError());
+    return RV_OK;
+}
+
 // defer_sync: do not wait for the device (nor look at the invalid-witness flag): the caller queues more work behind
 // the commitment and checks s->d_err itself after its own synchronisation
 static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
@@ -869,12 +998,16 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     ctx->phase(RV_PH_SETUP);
     ctx->count();
     launch_expand_seeds(ctx->stream, s->d_seeds, s->R, s->d_keys);
-    if ((rc = shard_setup_prg(s, nullptr))) return fail(rc);
-    InterpParams p{};
-    p.wit = s->d_wit;
-    Interp64Params p64{};
-    p64.wit = s->d_wit64;
-    if ((rc = shard_run(s, MODE_PROVE, p, p64))) return fail(rc);
+    if (c->rep_ok && (rep_mode() >= 2 || (rep_mode() == 1 && rep_count == RV_TOTAL_REPS))) {
+        if ((rc = shard_commit_rep(s))) return fail(rc);
+    } else {
+        if ((rc = shard_setup_prg(s, nullptr))) return fail(rc);
+        InterpParams p{};
+        p.wit = s->d_wit;
+        Interp64Params p64{};
+        p64.wit = s->d_wit64;
+        if ((rc = shard_run(s, MODE_PROVE, p, p64))) return fail(rc);
+    }
     if ((rc = shard_join(s))) return fail(rc);
     if (defer_sync) {
         ctx->prof.calls++;
@@ -1079,7 +1212,12 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
     ctx->count(any_on ? 4 : 1);
     launch_open_headers(ctx->stream, s->R, s->d_omit, s->d_seeds, s->d_keys, s->d_dig + 1 * DW, s->d_dig + 3 * DW, s->d_offs,
                         s->d_offs + s->R, L.l2r, L.l2c, L.l2i, L.l64r, L.l64c, L.l64i, d_out);
-    if (any_on) {
+    if (any_on && s->rep) {
+        // rep-major transcripts: only the opened repetitions' bytes are read at all
+        launch_rep_open(ctx->stream, s->d_on_rep, s->on_stride, s->c->d_rec_rows, cc.n_rec, 0, d_ol, s->d_omit, s->d_offs + 2 * s->R, d_out);
+        launch_rep_open(ctx->stream, s->d_pre_rep, s->pre_stride, nullptr, cc.n_pre, 1, d_ol, s->d_omit, s->d_offs + 3 * s->R, d_out);
+        launch_rep_open(ctx->stream, s->d_on_rep, s->on_stride, s->c->d_in_rows, cc.n_in, 1, d_ol, s->d_omit, s->d_offs + 4 * s->R, d_out);
+    } else if (any_on) {
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
         launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out);
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);

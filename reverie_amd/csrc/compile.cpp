@@ -539,7 +539,7 @@ static int run_pass(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
     return RV_OK;
 }
 
-int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk) {
+int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk, int force_lazy_k) {
     const auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (getenv("RV_COMPILE_STATS"))
@@ -560,7 +560,10 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
     // 11.2 -> 6.9 ms per proof).  Decide from the K = 1 compile; RV_LAZY_K overrides.
     int lazy_k = 1;
     bool forced = false;
-    if (const char* e = getenv("RV_LAZY_K")) {
+    if (force_lazy_k) {
+        lazy_k = std::min(std::max(force_lazy_k, 1), K);
+        forced = true;
+    } else if (const char* e = getenv("RV_LAZY_K")) {
         lazy_k = std::min(std::max(atoi(e), 1), K);
         forced = true;
     }

@@ -63,6 +63,8 @@ struct ChunkStart {
 };
 
 // returns RV_OK or RV_E_*
-int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr);
+// force_lazy_k: 0 = choose (RV_LAZY_K / circuit shape), 1..RV_LIN_K = that many base rows per wire at most
+int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr,
+                int force_lazy_k = 0);
 
 }  // namespace rv

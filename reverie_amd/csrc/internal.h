@@ -235,4 +235,19 @@ void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, cons
                          uint64_t lens2_rec, uint64_t lens2_corr, uint64_t lens2_in, uint64_t lens64_rec, uint64_t lens64_corr,
                          uint64_t lens64_in, uint8_t* d_out);
 
+// ---- rep-sliced prover path (rep.hip, repprog.h) ----
+struct RepLevel;
+struct RepSeg;
+struct RepRec;
+struct RepParams;
+void launch_bitslice_rk_rep(hipStream_t st, const uint8_t* d_rkbytes, uint32_t R, uint32_t* d_rk /*[RK_AREAS][128][R]*/);
+void launch_aes_rep_masks(hipStream_t st, const uint32_t* d_rk_rep, uint32_t R, uint64_t n_blocks, uint8_t* d_masks, uint64_t mask_stride);
+void launch_rep_clear(hipStream_t st, const RepLevel* d_levels, uint32_t n_levels, const RepSeg* d_segs, const RepRec* d_recs, const uint8_t* d_wit,
+                      uint8_t* d_vbits, int* d_err, uint32_t lds_slots);
+void launch_rep_interp(hipStream_t st, const RepParams& P, uint32_t R, uint32_t lds_slots);
+void launch_rep_open(hipStream_t st, const uint8_t* d_stream, uint64_t stride, const uint32_t* d_rows, uint64_t n_items, int kind,
+                     const OnlineList* d_ol, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
+uint32_t launch_b3_bytes(hipStream_t st, const uint8_t* d_streams, uint64_t stride_bytes, uint64_t n_bytes, uint32_t R, uint32_t* d_cv_a,
+                         uint32_t* d_cv_b, uint32_t* d_digest);
+
 }  // namespace rv

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __rest
     const uint32_t r = (uint32_t)(tid / n_chunks);
     if (r >= R) return;
     const uint64_t b0 = c * 1024;
-    const uint64_t len = (n_bytes - b0 < 1024) ? (n_bytes - b0) : 1024;  // multiple of 8
+    const uint64_t len = (n_bytes - b0 < 1024) ? (n_bytes - b0) : 1024;
     const uint32_t nblk = len == 0 ? 1 : (uint32_t)((len + 63) / 64);
     const uint32_t* src = streams + ((size_t)r * stride_bytes + b0) / 4;
     uint32_t cv[8];
@@ -262,7 +262,11 @@ __global__ __launch_bounds__(256) void k_b3_chunks_contig(const uint32_t* __rest
         if (b + 1 == nblk && n_chunks == 1 && root_ok) flags |= b3::ROOT;
         uint32_t m[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) m[k] = (4u * k < blen) ? src[16 * b + k] : 0u;
+        for (int k = 0; k < 16; k++) {
+            uint32_t w = (4u * k < blen) ? src[16 * b + k] : 0u;
+            if (4u * k < blen && 4u * k + 4 > blen) w &= (1u << (8 * (blen - 4u * k))) - 1u;  // byte streams: the last word may be partial
+            m[k] = w;
+        }
         uint32_t o[8];
         b3::compress<false>(cv, m, c + chunk_base, blen, flags, o);
 #pragma unroll
@@ -280,6 +284,16 @@ void launch_b3_contig_chunks(hipStream_t st, const uint64_t* d_streams, uint64_t
     const uint64_t threads = n * R;
     hipLaunchKernelGGL(k_b3_chunks_contig, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_streams,
                        stride_words * 8, n_bytes, R, n, d_cv, chunk_base, root_ok);
+}
+
+// byte streams [R][stride_bytes] (stride a multiple of 16), the first n_bytes of each hashed -> digests [R][8]
+uint32_t launch_b3_bytes(hipStream_t st, const uint8_t* d_streams, uint64_t stride_bytes, uint64_t n_bytes, uint32_t R, uint32_t* d_cv_a,
+                         uint32_t* d_cv_b, uint32_t* d_digest) {
+    const uint64_t n = n_bytes == 0 ? 1 : (n_bytes + 1023) / 1024;
+    const uint64_t threads = n * R;
+    hipLaunchKernelGGL(k_b3_chunks_contig, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_streams, stride_bytes, n_bytes,
+                       R, n, d_cv_a, (uint64_t)0, 1u);
+    return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);
 }
 
 uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
