@@ -875,6 +875,8 @@ static int shard_join(rv_shard* s) {
     return RV_OK;
 }
 
+// (a lane's mask window may start a few bytes before its segment's first mask: slack in front of every repetition's masks)
+constexpr size_t REP_MASK_FRONT = 16;
 // The rep-sliced prover (rep.hip): a workgroup per repetition, live wires in LDS, rep-major masks and transcripts.
 // Same digests as shard_setup_prg + shard_run, for the circuits build_rep_program accepts.
 static int shard_commit_rep(rv_shard* s) {
@@ -887,13 +889,13 @@ static int shard_commit_rep(rv_shard* s) {
     s->rep = true;
     const uint64_t n_blocks = cc.n_masks_pad / 128, n4 = (n_blocks + 3) / 4;
     auto pad = [](uint64_t n) { return (n + 64 + 1023) & ~(uint64_t)1023; };
-    s->mask_stride = pad(512 * n4);
+    s->mask_stride = pad(512 * n4 + REP_MASK_FRONT);
     s->on_stride = pad(cc.n_on);
     s->pre_stride = pad(cc.n_pre);
     const size_t cvw = b3_stream_scratch_words(std::max(cc.n_on, cc.n_pre), R);
     if ((rc = dalloc(ctx, (size_t)R * 8 * RK_BYTES, &s->d_rkbytes)) || (rc = dalloc(ctx, (size_t)RK_AREAS * 128 * R, &s->d_rk_rep)) ||
-        (rc = dalloc(ctx, (size_t)R * s->mask_stride, &s->d_masks_rep)) || (rc = dalloc(ctx, (size_t)R * s->on_stride, &s->d_on_rep)) ||
-        (rc = dalloc(ctx, (size_t)R * s->pre_stride, &s->d_pre_rep)) || (rc = dalloc(ctx, std::max<size_t>(c->rp.n_vb_bytes, 1), &s->d_vbits)) ||
+        (rc = dalloc(ctx, (size_t)R * s->mask_stride + REP_MASK_FRONT, &s->d_masks_rep)) || (rc = dalloc(ctx, (size_t)R * s->on_stride, &s->d_on_rep)) ||
+        (rc = dalloc(ctx, (size_t)R * s->pre_stride, &s->d_pre_rep)) || (rc = dalloc(ctx, std::max<size_t>(c->rp.n_vb_words, 1) * 4, &s->d_vbits)) ||
         (rc = dalloc(ctx, cvw, &s->d_cv[0])) || (rc = dalloc(ctx, cvw, &s->d_cv[1])) || (rc = dalloc(ctx, (size_t)4 * R * 8, &s->d_dig)))
         return rc;
     if (!s->d_err && (rc = dalloc(ctx, 1, &s->d_err))) return rc;
@@ -902,18 +904,18 @@ static int shard_commit_rep(rv_shard* s) {
     launch_bitslice_rk_rep(st, s->d_rkbytes, R, s->d_rk_rep);
     ctx->count(2);
     ctx->phase(RV_PH_MASKS);
-    launch_aes_rep_masks(st, s->d_rk_rep, R, n_blocks, s->d_masks_rep, s->mask_stride);
+    launch_aes_rep_masks(st, s->d_rk_rep, R, n_blocks, s->d_masks_rep + REP_MASK_FRONT, s->mask_stride);
     ctx->count();
     ctx->phase(RV_PH_INTERP);
     HIPCHK(hipMemsetAsync(s->d_err, 0, 8 * sizeof(int), st));
-    launch_rep_clear(st, c->d_rep_levels, c->rp.n_levels, c->d_rep_segs, c->d_rep_recs, s->d_wit, s->d_vbits, s->d_err, c->rp.lds_slots);
+    launch_rep_clear(st, c->d_rep_levels, c->rp.n_levels, c->d_rep_segs, c->d_rep_recs, s->d_wit, (uint32_t*)s->d_vbits, s->d_err, c->rp.lds_slots);
     RepParams P{};
     P.levels = c->d_rep_levels;
     P.segs = c->d_rep_segs;
     P.recs = c->d_rep_recs;
-    P.vbits = s->d_vbits;
+    P.vbits = (const uint32_t*)s->d_vbits;
     P.wit = s->d_wit;
-    P.masks = s->d_masks_rep;
+    P.masks = s->d_masks_rep + REP_MASK_FRONT;
     P.on = s->d_on_rep;
     P.pre = s->d_pre_rep;
     P.mask_stride = s->mask_stride;

@@ -243,7 +243,7 @@ struct RepParams;
 void launch_bitslice_rk_rep(hipStream_t st, const uint8_t* d_rkbytes, uint32_t R, uint32_t* d_rk /*[RK_AREAS][128][R]*/);
 void launch_aes_rep_masks(hipStream_t st, const uint32_t* d_rk_rep, uint32_t R, uint64_t n_blocks, uint8_t* d_masks, uint64_t mask_stride);
 void launch_rep_clear(hipStream_t st, const RepLevel* d_levels, uint32_t n_levels, const RepSeg* d_segs, const RepRec* d_recs, const uint8_t* d_wit,
-                      uint8_t* d_vbits, int* d_err, uint32_t lds_slots);
+                      uint32_t* d_vbits, int* d_err, uint32_t lds_slots);
 void launch_rep_interp(hipStream_t st, const RepParams& P, uint32_t R, uint32_t lds_slots);
 void launch_rep_open(hipStream_t st, const uint8_t* d_stream, uint64_t stride, const uint32_t* d_rows, uint64_t n_items, int kind,
                      const OnlineList* d_ol, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);

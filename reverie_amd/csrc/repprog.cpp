@@ -96,7 +96,6 @@ bool build_rep_program(const Compiled& cc, uint32_t lds_slots, RepProgram& out, 
     slot[cc.zero_row] = 0;
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> dies(n_levels + 1);  // level -> (start quad, n quads) freed after it
     out.levels.assign(n_levels, RepLevel{0, 0});
-    out.n_mul_recs = 0;
     auto operand = [&](const Gate& g, bool second, uint32_t* enc) -> bool {
         const uint32_t n = second ? g_nb(g) : g_na(g);
         const uint32_t c = second ? g_cb(g) : g_ca(g);
@@ -132,10 +131,12 @@ bool build_rep_program(const Compiled& cc, uint32_t lds_slots, RepProgram& out, 
                 n++;
             }
             s.count = n;
-            // records: one {a, b} pair per gate, padded to a multiple of four per segment
+            s.off = (op == G_MUL || op == G_INPUT) ? (s.eo0 & 3u) : 0u;
+            // records: one {a, b} pair per gate behind `off` dummies, padded to a multiple of four per segment
             const bool has_recs = op != G_INPUT;
             if (has_recs) {
                 s.first = (uint32_t)out.recs.size();
+                for (uint32_t k = 0; k < s.off; k++) out.recs.push_back(RepRec{0, 0});
                 for (uint32_t k = 0; k < n; k++) {
                     const Gate& g = cc.gates[i + k];
                     RepRec r{0, 0};
@@ -152,18 +153,17 @@ bool build_rep_program(const Compiled& cc, uint32_t lds_slots, RepProgram& out, 
                     out.recs.push_back(r);
                 }
                 while (out.recs.size() % 4) out.recs.push_back(RepRec{0, 0});
-                if (op == G_MUL) out.n_mul_recs += (n + 3) / 4 * 4;
             }
             // output slots: one contiguous run of quads per segment (AssertZero writes nothing)
             if (op != G_ASSERT) {
-                const uint32_t nq = (n + 3) / 4;
+                const uint32_t nq = (s.off + n + 3) / 4;
                 uint32_t q0 = 0;
                 if (!pool.take(nq, &q0)) return no("live wires do not fit the LDS");
                 s.dst0 = 4 * q0;
                 int32_t dead = (int32_t)l;  // the run is released once its last reader has run
                 for (uint32_t k = 0; k < n; k++) {
                     const Gate& g = cc.gates[i + k];
-                    slot[g.dst] = s.dst0 + k;
+                    slot[g.dst] = s.dst0 + s.off + k;
                     dead = std::max(dead, last_use[g.dst]);
                 }
                 dies[(size_t)dead].emplace_back(q0, nq);
@@ -182,9 +182,9 @@ bool build_rep_program(const Compiled& cc, uint32_t lds_slots, RepProgram& out, 
         for (RepSeg& s : out.segs)
             if (s.kind == RS_MUL) {
                 s.vb0 = at;
-                at += (s.count + 3) / 4;
+                at += (s.off + s.count + 3) / 4;
             }
-        out.n_vb_bytes = at;
+        out.n_vb_words = at;
     }
     out.lds_slots = std::max<uint32_t>(4 * pool.high, 4);
     out.n_levels = (uint32_t)n_levels;

@@ -23,17 +23,23 @@
 namespace rv {
 
 enum RepSegKind : uint32_t { RS_MUL = 0, RS_XOR = 1, RS_INPUT = 2, RS_ASSERT = 3 };
-constexpr uint32_t REP_SEG_MAX = 256;  // gates per segment: 4 per lane
+// Gates per segment.  A lane handles the four gates whose ONLINE-TRANSCRIPT bytes share an aligned dword, so a segment
+// that starts `off` = eo0 % 4 bytes into a dword occupies ceil((off + count) / 4) <= 64 lanes; 252 is a multiple of four
+// (back-to-back segments of a level keep the same `off`) and leaves room for off <= 3.
+constexpr uint32_t REP_SEG_MAX = 252;
 
 struct RepRec {
     uint32_t a, b;  // operand LDS slot | constant << 31   (Xor: a carries the gate's constant; AssertZero: a only)
 };
 
 struct RepSeg {
-    uint32_t kind, first, count, dst0;  // first: first record (multiple of 4); gate i writes slot dst0 + i (dst0 multiple of 4)
+    uint32_t kind, first, count, dst0;  // lane L, k = 0..3 <-> gate i = 4L + k - off (valid when 0 <= i < count):
+                                        //   record first + 4L + k (first: multiple of 4; the `off` leading records are dummies),
+                                        //   output slot dst0 + 4L + k (dst0: multiple of 4)
     uint32_t m0, eo0, ep0, x0;          // Mul: masks m0 + 2i (+1), online byte eo0 + i, preprocessing byte ep0 + i
                                         // Input: mask m0 + i, online byte eo0 + i, witness x0 + i;  AssertZero: online byte eo0 + i
-    uint32_t vb0, pad;                  // Mul: first byte of the segment's operand-value bits (2 bits per gate)
+    uint32_t vb0, off;                  // Mul: the segment's operand-value words (one u32 per lane, see k_rep_clear); off = eo0 % 4
+                                        // for Mul / Input segments, 0 otherwise
 };
 
 struct RepLevel {
@@ -46,7 +52,7 @@ struct RepParams {
     const RepLevel* levels;
     const RepSeg* segs;
     const RepRec* recs;
-    const uint8_t* vbits;
+    const uint32_t* vbits;
     const uint8_t* wit;
     const uint8_t* masks;
     uint8_t* on;
@@ -60,7 +66,7 @@ struct RepProgram {
     std::vector<RepSeg> segs;
     std::vector<RepRec> recs;
     uint32_t n_levels = 0, lds_slots = 0;
-    uint32_t n_mul_recs = 0, n_vb_bytes = 0;
+    uint32_t n_vb_words = 0;  // operand-value words of all Mul segments (per proof)
 };
 
 // false (and *why) when the circuit cannot take the rep-sliced path
