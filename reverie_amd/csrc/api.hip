@@ -378,13 +378,12 @@ static uint32_t rep_lds_budget() {
     }();
     return v;
 }
-// RV_REP: 0 = never take the rep-sliced path, 1 (default) = whole proofs (all 256 repetitions on this GPU), 2 = shards too
+// RV_REP: 0 (default) = the row path everywhere; 1 = the rep-sliced path for whole proofs (all 256 repetitions on this
+// GPU) of circuits it accepts; 2 = for shards too.  Read at every call (tests switch it).  Off by default: measured on
+// MI355X it is byte-identical but not yet faster than the row path ("Rep-sliced path").
 static int rep_mode() {
-    static const int v = [] {
-        const char* e = getenv("RV_REP");
-        return e ? atoi(e) : 1;
-    }();
-    return v;
+    const char* e = getenv("RV_REP");
+    return e ? atoi(e) : 0;
 }
 
 static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
@@ -888,7 +887,7 @@ static int shard_commit_rep(rv_shard* s) {
     int rc;
     s->rep = true;
     const uint64_t n_blocks = cc.n_masks_pad / 128, n4 = (n_blocks + 3) / 4;
-    auto pad = [](uint64_t n) { return (n + 64 + 1023) & ~(uint64_t)1023; };
+    auto pad = [](uint64_t n) { return (n + 1024 + 1023) & ~(uint64_t)1023; };  // (lanes past a segment's end still load: slack behind)
     s->mask_stride = pad(512 * n4 + REP_MASK_FRONT);
     s->on_stride = pad(cc.n_on);
     s->pre_stride = pad(cc.n_pre);

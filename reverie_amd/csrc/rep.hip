@@ -57,151 +57,238 @@ __device__ __forceinline__ void store_part(uint8_t* p, uint32_t w, int lo, int h
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cleartext evaluation (one workgroup, one byte per slot).  Produces, for every Mul segment, one word per lane: bit
-// 8k = value of operand a of the lane's gate k, bit 8k + 1 = value of operand b (constants included) -- what
-// k_rep_interp needs to rebuild the public corrections -- and checks the AssertZero gates.  It only depends on the
-// witness, so it runs next to the mask generator.
+// Both kernels walk the segments wavefront by wavefront: wave w takes segment seg0 + w, + 16, ... of every level, level
+// after level, with one workgroup barrier per level.  A segment step is a chain  header -> operand records / masks (L2
+// or HBM) -> LDS gathers -> arithmetic -> stores; left alone every step pays the whole chain (1.7 us per step measured,
+// 3.9 ms per proof, the wavefronts idle).  None of the loads depends on the LDS state, so each wave runs them ahead of
+// its own processing in a ring of REP_DEPTH segments -- ACROSS level boundaries (only the processing waits for the
+// barrier): the ring holds the header (scalar registers) and the lane's records / mask dwords / operand values of the
+// next REP_DEPTH segments of the wave, and the header of the one after.  Records and operand-value words have a fixed
+// stride per segment (REP_SEG_RECS, 64), so their addresses need no header.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_rep_clear(const RepLevel* __restrict__ levels, uint32_t n_levels, const RepSeg* __restrict__ segs,
-                                                    const RepRec* __restrict__ recs, const uint8_t* __restrict__ wit, uint32_t* __restrict__ vbits,
-                                                    int* __restrict__ err) {
-    extern __shared__ uint8_t v[];
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) *(uint32_t*)v = 0;
-    __syncthreads();
-    for (uint32_t l = 0; l < n_levels; l++) {
-        const RepLevel lv = levels[l];
-        for (uint32_t si = lv.seg0 + wave; si < lv.seg1; si += 16) {
-            const RepSeg s = segs[si];
-            const int i0 = (int)(4 * lane) - (int)s.off;  // gate index of the lane's byte 0
-            if (i0 >= (int)s.count) continue;
-            uint32_t out4 = 0;
-            if (s.kind == RS_INPUT) {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (i0 + k >= 0 && i0 + k < (int)s.count) out4 |= (wit[s.x0 + i0 + k] ? 1u : 0u) << (8 * k);
-                *(uint32_t*)(v + s.dst0 + 4 * lane) = out4;
-                continue;
-            }
-            const uint4* rp = (const uint4*)(recs + s.first + 4 * lane);
-            const uint4 r0 = rp[0], r1 = rp[1];
-            const uint32_t ia[4] = {r0.x, r0.z, r1.x, r1.z}, ib[4] = {r0.y, r0.w, r1.y, r1.w};
-            uint32_t va[4], vb[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                va[k] = v[ia[k] & 0x7FFFFFFFu];
-                vb[k] = s.kind == RS_ASSERT ? 0u : (uint32_t)v[ib[k] & 0x7FFFFFFFu];
-            }
-            const uint32_t A = pack4(va[0], va[1], va[2], va[3]) ^ pack4(ia[0] >> 31, ia[1] >> 31, ia[2] >> 31, ia[3] >> 31);
-            const uint32_t B = pack4(vb[0], vb[1], vb[2], vb[3]) ^ pack4(ib[0] >> 31, ib[1] >> 31, ib[2] >> 31, ib[3] >> 31);
-            if (s.kind == RS_MUL) {
-                vbits[s.vb0 + lane] = A | (B << 1);
-                *(uint32_t*)(v + s.dst0 + 4 * lane) = A & B;
-            } else if (s.kind == RS_XOR) {
-                *(uint32_t*)(v + s.dst0 + 4 * lane) = A ^ B;
-            } else {
-                // AssertZero on a wire that is not zero (transcript/prover.rs:221-228 panics)
-                uint32_t bad = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (i0 + k >= 0 && i0 + k < (int)s.count) bad |= (A >> (8 * k)) & 1u;
-                if (bad) atomicOr(err, RV_E_WITNESS_INVALID);
-            }
+constexpr int REP_DEPTH = 4;
+
+struct SegData {
+    uint4 r0, r1;         // the lane's four operand records
+    uint32_t w0, w1, w2;  // Mul / Input: the aligned dwords around the lane's mask bytes
+    uint32_t vw;          // Mul: operand values (k_rep_clear)
+};
+// a wave's position in its segment sequence (all wave-uniform)
+struct SegIt {
+    uint32_t l, si, seg1;
+};
+__device__ __forceinline__ void it_settle(SegIt& it, const RepLevel* __restrict__ levels, uint32_t n_levels, uint32_t wave) {
+    while (it.l < n_levels && it.si >= it.seg1) {
+        it.l++;
+        if (it.l < n_levels) {
+            const RepLevel lv = levels[it.l];
+            it.si = lv.seg0 + wave;
+            it.seg1 = lv.seg1;
         }
-        __syncthreads();
+    }
+}
+// byte offset of the lane's first mask inside the repetition's mask array (may be a few bytes negative: front slack)
+__device__ __forceinline__ int64_t seg_mask_off(const RepSeg& s, uint32_t lane) {
+    const int i0 = (int)(4 * lane) - (int)s.off;
+    return s.kind == RS_MUL ? (int64_t)s.m0 + 2 * (int64_t)i0 : (int64_t)s.m0 + i0;
+}
+template <bool CLEAR>
+__device__ __forceinline__ void seg_fetch(const RepRec* __restrict__ recs, const uint32_t* __restrict__ vbits, const uint8_t* masks, const RepSeg& s,
+                                          uint32_t si, uint32_t lane, SegData& d) {
+    if (s.kind != RS_INPUT) {
+        const uint4* rp = (const uint4*)(recs + (size_t)si * REP_SEG_RECS + 4 * lane);
+        d.r0 = rp[0];
+        d.r1 = rp[1];
+    }
+    if (!CLEAR) {
+        if (s.kind == RS_MUL || s.kind == RS_INPUT) {
+            const uintptr_t a = (uintptr_t)(masks + seg_mask_off(s, lane));
+            const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+            d.w0 = q[0];
+            d.w1 = q[1];
+            d.w2 = q[2];
+        }
+        if (s.kind == RS_MUL) d.vw = vbits[(size_t)si * 64 + lane];
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The interpreter: blockIdx.x = repetition, 16 wavefronts deal a level's segments among themselves
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_rep_interp(RepParams P) {
+// One segment.  CLEAR: cleartext values (one byte per slot), the operand-value words of the Mul segments, the AssertZero
+// check; otherwise the interpreter proper on the repetition's mask bytes.
+template <bool CLEAR>
+__device__ __forceinline__ void seg_process(uint8_t* lds, const RepSeg& s, uint32_t si, const SegData& d, uint32_t lane, const uint8_t* masks, uint8_t* on,
+                                            uint8_t* pre, const uint8_t* __restrict__ wit, uint32_t* __restrict__ vbits_out, int* __restrict__ err) {
+    const int i0 = (int)(4 * lane) - (int)s.off;  // gate index of the lane's byte 0; bytes k with 0 <= i0 + k < count are real
+    if (i0 >= (int)s.count) return;
+    const int lo = -i0, hi = (int)s.count - i0;  // the real bytes of this lane: [max(lo, 0), min(hi, 4))
+    const uint32_t ia[4] = {d.r0.x, d.r0.z, d.r1.x, d.r1.z}, ib[4] = {d.r0.y, d.r0.w, d.r1.y, d.r1.w};
+    uint32_t* dst = (uint32_t*)(lds + s.dst0 + 4 * lane);
+    if (CLEAR) {
+        if (s.kind == RS_INPUT) {
+            uint32_t out4 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k >= lo && k < hi) out4 |= (wit[s.x0 + i0 + k] ? 1u : 0u) << (8 * k);
+            *dst = out4;
+            return;
+        }
+        uint32_t va[4], vb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            va[k] = lds[ia[k] & 0x7FFFFFFFu];
+            vb[k] = lds[ib[k] & 0x7FFFFFFFu];  // (AssertZero records have b = the zero slot)
+        }
+        const uint32_t A = pack4(va[0], va[1], va[2], va[3]) ^ pack4(ia[0] >> 31, ia[1] >> 31, ia[2] >> 31, ia[3] >> 31);
+        const uint32_t B = pack4(vb[0], vb[1], vb[2], vb[3]) ^ pack4(ib[0] >> 31, ib[1] >> 31, ib[2] >> 31, ib[3] >> 31);
+        if (s.kind == RS_MUL) {
+            vbits_out[(size_t)si * 64 + lane] = A | (B << 1);
+            *dst = A & B;
+        } else if (s.kind == RS_XOR) {
+            *dst = A ^ B;
+        } else {
+            // AssertZero on a wire that is not zero (transcript/prover.rs:221-228 panics)
+            uint32_t bad = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k >= lo && k < hi) bad |= (A >> (8 * k)) & 1u;
+            if (bad) atomicOr(err, RV_E_WITNESS_INVALID);
+        }
+        return;
+    }
+    const uint32_t msh = (uint32_t)((uintptr_t)(masks + seg_mask_off(s, lane)) & 3);
+    if (s.kind == RS_MUL) {
+        uint32_t ma[4], mb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ma[k] = lds[ia[k] & 0x7FFFFFFFu];
+            mb[k] = lds[ib[k] & 0x7FFFFFFFu];
+        }
+        // lambda_ab, lambda_new of the lane's four gates: 8 mask bytes from m0 + 2 i0
+        const uint32_t mk0 = __builtin_amdgcn_alignbyte(d.w1, d.w0, msh), mk1 = __builtin_amdgcn_alignbyte(d.w2, d.w1, msh);
+        const uint32_t MA = pack4(ma[0], ma[1], ma[2], ma[3]), MB = pack4(mb[0], mb[1], mb[2], mb[3]);
+        const uint32_t LAB = __builtin_amdgcn_perm(mk1, mk0, 0x06040200u), LNEW = __builtin_amdgcn_perm(mk1, mk0, 0x07050301u);
+        const uint32_t RA = par4(MA), RB = par4(MB), RAB = par4(LAB);
+        const uint32_t CA = (d.vw & 0x01010101u) ^ RA, CB = ((d.vw >> 1) & 0x01010101u) ^ RB;  // corr = value ^ recon(mask)
+        const uint32_t D = (RA & RB) ^ RAB;                                                    // single.rs:38-45
+        const uint32_t S = (MB & smear4(CA)) ^ (MA & smear4(CB)) ^ LAB ^ LNEW;                 // single.rs:56-61
+        *dst = LNEW;
+        store_part(on + (s.eo0 - s.off) + 4 * lane, S, lo, hi);
+        // the preprocessing bytes sit at ep0 + i: the same dword grid as the online bytes only if ep0 = eo0 (mod 4)
+        const uint32_t D4 = smear4(D);
+        if (((s.ep0 - s.eo0) & 3u) == 0) {
+            store_part(pre + (s.ep0 - s.off) + 4 * lane, D4, lo, hi);
+        } else {
+            for (int k = lo < 0 ? 0 : lo; k < (hi > 4 ? 4 : hi); k++) pre[(int64_t)s.ep0 + i0 + k] = (uint8_t)(D4 >> (8 * k));
+        }
+    } else if (s.kind == RS_XOR) {
+        uint32_t x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = (uint32_t)(lds[ia[k] & 0x7FFFFFFFu] ^ lds[ib[k] & 0x7FFFFFFFu]);
+        *dst = pack4(x[0], x[1], x[2], x[3]);
+    } else if (s.kind == RS_INPUT) {
+        // prover.rs:181-199: mask = next(), corr = witness - recon(mask), hashed (and recorded) as a 0x00/0xFF byte
+        const uint32_t lam4 = __builtin_amdgcn_alignbyte(d.w1, d.w0, msh);
+        uint32_t w4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k >= lo && k < hi) w4 |= (wit[s.x0 + i0 + k] ? 1u : 0u) << (8 * k);
+        *dst = lam4;
+        store_part(on + (s.eo0 - s.off) + 4 * lane, smear4(w4 ^ par4(lam4)), lo, hi);
+    } else {
+        // AssertZero: transcript.reconstruct(mask) hashes and records the share (prover.rs:221-228); the value check
+        // itself is the cleartext pass's
+        for (int k = lo < 0 ? 0 : lo; k < (hi > 4 ? 4 : hi); k++) on[s.eo0 + i0 + k] = lds[ia[k] & 0x7FFFFFFFu];
+    }
+}
+
+// CLEAR = true: the cleartext pass (one workgroup; P.vbits is written).  It only depends on the witness, so it runs
+// next to the mask generator.  CLEAR = false: the interpreter, blockIdx.x = repetition.
+template <bool CLEAR>
+__global__ __launch_bounds__(1024) void k_rep(RepParams P, uint32_t* __restrict__ vbits_out, int* __restrict__ err) {
     extern __shared__ uint8_t lds[];
     const uint32_t rep = blockIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint8_t* masks = P.masks + (size_t)rep * P.mask_stride;
-    uint8_t* on = P.on + (size_t)rep * P.on_stride;
-    uint8_t* pre = P.pre + (size_t)rep * P.pre_stride;
+    const uint8_t* masks = CLEAR ? nullptr : P.masks + (size_t)rep * P.mask_stride;
+    uint8_t* on = CLEAR ? nullptr : P.on + (size_t)rep * P.on_stride;
+    uint8_t* pre = CLEAR ? nullptr : P.pre + (size_t)rep * P.pre_stride;
     if (threadIdx.x == 0) *(uint32_t*)lds = 0;  // the zero row
     __syncthreads();
-    for (uint32_t l = 0; l < P.n_levels; l++) {
-        const RepLevel lv = P.levels[l];
-        for (uint32_t si = lv.seg0 + wave; si < lv.seg1; si += 16) {
-            const RepSeg s = P.segs[si];
-            const int i0 = (int)(4 * lane) - (int)s.off;  // gate index of the lane's byte 0; bytes k with 0 <= i0 + k < count are real
-            if (i0 >= (int)s.count) continue;
-            const int lo = -i0, hi = (int)s.count - i0;  // the real bytes of this lane: [max(lo, 0), min(hi, 4))
-            if (s.kind == RS_MUL) {
-                const uint4* rp = (const uint4*)(P.recs + s.first + 4 * lane);
-                const uint4 r0 = rp[0], r1 = rp[1];
-                const uint32_t vw = P.vbits[s.vb0 + lane];
-                // lambda_ab, lambda_new of the lane's four gates: 8 mask bytes from m0 + 2 i0
-                const uint2 mk = load8_unaligned(masks + (int64_t)s.m0 + 2 * (int64_t)i0);
-                const uint32_t ia[4] = {r0.x, r0.z, r1.x, r1.z}, ib[4] = {r0.y, r0.w, r1.y, r1.w};
-                uint32_t ma[4], mb[4];
+    // the ring: entry j = the j-th next segment of this wave
+    uint32_t el[REP_DEPTH], esi[REP_DEPTH];
+    RepSeg eh[REP_DEPTH];
+    SegData ed[REP_DEPTH];
+    SegIt f{0, 0, 0};
+    if (P.n_levels) {
+        const RepLevel lv = P.levels[0];
+        f.si = lv.seg0 + wave;
+        f.seg1 = lv.seg1;
+    }
+    it_settle(f, P.levels, P.n_levels, wave);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    ma[k] = lds[ia[k] & 0x7FFFFFFFu];
-                    mb[k] = lds[ib[k] & 0x7FFFFFFFu];
-                }
-                const uint32_t MA = pack4(ma[0], ma[1], ma[2], ma[3]), MB = pack4(mb[0], mb[1], mb[2], mb[3]);
-                const uint32_t LAB = __builtin_amdgcn_perm(mk.y, mk.x, 0x06040200u), LNEW = __builtin_amdgcn_perm(mk.y, mk.x, 0x07050301u);
-                const uint32_t RA = par4(MA), RB = par4(MB), RAB = par4(LAB);
-                const uint32_t CA = (vw & 0x01010101u) ^ RA, CB = ((vw >> 1) & 0x01010101u) ^ RB;  // corr = value ^ recon(mask)
-                const uint32_t D = (RA & RB) ^ RAB;                                                // single.rs:38-45
-                const uint32_t S = (MB & smear4(CA)) ^ (MA & smear4(CB)) ^ LAB ^ LNEW;             // single.rs:56-61
-                *(uint32_t*)(lds + s.dst0 + 4 * lane) = LNEW;
-                store_part(on + (s.eo0 - s.off) + 4 * lane, S, lo, hi);
-                // the preprocessing bytes sit at ep0 + i: the same dword grid as the online bytes only if ep0 = eo0 (mod 4)
-                const uint32_t D4 = smear4(D);
-                const uint32_t sp = (s.ep0 - s.eo0) & 3u;
-                if (sp == 0) {
-                    store_part(pre + (s.ep0 - s.off) + 4 * lane, D4, lo, hi);
-                } else {
-                    for (int k = lo < 0 ? 0 : lo; k < (hi > 4 ? 4 : hi); k++) pre[(int64_t)s.ep0 + i0 + k] = (uint8_t)(D4 >> (8 * k));
-                }
-            } else if (s.kind == RS_XOR) {
-                const uint4* rp = (const uint4*)(P.recs + s.first + 4 * lane);
-                const uint4 r0 = rp[0], r1 = rp[1];
-                const uint32_t ia[4] = {r0.x, r0.z, r1.x, r1.z}, ib[4] = {r0.y, r0.w, r1.y, r1.w};
-                uint32_t x[4];
+    for (int j = 0; j < REP_DEPTH; j++) {
+        el[j] = f.l;
+        esi[j] = f.si;
+        if (f.l < P.n_levels) {
+            eh[j] = P.segs[f.si];
+            seg_fetch<CLEAR>(P.recs, P.vbits, masks, eh[j], f.si, lane, ed[j]);
+            f.si += 16;
+            it_settle(f, P.levels, P.n_levels, wave);
+        }
+    }
+    RepSeg hn{};  // header of the segment the fetch position `f` points at
+    if (f.l < P.n_levels) hn = P.segs[f.si];
+    uint32_t done_levels = 0;  // barriers this wave has passed = levels whose outputs are visible
+    bool more = true;
+    while (more) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) x[k] = (uint32_t)(lds[ia[k] & 0x7FFFFFFFu] ^ lds[ib[k] & 0x7FFFFFFFu]);
-                *(uint32_t*)(lds + s.dst0 + 4 * lane) = pack4(x[0], x[1], x[2], x[3]);
-            } else if (s.kind == RS_INPUT) {
-                // prover.rs:181-199: mask = next(), corr = witness - recon(mask), hashed (and recorded) as a 0x00/0xFF byte
-                const uint32_t lam4 = load4_unaligned(masks + (int64_t)s.m0 + i0);
-                uint32_t w4 = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (k >= lo && k < hi) w4 |= (P.wit[s.x0 + i0 + k] ? 1u : 0u) << (8 * k);
-                *(uint32_t*)(lds + s.dst0 + 4 * lane) = lam4;
-                store_part(on + (s.eo0 - s.off) + 4 * lane, smear4(w4 ^ par4(lam4)), lo, hi);
-            } else {
-                // AssertZero: transcript.reconstruct(mask) hashes and records the share (prover.rs:221-228); the value
-                // check itself is k_rep_clear's
-                for (int k = lo < 0 ? 0 : lo; k < (hi > 4 ? 4 : hi); k++) on[s.eo0 + i0 + k] = lds[P.recs[s.first + 4 * lane + k].a & 0x7FFFFFFFu];
+        for (int j = 0; j < REP_DEPTH; j++) {
+            if (el[j] >= P.n_levels) {
+                more = false;
+                break;
+            }
+            while (done_levels < el[j]) {
+                __syncthreads();
+                done_levels++;
+            }
+            seg_process<CLEAR>(lds, eh[j], esi[j], ed[j], lane, masks, on, pre, P.wit, vbits_out, err);
+            // refill the slot with the segment at the fetch position; move that position on and ask for its header
+            el[j] = f.l;
+            esi[j] = f.si;
+            if (f.l < P.n_levels) {
+                eh[j] = hn;
+                seg_fetch<CLEAR>(P.recs, P.vbits, masks, eh[j], f.si, lane, ed[j]);
+                f.si += 16;
+                it_settle(f, P.levels, P.n_levels, wave);
+                if (f.l < P.n_levels) hn = P.segs[f.si];
             }
         }
+    }
+    // every wavefront passes the same number of barriers (one per level but the last)
+    while (done_levels + 1 < P.n_levels) {
         __syncthreads();
+        done_levels++;
     }
 }
 
 void launch_rep_clear(hipStream_t st, const RepLevel* d_levels, uint32_t n_levels, const RepSeg* d_segs, const RepRec* d_recs, const uint8_t* d_wit,
                       uint32_t* d_vbits, int* d_err, uint32_t lds_slots) {
     static bool attr = [] {
-        (void)hipFuncSetAttribute((const void*)k_rep_clear, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_rep_interp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_rep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_rep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)attr;
-    hipLaunchKernelGGL(k_rep_clear, dim3(1), dim3(1024), lds_slots, st, d_levels, n_levels, d_segs, d_recs, d_wit, d_vbits, d_err);
+    RepParams P{};
+    P.levels = d_levels;
+    P.segs = d_segs;
+    P.recs = d_recs;
+    P.wit = d_wit;
+    P.n_levels = n_levels;
+    hipLaunchKernelGGL(k_rep<true>, dim3(1), dim3(1024), lds_slots, st, P, d_vbits, d_err);
 }
 
 void launch_rep_interp(hipStream_t st, const RepParams& P, uint32_t R, uint32_t lds_slots) {
-    hipLaunchKernelGGL(k_rep_interp, dim3(R), dim3(1024), lds_slots, st, P);
+    hipLaunchKernelGGL(k_rep<false>, dim3(R), dim3(1024), lds_slots, st, P, (uint32_t*)nullptr, (int*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -134,10 +134,13 @@ bool build_rep_program(const Compiled& cc, uint32_t lds_slots, RepProgram& out, 
             s.off = (op == G_MUL || op == G_INPUT) ? (s.eo0 & 3u) : 0u;
             // records: one {a, b} pair per gate behind `off` dummies, padded to a multiple of four per segment
             const bool has_recs = op != G_INPUT;
+            if ((uint64_t)(out.segs.size() + 1) * REP_SEG_RECS > 0xFFFFFFFFull) return no("too many segments");
+            s.first = (uint32_t)(out.segs.size() * REP_SEG_RECS);
+            s.vb0 = (uint32_t)(out.segs.size() * 64);
+            out.recs.resize((out.segs.size() + 1) * (size_t)REP_SEG_RECS, RepRec{0, 0});
             if (has_recs) {
-                s.first = (uint32_t)out.recs.size();
-                for (uint32_t k = 0; k < s.off; k++) out.recs.push_back(RepRec{0, 0});
-                for (uint32_t k = 0; k < n; k++) {
+                size_t at = s.first + s.off;
+                for (uint32_t k = 0; k < n; k++, at++) {
                     const Gate& g = cc.gates[i + k];
                     RepRec r{0, 0};
                     bool ok = true;
@@ -150,9 +153,8 @@ bool build_rep_program(const Compiled& cc, uint32_t lds_slots, RepProgram& out, 
                         ok = operand(g, false, &r.a) && (op == G_ASSERT || operand(g, true, &r.b));
                     }
                     if (!ok) return no("internal: operand row without a slot");
-                    out.recs.push_back(r);
+                    out.recs[at] = r;
                 }
-                while (out.recs.size() % 4) out.recs.push_back(RepRec{0, 0});
             }
             // output slots: one contiguous run of quads per segment (AssertZero writes nothing)
             if (op != G_ASSERT) {
@@ -176,16 +178,7 @@ bool build_rep_program(const Compiled& cc, uint32_t lds_slots, RepProgram& out, 
         dies[l].clear();
         dies[l].shrink_to_fit();
     }
-    // MUL records get the value bits of their operands: index them densely in segment order
-    {
-        uint32_t at = 0;
-        for (RepSeg& s : out.segs)
-            if (s.kind == RS_MUL) {
-                s.vb0 = at;
-                at += (s.off + s.count + 3) / 4;
-            }
-        out.n_vb_words = at;
-    }
+    out.n_vb_words = (uint32_t)(out.segs.size() * 64);
     out.lds_slots = std::max<uint32_t>(4 * pool.high, 4);
     out.n_levels = (uint32_t)n_levels;
     if (why) *why = "";

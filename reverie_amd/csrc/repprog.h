@@ -22,7 +22,8 @@
 
 namespace rv {
 
-enum RepSegKind : uint32_t { RS_MUL = 0, RS_XOR = 1, RS_INPUT = 2, RS_ASSERT = 3 };
+enum RepSegKind : uint32_t { RS_MUL = 0, RS_XOR = 1, RS_INPUT = 2, RS_ASSERT = 3, RS_NONE = 4 };
+constexpr uint32_t REP_SEG_RECS = 256;  // records reserved per segment (its recs start at segment index * REP_SEG_RECS): addressable without the header
 // Gates per segment.  A lane handles the four gates whose ONLINE-TRANSCRIPT bytes share an aligned dword, so a segment
 // that starts `off` = eo0 % 4 bytes into a dword occupies ceil((off + count) / 4) <= 64 lanes; 252 is a multiple of four
 // (back-to-back segments of a level keep the same `off`) and leaves room for off <= 3.
@@ -34,12 +35,13 @@ struct RepRec {
 
 struct RepSeg {
     uint32_t kind, first, count, dst0;  // lane L, k = 0..3 <-> gate i = 4L + k - off (valid when 0 <= i < count):
-                                        //   record first + 4L + k (first: multiple of 4; the `off` leading records are dummies),
+                                        //   record first + 4L + k (first = segment index * REP_SEG_RECS; the `off` leading records are dummies),
                                         //   output slot dst0 + 4L + k (dst0: multiple of 4)
     uint32_t m0, eo0, ep0, x0;          // Mul: masks m0 + 2i (+1), online byte eo0 + i, preprocessing byte ep0 + i
                                         // Input: mask m0 + i, online byte eo0 + i, witness x0 + i;  AssertZero: online byte eo0 + i
-    uint32_t vb0, off;                  // Mul: the segment's operand-value words (one u32 per lane, see k_rep_clear); off = eo0 % 4
-                                        // for Mul / Input segments, 0 otherwise
+    uint32_t vb0, off;                  // operand-value words of the segment: vb0 = segment index * 64 (one u32 per lane, see
+                                        // k_rep_clear); off = eo0 % 4 for Mul / Input segments, 0 otherwise
+    uint32_t pad0, pad1;                // 48 bytes: three 16-byte loads
 };
 
 struct RepLevel {

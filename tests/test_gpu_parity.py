@@ -961,3 +961,47 @@ def test_library_communicator_world1(rv, oracle, rule_seeds):
                                            C.byref(out), C.byref(n)))
     assert bytes(rv.Proof(_owned=(C.c_void_p(out.value), n.value))) == want
     _lib.lib().rv_comm_destroy(C.c_void_p(cm[0]))
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_rep_sliced_path(rv, oracle, rule_seeds, monkeypatch, mode):
+    """RV_REP=1/2: the rep-sliced prover (a workgroup per repetition, live wires in LDS, rep-major masks and transcripts,
+    the cleartext pre-pass instead of stored corrections) must produce the same bytes as the oracle -- golden circuits,
+    Bristol-style random circuits with constants and wire reuse, a layered circuit with several segments per level and
+    misaligned transcript offsets, and (mode 2) repetition shards"""
+    from reverie_amd.dist import HipShardBackend, assemble
+    from reverie_amd.proof import challenge, combine_digests
+
+    monkeypatch.setenv("RV_REP", mode)
+    for name in ("adder64", "gf2_mix", "empty"):
+        m, prog, w2, w64, wc, gold = load_case(name)
+        assert bytes(rv.Proof.new(prog, w2, w64, wc, seeds=rule_seeds)) == gold
+    rng = np.random.default_rng(77)
+    for trial in range(4):
+        prog, wit, wc = circuits.random_gf2(rng, n_in=int(rng.integers(1, 40)), n_gates=int(rng.integers(50, 3000)), n_wires=int(rng.integers(8, 200)))
+        prog = prog[prog["opcode"] != 1]  # (Random gates keep a circuit on the row path)
+        seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+        try:
+            want = oracle.prove(prog, wit, [], wc, seeds)
+        except oracle.OracleError:
+            continue  # removing the Random gates broke an assertion
+        assert bytes(rv.Proof.new(prog, wit, [], wc, seeds=seeds)) == want, trial
+    for n_in, width, layers in ((37, 1024, 9), (4096, 4096, 5)):
+        prog, wit, wc, st = circuits.layered_gf2(n_in=n_in, width=width, layers=layers)
+        want = oracle.prove(prog, wit, [], wc, rule_seeds)
+        c = rv.Circuit(prog, wc)
+        assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == want
+        bad = wit.copy()
+        bad[0] ^= 1
+        with pytest.raises(rv.ReverieError) as e:
+            rv.Proof.new(c, bad, [], seeds=rule_seeds)
+        assert e.value.code == 1
+        if mode == "2":
+            be = HipShardBackend(c)
+            shards = [be.commit(wit, [], rule_seeds[b:b + 64], b, 64) for b in range(0, 256, 64)]
+            comm = combine_digests(np.concatenate([be.digests(s) for s in shards]))
+            omit = challenge(comm)
+            parts = [be.open(s, omit)[:2] for s in shards]
+            for s in shards:
+                be.destroy(s)
+            assert assemble(comm, parts) == want
