@@ -1,0 +1,19 @@
+#!/bin/bash
+# Profiles of the benchmarked configuration at HEAD -> gpurun_out/<tag>/ (copy the summaries into profiles/):
+#   tools/profile_round.sh r02        (run on the GPU box: gpurun -- tools/profile_round.sh r02)
+tag=$1
+out=/root/repo/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+W=2; K=6; N=$((W+K))
+B="python /root/repo/bench.py --no-secondary --no-cpu-baseline --steps $K --warmup $W"
+rocprofv3 --kernel-trace --stats -d $out/trace -- $B > $out/bench_trace.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE -d $out/fetch -- $B > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $out/write -- $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d $out/sq -- $B > /dev/null 2>&1
+cd /root/repo
+python tools/prof_summary.py $(ls $out/trace/*/*_results.db | head -1) $N > $out/${tag}_bench_kernel_stats.txt
+python tools/pmc_summary.py $(ls $out/fetch/*/*_results.db | head -1) $(ls $out/write/*/*_results.db | head -1) $N $out/${tag}_pmc_traffic > /dev/null
+python tools/prof_summary.py $(ls $out/sq/*/*_results.db | head -1) $N | sed -n '/counters_collection/,$p' > $out/${tag}_sq_counters.txt
+rm -rf $out/trace $out/fetch $out/write $out/sq
+head -12 $out/${tag}_bench_kernel_stats.txt; head -12 $out/${tag}_pmc_traffic.txt
