@@ -362,6 +362,9 @@ struct rv_circuit {
     };
     std::vector<NarrowRun> narrow_runs;
     std::vector<int32_t> run_of_level;  // index into narrow_runs or -1
+    // MODE_PROVE_V (cleartext wire values instead of corr rows, internal.h) is possible: pure GF(2), no Random / B2A
+    // gates, every level launched on its own (no single-workgroup narrow runs)
+    bool vclr_ok = false;
     // rep-sliced prover path (repprog.h): present when the circuit is eligible
     bool rep_ok = false;
     RepProgram rp;  // host copy without the big vectors (only counts are read after the upload)
@@ -545,6 +548,17 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
     c->cc.info.device_bytes = cc.gates.size() * sizeof(Gate) + (cc.rec_rows.size() + cc.in_rows.size()) * 4 +
                               cc.gates64.size() * sizeof(Gate64) + (cc.rec_offs64.size() + cc.in_offs64.size()) * 8;
     c->cc.info.scratch_bytes = scratch_bytes_for(cc, RV_TOTAL_REPS);
+    {
+        // (MODE_PROVE_V launches every level on its own: fine when only a handful of levels sit in narrow runs)
+        size_t narrow_levels = 0;
+        for (const auto& r : c->narrow_runs) narrow_levels += r.second - r.first;
+        c->vclr_ok = cc.gates64.empty() && narrow_levels <= 16 && !cc.row_prg_base;
+    }
+    for (const Gate& g : cc.gates)
+        if (g_op(g) == G_RANDOM || g_op(g) == G_RECON) {
+            c->vclr_ok = false;
+            break;
+        }
     return RV_OK;
 }
 
@@ -622,6 +636,7 @@ struct rv_shard {
     uint32_t* d_on = nullptr;
     uint8_t* d_pre = nullptr;     // [n_pre][NQ/2]
     uint8_t* d_wit = nullptr;
+    uint8_t* d_vclr = nullptr;  // MODE_PROVE_V: cleartext value per share row
     // rep-sliced prover path (rep.hip): rep-major masks / transcripts instead of the row arrays above
     bool rep = false;
     uint8_t *d_masks_rep = nullptr, *d_on_rep = nullptr, *d_pre_rep = nullptr, *d_vbits = nullptr;
@@ -661,7 +676,7 @@ struct rv_shard {
         ev_setup = nullptr;
         void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk,    d_masks,  d_wires,   d_on,     d_pre,    d_wit,  d_cv[0],
                       d_cv[1], d_dig,  d_h,       d_err,   d_omit,   d_offs,    d_out,    d_masks64, d_wmask64,
-                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep};
+                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr};
         for (void* p : ps) ctx->release(p);
         for (void* p : extra) ctx->release(p);
     }
@@ -791,7 +806,7 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
             HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
             waited++;
         }
-        if (s->c->run_of_level[l] >= 0) {
+        if (s->c->run_of_level[l] >= 0 && mode != MODE_PROVE_V) {
             // a run of narrow levels: one launch for the whole run (its mask needs were waited for above
             // level by level as the loop advances, so wait for the run's last level first)
             const auto& run = s->c->narrow_runs[(size_t)s->c->run_of_level[l]];
@@ -808,7 +823,7 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
         }
         if (cc.level_start[l + 1] > cc.level_start[l]) {
             // the level that follows as a launch of its own (not a narrow run) gets its first gate records prefetched
-            const LevelRange* next = (l + 1 < n_levels && s->c->run_of_level[l + 1] < 0 && cc.level_start[l + 2] > cc.level_start[l + 1])
+            const LevelRange* next = (l + 1 < n_levels && (s->c->run_of_level[l + 1] < 0 || mode == MODE_PROVE_V) && cc.level_start[l + 2] > cc.level_start[l + 1])
                                          ? &cc.level_range[l + 1]
                                          : nullptr;
             launch_interp(sb, mode, s->c->d_gates, cc.level_range[l], p, next);
@@ -1007,7 +1022,19 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         p.wit = s->d_wit;
         Interp64Params p64{};
         p64.wit = s->d_wit64;
-        if ((rc = shard_run(s, MODE_PROVE, p, p64))) return fail(rc);
+        int mode = MODE_PROVE;
+        static const bool vclr_on = [] {
+            const char* e = getenv("RV_VCLR");
+            return !e || atoi(e) != 0;
+        }();
+        if (vclr_on && c->vclr_ok && rep_count == RV_TOTAL_REPS && !ctx->pipeline) {
+            // whole proofs of eligible circuits: cleartext values instead of corr rows (internal.h: MODE_PROVE_V)
+            if ((rc = dalloc(ctx, (size_t)cc.n_rows, &s->d_vclr))) return fail(rc);
+            if (hipMemsetAsync(s->d_vclr + cc.zero_row, 0, 1, ctx->stream) != hipSuccess) return fail(RV_E_DEVICE);
+            p.vclr = s->d_vclr;
+            mode = MODE_PROVE_V;
+        }
+        if ((rc = shard_run(s, mode, p, p64))) return fail(rc);
     }
     if ((rc = shard_join(s))) return fail(rc);
     if (defer_sync) {

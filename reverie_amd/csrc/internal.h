@@ -102,7 +102,12 @@ struct Interp64Params {
     int* err;
 };
 
-enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1 };
+// MODE_PROVE_V: the prover without corr rows.  A wire's public correction is  value XOR reconstruct(mask), and the prover
+// knows every wire's cleartext value -- one bit per share row, the same in all repetitions (InterpParams::vclr, maintained
+// by the interpreter itself level by level).  The three 32-byte corr-row accesses of a gate become one-byte accesses at
+// wave-uniform addresses.  Not for circuits with Random gates / B2A (values that differ between repetitions) and only
+// in the one-launch-per-level kernels (a level reads what the previous LAUNCH wrote).
+enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1, MODE_PROVE_V = 2 };
 // bit set in the device error word when an AssertZero of an online-verified repetition does not reconstruct to zero
 // (VerifierTranscriptOnline.okay, online.rs:175-177; only the strict verifier looks at it)
 constexpr int RV_DEV_ZERO_CHECK = 0x100;
@@ -113,6 +118,7 @@ struct InterpParams {
     uint8_t* corr;            // [n_rows][NQ/2]
     uint32_t* on;
     uint8_t* pre;             // [n_pre][NQ/2]
+    uint8_t* vclr;            // MODE_PROVE_V: [n_rows] cleartext value of every share row's wire (0 / 1)
     const uint8_t* wit;       // prover: witness bits, one byte each
     const uint32_t* on_mask;  // verify: [NQ] 0xFF byte per online-verified rep
     const uint32_t* sup_in;   // verify: [n_inputs][NQ] supplied masked inputs (smeared)

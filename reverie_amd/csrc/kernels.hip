@@ -71,24 +71,40 @@ __device__ __forceinline__ uint32_t gather_corr(const uint8_t* corr, const uint3
     return (gather_corr_byte(corr, ids, NQ, q >> 1) >> (4 * (q & 1))) & 0xFu;
 }
 
+// MODE_PROVE_V: cleartext value of an operand = XOR of its base rows' values (unused slots hold the zero row, value 0)
+__device__ __forceinline__ uint32_t gather_vclr(const uint8_t* vclr, const uint32_t* ids) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < RV_LIN_K; i++) v ^= vclr[ids[i]];
+    return v;
+}
+
 template <int MODE>
 __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParams& p, uint32_t NQ, uint32_t q, uint32_t onm) {
     switch (g_op(g)) {
     case G_INPUT: {
         const uint32_t lam = p.rows[(size_t)g.m * NQ + q];
         uint32_t corr;
-        if (MODE == MODE_PROVE) {
+        if (MODE != MODE_VERIFY) {
             const uint32_t w = p.wit[g.x] ? 0xFFFFFFFFu : 0u;
             corr = w ^ recon32(lam);
         } else {
             corr = onm ? (p.sup_in[(size_t)g.x * NQ + q] & onm) : 0u;  // (rows of quads without an opened repetition are never written)
         }
-        if (MODE == MODE_PROVE || onm) p.on[(size_t)g.eo * NQ + q] = corr;
-        store_bits(p.corr, g.dst, NQ, q, corr);
+        if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = corr;
+        if (MODE == MODE_PROVE_V) {
+            if (q == 0) p.vclr[g.dst] = p.wit[g.x] ? 1 : 0;
+        } else {
+            store_bits(p.corr, g.dst, NQ, q, corr);
+        }
         break;
     }
     case G_XORK: {
         p.rows[(size_t)g.dst * NQ + q] = gather_rows(p.rows, g.a, NQ, q) ^ gather_rows(p.rows, g.b, NQ, q);
+        if (MODE == MODE_PROVE_V) {
+            if (q == 0) p.vclr[g.dst] = (uint8_t)(g_ca(g) ^ gather_vclr(p.vclr, g.a) ^ gather_vclr(p.vclr, g.b));
+            break;
+        }
         // corr bits: plain byte XOR, no expansion needed
         if (!(q & 1)) {
             const size_t h = NQ >> 1, o = q >> 1;
@@ -104,13 +120,21 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     case G_MUL: {
         const uint32_t lx = gather_rows(p.rows, g.a, NQ, q), ly = gather_rows(p.rows, g.b, NQ, q);
         const uint32_t lab = p.rows[(size_t)g.m * NQ + q], lnew = p.rows[(size_t)(g.m + 1) * NQ + q];
-        const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
-        const uint32_t cy = expand4(gather_corr(p.corr, g.b, NQ, q)) ^ (g_cb(g) ? 0xFFFFFFFFu : 0u);
         const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
+        uint32_t cx, cy, vx = 0, vy = 0;
+        if (MODE == MODE_PROVE_V) {
+            vx = gather_vclr(p.vclr, g.a) ^ g_ca(g);
+            vy = gather_vclr(p.vclr, g.b) ^ g_cb(g);
+            cx = a ^ (vx ? 0xFFFFFFFFu : 0u);  // corr = value - reconstruct(mask)
+            cy = b ^ (vy ? 0xFFFFFFFFu : 0u);
+        } else {
+            cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
+            cy = expand4(gather_corr(p.corr, g.b, NQ, q)) ^ (g_cb(g) ? 0xFFFFFFFFu : 0u);
+        }
         uint32_t delta = (a & b) ^ c;
         uint32_t s = (ly & cx) ^ (lx & cy) ^ lab ^ lnew;
         uint32_t r;
-        if (MODE == MODE_PROVE) {
+        if (MODE != MODE_VERIFY) {
             r = recon32(s);
         } else {
             // online-verified reps: supplied correction, add the unopened player's broadcast
@@ -123,9 +147,13 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         // verifier: the online transcript is only hashed for quads that hold an opened repetition (the other
         // repetitions' online digests come from the proof), so only those lanes store -- in the verifier's slot order
         // they are the first ten quads of a row, two 32-byte sectors instead of eight
-        if (MODE == MODE_PROVE || onm) p.on[(size_t)g.eo * NQ + q] = s;
+        if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = s;
         store_bits(p.pre, g.ep, NQ, q, delta);
-        store_bits(p.corr, g.dst, NQ, q, r ^ delta ^ (cx & cy));
+        if (MODE == MODE_PROVE_V) {
+            if (q == 0) p.vclr[g.dst] = (uint8_t)(vx & vy);
+        } else {
+            store_bits(p.corr, g.dst, NQ, q, r ^ delta ^ (cx & cy));
+        }
         break;
     }
     case G_RECON: {
@@ -143,8 +171,11 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     case G_ASSERT: {
         uint32_t m = gather_rows(p.rows, g.a, NQ, q);
         if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * NQ + q];
-        if (MODE == MODE_PROVE || onm) p.on[(size_t)g.eo * NQ + q] = m;
-        {
+        if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = m;
+        if (MODE == MODE_PROVE_V) {
+            // the wire's value itself must be zero (prover.rs:221-228), the same in every repetition
+            if (q == 0 && (gather_vclr(p.vclr, g.a) ^ g_ca(g)) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+        } else {
             const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
             if (MODE == MODE_PROVE) {
                 if ((recon32(m) ^ cx) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
@@ -264,7 +295,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
             ca[u][i] = 0;
             if (i == 0 || i < na) {
                 ra[u][i] = p.rows[(size_t)g[u].a[i] * NQ + q];
-                ca[u][i] = p.corr[(size_t)g[u].a[i] * H + (q >> 1)];
+                ca[u][i] = MODE == MODE_PROVE_V ? p.vclr[g[u].a[i]] : p.corr[(size_t)g[u].a[i] * H + (q >> 1)];
             }
         }
 #pragma unroll
@@ -273,7 +304,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
             cb[u][i] = 0;
             if (i == 0 || i < nb) {
                 rb[u][i] = p.rows[(size_t)g[u].b[i] * NQ + q];
-                cb[u][i] = p.corr[(size_t)g[u].b[i] * H + (q >> 1)];
+                cb[u][i] = MODE == MODE_PROVE_V ? p.vclr[g[u].b[i]] : p.corr[(size_t)g[u].b[i] * H + (q >> 1)];
             }
         }
         // lambda_ab is read exactly once and the online row is not read again before the hash phase: nontemporal, so
@@ -309,28 +340,39 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        const uint32_t cx = expand4((bx[u] >> (4 * (q & 1))) & 0xFu) ^ (g_ca(g[u]) ? 0xFFFFFFFFu : 0u);
-        const uint32_t cy = expand4((by[u] >> (4 * (q & 1))) & 0xFu) ^ (g_cb(g[u]) ? 0xFFFFFFFFu : 0u);
         const uint32_t a = recon32(lx[u]), b = recon32(ly[u]), c = recon32(lab[u]);
+        uint32_t cx, cy;
+        const uint32_t vx = (bx[u] ^ g_ca(g[u])) & 1u, vy = (by[u] ^ g_cb(g[u])) & 1u;  // MODE_PROVE_V: the operands' cleartext values
+        if (MODE == MODE_PROVE_V) {
+            cx = a ^ (vx ? 0xFFFFFFFFu : 0u);  // corr = value - reconstruct(mask)
+            cy = b ^ (vy ? 0xFFFFFFFFu : 0u);
+        } else {
+            cx = expand4((bx[u] >> (4 * (q & 1))) & 0xFu) ^ (g_ca(g[u]) ? 0xFFFFFFFFu : 0u);
+            cy = expand4((by[u] >> (4 * (q & 1))) & 0xFu) ^ (g_cb(g[u]) ? 0xFFFFFFFFu : 0u);
+        }
         uint32_t delta = (a & b) ^ c;
         uint32_t s = (ly[u] & cx) ^ (lx[u] & cy) ^ lab[u] ^ lnew[u];
-        uint32_t r;
+        uint32_t r = 0;
         if (MODE == MODE_PROVE) {
             r = recon32(s);
-        } else {
+        } else if (MODE == MODE_VERIFY) {
             delta = (sc[u] & onm) | (delta & ~onm);
             s ^= sr[u];
             r = recon32(s) & onm;
         }
-        if (MODE == MODE_PROVE || onm) __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
+        if (MODE != MODE_VERIFY || onm) __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
         store_bits(p.pre, g[u].ep, NQ, q, delta);
-        store_bits(p.corr, g[u].dst, NQ, q, r ^ delta ^ (cx & cy));
+        if (MODE == MODE_PROVE_V) {
+            if (q == 0) p.vclr[g[u].dst] = (uint8_t)(vx & vy);
+        } else {
+            store_bits(p.corr, g[u].dst, NQ, q, r ^ delta ^ (cx & cy));
+        }
     }
     pf_sink(pfv);
 }
 
 // G_XORK: N = base rows loaded per gate (2: a[0], a[1]; 6: a[0..2], b[0..2] with zero-row padding)
-template <int NQ, int U, int N>
+template <int MODE, int NQ, int U, int N>
 __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
                                      const Gate* pf = nullptr) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
@@ -349,8 +391,12 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
             // only the slots the gate uses (N == 2: both by construction)
             if (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) {
                 rr[u][i] = p.rows[(size_t)id * NQ + q];
-                // H corr bytes per row: the first H lanes of the gate's lane group carry them
-                if (q < H) cc[u][i] = p.corr[(size_t)id * H + q];
+                // H corr bytes per row: the first H lanes of the gate's lane group carry them (MODE_PROVE_V: one value byte)
+                if (MODE == MODE_PROVE_V) {
+                    if (q == 0) cc[u][i] = p.vclr[id];
+                } else if (q < H) {
+                    cc[u][i] = p.corr[(size_t)id * H + q];
+                }
             }
         }
     }
@@ -368,7 +414,11 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
 #pragma unroll
     for (int u = 0; u < U; u++) {
         p.rows[(size_t)g[u].dst * NQ + q] = x[u];
-        if (q < H) p.corr[(size_t)g[u].dst * H + q] = (uint8_t)(bx[u] ^ (g_ca(g[u]) ? 0xFFu : 0u));
+        if (MODE == MODE_PROVE_V) {
+            if (q == 0) p.vclr[g[u].dst] = (uint8_t)((bx[u] ^ g_ca(g[u])) & 1u);
+        } else if (q < H) {
+            p.corr[(size_t)g[u].dst * H + q] = (uint8_t)(bx[u] ^ (g_ca(g[u]) ? 0xFFu : 0u));
+        }
     }
     pf_sink(pfv);
 }
@@ -414,8 +464,8 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
             if (PF && pf->dist) t = pf_target<U * GPW>(pf_gates, *pf, slot + (g0 - begin[c]) / STEP);
             if (c == 0) mulU<MODE, NQ, U, 1, 1>(gates, g0, p, sub, q, onm, t);               // G_MUL, one base per operand
             if (c == 1 && GENERAL) mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K>(gates, g0, p, sub, q, onm, t); // other G_MUL
-            if (c == 2) xorU<NQ, UX, 2>(gates, g0, p, sub, q, t);                            // G_XORK of two bases
-            if (c == 3 && GENERAL) xorU<NQ, UX, 2 * RV_LIN_K>(gates, g0, p, sub, q, t);                 // other G_XORK
+            if (c == 2) xorU<MODE, NQ, UX, 2>(gates, g0, p, sub, q, t);                            // G_XORK of two bases
+            if (c == 3 && GENERAL) xorU<MODE, NQ, UX, 2 * RV_LIN_K>(gates, g0, p, sub, q, t);                 // other G_XORK
         }
         slot += n_full;
     }
@@ -512,7 +562,14 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
     uint64_t blocks = (waves + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    if (mode == MODE_PROVE) {
+    if (mode == MODE_PROVE_V) {
+        if constexpr (NQ == 64) {  // whole proofs only
+            if (general)
+                hipLaunchKernelGGL((k_interp_full<MODE_PROVE_V, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
+            else
+                hipLaunchKernelGGL((k_interp_full<MODE_PROVE_V, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
+        }
+    } else if (mode == MODE_PROVE) {
         if (general)
             hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
         else

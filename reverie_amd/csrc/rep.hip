@@ -52,8 +52,19 @@ __device__ __forceinline__ void store_part(uint8_t* p, uint32_t w, int lo, int h
     if (lo <= 0 && hi >= 4) {
         *(uint32_t*)p = w;
     } else {
-        for (int k = lo < 0 ? 0 : lo; k < (hi > 4 ? 4 : hi); k++) p[k] = (uint8_t)(w >> (8 * k));
+        // (a fixed number of predicated stores: a loop of stores with a run-time trip count leaves the compiler's
+        // s_waitcnt bookkeeping without a bound and every later wait becomes vmcnt(0) -- the end of all prefetching)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k >= lo && k < hi) p[k] = (uint8_t)(w >> (8 * k));
     }
+}
+// workgroup barrier that orders LDS only: __syncthreads() also drains every outstanding global load (vmcnt(0)), i.e. the
+// prefetch ring, once per level
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -177,7 +188,9 @@ __device__ __forceinline__ void seg_process(uint8_t* lds, const RepSeg& s, uint3
         if (((s.ep0 - s.eo0) & 3u) == 0) {
             store_part(pre + (s.ep0 - s.off) + 4 * lane, D4, lo, hi);
         } else {
-            for (int k = lo < 0 ? 0 : lo; k < (hi > 4 ? 4 : hi); k++) pre[(int64_t)s.ep0 + i0 + k] = (uint8_t)(D4 >> (8 * k));
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k >= lo && k < hi) pre[(int64_t)s.ep0 + i0 + k] = (uint8_t)(D4 >> (8 * k));
         }
     } else if (s.kind == RS_XOR) {
         uint32_t x[4];
@@ -196,7 +209,9 @@ __device__ __forceinline__ void seg_process(uint8_t* lds, const RepSeg& s, uint3
     } else {
         // AssertZero: transcript.reconstruct(mask) hashes and records the share (prover.rs:221-228); the value check
         // itself is the cleartext pass's
-        for (int k = lo < 0 ? 0 : lo; k < (hi > 4 ? 4 : hi); k++) on[s.eo0 + i0 + k] = lds[ia[k] & 0x7FFFFFFFu];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k >= lo && k < hi) on[s.eo0 + i0 + k] = lds[ia[k] & 0x7FFFFFFFu];
     }
 }
 
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(1024) void k_rep(RepParams P, uint32_t* __restrict_
                 break;
             }
             while (done_levels < el[j]) {
-                __syncthreads();
+                lds_barrier();
                 done_levels++;
             }
             seg_process<CLEAR>(lds, eh[j], esi[j], ed[j], lane, masks, on, pre, P.wit, vbits_out, err);
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(1024) void k_rep(RepParams P, uint32_t* __restrict_
     }
     // every wavefront passes the same number of barriers (one per level but the last)
     while (done_levels + 1 < P.n_levels) {
-        __syncthreads();
+        lds_barrier();
         done_levels++;
     }
 }
