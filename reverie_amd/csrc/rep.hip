@@ -68,36 +68,31 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Both kernels walk the segments wavefront by wavefront: wave w takes segment seg0 + w, + 16, ... of every level, level
-// after level, with one workgroup barrier per level.  A segment step is a chain  header -> operand records / masks (L2
-// or HBM) -> LDS gathers -> arithmetic -> stores; left alone every step pays the whole chain (1.7 us per step measured,
-// 3.9 ms per proof, the wavefronts idle).  None of the loads depends on the LDS state, so each wave runs them ahead of
-// its own processing in a ring of REP_DEPTH segments -- ACROSS level boundaries (only the processing waits for the
-// barrier): the ring holds the header (scalar registers) and the lane's records / mask dwords / operand values of the
-// next REP_DEPTH segments of the wave, and the header of the one after.  Records and operand-value words have a fixed
-// stride per segment (REP_SEG_RECS, 64), so their addresses need no header.
+// Both kernels walk a level's segments wavefront by wavefront (wave w takes REP_BATCH consecutive segments starting at
+// seg0 + w * REP_BATCH, then 16 * REP_BATCH further on, ...), one LDS-only workgroup barrier per level.  A segment step is
+// a chain  header -> operand records / masks -> LDS gathers -> arithmetic -> stores, and with one workgroup per CU (the
+// LDS is full of wires) there are only four wavefronts per SIMD to hide it.  Measured on the 10^7-gate circuit
+// (tools/rep_time.py; DESIGN.md "Rep-sliced path"):
+//   one segment per trip                                      3.9 ms interpreter, 3.1 ms cleartext pass (SQ_WAIT_ANY 69 %)
+//   software prefetch into a register ring, 2 and 4 deep      no gain: with memory operations inside the step's branches
+//                                                             the compiler puts s_waitcnt vmcnt(0) in front of every use
+//   a prefetcher wavefront pulling the next level into L2     slower (4.7 ms): one consumer less, L2 hits no faster
+//   (fire-and-forget LDS-DMA loads into a sink)
+//   REP_BATCH = 4 segments per trip (headers, then records /  3.1 ms + 3.1 ms -- what is built here; 2: the same, 8: spills
+//   masks, then gathers of the whole batch issued together)
+//   the same without stores, mask loads and random gathers    2.0 ms: the skeleton itself is the cost
+// Records and operand-value words have a fixed stride per segment (REP_SEG_RECS, 64): their addresses need no header.
 // ------------------------------------------------------------------------------------------------
-constexpr int REP_DEPTH = 4;
+#ifndef REP_BATCH
+#define REP_BATCH 4
+#endif
+constexpr uint32_t REP_WAVES = 16;
 
 struct SegData {
     uint4 r0, r1;         // the lane's four operand records
     uint32_t w0, w1, w2;  // Mul / Input: the aligned dwords around the lane's mask bytes
     uint32_t vw;          // Mul: operand values (k_rep_clear)
 };
-// a wave's position in its segment sequence (all wave-uniform)
-struct SegIt {
-    uint32_t l, si, seg1;
-};
-__device__ __forceinline__ void it_settle(SegIt& it, const RepLevel* __restrict__ levels, uint32_t n_levels, uint32_t wave) {
-    while (it.l < n_levels && it.si >= it.seg1) {
-        it.l++;
-        if (it.l < n_levels) {
-            const RepLevel lv = levels[it.l];
-            it.si = lv.seg0 + wave;
-            it.seg1 = lv.seg1;
-        }
-    }
-}
 // byte offset of the lane's first mask inside the repetition's mask array (may be a few bytes negative: front slack)
 __device__ __forceinline__ int64_t seg_mask_off(const RepSeg& s, uint32_t lane) {
     const int i0 = (int)(4 * lane) - (int)s.off;
@@ -106,6 +101,7 @@ __device__ __forceinline__ int64_t seg_mask_off(const RepSeg& s, uint32_t lane) 
 template <bool CLEAR>
 __device__ __forceinline__ void seg_fetch(const RepRec* __restrict__ recs, const uint32_t* __restrict__ vbits, const uint8_t* masks, const RepSeg& s,
                                           uint32_t si, uint32_t lane, SegData& d) {
+    if (s.kind == RS_NONE) return;
     if (s.kind != RS_INPUT) {
         const uint4* rp = (const uint4*)(recs + (size_t)si * REP_SEG_RECS + 4 * lane);
         d.r0 = rp[0];
@@ -125,9 +121,22 @@ __device__ __forceinline__ void seg_fetch(const RepRec* __restrict__ recs, const
 
 // One segment.  CLEAR: cleartext values (one byte per slot), the operand-value words of the Mul segments, the AssertZero
 // check; otherwise the interpreter proper on the repetition's mask bytes.
+// the LDS gathers of a step, the same for every kind (a segment without records reads the zero slot): issued for
+// all segments of a wave's batch before any of them is used
+__device__ __forceinline__ void seg_gather(const uint8_t* lds, const SegData& d, uint32_t ga[4], uint32_t gb[4]) {
+    const uint32_t ia[4] = {d.r0.x, d.r0.z, d.r1.x, d.r1.z}, ib[4] = {d.r0.y, d.r0.w, d.r1.y, d.r1.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        ga[k] = lds[ia[k] & 0x7FFFFFFFu];
+        gb[k] = lds[ib[k] & 0x7FFFFFFFu];
+    }
+}
+
 template <bool CLEAR>
-__device__ __forceinline__ void seg_process(uint8_t* lds, const RepSeg& s, uint32_t si, const SegData& d, uint32_t lane, const uint8_t* masks, uint8_t* on,
-                                            uint8_t* pre, const uint8_t* __restrict__ wit, uint32_t* __restrict__ vbits_out, int* __restrict__ err) {
+__device__ __forceinline__ void seg_process(uint8_t* lds, const RepSeg& s, uint32_t si, const SegData& d, const uint32_t ga[4], const uint32_t gb[4],
+                                            uint32_t lane, const uint8_t* masks, uint8_t* on, uint8_t* pre, const uint8_t* __restrict__ wit,
+                                            uint32_t* __restrict__ vbits_out, int* __restrict__ err) {
+    if (s.kind == RS_NONE) return;
     const int i0 = (int)(4 * lane) - (int)s.off;  // gate index of the lane's byte 0; bytes k with 0 <= i0 + k < count are real
     if (i0 >= (int)s.count) return;
     const int lo = -i0, hi = (int)s.count - i0;  // the real bytes of this lane: [max(lo, 0), min(hi, 4))
@@ -142,12 +151,8 @@ __device__ __forceinline__ void seg_process(uint8_t* lds, const RepSeg& s, uint3
             *dst = out4;
             return;
         }
-        uint32_t va[4], vb[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            va[k] = lds[ia[k] & 0x7FFFFFFFu];
-            vb[k] = lds[ib[k] & 0x7FFFFFFFu];  // (AssertZero records have b = the zero slot)
-        }
+        const uint32_t* va = ga;
+        const uint32_t* vb = gb;  // (AssertZero records have b = the zero slot)
         const uint32_t A = pack4(va[0], va[1], va[2], va[3]) ^ pack4(ia[0] >> 31, ia[1] >> 31, ia[2] >> 31, ia[3] >> 31);
         const uint32_t B = pack4(vb[0], vb[1], vb[2], vb[3]) ^ pack4(ib[0] >> 31, ib[1] >> 31, ib[2] >> 31, ib[3] >> 31);
         if (s.kind == RS_MUL) {
@@ -167,12 +172,8 @@ __device__ __forceinline__ void seg_process(uint8_t* lds, const RepSeg& s, uint3
     }
     const uint32_t msh = (uint32_t)((uintptr_t)(masks + seg_mask_off(s, lane)) & 3);
     if (s.kind == RS_MUL) {
-        uint32_t ma[4], mb[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            ma[k] = lds[ia[k] & 0x7FFFFFFFu];
-            mb[k] = lds[ib[k] & 0x7FFFFFFFu];
-        }
+        const uint32_t* ma = ga;
+        const uint32_t* mb = gb;
         // lambda_ab, lambda_new of the lane's four gates: 8 mask bytes from m0 + 2 i0
         const uint32_t mk0 = __builtin_amdgcn_alignbyte(d.w1, d.w0, msh), mk1 = __builtin_amdgcn_alignbyte(d.w2, d.w1, msh);
         const uint32_t MA = pack4(ma[0], ma[1], ma[2], ma[3]), MB = pack4(mb[0], mb[1], mb[2], mb[3]);
@@ -193,10 +194,7 @@ __device__ __forceinline__ void seg_process(uint8_t* lds, const RepSeg& s, uint3
                 if (k >= lo && k < hi) pre[(int64_t)s.ep0 + i0 + k] = (uint8_t)(D4 >> (8 * k));
         }
     } else if (s.kind == RS_XOR) {
-        uint32_t x[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = (uint32_t)(lds[ia[k] & 0x7FFFFFFFu] ^ lds[ib[k] & 0x7FFFFFFFu]);
-        *dst = pack4(x[0], x[1], x[2], x[3]);
+        *dst = pack4(ga[0] ^ gb[0], ga[1] ^ gb[1], ga[2] ^ gb[2], ga[3] ^ gb[3]);
     } else if (s.kind == RS_INPUT) {
         // prover.rs:181-199: mask = next(), corr = witness - recon(mask), hashed (and recorded) as a 0x00/0xFF byte
         const uint32_t lam4 = __builtin_amdgcn_alignbyte(d.w1, d.w0, msh);
@@ -211,7 +209,7 @@ __device__ __forceinline__ void seg_process(uint8_t* lds, const RepSeg& s, uint3
         // itself is the cleartext pass's
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (k >= lo && k < hi) on[s.eo0 + i0 + k] = lds[ia[k] & 0x7FFFFFFFu];
+            if (k >= lo && k < hi) on[s.eo0 + i0 + k] = (uint8_t)ga[k];
     }
 }
 
@@ -228,68 +226,44 @@ __global__ __launch_bounds__(1024) void k_rep(RepParams P, uint32_t* __restrict_
     uint8_t* pre = CLEAR ? nullptr : P.pre + (size_t)rep * P.pre_stride;
     if (threadIdx.x == 0) *(uint32_t*)lds = 0;  // the zero row
     __syncthreads();
-    // the ring: entry j = the j-th next segment of this wave
-    uint32_t el[REP_DEPTH], esi[REP_DEPTH];
-    RepSeg eh[REP_DEPTH];
-    SegData ed[REP_DEPTH];
-    SegIt f{0, 0, 0};
-    if (P.n_levels) {
-        const RepLevel lv = P.levels[0];
-        f.si = lv.seg0 + wave;
-        f.seg1 = lv.seg1;
-    }
-    it_settle(f, P.levels, P.n_levels, wave);
+    for (uint32_t l = 0; l < P.n_levels; l++) {
+        const RepLevel lv = P.levels[l];
+        {
+            // REP_BATCH consecutive segments per trip: their headers, then their records / masks, then their LDS gathers are
+            // each issued together, so a trip pays the header -> data -> gather chain once for the whole batch (there are only
+            // four wavefronts per SIMD to hide it otherwise)
+            for (uint32_t s0 = lv.seg0 + wave * REP_BATCH; s0 < lv.seg1; s0 += REP_WAVES * REP_BATCH) {
+                RepSeg h[REP_BATCH];
+                SegData d[REP_BATCH];
+                uint32_t ga[REP_BATCH][4], gb[REP_BATCH][4];
 #pragma unroll
-    for (int j = 0; j < REP_DEPTH; j++) {
-        el[j] = f.l;
-        esi[j] = f.si;
-        if (f.l < P.n_levels) {
-            eh[j] = P.segs[f.si];
-            seg_fetch<CLEAR>(P.recs, P.vbits, masks, eh[j], f.si, lane, ed[j]);
-            f.si += 16;
-            it_settle(f, P.levels, P.n_levels, wave);
-        }
-    }
-    RepSeg hn{};  // header of the segment the fetch position `f` points at
-    if (f.l < P.n_levels) hn = P.segs[f.si];
-    uint32_t done_levels = 0;  // barriers this wave has passed = levels whose outputs are visible
-    bool more = true;
-    while (more) {
+                for (uint32_t j = 0; j < REP_BATCH; j++) {
+                    if (s0 + j < lv.seg1)
+                        h[j] = P.segs[s0 + j];
+                    else
+                        h[j].kind = RS_NONE, h[j].count = 0, h[j].off = 0;
+                }
 #pragma unroll
-        for (int j = 0; j < REP_DEPTH; j++) {
-            if (el[j] >= P.n_levels) {
-                more = false;
-                break;
-            }
-            while (done_levels < el[j]) {
-                lds_barrier();
-                done_levels++;
-            }
-            seg_process<CLEAR>(lds, eh[j], esi[j], ed[j], lane, masks, on, pre, P.wit, vbits_out, err);
-            // refill the slot with the segment at the fetch position; move that position on and ask for its header
-            el[j] = f.l;
-            esi[j] = f.si;
-            if (f.l < P.n_levels) {
-                eh[j] = hn;
-                seg_fetch<CLEAR>(P.recs, P.vbits, masks, eh[j], f.si, lane, ed[j]);
-                f.si += 16;
-                it_settle(f, P.levels, P.n_levels, wave);
-                if (f.l < P.n_levels) hn = P.segs[f.si];
+                for (uint32_t j = 0; j < REP_BATCH; j++) {
+                    d[j] = SegData{};
+                    seg_fetch<CLEAR>(P.recs, P.vbits, masks, h[j], s0 + j, lane, d[j]);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < REP_BATCH; j++) seg_gather(lds, d[j], ga[j], gb[j]);
+#pragma unroll
+                for (uint32_t j = 0; j < REP_BATCH; j++)
+                    seg_process<CLEAR>(lds, h[j], s0 + j, d[j], ga[j], gb[j], lane, masks, on, pre, P.wit, vbits_out, err);
             }
         }
-    }
-    // every wavefront passes the same number of barriers (one per level but the last)
-    while (done_levels + 1 < P.n_levels) {
         lds_barrier();
-        done_levels++;
     }
 }
 
 void launch_rep_clear(hipStream_t st, const RepLevel* d_levels, uint32_t n_levels, const RepSeg* d_segs, const RepRec* d_recs, const uint8_t* d_wit,
                       uint32_t* d_vbits, int* d_err, uint32_t lds_slots) {
     static bool attr = [] {
-        (void)hipFuncSetAttribute((const void*)k_rep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_rep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_rep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        (void)hipFuncSetAttribute((const void*)k_rep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         return true;
     }();
     (void)attr;
