@@ -20,6 +20,7 @@
 #include "internal.h"
 #include "launch.h"
 #include "repprog.h"
+#include "ldsrun.h"
 
 using namespace rv;
 
@@ -371,6 +372,15 @@ struct rv_circuit {
     RepLevel* d_rep_levels = nullptr;
     RepSeg* d_rep_segs = nullptr;
     RepRec* d_rep_recs = nullptr;
+    // LDS runs (ldsrun.h): narrow stretches whose live wires fit the LDS; preferred over narrow_runs when the shard's
+    // row width is a multiple of the run's slice width
+    struct LdsPlan {
+        LdsRun run;
+        uint32_t qs;
+    };
+    std::vector<LdsPlan> lds_runs;
+    std::vector<int32_t> lds_run_of_level;  // index into lds_runs or -1
+    LdsRec* d_lds_recs = nullptr;
 };
 
 // LDS the rep-sliced interpreter may use for wire slots (a workgroup owns the CU: 160 KiB minus a little headroom)
@@ -539,6 +549,59 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
             l = e;
         }
     }
+    {
+        // LDS runs over the maximal narrow stretches (RV_LDS_RUN=0 switches them off; RV_LDS_QS=2/4 fixes the slice width)
+        const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+        c->lds_run_of_level.assign(n_levels, -1);
+        const int lds_on = getenv("RV_LDS_RUN") ? atoi(getenv("RV_LDS_RUN")) : 1;  // (read per circuit: the tests switch them)
+        const uint32_t qs_env = getenv("RV_LDS_QS") ? (uint32_t)atoi(getenv("RV_LDS_QS")) : 0;
+        static const uint32_t NARROW = std::min<uint32_t>(getenv("RV_NARROW") ? (uint32_t)atoi(getenv("RV_NARROW")) : 256, 512);
+        bool any = false;
+        for (size_t l = 0; l < n_levels && !any; l++) any = c->run_of_level[l] >= 0;
+        if (lds_on && any && !cc.row_prg_base) {
+            LdsRunScratch scratch;
+            scratch.init(cc);
+            std::vector<LdsRec> recs;
+            auto narrow = [&](size_t i) {
+                const bool no64 = cc.level_start64.empty() || cc.level_start64[i + 1] == cc.level_start64[i];
+                return no64 && cc.level_start[i + 1] - cc.level_start[i] <= NARROW;
+            };
+            size_t l = 0;
+            while (l < n_levels) {
+                if (!narrow(l)) {
+                    l++;
+                    continue;
+                }
+                size_t e = l;
+                while (e < n_levels && narrow(e)) e++;
+                if (e - l >= 3) {
+                    const uint64_t n_g = cc.level_start[e] - cc.level_start[l];
+                    const uint32_t qs = (qs_env == 2 || qs_env == 4) ? qs_env : (n_g / (e - l) <= 24 ? 4u : 2u);
+                    const size_t budget = 160 * 1024 - 1024;
+                    const size_t fixed = lds_run_bytes(qs, 0);
+                    const uint32_t max_slots = (uint32_t)std::min<size_t>((budget - fixed) / (qs * 5), LR_NONE - 1);
+                    rv_circuit::LdsPlan plan{};
+                    plan.qs = qs;
+                    if (build_lds_run(cc, (uint32_t)l, (uint32_t)e, qs, max_slots, scratch, recs, plan.run)) {
+                        for (size_t i = l; i < e; i++) c->lds_run_of_level[i] = (int32_t)c->lds_runs.size();
+                        c->lds_runs.push_back(plan);
+                    }
+                }
+                l = e;
+            }
+            if (!recs.empty()) {
+                if ((rc = up(recs.data(), recs.size() * sizeof(LdsRec), (void**)&c->d_lds_recs))) {
+                    rv_circuit_destroy(c);
+                    return rc;
+                }
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+            }
+            if (getenv("RV_COMPILE_STATS"))
+                for (const auto& pl : c->lds_runs)
+                    fprintf(stderr, "[rv circuit] LDS run: levels [%u, %u), %u steps of %u gates, %u slots (%zu KiB of LDS)\n", pl.run.l0, pl.run.l1,
+                            pl.run.n_steps, 64 / pl.qs, pl.run.n_slots, lds_run_bytes(pl.qs, pl.run.n_slots) >> 10);
+        }
+    }
     if (getenv("RV_COMPILE_STATS")) {
         size_t n_tiny = 0, n_med = 0, lv_tiny = 0, lv_med = 0;
         for (const auto& r : c->narrow_runs) (r.tiny == 1 ? n_tiny : n_med)++, (r.tiny == 1 ? lv_tiny : lv_med) += r.second - r.first;
@@ -575,6 +638,7 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     c->ctx->release(c->d_rep_levels);
     c->ctx->release(c->d_rep_segs);
     c->ctx->release(c->d_rep_recs);
+    c->ctx->release(c->d_lds_recs);
     delete c;
 }
 
@@ -805,6 +869,20 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
                (waited == 0 ? 0 : s->mask_chunks[waited - 1].first) < cc.level_need_blocks[l]) {
             HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
             waited++;
+        }
+        if (mode != MODE_PROVE_V && s->c->lds_run_of_level[l] >= 0 && p.NQ % s->c->lds_runs[(size_t)s->c->lds_run_of_level[l]].qs == 0) {
+            // a narrow stretch with its live wires in LDS: one launch, NQ / qs workgroups
+            const auto& pl = s->c->lds_runs[(size_t)s->c->lds_run_of_level[l]];
+            if (l == pl.run.l0) {
+                while (waited < s->mask_chunks.size() &&
+                       (waited == 0 ? 0 : s->mask_chunks[waited - 1].first) < cc.level_need_blocks[pl.run.l1 - 1]) {
+                    HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
+                    waited++;
+                }
+                launch_interp_lds(sb, mode, pl.qs, p.NQ, s->c->d_lds_recs + pl.run.rec0, pl.run.n_steps, pl.run.n_slots, p, nullptr, 1);
+                ctx->count();
+            }
+            continue;
         }
         if (s->c->run_of_level[l] >= 0 && mode != MODE_PROVE_V) {
             // a run of narrow levels: one launch for the whole run (its mask needs were waited for above

@@ -18,39 +18,11 @@
 #include <algorithm>
 
 #include "b3.h"
+#include "gf2dev.h"
 #include "internal.h"
 #include "launch.h"
 
 namespace rv {
-
-// DomainGF2::reconstruct on a quad word: per-byte parity, smeared to 0x00/0xFF
-__device__ __forceinline__ uint32_t recon32(uint32_t t) {
-    t ^= t >> 4;
-    t ^= t >> 2;
-    t ^= t >> 1;
-    t &= 0x01010101u;
-    return (t << 8) - t;
-}
-
-// corr / preprocessing bits are stored one bit per repetition: nibble bit k <-> byte k of the
-// smeared word (LSB-first), i.e. repetition 4q + 3 - k
-__device__ __forceinline__ uint32_t expand4(uint32_t n) {
-    const uint32_t t = (n | (n << 7) | (n << 14) | (n << 21)) & 0x01010101u;
-    return (t << 8) - t;
-}
-__device__ __forceinline__ uint32_t compress4(uint32_t x) {
-    const uint32_t y = x & 0x08040201u;
-    return (y | (y >> 8) | (y >> 16) | (y >> 24)) & 0xFu;
-}
-__device__ __forceinline__ uint32_t load_bits(const uint8_t* base, size_t row, uint32_t NQ, uint32_t q) {
-    return expand4(((uint32_t)base[row * (NQ >> 1) + (q >> 1)] >> (4 * (q & 1))) & 0xFu);
-}
-// the two quads sharing a byte are adjacent lanes of the same gate
-__device__ __forceinline__ void store_bits(uint8_t* base, size_t row, uint32_t NQ, uint32_t q, uint32_t smeared) {
-    const uint32_t n = compress4(smeared);
-    const uint32_t other = __shfl_xor(n, 1);
-    if (!(q & 1)) base[row * (NQ >> 1) + (q >> 1)] = (uint8_t)(n | (other << 4));
-}
 
 // XOR of the n listed base rows / their corr bits.  Unused slots hold the zero row, so all
 // RV_LIN_K slots are loaded unconditionally with STATIC indices (a runtime-indexed id array would

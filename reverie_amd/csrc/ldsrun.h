@@ -1,0 +1,71 @@
+// Narrow / deep stretches of a GF(2) circuit with the live wires in LDS ("LDS runs").
+//
+// A stretch of consecutive narrow dependency levels (ripple-carry adders, AES / SHA rounds from Bristol files: thousands
+// of levels of a few dozen gates) is latency-bound in the row interpreter: every level is one L2 round trip for the
+// operand rows plus a workgroup barrier, ~1.2 us, on ONE compute unit (k_interp_narrow, kernels.hip).  Here the
+// repetitions of the shard are cut into NQ / QS independent slices of QS quad words (4 QS repetitions); a slice is one
+// workgroup whose CONSUMER wavefront walks the run step by step -- a step = up to 64 / QS gates of one level, one lane
+// per (gate, quad word) -- with every wire that is live inside the run in an LDS slot (QS share words + QS corr bytes).
+// LDS operations of one wavefront execute in order, so consecutive steps need no barrier and no wait: a step costs its
+// LDS gather latency plus its arithmetic.  Nothing on the consumer's path touches global memory except fire-and-forget
+// stores (transcript rows, live-out wires): a PRODUCER wavefront of the same workgroup stages the step records and
+// every global operand a step needs (fresh mask rows, witness bits / supplied openings) into an LDS ring one chunk of
+// steps ahead, and the two meet at an LDS-only barrier once per chunk.
+//
+// The program (one record per gate slot of a step, slots allocated by liveness) is built on the host at circuit-compile
+// time; it does not depend on NQ, only on QS.
+//
+// Reference semantics: interpreter/single.rs:25-157 (Instance::step) exactly as interp_one_impl (kernels.hip) restates
+// them; this is a second schedule of the same gates, not a second implementation of the protocol.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "compile.h"
+
+namespace rv {
+
+constexpr uint32_t LR_CHUNK = 16;         // steps per producer/consumer hand-over
+constexpr uint32_t LR_NONE = 0xFFFFu;     // no LDS slot (a result nothing inside the run reads)
+// record kinds: GateOp values 0..5, plus
+constexpr uint32_t LK_LOAD = 6;           // live-in wire: slot <- global row `m` and its corr bits
+constexpr uint32_t LK_NOP = 7;
+constexpr uint32_t LF_CA = 1u << 4, LF_CB = 1u << 5;  // operand constants
+constexpr uint32_t LF_OUT = 1u << 6;      // the result is read after the run: also store row / corr bits to global memory
+
+struct LdsRec {  // 32 bytes
+    uint16_t a[RV_LIN_K], b[RV_LIN_K];  // operand slots (unused: slot 0 = the zero wire)
+    uint16_t dst;                       // result slot or LR_NONE
+    uint16_t op;                        // kind | LF_*
+    uint32_t eo, ep;                    // transcript rows (as in Gate)
+    uint32_t m;                         // Input / Random / Mul: first PRG mask row; Xor / Recon / Load: the global row of the result
+    uint32_t x;                         // as in Gate
+};
+static_assert(sizeof(LdsRec) == 32, "LdsRec layout");
+
+struct LdsRun {
+    uint32_t l0 = 0, l1 = 0;   // levels [l0, l1)
+    uint32_t n_steps = 0;      // multiple of LR_CHUNK
+    uint32_t n_slots = 0;      // LDS slots needed (slot 0 = the zero wire)
+    uint64_t rec0 = 0;         // first record in the circuit's record array; step s, gate k: rec0 + s * (64 / QS) + k
+};
+
+// LDS bytes a run needs at slice width QS (ring of two chunks + the wire slots)
+inline size_t lds_run_bytes(uint32_t QS, uint32_t n_slots) {
+    const size_t ring = 2 * (size_t)LR_CHUNK * ((64 / QS) * sizeof(LdsRec) + 64 * 16);
+    return ring + (size_t)n_slots * QS * 5 + 64;
+}
+
+struct LdsRunScratch {  // per circuit, sized n_rows, shared by all runs
+    std::vector<int32_t> last_use_level;  // last level that reads the row (-1: never)
+    std::vector<uint32_t> slot_of;        // row -> slot during a build (0xFFFFFFFF otherwise)
+    std::vector<int32_t> last_step;
+    void init(const Compiled& cc);
+};
+
+// Appends the run's records to `recs`.  false: the live wires do not fit `max_slots` (nothing appended).
+bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, uint32_t max_slots, LdsRunScratch& scratch,
+                   std::vector<LdsRec>& recs, LdsRun& run);
+
+}  // namespace rv

@@ -1,0 +1,172 @@
+// see ldsrun.h
+#include "ldsrun.h"
+
+#include <algorithm>
+#include <functional>
+#include <queue>
+
+namespace rv {
+
+namespace {
+constexpr uint32_t UNSET = 0xFFFFFFFFu, DEFINED = 0xFFFFFFFEu, LIVE_IN = 0xFFFFFFFDu;
+
+LdsRec nop_rec() {
+    LdsRec r{};
+    r.dst = (uint16_t)LR_NONE;
+    r.op = (uint16_t)LK_NOP;
+    return r;
+}
+}  // namespace
+
+void LdsRunScratch::init(const Compiled& cc) {
+    last_use_level.assign(cc.n_rows, -1);
+    slot_of.assign(cc.n_rows, UNSET);
+    last_step.assign(cc.n_rows, -1);
+    const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+    for (size_t l = 0; l < n_levels; l++)
+        for (uint32_t i = cc.level_start[l]; i < cc.level_start[l + 1]; i++) {
+            const Gate& g = cc.gates[i];
+            for (int k = 0; k < RV_LIN_K; k++) {
+                last_use_level[g.a[k]] = (int32_t)l;
+                last_use_level[g.b[k]] = (int32_t)l;
+            }
+        }
+    // B2A reads 64 consecutive GF(2) wires' rows from the Z64 interpreter: those rows must stay in global memory
+    for (size_t l = 0; l + 1 < cc.level_start64.size(); l++)
+        for (uint32_t i = cc.level_start64[l]; i < cc.level_start64[l + 1]; i++) {
+            const Gate64& g = cc.gates64[i];
+            if (g.op != G64_B2A) continue;
+            for (uint32_t k = 0; k < 64; k++)
+                if ((uint64_t)g.a + k < cc.n_rows) last_use_level[g.a + k] = std::max(last_use_level[g.a + k], (int32_t)l);
+        }
+}
+
+bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, uint32_t max_slots, LdsRunScratch& S,
+                   std::vector<LdsRec>& recs, LdsRun& run) {
+    const uint32_t GPS = 64 / QS;
+    const uint32_t zero = (uint32_t)cc.zero_row;
+    std::vector<uint32_t> touched, live_in;
+    auto reset = [&] {
+        for (uint32_t r : touched) {
+            S.slot_of[r] = UNSET;
+            S.last_step[r] = -1;
+        }
+    };
+    auto touch = [&](uint32_t r, uint32_t mark) {
+        if (S.slot_of[r] == UNSET) {
+            S.slot_of[r] = mark;
+            touched.push_back(r);
+        }
+    };
+    // ---- pass 1: live-in rows (read before any definition inside the run)
+    for (uint32_t i = cc.level_start[l0]; i < cc.level_start[l1]; i++) {
+        const Gate& g = cc.gates[i];
+        for (int k = 0; k < 2 * RV_LIN_K; k++) {
+            const uint32_t r = k < RV_LIN_K ? g.a[k] : g.b[k - RV_LIN_K];
+            if (r == zero || S.slot_of[r] != UNSET) continue;
+            touch(r, LIVE_IN);
+            live_in.push_back(r);
+        }
+        if (g_op(g) != G_ASSERT) touch(g.dst, DEFINED);
+    }
+    // ---- step numbering: load steps, then every level cut into steps of GPS gates
+    const uint32_t n_load_steps = (uint32_t)((live_in.size() + GPS - 1) / GPS);
+    std::vector<uint32_t> level_step0(l1 - l0 + 1);
+    uint32_t n_steps = n_load_steps;
+    for (uint32_t l = l0; l < l1; l++) {
+        level_step0[l - l0] = n_steps;
+        n_steps += (cc.level_start[l + 1] - cc.level_start[l] + GPS - 1) / GPS;
+    }
+    level_step0[l1 - l0] = n_steps;
+    const uint32_t n_steps_pad = (n_steps + LR_CHUNK - 1) / LR_CHUNK * LR_CHUNK;
+    // ---- pass 2: last step that reads each row
+    for (uint32_t l = l0; l < l1; l++)
+        for (uint32_t i = cc.level_start[l]; i < cc.level_start[l + 1]; i++) {
+            const Gate& g = cc.gates[i];
+            const int32_t st = (int32_t)(level_step0[l - l0] + (i - cc.level_start[l]) / GPS);
+            for (int k = 0; k < RV_LIN_K; k++) {
+                if (g.a[k] != zero) S.last_step[g.a[k]] = st;
+                if (g.b[k] != zero) S.last_step[g.b[k]] = st;
+            }
+        }
+    // ---- pass 3: slots by liveness (lowest free slot first, so the high-water mark stays small) and the records
+    std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> free_slots;
+    uint32_t fresh = 1;  // slot 0: the zero wire
+    bool fits = true;
+    auto take = [&]() -> uint32_t {
+        if (!free_slots.empty()) {
+            const uint32_t s = free_slots.top();
+            free_slots.pop();
+            return s;
+        }
+        if (fresh >= max_slots || fresh >= LR_NONE) {
+            fits = false;
+            return 0;
+        }
+        return fresh++;
+    };
+    std::vector<std::vector<uint32_t>> dies(n_steps_pad + 1);
+    const size_t rec_base = recs.size();
+    recs.resize(rec_base + (size_t)n_steps_pad * GPS, nop_rec());
+    auto define = [&](uint32_t row, uint32_t step) -> uint16_t {  // slot for a row written at `step` (LR_NONE if nothing here reads it)
+        if (S.last_step[row] < 0) {
+            S.slot_of[row] = DEFINED;
+            return (uint16_t)LR_NONE;
+        }
+        const uint32_t s = take();
+        S.slot_of[row] = s;
+        dies[(size_t)S.last_step[row]].push_back(s);
+        (void)step;
+        return (uint16_t)s;
+    };
+    auto release = [&](uint32_t step) {
+        for (uint32_t s : dies[step]) free_slots.push(s);
+        std::vector<uint32_t>().swap(dies[step]);
+    };
+    uint32_t step = 0;
+    for (size_t i = 0; i < live_in.size() && fits; i++) {
+        step = (uint32_t)(i / GPS);
+        LdsRec& r = recs[rec_base + (size_t)step * GPS + i % GPS];
+        r.op = (uint16_t)LK_LOAD;
+        r.m = live_in[i];
+        r.dst = define(live_in[i], step);
+        if (i % GPS == GPS - 1 || i + 1 == live_in.size()) release(step);
+    }
+    for (uint32_t l = l0; l < l1 && fits; l++) {
+        const uint32_t lo = cc.level_start[l], hi = cc.level_start[l + 1];
+        for (uint32_t i = lo; i < hi && fits; i++) {
+            const Gate& g = cc.gates[i];
+            step = level_step0[l - l0] + (i - lo) / GPS;
+            LdsRec& r = recs[rec_base + (size_t)step * GPS + (i - lo) % GPS];
+            const uint32_t op = g_op(g);
+            for (int k = 0; k < RV_LIN_K; k++) {
+                r.a[k] = g.a[k] == zero ? 0 : (uint16_t)S.slot_of[g.a[k]];
+                r.b[k] = g.b[k] == zero ? 0 : (uint16_t)S.slot_of[g.b[k]];
+            }
+            uint32_t flags = (g_ca(g) ? LF_CA : 0u) | (g_cb(g) ? LF_CB : 0u);
+            r.eo = g.eo;
+            r.ep = g.ep;
+            r.x = g.x;
+            r.m = (op == G_XORK || op == G_RECON) ? g.dst : g.m;
+            if (op != G_ASSERT) {
+                r.dst = define(g.dst, step);
+                if (S.last_use_level[g.dst] >= (int32_t)l1) flags |= LF_OUT;
+            }
+            r.op = (uint16_t)(op | flags);
+            if ((i - lo) % GPS == GPS - 1 || i + 1 == hi) release(step);
+        }
+    }
+    reset();
+    if (!fits) {
+        recs.resize(rec_base);
+        return false;
+    }
+    run.l0 = l0;
+    run.l1 = l1;
+    run.n_steps = n_steps_pad;
+    run.n_slots = fresh;
+    run.rec0 = rec_base;
+    return true;
+}
+
+}  // namespace rv

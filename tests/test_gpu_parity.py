@@ -1005,3 +1005,122 @@ def test_rep_sliced_path(rv, oracle, rule_seeds, monkeypatch, mode):
             for s in shards:
                 be.destroy(s)
             assert assemble(comm, parts) == want
+
+
+def _hourglass(seed=5):
+    """600 inputs (a wide level), 40 narrow layers of 32 gates reading them, then 1024 Mul gates (a wide level again) that
+    read wires of the narrow part and inputs, folded by Add gates into asserts: the narrow stretch has live-in AND
+    live-out wires"""
+    prog, wit, wc, st = circuits.layered_gf2(n_in=600, width=32, layers=40, fold_to=32, seed=0x5EED0000000000AA + seed)
+    rng = np.random.default_rng(seed)
+    # clear values of every wire of the SSA part (inputs, then layer outputs), to make the final asserts valid
+    vals = np.zeros(wc[1] + 4096, np.uint8)
+    vals[:600] = wit
+    for op in prog:
+        oc, d, a, b = int(op["opcode"]), int(op["dst"]), int(op["a"]), int(op["b"])
+        if oc == circuits.OP_MUL:
+            vals[d] = vals[a] & vals[b]
+        elif oc == circuits.OP_ADD:
+            vals[d] = vals[a] ^ vals[b]
+        elif oc == circuits.OP_ADDCONST:
+            vals[d] = vals[a] ^ (int(op["imm"]) & 1)
+    n0 = wc[1]
+    wide = np.zeros(1024, circuits.OP_DTYPE)
+    wide["domain"] = circuits.DOM_GF2
+    wide["opcode"] = circuits.OP_MUL
+    wide["dst"] = np.arange(n0, n0 + 1024, dtype=np.uint32)
+    wide["a"] = rng.integers(600 + 32 * 30, 600 + 32 * 40, 1024).astype(np.uint32)   # the last ten narrow layers
+    wide["b"] = np.where(rng.random(1024) < 0.5, rng.integers(0, 600, 1024), rng.integers(600, 600 + 32 * 40, 1024)).astype(np.uint32)
+    vals[n0:n0 + 1024] = vals[wide["a"]] & vals[wide["b"]]
+    tail = []
+    cur = list(range(n0, n0 + 1024))
+    nxt = n0 + 1024
+    while len(cur) > 4:
+        half = len(cur) // 2
+        t = np.zeros(half, circuits.OP_DTYPE)
+        t["domain"] = circuits.DOM_GF2
+        t["opcode"] = circuits.OP_ADD
+        t["dst"] = np.arange(nxt, nxt + half, dtype=np.uint32)
+        t["a"] = np.array(cur[:half], np.uint32)
+        t["b"] = np.array(cur[half:], np.uint32)
+        vals[nxt:nxt + half] = vals[t["a"]] ^ vals[t["b"]]
+        tail.append(t)
+        cur = list(range(nxt, nxt + half))
+        nxt += half
+    t = np.zeros(2 * len(cur), circuits.OP_DTYPE)
+    t["domain"] = circuits.DOM_GF2
+    t["opcode"][0::2] = circuits.OP_ADDCONST
+    t["dst"][0::2] = np.arange(nxt, nxt + len(cur), dtype=np.uint32)
+    t["a"][0::2] = np.array(cur, np.uint32)
+    t["imm"][0::2] = vals[cur].astype(np.uint64)
+    t["opcode"][1::2] = circuits.OP_ASSERTZERO
+    t["a"][1::2] = np.arange(nxt, nxt + len(cur), dtype=np.uint32)
+    nxt += len(cur)
+    return np.ascontiguousarray(np.concatenate([prog, wide] + tail + [t])), wit, (0, nxt)
+
+
+@pytest.mark.parametrize("qs", ["0", "2", "4"])
+def test_lds_runs(rv, oracle, rule_seeds, monkeypatch, qs):
+    """Narrow stretches with the live wires in LDS (csrc/ldsrun.*; slice width RV_LDS_QS): prover and verifier must agree
+    with the oracle byte for byte -- random narrow programs with every op kind (Random gates, constants, wire reuse,
+    asserts), mixed GF(2) / Z64 / B2A programs (narrow GF(2) stretches between Z64 levels), a circuit whose narrow stretch
+    has live-in and live-out wires, a rejected witness, tampered proofs, and repetition shards of 128 / 64 / 32"""
+    from reverie_amd.dist import HipShardBackend, assemble
+    from reverie_amd.proof import challenge, combine_digests
+
+    monkeypatch.setenv("RV_LDS_QS", qs)
+    rng = np.random.default_rng(1234 + int(qs))
+    for trial in range(5):
+        prog, wit, wc = circuits.random_gf2(rng, n_in=int(rng.integers(1, 60)), n_gates=int(rng.integers(100, 4000)), n_wires=int(rng.integers(8, 300)))
+        seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+        want = oracle.prove(prog, wit, [], wc, seeds)
+        proof = rv.Proof.new(prog, wit, [], wc, seeds=seeds)
+        assert bytes(proof) == want, trial
+        assert proof.verify(prog, wc), trial
+        bad = bytearray(want)
+        bad[int(rng.integers(40, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            w = oracle.verify(prog, wc, bytes(bad))
+        except oracle.OracleError:
+            w = None
+        try:
+            g = rv.Proof(bytes(bad)).verify(prog, wc, strict=False)
+        except rv.ReverieError:
+            g = None
+        assert g == w, trial
+    for trial in range(3):
+        prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=int(rng.integers(100, 600)))
+        seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+        want = oracle.prove(prog, w2, w64, wc, seeds)
+        proof = rv.Proof.new(prog, w2, w64, wc, seeds=seeds)
+        assert bytes(proof) == want, trial
+        assert proof.verify(prog, wc), trial
+    prog, wit, wc = _hourglass()
+    want = oracle.prove(prog, wit, [], wc, rule_seeds)
+    c = rv.Circuit(prog, wc)
+    proof = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+    assert bytes(proof) == want
+    assert proof.verify(c)
+    monkeypatch.setenv("RV_LDS_RUN", "0")
+    assert bytes(rv.Proof.new(prog, wit, [], wc, seeds=rule_seeds)) == want  # (the row path on the same circuit)
+    monkeypatch.delenv("RV_LDS_RUN")
+    bad = wit.copy()
+    bad[3] ^= 1
+    try:
+        oracle.prove(prog, bad, [], wc, rule_seeds)
+        rejected = False
+    except oracle.OracleError:
+        rejected = True
+    if rejected:
+        with pytest.raises(rv.ReverieError) as e:
+            rv.Proof.new(c, bad, [], seeds=rule_seeds)
+        assert e.value.code == 1
+    be = HipShardBackend(c)
+    for per in (128, 64, 32):
+        shards = [be.commit(wit, [], rule_seeds[b:b + per], b, per) for b in range(0, 256, per)]
+        comm = combine_digests(np.concatenate([be.digests(s) for s in shards]))
+        omit = challenge(comm)
+        parts = [be.open(s, omit)[:2] for s in shards]
+        for s in shards:
+            be.destroy(s)
+        assert assemble(comm, parts) == want, per
