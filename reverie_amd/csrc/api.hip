@@ -579,7 +579,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
                     const uint32_t qs = (qs_env == 2 || qs_env == 4) ? qs_env : (n_g / (e - l) <= 24 ? 4u : 2u);
                     const size_t budget = 160 * 1024 - 1024;
                     const size_t fixed = lds_run_bytes(qs, 0);
-                    const uint32_t max_slots = (uint32_t)std::min<size_t>((budget - fixed) / (qs * 5), LR_NONE - 1);
+                    const uint32_t max_slots = (uint32_t)std::min<size_t>((budget - fixed) / (qs * 8), LR_NONE - 1);
                     rv_circuit::LdsPlan plan{};
                     plan.qs = qs;
                     if (build_lds_run(cc, (uint32_t)l, (uint32_t)e, qs, max_slots, scratch, recs, plan.run)) {
@@ -854,6 +854,16 @@ static int shard_run_alloc(rv_shard* s, InterpParams& p, Interp64Params& p64) {
     p64.NQ = s->NQ;
     p64.err = s->d_err;
     return RV_OK;
+}
+
+// Batched proofs: an LDS run takes NQ / qs workgroups per proof, each alone on a compute unit and mostly waiting on its
+// own dependency chain -- better than one workgroup per proof (k_interp_narrow_b, ~3x slower per proof) only while the
+// whole batch still finds room on the chip at once or nearly so (RV_LDS_BATCH_WGS overrides the limit)
+static bool lds_run_for_batch(const rv_circuit* c, size_t level, size_t batch) {
+    if (c->lds_run_of_level[level] < 0) return false;
+    const auto& pl = c->lds_runs[(size_t)c->lds_run_of_level[level]];
+    const size_t limit = getenv("RV_LDS_BATCH_WGS") ? (size_t)atoll(getenv("RV_LDS_BATCH_WGS")) : 768;
+    return batch * (RV_TOTAL_REPS / 4 / pl.qs) <= limit;
 }
 
 static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const Interp64Params& p64) {
@@ -1806,6 +1816,13 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
     {
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
         for (size_t l = 0; l < n_levels; l++) {
+            if (lds_run_for_batch(c, l, batch)) {
+                const auto& pl = c->lds_runs[(size_t)c->lds_run_of_level[l]];
+                if (l == pl.run.l0)
+                    launch_interp_lds(ctx->stream, MODE_PROVE, pl.qs, RV_TOTAL_REPS / 4, c->d_lds_recs + pl.run.rec0, pl.run.n_steps, pl.run.n_slots,
+                                      InterpParams{}, d_pp, (uint32_t)batch);
+                continue;
+            }
             if (c->run_of_level[l] >= 0) {
                 const auto& run = c->narrow_runs[(size_t)c->run_of_level[l]];
                 if (l == run.first)
@@ -2559,6 +2576,13 @@ static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, 
     {
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
         for (size_t l = 0; l < n_levels; l++) {
+            if (lds_run_for_batch(c, l, B)) {
+                const auto& pl = c->lds_runs[(size_t)c->lds_run_of_level[l]];
+                if (l == pl.run.l0)
+                    launch_interp_lds(ctx->stream, MODE_VERIFY, pl.qs, RV_TOTAL_REPS / 4, c->d_lds_recs + pl.run.rec0, pl.run.n_steps, pl.run.n_slots,
+                                      InterpParams{}, d_pp, (uint32_t)B);
+                continue;
+            }
             if (c->run_of_level[l] >= 0) {
                 const auto& run = c->narrow_runs[(size_t)c->run_of_level[l]];
                 if (l == run.first)

@@ -5,7 +5,7 @@
 // operand rows plus a workgroup barrier, ~1.2 us, on ONE compute unit (k_interp_narrow, kernels.hip).  Here the
 // repetitions of the shard are cut into NQ / QS independent slices of QS quad words (4 QS repetitions); a slice is one
 // workgroup whose CONSUMER wavefront walks the run step by step -- a step = up to 64 / QS gates of one level, one lane
-// per (gate, quad word) -- with every wire that is live inside the run in an LDS slot (QS share words + QS corr bytes).
+// per (gate, quad word) -- with every wire that is live inside the run in an LDS slot (QS share words + QS words of corr bits).
 // LDS operations of one wavefront execute in order, so consecutive steps need no barrier and no wait: a step costs its
 // LDS gather latency plus its arithmetic.  Nothing on the consumer's path touches global memory except fire-and-forget
 // stores (transcript rows, live-out wires): a PRODUCER wavefront of the same workgroup stages the step records and
@@ -27,16 +27,19 @@
 namespace rv {
 
 constexpr uint32_t LR_CHUNK = 16;         // steps per producer/consumer hand-over
-constexpr uint32_t LR_NONE = 0xFFFFu;     // no LDS slot (a result nothing inside the run reads)
+constexpr uint32_t LR_NONE = 0xFFFFu;     // (builder) no LDS slot yet
 // record kinds: GateOp values 0..5, plus
 constexpr uint32_t LK_LOAD = 6;           // live-in wire: slot <- global row `m` and its corr bits
 constexpr uint32_t LK_NOP = 7;
 constexpr uint32_t LF_CA = 1u << 4, LF_CB = 1u << 5;  // operand constants
 constexpr uint32_t LF_OUT = 1u << 6;      // the result is read after the run: also store row / corr bits to global memory
+constexpr uint32_t LF_ON = 1u << 7;       // the gate puts a row on the online transcript (Input, Mul, AssertZero, Recon)
+// one-hot copy of the kind (the step code selects its results with masks made from these bits, not with branches)
+constexpr uint32_t LB_MUL = 8, LB_XOR = 9, LB_RECON = 10, LB_IN = 11, LB_OTHER = 12, LB_ASSERT = 13;
 
 struct LdsRec {  // 32 bytes
     uint16_t a[RV_LIN_K], b[RV_LIN_K];  // operand slots (unused: slot 0 = the zero wire)
-    uint16_t dst;                       // result slot or LR_NONE
+    uint16_t dst;                       // result slot (a result nothing inside the run reads goes to the run's scratch slot)
     uint16_t op;                        // kind | LF_*
     uint32_t eo, ep;                    // transcript rows (as in Gate)
     uint32_t m;                         // Input / Random / Mul: first PRG mask row; Xor / Recon / Load: the global row of the result
@@ -47,14 +50,14 @@ static_assert(sizeof(LdsRec) == 32, "LdsRec layout");
 struct LdsRun {
     uint32_t l0 = 0, l1 = 0;   // levels [l0, l1)
     uint32_t n_steps = 0;      // multiple of LR_CHUNK
-    uint32_t n_slots = 0;      // LDS slots needed (slot 0 = the zero wire)
+    uint32_t n_slots = 0;      // LDS slots needed (slot 0 = the zero wire, the last one = scratch)
     uint64_t rec0 = 0;         // first record in the circuit's record array; step s, gate k: rec0 + s * (64 / QS) + k
 };
 
 // LDS bytes a run needs at slice width QS (ring of two chunks + the wire slots)
 inline size_t lds_run_bytes(uint32_t QS, uint32_t n_slots) {
     const size_t ring = 2 * (size_t)LR_CHUNK * ((64 / QS) * sizeof(LdsRec) + 64 * 16);
-    return ring + (size_t)n_slots * QS * 5 + 64;
+    return ring + (size_t)n_slots * QS * 8 + 64;
 }
 
 struct LdsRunScratch {  // per circuit, sized n_rows, shared by all runs

@@ -10,10 +10,14 @@ namespace rv {
 namespace {
 constexpr uint32_t UNSET = 0xFFFFFFFFu, DEFINED = 0xFFFFFFFEu, LIVE_IN = 0xFFFFFFFDu;
 
+uint16_t op_word(uint32_t kind, uint32_t flags) {
+    const uint32_t hot = kind == G_MUL ? LB_MUL : kind == G_XORK ? LB_XOR : kind == G_RECON ? LB_RECON : kind == G_INPUT ? LB_IN : LB_OTHER;
+    return (uint16_t)(kind | flags | (1u << hot) | (kind == G_ASSERT ? 1u << LB_ASSERT : 0u));
+}
 LdsRec nop_rec() {
     LdsRec r{};
     r.dst = (uint16_t)LR_NONE;
-    r.op = (uint16_t)LK_NOP;
+    r.op = op_word(LK_NOP, 0);
     return r;
 }
 }  // namespace
@@ -127,7 +131,7 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
     for (size_t i = 0; i < live_in.size() && fits; i++) {
         step = (uint32_t)(i / GPS);
         LdsRec& r = recs[rec_base + (size_t)step * GPS + i % GPS];
-        r.op = (uint16_t)LK_LOAD;
+        r.op = op_word(LK_LOAD, 0);
         r.m = live_in[i];
         r.dst = define(live_in[i], step);
         if (i % GPS == GPS - 1 || i + 1 == live_in.size()) release(step);
@@ -144,6 +148,7 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
                 r.b[k] = g.b[k] == zero ? 0 : (uint16_t)S.slot_of[g.b[k]];
             }
             uint32_t flags = (g_ca(g) ? LF_CA : 0u) | (g_cb(g) ? LF_CB : 0u);
+            if (op == G_INPUT || op == G_MUL || op == G_ASSERT || op == G_RECON) flags |= LF_ON;
             r.eo = g.eo;
             r.ep = g.ep;
             r.x = g.x;
@@ -152,15 +157,19 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
                 r.dst = define(g.dst, step);
                 if (S.last_use_level[g.dst] >= (int32_t)l1) flags |= LF_OUT;
             }
-            r.op = (uint16_t)(op | flags);
+            r.op = op_word(op, flags);
             if ((i - lo) % GPS == GPS - 1 || i + 1 == hi) release(step);
         }
     }
     reset();
+    if (fits && (fresh >= max_slots || fresh >= LR_NONE)) fits = false;  // (the scratch slot)
     if (!fits) {
         recs.resize(rec_base);
         return false;
     }
+    for (size_t i = rec_base; i < recs.size(); i++)
+        if (recs[i].dst == LR_NONE) recs[i].dst = (uint16_t)fresh;  // results nothing here reads, no-ops
+    fresh++;
     run.l0 = l0;
     run.l1 = l1;
     run.n_steps = n_steps_pad;

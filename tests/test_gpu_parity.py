@@ -1115,6 +1115,17 @@ def test_lds_runs(rv, oracle, rule_seeds, monkeypatch, qs):
         with pytest.raises(rv.ReverieError) as e:
             rv.Proof.new(c, bad, [], seeds=rule_seeds)
         assert e.value.code == 1
+    # batched proofs: the LDS runs serve small batches, one workgroup per proof (k_interp_narrow_b) the large ones
+    nb = 4
+    bseeds = rng.integers(0, 256, (nb, 256, 16), dtype=np.uint8)
+    singles = [bytes(rv.Proof.new(c, wit, [], seeds=bseeds[b])) for b in range(nb)]
+    assert singles[0] == oracle.prove(prog, wit, [], wc, bseeds[0])
+    for limit in ("100000", "0"):
+        monkeypatch.setenv("RV_LDS_BATCH_WGS", limit)
+        got = rv.Proof.new_batch(c, np.tile(np.asarray(wit, np.uint8), (nb, 1)), seeds=bseeds)
+        assert [bytes(g) for g in got] == singles, limit
+        assert rv.verify_batch(c, got, strict=True) == [True] * nb, limit
+    monkeypatch.delenv("RV_LDS_BATCH_WGS")
     be = HipShardBackend(c)
     for per in (128, 64, 32):
         shards = [be.commit(wit, [], rule_seeds[b:b + per], b, per) for b in range(0, 256, per)]
