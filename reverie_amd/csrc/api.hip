@@ -575,8 +575,9 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
                 size_t e = l;
                 while (e < n_levels && narrow(e)) e++;
                 if (e - l >= 3) {
-                    const uint64_t n_g = cc.level_start[e] - cc.level_start[l];
-                    const uint32_t qs = (qs_env == 2 || qs_env == 4) ? qs_env : (n_g / (e - l) <= 24 ? 4u : 2u);
+                    // two quad words per slice: the fewest steps per level (64 / qs gates each) a pair of quads sharing
+                    // a preprocessing byte allows, and the most workgroups; 4 only on request
+                    const uint32_t qs = qs_env == 4 ? 4u : 2u;
                     const size_t budget = 160 * 1024 - 1024;
                     const size_t fixed = lds_run_bytes(qs, 0);
                     const uint32_t max_slots = (uint32_t)std::min<size_t>((budget - fixed) / (qs * 8), LR_NONE - 1);
@@ -889,7 +890,7 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
                     HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
                     waited++;
                 }
-                launch_interp_lds(sb, mode, pl.qs, p.NQ, s->c->d_lds_recs + pl.run.rec0, pl.run.n_steps, pl.run.n_slots, p, nullptr, 1);
+                launch_interp_lds(sb, mode, pl.qs, p.NQ, s->c->d_lds_recs + pl.run.rec0, pl.run.n_steps, pl.run.n_slots, pl.run.eo0, pl.run.ep0, p, nullptr, 1);
                 ctx->count();
             }
             continue;
@@ -1820,7 +1821,7 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
                 const auto& pl = c->lds_runs[(size_t)c->lds_run_of_level[l]];
                 if (l == pl.run.l0)
                     launch_interp_lds(ctx->stream, MODE_PROVE, pl.qs, RV_TOTAL_REPS / 4, c->d_lds_recs + pl.run.rec0, pl.run.n_steps, pl.run.n_slots,
-                                      InterpParams{}, d_pp, (uint32_t)batch);
+                                      pl.run.eo0, pl.run.ep0, InterpParams{}, d_pp, (uint32_t)batch);
                 continue;
             }
             if (c->run_of_level[l] >= 0) {
@@ -2580,7 +2581,7 @@ static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, 
                 const auto& pl = c->lds_runs[(size_t)c->lds_run_of_level[l]];
                 if (l == pl.run.l0)
                     launch_interp_lds(ctx->stream, MODE_VERIFY, pl.qs, RV_TOTAL_REPS / 4, c->d_lds_recs + pl.run.rec0, pl.run.n_steps, pl.run.n_slots,
-                                      InterpParams{}, d_pp, (uint32_t)B);
+                                      pl.run.eo0, pl.run.ep0, InterpParams{}, d_pp, (uint32_t)B);
                 continue;
             }
             if (c->run_of_level[l] >= 0) {

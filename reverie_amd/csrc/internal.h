@@ -165,7 +165,7 @@ void launch_interp_batched(hipStream_t st, const Gate* d_gates, const LevelRange
 // a narrow stretch with its live wires in LDS (ldsrun.h); d_pp != null: `batch` proofs, parameters from the device array
 struct LdsRec;
 void launch_interp_lds(hipStream_t st, int mode, uint32_t QS, uint32_t NQ, const LdsRec* d_recs, uint32_t n_steps, uint32_t n_slots,
-                       const InterpParams& p, const InterpParams* d_pp, uint32_t batch);
+                       uint32_t eo0, uint32_t ep0, const InterpParams& p, const InterpParams* d_pp, uint32_t batch);
 void launch_interp_narrow_batched(hipStream_t st, const Gate* d_gates, const LevelRange* d_level_range, uint32_t l0, uint32_t l1,
                                   int tiny, const InterpParams* d_pp, uint32_t batch, int mode = MODE_PROVE);
 void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t lo, uint32_t hi, const Interp64Params& p);

@@ -26,7 +26,7 @@
 
 namespace rv {
 
-constexpr uint32_t LR_CHUNK = 16;         // steps per producer/consumer hand-over
+constexpr uint32_t LR_CHUNK = 8;          // steps per producer/consumer hand-over
 constexpr uint32_t LR_NONE = 0xFFFFu;     // (builder) no LDS slot yet
 // record kinds: GateOp values 0..5, plus
 constexpr uint32_t LK_LOAD = 6;           // live-in wire: slot <- global row `m` and its corr bits
@@ -51,12 +51,13 @@ struct LdsRun {
     uint32_t l0 = 0, l1 = 0;   // levels [l0, l1)
     uint32_t n_steps = 0;      // multiple of LR_CHUNK
     uint32_t n_slots = 0;      // LDS slots needed (slot 0 = the zero wire, the last one = scratch)
+    uint32_t eo0 = 0, ep0 = 0; // lowest online / preprocessing transcript row written by the run
     uint64_t rec0 = 0;         // first record in the circuit's record array; step s, gate k: rec0 + s * (64 / QS) + k
 };
 
 // LDS bytes a run needs at slice width QS (ring of two chunks + the wire slots)
 inline size_t lds_run_bytes(uint32_t QS, uint32_t n_slots) {
-    const size_t ring = 2 * (size_t)LR_CHUNK * ((64 / QS) * sizeof(LdsRec) + 64 * 16);
+    const size_t ring = 2 * (size_t)LR_CHUNK * 4 * 64 * 16;  // per step and lane: four 16-byte fields (ldsrun.hip)
     return ring + (size_t)n_slots * QS * 8 + 64;
 }
 

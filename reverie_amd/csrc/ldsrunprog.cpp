@@ -128,6 +128,7 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
         std::vector<uint32_t>().swap(dies[step]);
     };
     uint32_t step = 0;
+    uint32_t eo_lo = 0xFFFFFFFFu, eo_hi = 0, ep_lo = 0xFFFFFFFFu, ep_hi = 0;
     for (size_t i = 0; i < live_in.size() && fits; i++) {
         step = (uint32_t)(i / GPS);
         LdsRec& r = recs[rec_base + (size_t)step * GPS + i % GPS];
@@ -148,7 +149,15 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
                 r.b[k] = g.b[k] == zero ? 0 : (uint16_t)S.slot_of[g.b[k]];
             }
             uint32_t flags = (g_ca(g) ? LF_CA : 0u) | (g_cb(g) ? LF_CB : 0u);
-            if (op == G_INPUT || op == G_MUL || op == G_ASSERT || op == G_RECON) flags |= LF_ON;
+            if (op == G_INPUT || op == G_MUL || op == G_ASSERT || op == G_RECON) {
+                flags |= LF_ON;
+                eo_lo = std::min(eo_lo, g.eo);
+                eo_hi = std::max(eo_hi, g.eo);
+            }
+            if (op == G_MUL) {
+                ep_lo = std::min(ep_lo, g.ep);
+                ep_hi = std::max(ep_hi, g.ep);
+            }
             r.eo = g.eo;
             r.ep = g.ep;
             r.x = g.x;
@@ -163,6 +172,10 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
     }
     reset();
     if (fits && (fresh >= max_slots || fresh >= LR_NONE)) fits = false;  // (the scratch slot)
+    // transcript stores use 32-bit byte offsets from the run's lowest row (rows are at most 256 bytes)
+    if (eo_lo > eo_hi) eo_lo = eo_hi = 0;
+    if (ep_lo > ep_hi) ep_lo = ep_hi = 0;
+    if ((uint64_t)(eo_hi - eo_lo) >= (1ull << 24) - 1 || (uint64_t)(ep_hi - ep_lo) >= (1ull << 24) - 1) fits = false;
     if (!fits) {
         recs.resize(rec_base);
         return false;
@@ -175,6 +188,8 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
     run.n_steps = n_steps_pad;
     run.n_slots = fresh;
     run.rec0 = rec_base;
+    run.eo0 = eo_lo;
+    run.ep0 = ep_lo;
     return true;
 }
 
