@@ -40,6 +40,7 @@ struct Builder {
     std::vector<Gate64> gates64;
     std::vector<uint32_t> level64;
     std::vector<int32_t> ssa_level64;
+    std::vector<uint32_t> ssa_row64;  // z64 SSA id -> where its mask row lives (wmask row id, or G64_MASK_ROW | PRG mask row)
     std::vector<uint32_t> cur64;
     uint32_t max_level = 0;
     bool any = false;
@@ -58,6 +59,7 @@ struct Builder {
         lin.emplace_back();  // SSA 0: the default wire = constant 0
         lvl_comp.push_back(-1);
         ssa_level64.push_back(-1);
+        ssa_row64.push_back(0);
         if (counting) uses.assign(1, 0);
     }
 
@@ -80,6 +82,7 @@ struct Builder {
     }
     uint32_t new_ssa64(int32_t lvl) {
         ssa_level64.push_back(lvl);
+        ssa_row64.push_back((uint32_t)(ssa_level64.size() - 1));  // its own wmask row, unless a fresh mask row IS the wire's mask
         return (uint32_t)(ssa_level64.size() - 1);
     }
     void use(uint32_t ssa) {
@@ -95,7 +98,16 @@ struct Builder {
         level.push_back(lvl);
         note(lvl);
     }
-    void emit64(const Gate64& g, uint32_t lvl) {
+    void emit64(const Gate64& g0, uint32_t lvl) {
+        Gate64 g = g0;
+        if (g.op != G64_B2A) {  // (B2A's a is a GF(2) row)
+            g.am = ssa_row64[g.a];
+            g.bm = ssa_row64[g.b];
+        }
+        // Input / Random / Mul: the result's mask is the fresh mask itself (z64 share.rs: the new sharing) -- later
+        // gates read that PRG row instead of a copy
+        if (g.op == G64_INPUT || g.op == G64_RANDOM) ssa_row64[g.dst] = G64_MASK_ROW | g.m;
+        if (g.op == G64_MUL) ssa_row64[g.dst] = G64_MASK_ROW | (g.m + 1);
         if (counting) return;
         gates64.push_back(g);
         level64.push_back(lvl);

@@ -76,7 +76,9 @@ struct Gate64 {
     uint32_t x;    // Input: witness index / input ordinal; Mul, AssertZero: reconstruction ordinal
     uint32_t xc;   // Mul, B2A: correction ordinal
     uint64_t imm;  // constants
+    uint32_t am, bm;  // where the operands' mask rows live: a wmask row (= the SSA id) or G64_MASK_ROW | PRG mask row
 };
+constexpr uint32_t G64_MASK_ROW = 0x80000000u;
 
 enum Gate64Op : uint32_t {
     G64_INPUT = 0, G64_ADD, G64_SUB, G64_ADDC, G64_SUBC, G64_MULC, G64_MUL, G64_ASSERT, G64_RANDOM, G64_CONST, G64_B2A

@@ -79,9 +79,10 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
         const Gate64 g = gates[gi];
         uint64_t* dm = p.wmask + (size_t)g.dst * S + 2 * l;
         uint64_t* dc = p.wcorr + (size_t)g.dst * p.R + r;
-        const uint64_t* am = p.wmask + (size_t)g.a * S + 2 * l;
+        // an operand's mask row: its own wmask row, or the fresh PRG mask row that IS the wire's mask (Input / Random / Mul results)
+        const uint64_t* am = ((g.am & G64_MASK_ROW) ? p.masks + (size_t)(g.am & ~G64_MASK_ROW) * S : p.wmask + (size_t)g.am * S) + 2 * l;
         const uint64_t* ac = p.wcorr + (size_t)g.a * p.R + r;
-        const uint64_t* bm = p.wmask + (size_t)g.b * S + 2 * l;
+        const uint64_t* bm = ((g.bm & G64_MASK_ROW) ? p.masks + (size_t)(g.bm & ~G64_MASK_ROW) * S : p.wmask + (size_t)g.bm * S) + 2 * l;
         const uint64_t* bc = p.wcorr + (size_t)g.b * p.R + r;
         switch (g.op) {
         case G64_INPUT: {
@@ -91,7 +92,6 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
                 corr = p.wit[g.x] - sum8(lam);
             else
                 corr = online ? p.sup_in[(size_t)g.x * p.R + r] : 0;
-            st2(dm, lam);
             if (pk == 0) {
                 *dc = corr;
                 p.on[(size_t)r * p.on_words + g.eo] = corr;
@@ -129,7 +129,6 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
             if (pk == 0) *dc = g.imm;
             break;
         case G64_RANDOM:
-            st2(dm, ld2(p.masks + (size_t)g.m * S + 2 * l));
             if (pk == 0) *dc = 0;
             break;
         case G64_MUL: {
@@ -149,7 +148,6 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
             st2_unaligned(p.on + (size_t)r * p.on_words + g.eo + 2 * pk, s);
             uint64_t rec = sum8(s);
             if (MODE == MODE_VERIFY && !online) rec = 0;
-            st2(dm, lnew);
             if (pk == 0) {
                 p.pre[(size_t)r * p.pre_words + g.ep] = delta;
                 *dc = rec + delta + cx * cy;
