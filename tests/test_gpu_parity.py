@@ -222,6 +222,38 @@ def test_z64_layered_vs_oracle(rv, oracle, rule_seeds):
     assert c.info["z64_muls"] == st["mul"]
 
 
+def test_z64_mid_size_vs_oracle_and_full_size_round_trip(rv, oracle, rule_seeds):
+    """config 5: 10^5 Mul gates of the full-size generator byte for byte against the oracle (the aliased
+    fresh mask rows, 16 384-wide levels), then the full 10^6-Mul circuit through prove -> strict verify, a second proof
+    with the same seeds (deterministic), and a flipped byte in the Z64 openings (must be rejected)"""
+    prog, wit, wc, st = circuits.layered_z64(n_mul=100_000)
+    assert st["mul"] >= 100_000
+    want = oracle.prove(prog, [], wit, wc, rule_seeds, threads=32)
+    c = rv.Circuit(prog, wc)
+    proof = rv.Proof.new(c, [], wit, seeds=rule_seeds)
+    assert bytes(proof) == want
+    assert proof.verify(c)
+    del proof, want, c
+    prog, wit, wc, st = circuits.layered_z64(n_mul=1_000_000)
+    c = rv.Circuit(prog, wc)
+    proof = rv.Proof.new(c, [], wit, seeds=rule_seeds)
+    assert proof.verify(c)
+    first = bytes(proof)
+    del proof
+    again = rv.Proof.new(c, [], wit, seeds=rule_seeds)
+    assert bytes(again) == first
+    del again
+    n = len(first)
+    bad = bytearray(first)
+    del first
+    bad[n - 216 * 48 - 4096] ^= 1
+    try:
+        ok = rv.Proof(bytes(bad)).verify(c, strict=False)
+    except rv.ReverieError:
+        ok = False
+    assert not ok
+
+
 def test_layered_circuit_vs_oracle(rv, oracle, rule_seeds):
     """config-4 generator at a size the oracle finishes in seconds"""
     prog, wit, wc, st = circuits.layered_gf2(n_in=256, width=2048, layers=12)
