@@ -145,6 +145,18 @@ def bristol_case(name):
     return prog, bits(block), info["wire_counts"], info["n_and"]
 
 
+def phase_ms(ctx, run, n):
+    """per-phase HIP-event times (ms per proof) of `run()`, which makes n proofs"""
+    from reverie_amd import _lib
+
+    L = _lib.lib()
+    L.rv_ctx_profile(ctx.handle, 1, 1, None)
+    run()
+    prof = _lib.Profile()
+    L.rv_ctx_profile(ctx.handle, 0, 0, C.byref(prof))
+    return {nm: prof.ms[i] / n for i, nm in enumerate(_lib.PHASES)}
+
+
 def secondary_records(ctx, seeds, quick):
     """Configs 2, 3 and 5 through the host-bytes entry points; every record carries its parity flag"""
     import circuits
@@ -164,8 +176,20 @@ def secondary_records(ctx, seeds, quick):
         want = oracle_lib.prove(prog, w2, [], wc, seeds, threads=8)
         rec = {"and_gates": n_and, "levels": circ.info["levels"], "proof_bytes": len(data),
                "single_proof_ms": statistics.median(lat) * 1e3, "single_proof_and_per_s": n_and / statistics.median(lat),
-               "bit_exact_vs_cpu": data == want, "verifies_strict": bool(reverie_amd.Proof(data).verify(circ))}
-        for B in (64, 256):
+               "bit_exact_vs_cpu": data == want, "verifies_strict": bool(reverie_amd.Proof(data).verify(circ)),
+               "phase_ms": phase_ms(ctx, lambda: hp.run(10), 10),
+               "note": "narrow levels run as LDS runs (csrc/ldsrun.*: 32 slices of 8 repetitions, live wires in LDS); "
+                       "RV_LDS_RUN=0 gives the one-workgroup row interpreter of round 1"}
+        pv = reverie_amd.Proof(data)
+        pv.verify(circ)
+        tv = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            pv.verify(circ)
+            tv.append(time.perf_counter() - t0)
+        rec["single_verify_ms"] = statistics.median(tv) * 1e3
+        del pv
+        for B in (8, 64, 256):
             rng = np.random.default_rng(B)
             bs = rng.integers(0, 256, (B, 256, 16), dtype=np.uint8)
             bs[0] = seeds
@@ -204,7 +228,11 @@ def secondary_records(ctx, seeds, quick):
     ok = bool(p.verify(circ))
     tv = time.perf_counter() - t0
     rec = {"mul_gates": st["mul"], "levels": circ.info["levels"], "proof_bytes": len(data), "ms_per_proof": dt / steps * 1e3,
-           "mul_per_s": st["mul"] * steps / dt, "verifies_strict": ok, "verify_ms": tv * 1e3}
+           "mul_per_s": st["mul"] * steps / dt, "verifies_strict": ok, "verify_ms": tv * 1e3,
+           "phase_ms": phase_ms(ctx, lambda: hp.run(2), 2),
+           "note": "host to host; the 640 MB proof alone is ~11 ms of PCIe; profiles/r02_z64_* hold the kernel trace and the "
+                   "PMC traffic (k_interp64 moves ~150 GB per proof at ~5.5 TB/s, k_aes_z64_masks is VALU-bound: 2.05e9 "
+                   "cipher blocks + the bit transposes)"}
     circ.close()
     del p, data
     sprog, sw64, swc, sst = circuits.layered_z64(n_mul=100_000)
