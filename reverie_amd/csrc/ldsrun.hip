@@ -131,13 +131,44 @@ __device__ __forceinline__ void lds_put(uint32_t addr, uint32_t a, uint32_t b) {
     *(lds_u32x2*)(uintptr_t)addr = v;
 }
 
+// what a step leaves for later: its transcript stores and rare paths run AFTER the next step's LDS gathers have been
+// issued, i.e. inside the latency that step would otherwise sit out (nothing here touches LDS)
+struct LrPending {
+    uint32_t op = 0, on_val = 0, delta = 0, on_off = 0, pre_off = 0, drow = 0, dcorr = 0, bad = 0, grow = 0;
+};
+
 template <int MODE>
-__device__ __forceinline__ void lr_step(const uint4 f0, const uint4 f1, const uint4 v, const uint4 f3, uint8_t* on_base,
+__device__ __forceinline__ void lr_flush(const LrPending& w, uint8_t* on_base, uint8_t* pre_base, const InterpParams& p, uint32_t NQ,
+                                         uint32_t q, uint32_t onm) {
+    const uint32_t op = w.op;
+    if ((op & LF_ON) && (MODE != MODE_VERIFY || onm)) *(uint32_t*)(on_base + (size_t)w.on_off) = w.on_val;
+    if (op & (1u << LB_MUL)) {
+        const uint32_t n = compress4(w.delta);
+        const uint32_t other = pair_swap(n);
+        if (!(q & 1)) pre_base[(size_t)w.pre_off] = (uint8_t)(n | (other << 4));
+    }
+    if (op & (LF_OUT | (1u << LB_ASSERT))) {  // the rare ones
+        if (op & (1u << LB_ASSERT)) {
+            // prover.rs:221-228 / online.rs:175-177
+            if (w.bad) atomicOr(p.err, MODE == MODE_VERIFY ? RV_DEV_ZERO_CHECK : RV_E_WITNESS_INVALID);
+        }
+        if (op & LF_OUT) {  // read again after the run: the row interpreter's layout in global memory
+            if (op & ((1u << LB_XOR) | (1u << LB_RECON))) p.rows[(size_t)w.grow * NQ + q] = w.drow;
+            store_bits(p.corr, w.grow, NQ, q, w.dcorr);
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void lr_step(const uint4 f0, const uint4 f1, const uint4 v, const uint4 f3, LrPending& pend, uint8_t* on_base,
                                         uint8_t* pre_base, const InterpParams& p, uint32_t NQ, uint32_t q, uint32_t onm) {
     const uint32_t op = f1.w;
     // (the fields hold absolute LDS addresses: no base register to add)
     const uint2 A0 = lds_get(f0.x), A1 = lds_get(f0.y), A2 = lds_get(f0.z);
     const uint2 B0 = lds_get(f0.w), B1 = lds_get(f1.x), B2 = lds_get(f1.y);
+    __builtin_amdgcn_sched_barrier(0);
+    lr_flush<MODE>(pend, on_base, pre_base, p, NQ, q, onm);  // the previous step's stores, while the gathers are in flight
+    __builtin_amdgcn_sched_barrier(0);
     // 0 / ~0 masks (one v_bfe_i32 each): operand constants, the gate's kind
     const uint32_t ca = (uint32_t)((int32_t)(op << 27) >> 31), cb = (uint32_t)((int32_t)(op << 26) >> 31);
     const uint32_t mm = (uint32_t)((int32_t)(op << (31 - LB_MUL)) >> 31), mx = (uint32_t)((int32_t)(op << (31 - LB_XOR)) >> 31);
@@ -160,27 +191,18 @@ __device__ __forceinline__ void lr_step(const uint4 f0, const uint4 f1, const ui
     }
     const uint32_t r_raw = recon32(t);
     const uint32_t r = MODE == MODE_VERIFY ? (r_raw & onm) : r_raw;
-    if ((op & LF_ON) && (MODE != MODE_VERIFY || onm)) *(uint32_t*)(on_base + (size_t)f3.y) = (corr_in & mi) | (t & ~mi);
-    if (mm) {
-        const uint32_t n = compress4(delta);
-        const uint32_t other = pair_swap(n);
-        if (!(q & 1)) pre_base[(size_t)f3.z] = (uint8_t)(n | (other << 4));
-    }
     const uint32_t drow = (v.y & mm) | ((lx ^ ly) & mx) | (v.x & (mi | mo));
     const uint32_t dcorr = ((r ^ delta ^ (cx & cy)) & mm) | ((cx ^ cy ^ cb) & mx) | ((r ^ cx) & mr) | (corr_in & mi) | (v.z & mo);
     lds_put(f1.z, drow, dcorr);
-    if (op & (LF_OUT | (1u << LB_ASSERT))) {  // the rare ones
-        if (op & (1u << LB_ASSERT)) {
-            // prover.rs:221-228 / online.rs:175-177
-            const uint32_t bad = (r_raw ^ cx) & (MODE == MODE_VERIFY ? onm : 0xFFFFFFFFu);
-            if (bad) atomicOr(p.err, MODE == MODE_VERIFY ? RV_DEV_ZERO_CHECK : RV_E_WITNESS_INVALID);
-        }
-        if (op & LF_OUT) {  // read again after the run: the row interpreter's layout in global memory
-            const uint32_t grow = f3.w;
-            if (mx | mr) p.rows[(size_t)grow * NQ + q] = drow;
-            store_bits(p.corr, grow, NQ, q, dcorr);
-        }
-    }
+    pend.op = op;
+    pend.on_val = (corr_in & mi) | (t & ~mi);
+    pend.delta = delta;
+    pend.on_off = f3.y;
+    pend.pre_off = f3.z;
+    pend.drow = drow;
+    pend.dcorr = dcorr;
+    pend.bad = (r_raw ^ cx) & (MODE == MODE_VERIFY ? onm : 0xFFFFFFFFu);
+    pend.grow = f3.w;
 }
 
 template <int MODE, int QS, bool BATCH>
@@ -201,6 +223,7 @@ __global__ __launch_bounds__(64 * (1 + LR_PRODUCERS)) void k_interp_lds(LdsRunPa
         uint8_t* pre_base = p.pre + (size_t)rp.ep0 * (NQ >> 1);
         if (lane < QS) ((uint2*)(lr_smem + LR_RING_BYTES))[lane] = make_uint2(0u, 0u);  // the zero wire
         lr_barrier();
+        LrPending pend;
         for (uint32_t c = 0; c < n_chunks; c++) {
             const uint4* f = ring + (c & 1u) * (LR_CHUNK * 4 * 64) + lane;
             uint4 n0 = f[0], n1 = f[64], n2 = f[128], n3 = f[192];
@@ -213,10 +236,11 @@ __global__ __launch_bounds__(64 * (1 + LR_PRODUCERS)) void k_interp_lds(LdsRunPa
                     n2 = f[(s + 1) * 256 + 128];
                     n3 = f[(s + 1) * 256 + 192];
                 }
-                lr_step<MODE>(c0, c1, c2, c3, on_base, pre_base, p, NQ, q, onm);
+                lr_step<MODE>(c0, c1, c2, c3, pend, on_base, pre_base, p, NQ, q, onm);
             }
             lr_barrier();
         }
+        lr_flush<MODE>(pend, on_base, pre_base, p, NQ, q, onm);
     } else {
         // ---- producers, three chunks deep: while the consumer works on chunk c a producer writes chunk c + 1 into the
         // other buffer from operands it requested one iteration ago, requests the operands of chunk c + 2 with records
