@@ -109,7 +109,7 @@ int rv_ctx_sync(rv_ctx *ctx);
 enum {
     RV_PH_SETUP = 0,  /* seed expansion, key schedules, round-key bitslicing          */
     RV_PH_MASKS = 1,  /* k_aes_gf2_masks: bitsliced AES-128-CTR mask generator         */
-    RV_PH_INTERP = 2, /* k_interp_full / k_interp_narrow / k_interp64: one launch per dependency level or narrow run */
+    RV_PH_INTERP = 2, /* k_interp_full / k_interp64: one launch per dependency level; k_interp_lds (or k_interp_narrow): one per narrow stretch */
     RV_PH_HASH = 3,   /* k_b3_chunks(_bits,_contig) + k_b3_reduce + k_b3_tree_tail: transcript BLAKE3 */
     RV_PH_JOIN = 4,   /* k_join                                                        */
     RV_PH_OPEN = 5,   /* k_fs_challenge + k_open_headers + k_extract_rows / k_extract_from_bits / k_extract64 */
