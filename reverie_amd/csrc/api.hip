@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <condition_variable>
 #include <map>
 #include <string>
 #include <mutex>
@@ -618,11 +619,12 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         for (const auto& r : c->narrow_runs) narrow_levels += r.second - r.first;
         c->vclr_ok = cc.gates64.empty() && narrow_levels <= 16 && !cc.row_prg_base;
     }
-    for (const Gate& g : cc.gates)
-        if (g_op(g) == G_RANDOM || g_op(g) == G_RECON) {
-            c->vclr_ok = false;
-            break;
-        }
+    if (c->vclr_ok)
+        for (const Gate& g : cc.gates)
+            if (g_op(g) == G_RANDOM || g_op(g) == G_RECON) {
+                c->vclr_ok = false;
+                break;
+            }
     return RV_OK;
 }
 

@@ -551,6 +551,48 @@ static int run_pass(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
     return RV_OK;
 }
 
+void count_masks(const rv_op* ops, size_t n_ops, uint64_t* gf2_masks, uint64_t* z64_masks) {
+    uint64_t m2 = 0, m64 = 0;
+    for (size_t i = 0; i < n_ops; i++) {
+        const rv_op& op = ops[i];
+        const bool one = op.opcode == RV_OP_INPUT || op.opcode == RV_OP_RANDOM;
+        if (op.domain == RV_DOM_GF2)
+            m2 += one ? 1 : (op.opcode == RV_OP_MUL ? 2 : 0);
+        else if (op.domain == RV_DOM_Z64)
+            m64 += one ? 1 : (op.opcode == RV_OP_MUL ? 2 : 0);
+        else if (op.domain == RV_DOM_B2A) {  // run_pass: 64 g_random + 63 g_mul, one Z64 mask
+            m2 += 64 + 63 * 2;
+            m64 += 1;
+        }
+    }
+    *gf2_masks = m2;
+    *z64_masks = m64;
+}
+
+void relocate_chunk(Compiled& cc, uint64_t on0, uint64_t pre0, uint64_t on_words64_0, uint64_t pre_words64_0) {
+    if (on0 || pre0) {
+        for (Gate& g : cc.gates) {  // (eo / ep of gates without a transcript row are never read)
+            g.eo += (uint32_t)on0;
+            g.ep += (uint32_t)pre0;
+        }
+        for (uint32_t& r : cc.rec_rows) r += (uint32_t)on0;
+        for (uint32_t& r : cc.in_rows) r += (uint32_t)on0;
+        for (uint32_t& r : cc.level_done_on) r += (uint32_t)on0;
+        cc.n_on += on0;
+        cc.n_pre += pre0;
+    }
+    if (on_words64_0 || pre_words64_0) {
+        for (Gate64& g : cc.gates64) {
+            g.eo += on_words64_0;
+            g.ep += pre_words64_0;
+        }
+        for (uint64_t& o : cc.rec_offs64) o += on_words64_0;
+        for (uint64_t& o : cc.in_offs64) o += on_words64_0;
+        cc.on_words64 += on_words64_0;
+        cc.pre_words64 += pre_words64_0;
+    }
+}
+
 int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk, int force_lazy_k) {
     const auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {

@@ -62,6 +62,13 @@ struct ChunkStart {
     uint64_t on_words64_0 = 0, pre_words64_0 = 0;
 };
 
+// ShareGen::next() calls the ops make (generator/share.rs:54-65 as a pure count over the op list: Input / Random 1, Mul 2,
+// B2A 64 + 63 x 2 GF(2) and one Z64) -- all a chunk compiled AHEAD of its predecessors needs to know about them
+void count_masks(const rv_op* ops, size_t n_ops, uint64_t* gf2_masks, uint64_t* z64_masks);
+// A chunk compiled with zero transcript offsets, moved behind `on0` / `pre0` carried transcript rows and `on_words64_0` /
+// `pre_words64_0` carried Z64 words (they enter the compiled stream only as additive offsets)
+void relocate_chunk(Compiled& cc, uint64_t on0, uint64_t pre0, uint64_t on_words64_0, uint64_t pre_words64_0);
+
 // returns RV_OK or RV_E_*
 // force_lazy_k: 0 = choose (RV_LAZY_K / circuit shape), 1..RV_LIN_K = that many base rows per wire at most
 int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr,
