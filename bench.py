@@ -377,23 +377,29 @@ def main():
         launches = {n: int(prof.launches[i] // max(args.steps, 1)) for i, n in enumerate(_lib.PHASES)}
         dom = max(("masks", "interp", "hash"), key=lambda k: phases[k])
         row = 256 // world  # bytes per transcript / mask row on this rank
-        # algorithmic HBM bytes per proof of each phase, materialised variant
+        # algorithmic HBM bytes per proof of each phase, materialised variant.  A whole proof of a pure
+        # GF(2) circuit keeps one cleartext value byte per share row instead of the corr-bit rows (MODE_PROVE_V, the
+        # interpreter's template argument 2); repetition shards keep the corr rows (argument 0)
+        vclr = world == 1 and os.environ.get("RV_VCLR", "1") != "0" and os.environ.get("RV_PIPELINE", "0") == "0"
+        corr_and, corr_xor = (3, 3) if vclr else (3 * row // 8, 3 * row // 8)
         alg = {
             "masks": info["gf2_masks"] * row,  # writes every mask row once
-            # AND: 48 B gate + 4 share rows in + 2 corr-bit rows in + 1 out + online row + pre bits
-            # XOR: 48 B gate + 2 share rows in + 1 out + 3 corr-bit rows
+            # AND: 48 B gate + 4 share rows in (two operands, two fresh masks; the result's mask IS a fresh mask) + the
+            #      online row + pre bits out + corr: 2 rows in + 1 out of row/8 bytes each, or 3 value bytes
+            # XOR: 48 B gate + 2 share rows in + 1 out + 3 corr-bit rows / 3 value bytes
             # (XOR gates the device executes: the compiler drops linear gates nobody reads, 13.5 % of this circuit's)
-            "interp": (st["and"] * (48 + 4 * row + 3 * row // 8 + row + row // 8)
-                       + min(st["xor"], info["gf2_linear"]) * (48 + 3 * row + 3 * row // 8)),
+            "interp": (st["and"] * (48 + 4 * row + row + row // 8 + corr_and)
+                       + min(st["xor"], info["gf2_linear"]) * (48 + 3 * row + corr_xor)),
             "hash": (info["gf2_muls"] + info["gf2_inputs"] + info["gf2_asserts"]) * row + info["gf2_muls"] * row // 8,
         }
-        kname = {"masks": "rv::k_aes_gf2_masks<16>", "interp": "rv::k_interp_full<0, 64, false>", "hash": "rv::k_b3_chunks<4>"}[dom]
+        interp_arg = "2" if vclr else "0"
+        kname = {"masks": "rv::k_aes_gf2_masks<16>", "interp": f"rv::k_interp_full<{interp_arg}, {row // 4}, false>", "hash": "rv::k_b3_chunks<4>"}[dom]
         ach = alg[dom] / (phases[dom] * 1e-3) / 1e9 if phases[dom] > 0 else 0.0
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")
         if world == 1 and args.layers == 153 and args.p_and == 0.5 and os.path.exists(pmc_path):
             pk = json.load(open(pmc_path))["kernels"]
-            prefix = {"masks": "rv::k_aes_gf2_masks<", "interp": "rv::k_interp_full<0", "hash": "rv::k_b3_chunks<"}[dom]
+            prefix = {"masks": "rv::k_aes_gf2_masks<", "interp": f"rv::k_interp_full<{interp_arg}", "hash": "rv::k_b3_chunks<"}[dom]
             hits = [v["hbm_bytes_per_proof"] for k, v in pk.items() if k.startswith(prefix)]
             if hits:
                 traffic = sum(hits) / max(launches[dom], 1)
