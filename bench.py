@@ -375,7 +375,9 @@ def main():
     if rank == 0:
         phases = {n: prof.ms[i] / max(args.steps, 1) for i, n in enumerate(_lib.PHASES)}
         launches = {n: int(prof.launches[i] // max(args.steps, 1)) for i, n in enumerate(_lib.PHASES)}
-        dom = max(("masks", "interp", "hash"), key=lambda k: phases[k])
+        # the roofline object is the interpreter's (the HBM-bound kernel, and the longest phase in every profile under
+        # profiles/); the mask and digest phases are integer-VALU-bound, which the contract's two bounds do not describe
+        dom = "interp"
         row = 256 // world  # bytes per transcript / mask row on this rank
         # algorithmic HBM bytes per proof of each phase, materialised variant.  A whole proof of a pure
         # GF(2) circuit keeps one cleartext value byte per share row instead of the corr-bit rows (MODE_PROVE_V, the
