@@ -942,6 +942,57 @@ __global__ __launch_bounds__(64) void k_b3_tree_tail_small(const uint32_t* __res
     B_k_b3_tree_tail<64>{}(in, n_in, R, digest);
 }
 
+// The same top of the tree with ONE LANE per repetition (at most 64 chaining values): the lane folds its values the way
+// the incremental hasher does -- complete subtrees of 2^k chunks wait in slot k, the last value closes them from the
+// smallest up and the last parent carries ROOT -- n - 1 dependent compressions, but 64 repetitions per wavefront instead
+// of one.  For a batch of proofs that is the difference between 65 536 workgroups of one mostly idle wavefront each
+// (rv_prove_batch of 256 AES-128 proofs: 2 x 261 us) and 1 024 full wavefronts.
+struct B_k_b3_tree_lane {
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R, uint32_t* __restrict__ digest) const {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    auto load = [&](uint32_t i, uint32_t* cv) {
+        const uint4* p = (const uint4*)(in + ((size_t)i * R + r) * 8);
+        const uint4 a = p[0], b = p[1];
+        cv[0] = a.x, cv[1] = a.y, cv[2] = a.z, cv[3] = a.w, cv[4] = b.x, cv[5] = b.y, cv[6] = b.z, cv[7] = b.w;
+    };
+    uint32_t st[6][8], cur[8], o[8];
+    for (uint32_t i = 0; i + 1 < n_in; i++) {  // (uniform: every lane walks the same tree shape)
+        load(i, cur);
+        bool placed = false;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            if (placed) continue;
+            if ((i >> k) & 1u) {
+                b3::parent(st[k], cur, 0u, o);
+#pragma unroll
+                for (int w = 0; w < 8; w++) cur[w] = o[w];
+            } else {
+#pragma unroll
+                for (int w = 0; w < 8; w++) st[k][w] = cur[w];
+                placed = true;
+            }
+        }
+    }
+    const uint32_t last = n_in - 1;
+    load(last, cur);  // a single chunk is already its own root (the chunk kernels applied the ROOT flag)
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        if ((last >> k) & 1u) {
+            b3::parent(st[k], cur, (last >> (k + 1)) == 0 ? b3::ROOT : 0u, o);
+#pragma unroll
+            for (int w = 0; w < 8; w++) cur[w] = o[w];
+        }
+    }
+    uint4* d = (uint4*)(digest + (size_t)r * 8);
+    d[0] = make_uint4(cur[0], cur[1], cur[2], cur[3]);
+    d[1] = make_uint4(cur[4], cur[5], cur[6], cur[7]);
+}
+};
+__global__ __launch_bounds__(64) void k_b3_tree_lane(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R, uint32_t* __restrict__ digest) {
+    B_k_b3_tree_lane{}(in, n_in, R, digest);
+}
+
 // tree reduction of n chunk chaining values per repetition; the roots land in d_digest ([R][8] words)
 uint32_t b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n, uint32_t R, uint32_t* d_digest) {
     uint32_t launches = 1;
@@ -956,7 +1007,11 @@ uint32_t b3_reduce_tree(hipStream_t st, uint32_t* cur, uint32_t* nxt, uint64_t n
         launches++;
     }
     // a single chunk is already its own root (the chunk kernels applied the ROOT flag): cnt == 1 just copies
-    if (n <= 64)
+    // lane per repetition: always for a batch of proofs (gridDim.y supplies the parallelism), for a single proof only while
+    // its n - 1 dependent compressions (~1.2 us each) beat the workgroup version's log2(n) levels with their barriers
+    if (n <= 64 && ((g_recorder && g_recorder->batch >= 8) || n <= 4))
+        launch<B_k_b3_tree_lane, 64>(k_b3_tree_lane, st, dim3((R + 63) / 64), dim3(64), cur, (uint32_t)n, R, d_digest);
+    else if (n <= 64)
         launch<B_k_b3_tree_tail<64>, 64>(k_b3_tree_tail_small, st, dim3(R), dim3(64), cur, (uint32_t)n, R, d_digest);
     else
         launch<B_k_b3_tree_tail<(int)B3_TAIL>, 256>(k_b3_tree_tail, st, dim3(R), dim3(256), cur, (uint32_t)n, R, d_digest);
