@@ -291,7 +291,9 @@ def main():
     ctx = reverie_amd.Context(local)
     prog, wit, wc, st = circuits.layered_gf2(layers=args.layers, p_and=args.p_and)
     t0 = time.perf_counter()
-    circuit = reverie_amd.Circuit(prog, wc, ctx)
+    # one GPU: the circuit serves whole proofs (the RV_COMPILE_WHOLE_PROVER hint); repetition shards run fastest on the
+    # neutral gate stream
+    circuit = reverie_amd.Circuit(prog, wc, ctx, whole_prover=(world == 1))
     compile_s = time.perf_counter() - t0
     info = circuit.info
     backend = HipShardBackend(circuit)
@@ -379,23 +381,25 @@ def main():
         # profiles/); the mask and digest phases are integer-VALU-bound, which the contract's two bounds do not describe
         dom = "interp"
         row = 256 // world  # bytes per transcript / mask row on this rank
-        # algorithmic HBM bytes per proof of each phase, materialised variant.  A whole proof of a pure
-        # GF(2) circuit keeps one cleartext value byte per share row instead of the corr-bit rows (MODE_PROVE_V, the
-        # interpreter's template argument 2); repetition shards keep the corr rows (argument 0)
-        vclr = world == 1 and os.environ.get("RV_VCLR", "1") != "0" and os.environ.get("RV_PIPELINE", "0") == "0"
-        corr_and, corr_xor = (3, 3) if vclr else (3 * row // 8, 3 * row // 8)
+        # algorithmic HBM bytes per proof of each phase.  The prover of a pure GF(2) circuit keeps one
+        # cleartext value byte per share row instead of the corr-bit rows (MODE_PROVE_V, the interpreter's template
+        # argument 2)
+        vclr = os.environ.get("RV_VCLR", "1") != "0" and os.environ.get("RV_PIPELINE", "0") == "0" and row in (256, 128, 64, 32)
+        per_row_corr = 1 if vclr else row // 8  # bytes of corr bits / cleartext value next to every share row touched
+        n_dev_gates = info["gf2_muls"] + info["gf2_inputs"] + info["gf2_asserts"] + info["gf2_rows_written"]
         alg = {
             "masks": info["gf2_masks"] * row,  # writes every mask row once
-            # AND: 48 B gate + 4 share rows in (two operands, two fresh masks; the result's mask IS a fresh mask) + the
-            #      online row + pre bits out + corr: 2 rows in + 1 out of row/8 bytes each, or 3 value bytes
-            # XOR: 48 B gate + 2 share rows in + 1 out + 3 corr-bit rows / 3 value bytes
-            # (XOR gates the device executes: the compiler drops linear gates nobody reads, 13.5 % of this circuit's)
-            "interp": (st["and"] * (48 + 4 * row + row + row // 8 + corr_and)
-                       + min(st["xor"], info["gf2_linear"]) * (48 + 3 * row + corr_xor)),
+            # 48 B gate records; operand rows in (as compiled: with the RV_COMPILE_WHOLE_PROVER hint a Mul reads up to
+            # three rows per operand and fewer Xor gates exist at all); a Mul's two fresh mask rows in (its result's mask IS
+            # one of them); materialised rows out; online rows and preprocessing bits out
+            "interp": (n_dev_gates * 48
+                       + (info["gf2_operand_rows"] + 2 * info["gf2_muls"] + info["gf2_inputs"]) * (row + per_row_corr)
+                       + info["gf2_rows_written"] * (row + per_row_corr) + (info["gf2_muls"] + info["gf2_inputs"]) * per_row_corr
+                       + (info["gf2_muls"] + info["gf2_inputs"] + info["gf2_asserts"]) * row + info["gf2_muls"] * row // 8),
             "hash": (info["gf2_muls"] + info["gf2_inputs"] + info["gf2_asserts"]) * row + info["gf2_muls"] * row // 8,
         }
         interp_arg = "2" if vclr else "0"
-        kname = {"masks": "rv::k_aes_gf2_masks<16>", "interp": f"rv::k_interp_full<{interp_arg}, {row // 4}, false>", "hash": "rv::k_b3_chunks<4>"}[dom]
+        kname = {"masks": "rv::k_aes_gf2_masks<16>", "interp": f"rv::k_interp_full<{interp_arg}, {row // 4}, {'true' if world == 1 else 'false'}>", "hash": "rv::k_b3_chunks<4>"}[dom]
         ach = alg[dom] / (phases[dom] * 1e-3) / 1e9 if phases[dom] > 0 else 0.0
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")
@@ -433,6 +437,7 @@ def main():
             "config": {"workload": f"synthetic layered AND/XOR GF(2) circuit, {st['gates']} gates ({st['and']} AND), "
                                    f"{st['inputs']} inputs, {args.layers} layers x 65536, p_and={args.p_and}, 256 reps x 8 players, 40 online",
                        "boundary": boundary, "parallelism": f"reps/{world}", "levels": info["levels"], "compile_s": compile_s,
+                       "compile_hint": "RV_COMPILE_WHOLE_PROVER" if world == 1 else "none",
                        "gate_stream_upload_ms": info["upload_us"] / 1e3, "gate_stream_bytes": info["device_bytes"]},
             "roofline": roofline,
         }
@@ -449,14 +454,18 @@ def main():
             parity["sharded_proof_equals_single_gpu_proof"] = bytes(single) == bytes(last)
         result["parity"] = parity
         if world == 1 and not args.no_secondary:
-            # verifier: rv_verify (strict) from host proof bytes, second call timed
+            # verifier: rv_verify (strict) from host proof bytes, second call timed; the verifying party
+            # compiles the circuit for itself (no prover hint)
             host_proof = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
-            host_proof.verify(circuit)
+            vcirc = reverie_amd.Circuit(prog, wc, ctx)
+            host_proof.verify(vcirc)
             tp = time.perf_counter()
-            okp = bool(host_proof.verify(circuit))
+            okp = bool(host_proof.verify(vcirc))
             tp = time.perf_counter() - tp
+            vcirc.close()
             result["verifier"] = {"value": n_and / tp, "unit": "AND gates/s", "ms": tp * 1e3, "strict_ok": okp,
-                                  "note": "rv_verify (strict), host proof bytes (page-locked, as rv_prove returned them) in, one call"}
+                                  "note": "rv_verify (strict), host proof bytes (page-locked, as rv_prove returned them) in, one call; "
+                                          "circuit compiled by rv_circuit_compile (the prover's has the RV_COMPILE_WHOLE_PROVER hint)"}
             parity["rv_prove_is_deterministic"] = bytes(host_proof) == bytes(last)
             del host_proof
             # the same proof left in HBM (round 1's headline) -- or, with --device-resident, the host-to-host one

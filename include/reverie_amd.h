@@ -132,6 +132,17 @@ int rv_ctx_profile(rv_ctx *ctx, int enable, int reset, rv_profile *out);
  * reported here. */
 int rv_circuit_compile(rv_ctx *ctx, const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
                        rv_circuit **out);
+/* The same with a hint about how the circuit will be used.  Every entry point accepts any compiled circuit and
+ * produces identical bytes; the hint only chooses between gate streams that different users run at different speeds.
+ * RV_COMPILE_WHOLE_PROVER: mostly proofs of all 256 repetitions on one GPU (rv_prove, rv_prove_device,
+ * rv_prove_batch -- what Proof::new does, proof/mod.rs:119-175).  Linear gates of wide circuits are then kept as
+ * lazy sums of up to three rows instead of being materialised: the whole-proof interpreter keeps one cleartext value
+ * byte per row and reads full 256-byte rows, so the extra operand rows cost less than the Xor gates they replace (10^7-gate
+ * benchmark circuit: rv_prove 6.4 -> 6.15 ms); the verifier and repetition shards (32-byte to 128-byte rows, corr-bit
+ * rows per operand) run 3-15 % slower on such a stream, so rv_circuit_compile does not choose it. */
+#define RV_COMPILE_WHOLE_PROVER 1u
+int rv_circuit_compile_ex(rv_ctx *ctx, const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags,
+                          rv_circuit **out);
 void rv_circuit_destroy(rv_circuit *c);
 
 typedef struct rv_circuit_info {
@@ -145,6 +156,9 @@ typedef struct rv_circuit_info {
     uint64_t scratch_bytes;  /* HBM a full 256-repetition prove needs on top           */
     uint64_t compile_us;     /* host time of the gate-stream compiler                  */
     uint64_t upload_us;      /* allocation + host-to-device copy of the compiled gate stream (device_bytes), synchronised */
+    /* ABI 4: share rows the GF(2) interpreter reads as gate operands (a Mul's two fresh mask rows not counted) and
+     * computed rows it writes (materialised linear gates), per proof -- they depend on how linear gates were compiled */
+    uint64_t gf2_operand_rows, gf2_rows_written;
 } rv_circuit_info;
 int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
 

@@ -41,8 +41,9 @@ static int hip_fail(hipError_t e, const char* what, const char* file, int line) 
     } while (0)
 
 extern "C" const char* rv_last_error(void) { return g_last_error.c_str(); }
-extern "C" uint32_t rv_abi_version(void) { return 3; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
+extern "C" uint32_t rv_abi_version(void) { return 4; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
                                                         //    streaming prover, rv_prove_multi, reconstruct hooks
+                                                        // 4: rv_circuit_compile_ex (a pure addition)
 
 extern "C" const char* rv_strerror(int code) {
     switch (code) {
@@ -415,28 +416,36 @@ static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
     return b;
 }
 
-static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
+static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags,
                                   rv_circuit** out);
 static int circuit_upload(rv_ctx* ctx, rv_circuit* c);
 
-extern "C" int rv_circuit_compile(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
-                                  rv_circuit** out) {
+extern "C" int rv_circuit_compile_ex(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags,
+                                     rv_circuit** out) {
+    if (flags & ~RV_COMPILE_WHOLE_PROVER) return RV_E_ARG;
     try {  // no C++ exception may cross the C boundary
-        return rv_circuit_compile_impl(ctx, ops, n_ops, z64_wires, gf2_wires, out);
+        return rv_circuit_compile_impl(ctx, ops, n_ops, z64_wires, gf2_wires, flags, out);
     } catch (...) {
         g_last_error = "out of host memory";
         return RV_E_NOMEM;
     }
 }
 
-static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
+extern "C" int rv_circuit_compile(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires,
+                                  rv_circuit** out) {
+    return rv_circuit_compile_ex(ctx, ops, n_ops, z64_wires, gf2_wires, 0, out);
+}
+
+static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags,
                                   rv_circuit** out) {
     if (!ctx || !out || (n_ops && !ops)) return RV_E_ARG;
     *out = nullptr;
     rv_circuit* c = new rv_circuit();
     c->ctx = ctx;
     const auto t_begin = std::chrono::steady_clock::now();
-    int rc = compile_ops(ops, n_ops, z64_wires, gf2_wires, c->cc);
+    // RV_COMPILE_WHOLE_PROVER: lazy sums of up to RV_LIN_K rows for every circuit (the compiler chooses them on its own only
+    // for deep, narrow ones); RV_LAZY_K still overrides
+    int rc = compile_ops(ops, n_ops, z64_wires, gf2_wires, c->cc, nullptr, ((flags & RV_COMPILE_WHOLE_PROVER) && !getenv("RV_LAZY_K")) ? RV_LIN_K : 0);
     if (rc) {
         delete c;
         return rc;
@@ -1118,8 +1127,9 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
             const char* e = getenv("RV_VCLR");
             return !e || atoi(e) != 0;
         }();
-        if (vclr_on && c->vclr_ok && rep_count == RV_TOTAL_REPS && !ctx->pipeline) {
-            // whole proofs of eligible circuits: cleartext values instead of corr rows (internal.h: MODE_PROVE_V)
+        if (vclr_on && c->vclr_ok && (s->NQ == 64 || s->NQ == 32 || s->NQ == 16 || s->NQ == 8) && !ctx->pipeline) {
+            // eligible circuits (whole proofs and the repetition shards with a specialised interpreter): cleartext values
+            // instead of corr rows (internal.h: MODE_PROVE_V)
             if ((rc = dalloc(ctx, (size_t)cc.n_rows, &s->d_vclr))) return fail(rc);
             if (hipMemsetAsync(s->d_vclr + cc.zero_row, 0, 1, ctx->stream) != hipSuccess) return fail(RV_E_DEVICE);
             p.vclr = s->d_vclr;

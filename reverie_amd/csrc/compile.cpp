@@ -748,6 +748,12 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
     info.gf2_masks = out.n_masks;
     info.z64_masks = out.n_masks64;
     info.levels = n_levels;
+    for (const Gate& g : out.gates) {  // what the interpreter moves per repetition quad (bench.py prices its launches with these)
+        const uint32_t op = g_op(g);
+        if (op == G_MUL || op == G_XORK) info.gf2_operand_rows += g_na(g) + g_nb(g);
+        if (op == G_ASSERT || op == G_RECON) info.gf2_operand_rows += g_na(g);
+        if (op == G_XORK || op == G_RECON) info.gf2_rows_written++;
+    }
     lap("tables and row fix-up done");
     if (getenv("RV_COMPILE_STATS")) {  // interpreter HBM traffic model per 4-repetition quad column (x NQ x 4 B per row)
         uint64_t rd = 0, wr = 0, crd = 0, n_mul = 0, n_xor = 0, n_mul11 = 0;

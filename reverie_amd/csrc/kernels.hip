@@ -535,12 +535,10 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     if (mode == MODE_PROVE_V) {
-        if constexpr (NQ == 64) {  // whole proofs only
-            if (general)
-                hipLaunchKernelGGL((k_interp_full<MODE_PROVE_V, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
-            else
-                hipLaunchKernelGGL((k_interp_full<MODE_PROVE_V, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
-        }
+        if (general)
+            hipLaunchKernelGGL((k_interp_full<MODE_PROVE_V, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
+        else
+            hipLaunchKernelGGL((k_interp_full<MODE_PROVE_V, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
     } else if (mode == MODE_PROVE) {
         if (general)
             hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);

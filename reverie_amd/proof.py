@@ -60,14 +60,16 @@ class Context:
 class Circuit:
     """A gate stream compiled (levelised) and resident in HBM (rv_circuit)."""
 
-    def __init__(self, ops, wire_counts: Tuple[int, int], ctx: Optional[Context] = None):
+    def __init__(self, ops, wire_counts: Tuple[int, int], ctx: Optional[Context] = None, whole_prover: bool = False):
+        """whole_prover: the circuit will mostly serve whole proofs on one GPU (Proof.new / new_batch) -- the
+        RV_COMPILE_WHOLE_PROVER hint of rv_circuit_compile_ex; any use of the circuit still gives identical bytes."""
         self.ctx = ctx or Context.default()
         self.ops = program(ops) if len(ops) else np.zeros(0, OP_DTYPE)
         self.wire_counts = (int(wire_counts[0]), int(wire_counts[1]))  # (z64, gf2), proof/mod.rs:125
         self.handle = C.c_void_p()
-        _lib.check(_lib.lib().rv_circuit_compile(self.ctx.handle, _ptr(self.ops), C.c_size_t(len(self.ops)),
-                                                 C.c_size_t(self.wire_counts[0]), C.c_size_t(self.wire_counts[1]),
-                                                 C.byref(self.handle)))
+        _lib.check(_lib.lib().rv_circuit_compile_ex(self.ctx.handle, _ptr(self.ops), C.c_size_t(len(self.ops)),
+                                                    C.c_size_t(self.wire_counts[0]), C.c_size_t(self.wire_counts[1]),
+                                                    C.c_uint32(_lib.RV_COMPILE_WHOLE_PROVER if whole_prover else 0), C.byref(self.handle)))
 
     @property
     def info(self) -> dict:
@@ -94,12 +96,12 @@ class Circuit:
             pass
 
 
-def _as_circuit(circuit, wire_counts, ctx=None) -> Circuit:
+def _as_circuit(circuit, wire_counts, ctx=None, whole_prover=False) -> Circuit:
     if isinstance(circuit, Circuit):
         if wire_counts is not None and tuple(wire_counts) != circuit.wire_counts:
             raise ValueError("wire_counts differ from the compiled circuit's")
         return circuit
-    return Circuit(circuit, wire_counts, ctx)
+    return Circuit(circuit, wire_counts, ctx, whole_prover=whole_prover)
 
 
 def _witness(wit_gf2, wit_z64):
@@ -147,7 +149,7 @@ class Proof:
             seeds: Union[None, bytes, np.ndarray] = None, ctx: Optional[Context] = None) -> "Proof":
         """Proof::new.  `seeds` (256x16 bytes) injects the per-repetition seeds the reference
         draws from OsRng; None draws them from the OS."""
-        c = _as_circuit(circuit, wire_counts, ctx)
+        c = _as_circuit(circuit, wire_counts, ctx, whole_prover=True)  # (a program compiled for this one whole proof)
         g, z = _witness(wit_gf2, wit_z64)
         s = None
         if seeds is not None:
@@ -165,7 +167,7 @@ class Proof:
         """`len(wits_gf2)` proofs of one circuit in one pass (rv_prove_batch): every dependency level is launched
         once for the whole batch.  wits_gf2: [B][n] bits; wits_z64: [B][m] words or None; seeds: [B][256][16] bytes or
         None (OS randomness).  Each proof equals Proof.new(circuit, wits_gf2[b], wits_z64[b], seeds=seeds[b])."""
-        c = _as_circuit(circuit, wire_counts, ctx)
+        c = _as_circuit(circuit, wire_counts, ctx, whole_prover=True)
         g = np.ascontiguousarray(np.asarray(wits_gf2, dtype=np.uint8))
         if g.ndim != 2:
             raise ValueError("wits_gf2 must be [batch][n_bits]")

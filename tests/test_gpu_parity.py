@@ -1167,3 +1167,43 @@ def test_lds_runs(rv, oracle, rule_seeds, monkeypatch, qs):
         for s in shards:
             be.destroy(s)
         assert assemble(comm, parts) == want, per
+
+
+def test_compile_hint_whole_prover(rv, oracle, rule_seeds):
+    """rv_circuit_compile_ex(RV_COMPILE_WHOLE_PROVER): a different gate stream (linear gates kept as lazy sums), the same
+    bytes from every entry point -- whole proofs, batches, repetition shards, the verifier -- on a wide layered circuit,
+    a mixed GF(2) / Z64 / B2A program and a Bristol-style narrow one"""
+    from reverie_amd.dist import HipShardBackend, assemble
+    from reverie_amd.proof import challenge, combine_digests
+
+    rng = np.random.default_rng(99)
+    cases = [circuits.layered_gf2(n_in=300, width=4096, layers=9)[:3]]
+    prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=500)
+    cases.append((prog, w2, wc, w64))
+    prog, w2, wc = circuits.random_gf2(rng, n_in=40, n_gates=3000, n_wires=120)
+    cases.append((prog, w2, wc))
+    for case in cases:
+        prog, w2, wc = case[:3]
+        w64 = case[3] if len(case) > 3 else []
+        want = oracle.prove(prog, w2, w64, wc, rule_seeds)
+        hinted = rv.Circuit(prog, wc, whole_prover=True)
+        plain = rv.Circuit(prog, wc)
+        assert hinted.info["gf2_rows_written"] <= plain.info["gf2_rows_written"]
+        p1 = rv.Proof.new(hinted, w2, w64, seeds=rule_seeds)
+        assert bytes(p1) == want
+        assert bytes(rv.Proof.new(plain, w2, w64, seeds=rule_seeds)) == want
+        assert p1.verify(hinted) and p1.verify(plain)
+        if not len(w64):
+            got = rv.Proof.new_batch(hinted, np.tile(np.asarray(w2, np.uint8), (3, 1)), seeds=np.tile(rule_seeds, (3, 1, 1)))
+            assert all(bytes(g) == want for g in got)
+        be = HipShardBackend(hinted)
+        shards = [be.commit(w2, w64, rule_seeds[b:b + 64], b, 64) for b in range(0, 256, 64)]
+        comm = combine_digests(np.concatenate([be.digests(s) for s in shards]))
+        omit = challenge(comm)
+        parts = [be.open(s, omit)[:2] for s in shards]
+        for s in shards:
+            be.destroy(s)
+        assert assemble(comm, parts) == want
+    # the wide circuit really compiles differently
+    prog, w2, wc = cases[0]
+    assert rv.Circuit(prog, wc, whole_prover=True).info["gf2_rows_written"] < rv.Circuit(prog, wc).info["gf2_rows_written"]
