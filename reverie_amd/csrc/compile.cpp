@@ -183,7 +183,8 @@ struct Builder {
         const uint32_t f = uses[n_ssa];  // how often the result will be read
         // keep it symbolic when that costs no more row traffic than materialising it:
         // f readers x (n - 1) extra rows  vs  n reads + 1 write
-        const bool lazy = n <= 1 || (n <= lazy_k && (uint64_t)f * (uint32_t)(n - 1) <= (uint32_t)(n + 1));
+        static const uint32_t slack = getenv("RV_LAZY_SLACK") ? (uint32_t)atoi(getenv("RV_LAZY_SLACK")) : 1u;
+        const bool lazy = n <= 1 || (n <= lazy_k && (uint64_t)f * (uint32_t)(n - 1) <= (uint32_t)(n + slack));
         // a linear gate nobody reads has no effect on the proof (no transcript entry, no mask consumed): drop it
         // (13.5 % of the XOR gates of the random layered workload have fan-out zero)
         if (f == 0) return new_ssa(Lin());
