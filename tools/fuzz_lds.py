@@ -25,7 +25,7 @@ for case in range(n_cases):
         want = oracle_lib.prove(prog, w2, w64, wc, seeds, threads=8)
     except oracle_lib.OracleError:
         continue
-    c = reverie_amd.Circuit(prog, wc, ctx)
+    c = reverie_amd.Circuit(prog, wc, ctx, whole_prover=bool(rng.random() < 0.5))
     proof = reverie_amd.Proof.new(c, w2, w64, seeds=seeds)
     ok = bytes(proof) == want and bool(proof.verify(c))
     if not ok:
