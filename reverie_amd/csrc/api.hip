@@ -1689,7 +1689,11 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
         // prove alternate statements through the ordinary single-proof path.  Host bytes in, host proof bytes out on the
         // 10^7-gate circuit: 6.7 ms for a single rv_prove, 5.9 per proof with two threads, 5.4 with three, 5.5 with four
         // (device-resident proofs: 4.9 with two in flight, no gain from a third).
-        constexpr size_t T = 3;
+        constexpr size_t T_MAX = 8;
+        static const size_t T = [] {
+            const char* e = getenv("RV_BATCH_THREADS");
+            return (size_t)std::min(std::max(e ? atoi(e) : 3, 1), (int)T_MAX);
+        }();
         while (ctx->workers.size() < T) {
             rv_ctx* w = nullptr;
             int rcw = rv_ctx_create(ctx->device, &w);
@@ -1704,8 +1708,8 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
         const size_t stride = (open_layout(cc, canon, RV_TOTAL_REPS, true).total + 4095) & ~(size_t)4095;
         uint8_t* slab = (uint8_t*)g_pinned.get(std::max<size_t>(stride * batch, PinnedPool::MIN_BYTES));
         if (!slab) return RV_E_NOMEM;
-        int rcs[T] = {};
-        std::thread th[T];
+        int rcs[T_MAX] = {};
+        std::thread th[T_MAX];
         for (size_t t = 0; t < T; t++)
             th[t] = std::thread([&, t] {
                 try {
@@ -1720,7 +1724,7 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
                     rcs[t] = RV_E_NOMEM;
                 }
             });
-        for (auto& x : th) x.join();
+        for (size_t t = 0; t < T; t++) th[t].join();
         for (int r : rcs)
             if (r) {
                 for (size_t b = 0; b < batch; b++) proofs[b] = nullptr, proof_lens[b] = 0;

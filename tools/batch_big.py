@@ -15,7 +15,7 @@ import circuits  # noqa: E402
 import reverie_amd  # noqa: E402
 
 prog, wit, wc, st = circuits.layered_gf2(layers=int(os.environ.get("LAYERS", 153)))
-c = reverie_amd.Circuit(prog, wc)
+c = reverie_amd.Circuit(prog, wc, whole_prover=os.environ.get("HINT", "1") != "0")
 rng = np.random.default_rng(3)
 for B in [int(x) for x in os.environ.get("BATCHES", "2,4").split(",")]:
     seeds = rng.integers(0, 256, (B, 256, 16), dtype=np.uint8)
