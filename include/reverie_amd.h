@@ -418,6 +418,14 @@ int rv_hook_expand_seed(rv_ctx *ctx, const uint8_t *seeds, size_t n, uint8_t *ke
 int rv_hook_sharegen_gf2(rv_ctx *ctx, const uint8_t *keys, const uint32_t omit[8], size_t n, uint64_t *out);
 /* ShareGen<Z64>::next() x n -> n x 8 x 8 u64 */
 int rv_hook_sharegen_z64(rv_ctx *ctx, const uint8_t *keys, const uint32_t omit[8], size_t n, uint64_t *out);
+/* The gate-stream compiler alone (host only, no device: ctx-free): what rv_circuit_compile_ex would report through
+ * rv_circuit_get_info -- the counters that are pure functions of the op list (ShareGen::next() calls per repetition,
+ * generator/share.rs:54-65; transcript events, prover.rs:194,210,216), dependency levels, operand rows -- and the errors the
+ * reference raises while stepping (wire out of range, bad op).  device_bytes / scratch_bytes / upload_us stay zero.
+ * chunk_first_ops (0 = off): also checks, like a streaming feed cut every that many ops would, that every piece compiled
+ * on its own with the ShareGen phases predicted from the ops before it adds up to the whole (RV_E_DEVICE if not). */
+int rv_hook_compile_info(const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, size_t chunk_ops,
+                         rv_circuit_info *info);
 /* DomainGF2::reconstruct (gf2/domain.rs:47-63) on n packed u64 shares (bit 63 - (8*rep + player)) -> n ReconGF2 words
  * (one 0x00/0xFF byte per repetition), through the interpreter's own device function */
 int rv_hook_gf2_reconstruct(rv_ctx *ctx, const uint64_t *shares, size_t n, uint64_t *out);

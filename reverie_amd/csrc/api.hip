@@ -654,6 +654,45 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     delete c;
 }
 
+extern "C" int rv_hook_compile_info(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, size_t chunk_ops,
+                                    rv_circuit_info* info) {
+    if (!info || (n_ops && !ops) || (flags & ~RV_COMPILE_WHOLE_PROVER)) return RV_E_ARG;
+    try {
+        Compiled cc;
+        int rc = compile_ops(ops, n_ops, z64_wires, gf2_wires, cc, nullptr, ((flags & RV_COMPILE_WHOLE_PROVER) && !getenv("RV_LAZY_K")) ? RV_LIN_K : 0);
+        if (rc) return rc;
+        *info = cc.info;
+        if (chunk_ops) {
+            // the streaming prover's bookkeeping (stream.inc): pieces compiled independently, their ShareGen phases from
+            // count_masks of the ops before them, must consume exactly the whole program's masks and transcript events
+            uint64_t m2 = 0, m64 = 0, on = 0, pre = 0, muls = 0, onw = 0, prew = 0;
+            for (size_t at = 0; at < n_ops; at += chunk_ops) {
+                const size_t n = std::min(chunk_ops, n_ops - at);
+                ChunkStart cs;
+                cs.mask_phase = (uint32_t)(m2 % 128);
+                cs.mask64_phase = (uint32_t)(m64 % 2);
+                Compiled piece;
+                if ((rc = compile_ops(ops + at, n, z64_wires, gf2_wires, piece, &cs))) return rc;
+                uint64_t a = 0, b = 0;
+                count_masks(ops + at, n, &a, &b);
+                if (piece.n_masks - cs.mask_phase != a || piece.n_masks64 - cs.mask64_phase != b) return RV_E_DEVICE;
+                const uint64_t on_before = piece.n_on, pre_before = piece.n_pre;
+                relocate_chunk(piece, 7, 5, 3, 2);
+                if (piece.n_on != on_before + 7 || piece.n_pre != pre_before + 5) return RV_E_DEVICE;
+                m2 += a, m64 += b, on += on_before, pre += pre_before, muls += piece.info.gf2_muls;
+                onw += piece.on_words64 - 3, prew += piece.pre_words64 - 2;
+            }
+            if (m2 != cc.n_masks || m64 != cc.n_masks64 || on != cc.n_on || pre != cc.n_pre || muls != cc.info.gf2_muls || onw != cc.on_words64 ||
+                prew != cc.pre_words64)
+                return RV_E_DEVICE;
+        }
+        return RV_OK;
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
+}
+
 extern "C" int rv_circuit_get_info(const rv_circuit* c, rv_circuit_info* info) {
     if (!c || !info) return RV_E_ARG;
     *info = c->cc.info;
