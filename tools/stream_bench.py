@@ -27,8 +27,9 @@ def streaming_record(ctx, prog, wit, wc, st, seeds, want: bytes, chunk_ops: int 
            "gf2_wires": rwc[1], "bit_exact_vs_rv_prove": bytes(proof) == want,
            "device_bytes": {k: info[k] for k in ("wire_store_bytes", "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")},
            "note": "rv_prove_streaming, host ops in -> host proof bytes out, two passes over the op array; every chunk is compiled "
-                   "(levelised) on the host in each pass, on up to 6 worker threads ahead of the GPU -- still most of the time "
-                   "(~0.1 s of one core per 10^6 ops); the resident prover keeps ~6.4 GB for this circuit"}
+                   "(levelised) on the host, on up to 6 worker threads ahead of the GPU, and kept for pass 2 while it fits "
+                   "RV_STREAM_CACHE_MB -- still most of the time (~0.1 s of one core per 10^6 ops); the resident prover keeps "
+                   "~6.4 GB for this circuit"}
     del proof
     return rec
 
