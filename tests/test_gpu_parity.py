@@ -1204,6 +1204,7 @@ def test_compile_hint_whole_prover(rv, oracle, rule_seeds):
         for s in shards:
             be.destroy(s)
         assert assemble(comm, parts) == want
-    # the wide circuit really compiles differently
+    # the wide circuit really compiles differently (unless RV_LAZY_K fixes the choice for both)
     prog, w2, wc = cases[0]
-    assert rv.Circuit(prog, wc, whole_prover=True).info["gf2_rows_written"] < rv.Circuit(prog, wc).info["gf2_rows_written"]
+    if not os.environ.get("RV_LAZY_K"):
+        assert rv.Circuit(prog, wc, whole_prover=True).info["gf2_rows_written"] < rv.Circuit(prog, wc).info["gf2_rows_written"]
