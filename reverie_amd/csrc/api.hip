@@ -71,6 +71,10 @@ struct rv_ctx {
     hipStream_t stream2 = nullptr;  // the interpreter (HBM-bound), pipelined against the mask generator
     std::vector<rv_ctx*> workers;            // rv_prove_batch on large circuits: one worker context per host thread
     bool pipeline = false;          // RV_PIPELINE=1: mask generator and interpreter on two streams, chunk-wise (measured slower: DESIGN.md)
+    // Small proofs (AES-128: 99 KB) leave through this page-locked, device-mapped buffer: the opening kernels write into it
+    // and a one-lane kernel adds the error word, instead of two copy-engine operations of ~25 us each behind them
+    static constexpr size_t STAGE_BYTES = (size_t)1 << 20;
+    uint8_t* h_stage = nullptr;
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
         if (!sync_pool.empty()) {
@@ -225,6 +229,7 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     ctx->trim();
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (rv_ctx* w : ctx->workers) rv_ctx_destroy(w);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
@@ -1549,7 +1554,27 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         // in its final bincode form (comm included) and leaves in ONE copy; the host waits for the device once
         void* d = nullptr;
         size_t lens[4];
-        if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, nullptr, nullptr, /*no_sync=*/true))) break;
+        // small proofs: straight into the context's mapped staging buffer (the layout of a whole proof does not depend on
+        // the challenge, so its size is known before the openings exist); RV_SMALL_STAGE=0: the copy-engine path
+        static const bool small_stage = !(getenv("RV_SMALL_STAGE") && atoi(getenv("RV_SMALL_STAGE")) == 0);
+        uint8_t* stage_dev = nullptr;
+        size_t need = 0;
+        if (small_stage && !g_recorder) {
+            uint8_t canon[RV_TOTAL_REPS];
+            for (uint32_t r = 0; r < RV_TOTAL_REPS; r++) canon[r] = r < RV_ONLINE_REPS ? 0 : RV_PLAYERS;
+            need = open_layout(c->cc, canon, RV_TOTAL_REPS, true).total;
+            if (need + 64 <= rv_ctx::STAGE_BYTES) {
+                if (!ctx->h_stage && hipHostMalloc((void**)&ctx->h_stage, rv_ctx::STAGE_BYTES, hipHostMallocMapped) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx->h_stage = nullptr;
+                }
+                if (ctx->h_stage && hipHostGetDevicePointer((void**)&stage_dev, ctx->h_stage, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    stage_dev = nullptr;
+                }
+            }
+        }
+        if ((rc = shard_open_impl(s, nullptr, stage_dev, &d, lens, true, nullptr, nullptr, /*no_sync=*/true))) break;
         const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
         if (dst && total > dst_cap) {
             rc = RV_E_ARG;
@@ -1561,9 +1586,22 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
             break;
         }
         int err = 0;
-        if (hipMemcpyAsync(out, d, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        if (stage_dev) {
+            if (total != need) {
+                rc = RV_E_DEVICE;
+                break;
+            }
+            const size_t err_at = (total + 15) & ~(size_t)15;
+            launch_store_word(ctx->stream, s->d_err, (int*)(stage_dev + err_at));
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                rc = hip_fail(hipGetLastError(), "proof (staged)", __FILE__, __LINE__);
+                break;
+            }
+            memcpy(&err, ctx->h_stage + err_at, sizeof err);
+            memcpy(out, ctx->h_stage, total);
+        } else if (hipMemcpyAsync(out, d, total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                   hipMemcpyAsync(&err, s->d_err, sizeof err, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                   hipStreamSynchronize(ctx->stream) != hipSuccess) {
             rc = hip_fail(hipGetLastError(), "proof D2H", __FILE__, __LINE__);
             break;
         }

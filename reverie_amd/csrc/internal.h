@@ -164,6 +164,7 @@ void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const L
 // array of one InterpParams per proof
 void launch_interp_batched(hipStream_t st, const Gate* d_gates, const LevelRange& r, const InterpParams* d_pp, uint32_t batch,
                            int mode = MODE_PROVE);
+void launch_store_word(hipStream_t st, const int* d_src, int* dst_mapped);
 // a narrow stretch with its live wires in LDS (ldsrun.h); d_pp != null: `batch` proofs, parameters from the device array
 struct LdsRec;
 void launch_interp_lds(hipStream_t st, int mode, uint32_t QS, uint32_t NQ, const LdsRec* d_recs, uint32_t n_steps, uint32_t n_slots,

@@ -1720,4 +1720,8 @@ void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, cons
                        d_off64, l2r, l2c, l2i, l64r, l64c, l64i, d_out);
 }
 
+// the device error word into a host-mapped word (small proofs leave without a copy engine: api.hip, rv_prove_impl)
+__global__ void k_store_word(const int* __restrict__ src, int* __restrict__ dst) { *dst = *src; }
+void launch_store_word(hipStream_t st, const int* d_src, int* dst_mapped) { hipLaunchKernelGGL(k_store_word, dim3(1), dim3(1), 0, st, d_src, dst_mapped); }
+
 }  // namespace rv
