@@ -994,8 +994,14 @@ static int shard_run_hash(rv_shard* s) {
     ctx->phase(RV_PH_HASH);
     uint32_t* dig = s->d_dig;
     const size_t DW = (size_t)s->R * 8;
-    uint32_t n_launch = launch_b3_stream_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
-    n_launch += launch_b3_stream(ctx->stream, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 1 * DW, s->d_on_quads, s->n_on_quads);
+    uint32_t n_launch;
+    static const bool pair_on = !(getenv("RV_B3_PAIR") && atoi(getenv("RV_B3_PAIR")) == 0);
+    if (pair_on && !s->d_on_quads && launch_b3_pair_small(ctx->stream, s->d_pre, cc.n_pre, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW, dig + 1 * DW)) {
+        n_launch = 2;  // short transcripts (small circuits): both streams in the same two launches
+    } else {
+        n_launch = launch_b3_stream_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);
+        n_launch += launch_b3_stream(ctx->stream, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 1 * DW, s->d_on_quads, s->n_on_quads);
+    }
     // Z64 transcripts; for a pure GF(2) circuit both are empty and every digest is BLAKE3("") (one fill, not four launches)
     if (cc.pre_words64 == 0 && cc.on_words64 == 0) {
         static const std::vector<uint32_t> empty = [] {

@@ -714,8 +714,10 @@ struct B_k_b3_chunks {
     // chunk_base / root_ok (streaming prover): the stream handed in is a piece of a longer one -- its first chunk has
     // BLAKE3 chunk counter chunk_base, and a lone chunk only takes the ROOT flag when the caller knows it is the whole stream
     __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/, const uint32_t* __restrict__ quads, uint32_t n_quads, uint64_t chunk_base, uint32_t root_ok) const {
+    run((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stream, n_events, NQ, n_chunks, cvs, quads, n_quads, chunk_base, root_ok);
+    }
+    static __device__ __forceinline__ void run(uint64_t tid, const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, const uint32_t* __restrict__ quads, uint32_t n_quads, uint64_t chunk_base, uint32_t root_ok) {
     constexpr uint32_t SUBS = 4 / RPL;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lanes_per_chunk = (quads ? n_quads : NQ) * SUBS;
     const uint64_t c = tid / lanes_per_chunk;
     const uint32_t ql = (uint32_t)(tid % lanes_per_chunk);
@@ -777,7 +779,9 @@ __global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ 
 template <int RPL>
 struct B_k_b3_chunks_bits {
     __device__ __forceinline__ void operator()(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) const {
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    run((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stream, n_events, NQ, n_chunks, cvs, chunk_base, root_ok);
+    }
+    static __device__ __forceinline__ void run(uint64_t tid, const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) {
     constexpr uint32_t SUBS = 4 / RPL;
     const uint64_t c = tid / (NQ * SUBS);
     const uint32_t ql = (uint32_t)(tid % (NQ * SUBS));
@@ -899,8 +903,10 @@ constexpr uint32_t B3_TAIL = 512;
 template <int CAP>
 struct B_k_b3_tree_tail {
     __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R, uint32_t* __restrict__ digest) const {
+    run(blockIdx.x, in, n_in, R, digest);
+    }
+    static __device__ __forceinline__ void run(uint32_t r, const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R, uint32_t* __restrict__ digest) {
     __shared__ uint32_t cv[CAP][8 + 1];  // +1: odd row stride, no bank conflicts on the strided pair reads
-    const uint32_t r = blockIdx.x;
     for (uint32_t i = threadIdx.x; i < n_in * 8; i += blockDim.x) cv[i >> 3][i & 7] = in[((size_t)(i >> 3) * R + r) * 8 + (i & 7)];
     __syncthreads();
     uint32_t cnt = n_in;
@@ -989,6 +995,54 @@ struct B_k_b3_tree_lane {
 };
 __global__ __launch_bounds__(64) void k_b3_tree_lane(const uint32_t* __restrict__ in, uint32_t n_in, uint32_t R, uint32_t* __restrict__ digest) {
     B_k_b3_tree_lane{}(in, n_in, R, digest);
+}
+
+// Both transcripts of a small proof in the same two launches.  With a handful of chunks per stream the chunk kernels are
+// one dependent chain of 16 compressions per lane (~37 us) whatever the number of lanes, and the tree tops a few more:
+// run back to back, preprocessing then online, they are ~90 us of a 0.55 ms AES-128 proof.  The first blocks of a paired
+// launch take the preprocessing stream, the rest the online one (one repetition per lane in both).
+struct B_k_b3_chunks_pair {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
+                                               uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t NQ, uint32_t blocks_pre) const {
+    const uint64_t c_pre = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, c_on = n_on == 0 ? 1 : (n_on + 1023) / 1024;
+    if (blockIdx.x < blocks_pre)
+        B_k_b3_chunks_bits<1>::run((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, pre, n_pre, NQ, c_pre, cv_pre, 0, 1);
+    else
+        B_k_b3_chunks<1>::run((uint64_t)(blockIdx.x - blocks_pre) * blockDim.x + threadIdx.x, on, n_on, NQ, c_on, cv_on, nullptr, 0, 0, 1);
+    }
+};
+__global__ __launch_bounds__(256) void k_b3_chunks_pair(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
+                                                        uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t NQ, uint32_t blocks_pre) {
+    B_k_b3_chunks_pair{}(pre, n_pre, cv_pre, on, n_on, cv_on, NQ, blocks_pre);
+}
+// tree tops of both: workgroups [0, R) the preprocessing stream, [R, 2R) the online one
+struct B_k_b3_tree_tail_pair {
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in_a, uint32_t n_a, uint32_t* __restrict__ dig_a, const uint32_t* __restrict__ in_b, uint32_t n_b,
+                                               uint32_t* __restrict__ dig_b, uint32_t R) const {
+    if (blockIdx.x < R)
+        B_k_b3_tree_tail<64>::run(blockIdx.x, in_a, n_a, R, dig_a);
+    else
+        B_k_b3_tree_tail<64>::run(blockIdx.x - R, in_b, n_b, R, dig_b);
+    }
+};
+__global__ __launch_bounds__(64) void k_b3_tree_tail_pair(const uint32_t* __restrict__ in_a, uint32_t n_a, uint32_t* __restrict__ dig_a, const uint32_t* __restrict__ in_b,
+                                                          uint32_t n_b, uint32_t* __restrict__ dig_b, uint32_t R) {
+    B_k_b3_tree_tail_pair{}(in_a, n_a, dig_a, in_b, n_b, dig_b, R);
+}
+// true (and two launches issued) when both streams are short enough for the paired kernels; d_cv_a / d_cv_b each hold one
+// stream's chunk chaining values (the tree tops need no second buffer at this size)
+bool launch_b3_pair_small(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, const uint32_t* d_on, uint64_t n_on, uint32_t NQ, uint32_t* d_cv_a,
+                          uint32_t* d_cv_b, uint32_t* d_dig_pre, uint32_t* d_dig_on) {
+    const uint64_t c_pre = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, c_on = n_on == 0 ? 1 : (n_on + 1023) / 1024;
+    const uint32_t batch = g_recorder ? g_recorder->batch : 1u;
+    // (the same "few chunks" rule as the separate launchers' one-repetition-per-lane choice, and trees the small tail kernel takes)
+    if (c_pre > 64 || c_on > 64 || std::max(c_pre, c_on) * NQ * batch >= 64 * 1024) return false;
+    const uint32_t R = NQ * 4;
+    const uint32_t b_pre = (uint32_t)((c_pre * NQ * 4 + 255) / 256), b_on = (uint32_t)((c_on * NQ * 4 + 255) / 256);
+    launch<B_k_b3_chunks_pair, 256>(k_b3_chunks_pair, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, d_cv_a, d_on, n_on, d_cv_b, NQ, b_pre);
+    launch<B_k_b3_tree_tail_pair, 64>(k_b3_tree_tail_pair, st, dim3(2 * R), dim3(64), (const uint32_t*)d_cv_a, (uint32_t)c_pre, d_dig_pre,
+                                      (const uint32_t*)d_cv_b, (uint32_t)c_on, d_dig_on, R);
+    return true;
 }
 
 // tree reduction of n chunk chaining values per repetition; the roots land in d_digest ([R][8] words)
