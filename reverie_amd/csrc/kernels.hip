@@ -1731,34 +1731,39 @@ void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d
                                  d_omit, n_items, NQ, kind, d_rows_out);
 }
 
-// Fixed-size parts of the openings, one thread per repetition of the shard.
+// Fixed-size parts of the openings.
 //   online rep : omit | keys[8][16] with the omitted key zeroed | u64 len | .. | u64 len | .. | u64 len | ..
 //   other rep  : seed[16] | H_on[32]                           (proof/mod.rs:41-53, prover.rs:125-136,167-170)
 // d_off2/d_off64 give each rep's record offset inside the shard's concatenated output.
-__device__ inline void put_u64(uint8_t* p, uint64_t v) {
-    for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
-}
-
 struct B_k_open_headers {
+    // workgroup = (repetition, domain), thread = one header byte (consecutive lanes write consecutive bytes: the stores
+    // coalesce, also when the proof buffer is mapped host memory); a lane-per-repetition version that walked its ~300
+    // bytes one by one took 14 us of a 0.5 ms AES-128 proof
     __device__ __forceinline__ void operator()(uint32_t R, const uint8_t* __restrict__ omit, const uint8_t* __restrict__ seeds, const uint8_t* __restrict__ keys, const uint32_t* __restrict__ on2, const uint32_t* __restrict__ on64, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ off64, uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i, uint8_t* __restrict__ out) const {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.x >> 1, dom = blockIdx.x & 1u, i = threadIdx.x;
     if (r >= R) return;
     const uint32_t om = omit[r];
-    for (int dom = 0; dom < 2; dom++) {
-        uint8_t* o = out + (dom == 0 ? off2[r] : off64[r]);
-        if (om < 8) {
-            const uint64_t lr = dom == 0 ? l2r : l64r, lc = dom == 0 ? l2c : l64c, li = dom == 0 ? l2i : l64i;
+    uint8_t* o = out + (dom == 0 ? off2[r] : off64[r]);
+    if (om < 8) {
+        const uint64_t lr = dom == 0 ? l2r : l64r, lc = dom == 0 ? l2c : l64c, li = dom == 0 ? l2i : l64i;
+        if (i == 0) {
             o[0] = (uint8_t)om;
-            for (int p = 0; p < 8; p++)
-                for (int i = 0; i < 16; i++) o[1 + 16 * p + i] = (p == (int)om) ? 0 : keys[(size_t)r * 128 + 16 * p + i];
-            put_u64(o + 129, lr);
-            put_u64(o + 137 + lr, lc);
-            put_u64(o + 145 + lr + lc, li);
-        } else {
+        } else if (i < 129) {
+            const uint32_t p = (i - 1) >> 4;
+            o[i] = (p == om) ? (uint8_t)0 : keys[(size_t)r * 128 + (i - 1)];
+        } else if (i < 137) {
+            o[i] = (uint8_t)(lr >> (8 * (i - 129)));
+        } else if (i < 145) {
+            o[137 + lr + (i - 137)] = (uint8_t)(lc >> (8 * (i - 137)));
+        } else if (i < 153) {
+            o[145 + lr + lc + (i - 145)] = (uint8_t)(li >> (8 * (i - 145)));
+        }
+    } else {
+        if (i < 16) {
+            o[i] = seeds[(size_t)r * 16 + i];
+        } else if (i < 48) {
             const uint32_t* hon = (dom == 0 ? on2 : on64) + (size_t)r * 8;
-            for (int i = 0; i < 16; i++) o[i] = seeds[(size_t)r * 16 + i];
-            for (int k = 0; k < 8; k++)
-                for (int b = 0; b < 4; b++) o[16 + 4 * k + b] = (uint8_t)(hon[k] >> (8 * b));
+            o[i] = (uint8_t)(hon[(i - 16) >> 2] >> (8 * ((i - 16) & 3)));
         }
     }
 }
@@ -1770,7 +1775,7 @@ __global__ void k_open_headers(uint32_t R, const uint8_t* __restrict__ omit, con
 void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys,
                          const uint32_t* d_on2, const uint32_t* d_on64, const uint64_t* d_off2, const uint64_t* d_off64,
                          uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i, uint8_t* d_out) {
-    launch<B_k_open_headers, 64>(k_open_headers, st, dim3((R + 63) / 64), dim3(64), R, d_omit, d_seeds, d_keys, d_on2, d_on64, d_off2,
+    launch<B_k_open_headers, 192>(k_open_headers, st, dim3(2 * R), dim3(192), R, d_omit, d_seeds, d_keys, d_on2, d_on64, d_off2,
                        d_off64, l2r, l2c, l2i, l64r, l64c, l64i, d_out);
 }
 
