@@ -75,6 +75,9 @@ struct rv_ctx {
     // and a one-lane kernel adds the error word, instead of two copy-engine operations of ~25 us each behind them
     static constexpr size_t STAGE_BYTES = (size_t)1 << 20;
     uint8_t* h_stage = nullptr;
+    // ... and the seeds and the GF(2) witness of a whole proof enter through this one (one copy instead of two pageable ones)
+    static constexpr size_t IN_STAGE_BYTES = (size_t)64 << 10;
+    uint8_t* h_in = nullptr;
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
         if (!sync_pool.empty()) {
@@ -230,6 +233,7 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     ctx->trim();
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     for (rv_ctx* w : ctx->workers) rv_ctx_destroy(w);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
@@ -1149,13 +1153,25 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         rv_shard_destroy(s);
         return code;
     };
-    if ((rc = dalloc(ctx, (size_t)s->R * 16, &s->d_seeds)) || (rc = dalloc(ctx, (size_t)s->R * 128, &s->d_keys)) ||
-        (rc = dalloc(ctx, std::max<size_t>(cc.n_in, 1), &s->d_wit)))
-        return fail(rc);
-    if (hipMemcpyAsync(s->d_seeds, seeds, (size_t)s->R * 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        return fail(RV_E_DEVICE);
-    if (cc.n_in && hipMemcpyAsync(s->d_wit, wit_gf2, cc.n_in, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        return fail(RV_E_DEVICE);
+    // defer_sync callers (rv_prove and its relatives) wait for the stream before they return, so the page-locked input
+    // staging buffer is free again by the next call: seeds and witness go over in ONE asynchronous copy
+    const size_t seed_bytes = (size_t)s->R * 16;
+    const bool stage_in = defer_sync && seed_bytes + cc.n_in <= rv_ctx::IN_STAGE_BYTES &&
+                          (ctx->h_in || hipHostMalloc((void**)&ctx->h_in, rv_ctx::IN_STAGE_BYTES, hipHostMallocDefault) == hipSuccess);
+    if (!stage_in) (void)hipGetLastError();
+    if (stage_in) {
+        if ((rc = dalloc(ctx, seed_bytes + std::max<size_t>(cc.n_in, 1), &s->d_seeds)) || (rc = dalloc(ctx, (size_t)s->R * 128, &s->d_keys))) return fail(rc);
+        s->d_wit = s->d_seeds + seed_bytes;  // (inside d_seeds' block: the arena ignores it on release)
+        memcpy(ctx->h_in, seeds, seed_bytes);
+        if (cc.n_in) memcpy(ctx->h_in + seed_bytes, wit_gf2, cc.n_in);
+        if (hipMemcpyAsync(s->d_seeds, ctx->h_in, seed_bytes + cc.n_in, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(RV_E_DEVICE);
+    } else {
+        if ((rc = dalloc(ctx, seed_bytes, &s->d_seeds)) || (rc = dalloc(ctx, (size_t)s->R * 128, &s->d_keys)) ||
+            (rc = dalloc(ctx, std::max<size_t>(cc.n_in, 1), &s->d_wit)))
+            return fail(rc);
+        if (hipMemcpyAsync(s->d_seeds, seeds, seed_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(RV_E_DEVICE);
+        if (cc.n_in && hipMemcpyAsync(s->d_wit, wit_gf2, cc.n_in, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(RV_E_DEVICE);
+    }
     if (cc.n_in64) {
         if ((rc = dalloc(ctx, cc.n_in64, &s->d_wit64))) return fail(rc);
         if (hipMemcpyAsync(s->d_wit64, wit_z64, cc.n_in64 * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
