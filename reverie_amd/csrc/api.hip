@@ -1000,7 +1000,8 @@ static int shard_run_hash(rv_shard* s) {
     const size_t DW = (size_t)s->R * 8;
     uint32_t n_launch;
     static const bool pair_on = !(getenv("RV_B3_PAIR") && atoi(getenv("RV_B3_PAIR")) == 0);
-    if (pair_on && !s->d_on_quads && launch_b3_pair_small(ctx->stream, s->d_pre, cc.n_pre, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW, dig + 1 * DW)) {
+    if (pair_on && launch_b3_pair_small(ctx->stream, s->d_pre, cc.n_pre, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW, dig + 1 * DW,
+                                        s->d_on_quads, s->n_on_quads)) {
         n_launch = 2;  // short transcripts (small circuits): both streams in the same two launches
     } else {
         n_launch = launch_b3_stream_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW);

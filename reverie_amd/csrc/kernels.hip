@@ -1003,17 +1003,19 @@ __global__ __launch_bounds__(64) void k_b3_tree_lane(const uint32_t* __restrict_
 // launch take the preprocessing stream, the rest the online one (one repetition per lane in both).
 struct B_k_b3_chunks_pair {
     __device__ __forceinline__ void operator()(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
-                                               uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t NQ, uint32_t blocks_pre) const {
+                                               uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t NQ, uint32_t blocks_pre, const uint32_t* __restrict__ quads,
+                                               uint32_t n_quads) const {
     const uint64_t c_pre = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, c_on = n_on == 0 ? 1 : (n_on + 1023) / 1024;
     if (blockIdx.x < blocks_pre)
         B_k_b3_chunks_bits<1>::run((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, pre, n_pre, NQ, c_pre, cv_pre, 0, 1);
     else
-        B_k_b3_chunks<1>::run((uint64_t)(blockIdx.x - blocks_pre) * blockDim.x + threadIdx.x, on, n_on, NQ, c_on, cv_on, nullptr, 0, 0, 1);
+        B_k_b3_chunks<1>::run((uint64_t)(blockIdx.x - blocks_pre) * blockDim.x + threadIdx.x, on, n_on, NQ, c_on, cv_on, quads, n_quads, 0, 1);
     }
 };
 __global__ __launch_bounds__(256) void k_b3_chunks_pair(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
-                                                        uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t NQ, uint32_t blocks_pre) {
-    B_k_b3_chunks_pair{}(pre, n_pre, cv_pre, on, n_on, cv_on, NQ, blocks_pre);
+                                                        uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t NQ, uint32_t blocks_pre,
+                                                        const uint32_t* __restrict__ quads, uint32_t n_quads) {
+    B_k_b3_chunks_pair{}(pre, n_pre, cv_pre, on, n_on, cv_on, NQ, blocks_pre, quads, n_quads);
 }
 // tree tops of both: workgroups [0, R) the preprocessing stream, [R, 2R) the online one
 struct B_k_b3_tree_tail_pair {
@@ -1030,16 +1032,18 @@ __global__ __launch_bounds__(64) void k_b3_tree_tail_pair(const uint32_t* __rest
     B_k_b3_tree_tail_pair{}(in_a, n_a, dig_a, in_b, n_b, dig_b, R);
 }
 // true (and two launches issued) when both streams are short enough for the paired kernels; d_cv_a / d_cv_b each hold one
-// stream's chunk chaining values (the tree tops need no second buffer at this size)
+// stream's chunk chaining values (the tree tops need no second buffer at this size).  d_quads / n_quads as in
+// launch_b3_stream (the verifier hashes the online stream of the opened quads only; n_quads = 0 with a list: not paired)
 bool launch_b3_pair_small(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, const uint32_t* d_on, uint64_t n_on, uint32_t NQ, uint32_t* d_cv_a,
-                          uint32_t* d_cv_b, uint32_t* d_dig_pre, uint32_t* d_dig_on) {
+                          uint32_t* d_cv_b, uint32_t* d_dig_pre, uint32_t* d_dig_on, const uint32_t* d_quads, uint32_t n_quads) {
+    if (d_quads && !n_quads) return false;
     const uint64_t c_pre = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, c_on = n_on == 0 ? 1 : (n_on + 1023) / 1024;
     const uint32_t batch = g_recorder ? g_recorder->batch : 1u;
     // (the same "few chunks" rule as the separate launchers' one-repetition-per-lane choice, and trees the small tail kernel takes)
     if (c_pre > 64 || c_on > 64 || std::max(c_pre, c_on) * NQ * batch >= 64 * 1024) return false;
     const uint32_t R = NQ * 4;
-    const uint32_t b_pre = (uint32_t)((c_pre * NQ * 4 + 255) / 256), b_on = (uint32_t)((c_on * NQ * 4 + 255) / 256);
-    launch<B_k_b3_chunks_pair, 256>(k_b3_chunks_pair, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, d_cv_a, d_on, n_on, d_cv_b, NQ, b_pre);
+    const uint32_t b_pre = (uint32_t)((c_pre * NQ * 4 + 255) / 256), b_on = (uint32_t)((c_on * (d_quads ? n_quads : NQ) * 4 + 255) / 256);
+    launch<B_k_b3_chunks_pair, 256>(k_b3_chunks_pair, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, d_cv_a, d_on, n_on, d_cv_b, NQ, b_pre, d_quads, n_quads);
     launch<B_k_b3_tree_tail_pair, 64>(k_b3_tree_tail_pair, st, dim3(2 * R), dim3(64), (const uint32_t*)d_cv_a, (uint32_t)c_pre, d_dig_pre,
                                       (const uint32_t*)d_cv_b, (uint32_t)c_on, d_dig_on, R);
     return true;
