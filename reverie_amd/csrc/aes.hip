@@ -127,6 +127,21 @@ __global__ void k_key_schedule(const uint8_t* __restrict__ keys, uint32_t n_slot
     B_k_key_schedule{}(keys, n_slots, rkbytes);
 }
 
+// 32x32 bit-matrix transpose (Hacker's Delight 7-3), fully unrolled: registers only
+__device__ __forceinline__ void transpose32(uint32_t* A) {
+    uint32_t m = 0x0000FFFFu;
+#pragma unroll
+    for (int j = 16; j != 0; j >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+            const uint32_t t = (A[k] ^ (A[k + j] >> j)) & m;
+            A[k] ^= t;
+            A[k + j] ^= (t << j);
+        }
+        m ^= (m << (j >> 1));
+    }
+}
+
 // rk[(round*128 + 8*byte + bit)*NQ + q] = bit `bit` of round-key byte `byte` of the 32
 // slots of quad q, slot (i4, p) at bit 31 - (8*i4 + p).  Slots are numbered rep*8 + p.
 struct B_k_bitslice_rk {
@@ -140,13 +155,11 @@ struct B_k_bitslice_rk {
     uint32_t v[32];
 #pragma unroll
     for (uint32_t s = 0; s < 32; s++) v[s] = *(const uint32_t*)(rkbytes + RK_BYTES * (size_t)(q * 32 + s) + 4 * bg);
-#pragma unroll 1
-    for (uint32_t k = 0; k < 32; k++) {  // k = 8 * (byte in the group) + bit
-        uint32_t w = 0;
+    // w_k = bit k of the 32 slots' words, slot s at bit 31 - s: the 32x32 bit transpose (row i of the result holds bit 31 - i
+    // of every input row, input row j at bit 31 - j) read backwards
+    transpose32(v);
 #pragma unroll
-        for (uint32_t s = 0; s < 32; s++) w |= ((v[s] >> k) & 1u) << (31 - s);
-        rk[(size_t)(32 * bg + k) * NQ + q] = w;
-    }
+    for (uint32_t k = 0; k < 32; k++) rk[(size_t)(32 * bg + k) * NQ + q] = v[31 - k];  // k = 8 * (byte in the group) + bit
 }
 };
 __global__ void k_bitslice_rk(const uint8_t* __restrict__ rkbytes, uint32_t NQ, uint32_t* __restrict__ rk) {
@@ -509,20 +522,6 @@ void launch_key_schedule(hipStream_t st, const uint8_t* d_keys, uint32_t n_slots
 void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, uint32_t* d_rk) {
     uint32_t n = (RK_BYTES / 4) * NQ;
     launch<B_k_bitslice_rk, 256>(k_bitslice_rk, st, dim3((n + 255) / 256), dim3(256), d_rkbytes, NQ, d_rk);
-}
-// 32x32 bit-matrix transpose (Hacker's Delight 7-3), fully unrolled: registers only
-__device__ __forceinline__ void transpose32(uint32_t* A) {
-    uint32_t m = 0x0000FFFFu;
-#pragma unroll
-    for (int j = 16; j != 0; j >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
-            const uint32_t t = (A[k] ^ (A[k + j] >> j)) & m;
-            A[k] ^= t;
-            A[k + j] ^= (t << j);
-        }
-        m ^= (m << (j >> 1));
-    }
 }
 
 // Measured (round 2, config 5: 2.05e9 cipher blocks per proof, 26.8 ms): with the stores left out the kernel takes 24.5 ms,
