@@ -109,7 +109,9 @@ __device__ __forceinline__ void lr_stage(const LrRecs& R, const LrVals& V, uint4
         uint4* f = ring_step0 + s * 4 * 64;
         f[0] = make_uint4(addr(r0.x & 0xFFFFu), addr(r0.x >> 16), addr(r0.y & 0xFFFFu), addr(r0.y >> 16));
         f[64] = make_uint4(addr(r0.z & 0xFFFFu), addr(r0.z >> 16), addr(r0.w & 0xFFFFu), op);
-        f[128] = make_uint4(m0, m1, a, b);
+        // (the prover has no use for the fourth word: it carries reconstruct(m1), which takes a reconstruct off the
+        // consumer's dependency chain -- see lr_step)
+        f[128] = make_uint4(m0, m1, a, MODE != MODE_VERIFY ? recon32(m1) : b);
         f[192] = make_uint4(recon32(m0), ((r1.x - rp.eo0) * NQ + q) * 4u, (r1.y - rp.ep0) * (NQ >> 1) + (q >> 1), r1.z + (kind == G_MUL ? 1u : 0u));
     }
 }
@@ -189,7 +191,19 @@ __device__ __forceinline__ void lr_step(const uint4 f0, const uint4 f1, const ui
         delta = (v.z & onm) | (delta & ~onm);  // online-verified repetitions: the supplied correction
         t ^= onm ? v.w : 0u;                   // ... and the omitted player's broadcast
     }
-    const uint32_t r_raw = recon32(t);
+    // reconstruct(t) without a second reconstruct behind the gathers (a lone wavefront pays ~10 cycles per DEPENDENT
+    // instruction: the step is bound by its longest chain, not by its instruction count): reconstruct is linear, and a
+    // share word ANDed with a per-repetition 0x00 / 0xFF mask reconstructs to the AND of its reconstruction with that mask,
+    // so for a Mul  reconstruct(s) = (b & cx) ^ (a & cy) ^ reconstruct(m0) ^ reconstruct(m1);  AssertZero / Recon: a
+    // (prover only: the verifier's fourth word is the omitted player's broadcast, and two extra reconstructs next to the
+    // chain cost it more than the one on the chain -- measured)
+    uint32_t r_raw;
+    if (MODE != MODE_VERIFY) {
+        const uint32_t r_mul = (b & cx) ^ (a & cy) ^ c ^ v.w;
+        r_raw = (r_mul & mm) | (a & ~mm);
+    } else {
+        r_raw = recon32(t);
+    }
     const uint32_t r = MODE == MODE_VERIFY ? (r_raw & onm) : r_raw;
     const uint32_t drow = (v.y & mm) | ((lx ^ ly) & mx) | (v.x & (mi | mo));
     const uint32_t dcorr = ((r ^ delta ^ (cx & cy)) & mm) | ((cx ^ cy ^ cb) & mx) | ((r ^ cx) & mr) | (corr_in & mi) | (v.z & mo);
