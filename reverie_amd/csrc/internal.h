@@ -167,6 +167,7 @@ void launch_interp_batched(hipStream_t st, const Gate* d_gates, const LevelRange
 bool launch_b3_pair_small(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, const uint32_t* d_on, uint64_t n_on, uint32_t NQ, uint32_t* d_cv_a,
                           uint32_t* d_cv_b, uint32_t* d_dig_pre, uint32_t* d_dig_on, const uint32_t* d_quads = nullptr, uint32_t n_quads = 0);
 void launch_store_word(hipStream_t st, const int* d_src, int* dst_mapped);
+void launch_store_words(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, const int* d_err, int* dst_err_mapped);
 // a narrow stretch with its live wires in LDS (ldsrun.h); d_pp != null: `batch` proofs, parameters from the device array
 struct LdsRec;
 void launch_interp_lds(hipStream_t st, int mode, uint32_t QS, uint32_t NQ, const LdsRec* d_recs, uint32_t n_steps, uint32_t n_slots,

@@ -1786,5 +1786,14 @@ void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, cons
 // the device error word into a host-mapped word (small proofs leave without a copy engine: api.hip, rv_prove_impl)
 __global__ void k_store_word(const int* __restrict__ src, int* __restrict__ dst) { *dst = *src; }
 void launch_store_word(hipStream_t st, const int* d_src, int* dst_mapped) { hipLaunchKernelGGL(k_store_word, dim3(1), dim3(1), 0, st, d_src, dst_mapped); }
+// a few KB (the verifier's 256 digests) plus the error word into host-mapped memory, for the same reason
+__global__ void k_store_words(const uint32_t* __restrict__ src, uint32_t n_words, uint32_t* __restrict__ dst, const int* __restrict__ err, int* __restrict__ dst_err) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) dst[i] = src[i];
+    if (i == 0 && err) *dst_err = *err;
+}
+void launch_store_words(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, const int* d_err, int* dst_err_mapped) {
+    hipLaunchKernelGGL(k_store_words, dim3((n_words + 255) / 256), dim3(256), 0, st, d_src, n_words, dst_mapped, d_err, dst_err_mapped);
+}
 
 }  // namespace rv
