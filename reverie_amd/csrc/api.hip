@@ -76,7 +76,7 @@ struct rv_ctx {
     static constexpr size_t STAGE_BYTES = (size_t)1 << 20;
     uint8_t* h_stage = nullptr;
     // ... and the seeds and the GF(2) witness of a whole proof enter through this one (one copy instead of two pageable ones)
-    static constexpr size_t IN_STAGE_BYTES = (size_t)64 << 10;
+    static constexpr size_t IN_STAGE_BYTES = (size_t)1 << 20;
     uint8_t* h_in = nullptr;
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
@@ -2206,23 +2206,88 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     uint64_t* d_src = nullptr;
     uint32_t *d_keep = nullptr, *d_onm = nullptr, *d_sup_in = nullptr, *d_sup_corr = nullptr, *d_sup_rec = nullptr;
     auto track = [&](void* p) { s->extra.push_back(p); };
-    if ((rc = dalloc(ctx, (size_t)R * 16, &s->d_seeds)) || (rc = dalloc(ctx, (size_t)R * 128, &s->d_keys)) ||
-        (rc = dalloc(ctx, R, &s->d_omit)))
-        return fail(rc);
-    if ((rc = dalloc(ctx, proof_len, &d_proof))) return fail(rc);
-    track(d_proof);
-    if ((rc = dalloc(ctx, src.size(), &d_src))) return fail(rc);
-    track(d_src);
-    if ((rc = dalloc(ctx, NQ, &d_keep))) return fail(rc);
-    track(d_keep);
-    if ((rc = dalloc(ctx, NQ, &d_onm))) return fail(rc);
-    track(d_onm);
     std::vector<uint32_t> on_quads;
     for (uint32_t q = 0; q < NQ; q++)
         if (onm[q]) on_quads.push_back(q);
+    // ---- staging (one copy each instead of one per repetition): opened player keys (online.rs:101-113) and the
+    //      online commitments the preprocessing slots carry over from the proof (preprocess.rs:55-57)
+    std::vector<uint8_t> hkeys((size_t)R * 128, 0), hco((size_t)R * 32, 0), hkeys64, hco64((size_t)R * 32, 0);
+    if (has64) hkeys64.assign((size_t)R * 128, 0);
+    for (uint32_t r = 0; r < R; r++) {
+        if (omit[r] < 8) {
+            memcpy(&hkeys[(size_t)r * 128], proof + P.gf2.on[slot_begin + r].keys, 128);
+            if (has64 && omit64[r] < 8) memcpy(&hkeys64[(size_t)r * 128], proof + P.z64.on[slot_begin + r].keys, 128);
+        } else {
+            const uint32_t k = slot_begin + r - RV_ONLINE_REPS;
+            memcpy(&hco[(size_t)r * 32], proof + P.gf2.pre[k].comm_online, 32);
+            memcpy(&hco64[(size_t)r * 32], proof + P.z64.pre[k].comm_online, 32);
+        }
+    }
     uint32_t* d_on_quads = nullptr;
-    if ((rc = dalloc(ctx, std::max<size_t>(on_quads.size(), 1), &d_on_quads))) return fail(rc);
-    track(d_on_quads);
+    uint8_t *d_hkeys = nullptr, *d_hco = nullptr, *d_hkeys64 = nullptr, *d_hco64 = nullptr;
+    // A small GF(2) proof goes over in ONE copy: every host array above and the proof itself are packed into the
+    // page-locked input staging buffer and land in one device block (ten pageable copies of ~10 us each otherwise).
+    // The function waits for the stream before it returns, so the buffer is free again by the next call.
+    size_t blob_bytes = 0;
+    auto seg = [&](size_t len) {
+        const size_t o = blob_bytes;
+        blob_bytes += (len + 15) & ~(size_t)15;
+        return o;
+    };
+    const size_t o_seeds = seg(seeds.size()), o_omit = seg(omit.size()), o_keep = seg((size_t)NQ * 4), o_onm = seg((size_t)NQ * 4),
+                 o_onq = seg(std::max<size_t>(on_quads.size(), 1) * 4), o_hkeys = seg(hkeys.size()), o_hco = seg(hco.size()),
+                 o_hco64 = seg(hco64.size()), o_src = seg(src.size() * 8), o_proof = seg(proof_len);
+    static const bool small_stage = !(getenv("RV_SMALL_STAGE") && atoi(getenv("RV_SMALL_STAGE")) == 0);
+    bool blob = small_stage && !has64 && !ctx->pipeline && !g_recorder && blob_bytes <= rv_ctx::IN_STAGE_BYTES;
+    if (blob && !ctx->h_in && hipHostMalloc((void**)&ctx->h_in, rv_ctx::IN_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->h_in = nullptr;
+        blob = false;
+    }
+    if (blob) {
+        if ((rc = dalloc(ctx, blob_bytes, &s->d_seeds)) || (rc = dalloc(ctx, (size_t)R * 128, &s->d_keys))) return fail(rc);
+        uint8_t* b = s->d_seeds;  // (pointers inside d_seeds' block: the arena ignores them on release)
+        s->d_omit = b + o_omit;
+        d_keep = (uint32_t*)(b + o_keep);
+        d_onm = (uint32_t*)(b + o_onm);
+        d_on_quads = (uint32_t*)(b + o_onq);
+        d_hkeys = b + o_hkeys;
+        d_hco = b + o_hco;
+        d_hco64 = b + o_hco64;
+        d_src = (uint64_t*)(b + o_src);
+        d_proof = b + o_proof;
+        uint8_t* h = ctx->h_in;
+        memcpy(h + o_seeds, seeds.data(), seeds.size());
+        memcpy(h + o_omit, omit.data(), omit.size());
+        memcpy(h + o_keep, keep.data(), (size_t)NQ * 4);
+        memcpy(h + o_onm, onm.data(), (size_t)NQ * 4);
+        if (!on_quads.empty()) memcpy(h + o_onq, on_quads.data(), on_quads.size() * 4);
+        memcpy(h + o_hkeys, hkeys.data(), hkeys.size());
+        memcpy(h + o_hco, hco.data(), hco.size());
+        memcpy(h + o_hco64, hco64.data(), hco64.size());
+        memcpy(h + o_src, src.data(), src.size() * 8);
+        memcpy(h + o_proof, proof, proof_len);
+    } else {
+        if ((rc = dalloc(ctx, (size_t)R * 16, &s->d_seeds)) || (rc = dalloc(ctx, (size_t)R * 128, &s->d_keys)) ||
+            (rc = dalloc(ctx, R, &s->d_omit)))
+            return fail(rc);
+        if ((rc = dalloc(ctx, proof_len, &d_proof))) return fail(rc);
+        track(d_proof);
+        if ((rc = dalloc(ctx, src.size(), &d_src))) return fail(rc);
+        track(d_src);
+        if ((rc = dalloc(ctx, NQ, &d_keep))) return fail(rc);
+        track(d_keep);
+        if ((rc = dalloc(ctx, NQ, &d_onm))) return fail(rc);
+        track(d_onm);
+        if ((rc = dalloc(ctx, std::max<size_t>(on_quads.size(), 1), &d_on_quads))) return fail(rc);
+        track(d_on_quads);
+        if ((rc = dalloc(ctx, hkeys.size(), &d_hkeys))) return fail(rc);
+        track(d_hkeys);
+        if ((rc = dalloc(ctx, hco.size(), &d_hco))) return fail(rc);
+        track(d_hco);
+        if ((rc = dalloc(ctx, hco64.size(), &d_hco64))) return fail(rc);
+        track(d_hco64);
+    }
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_in, 1) * NQ, &d_sup_in))) return fail(rc);
     track(d_sup_in);
     if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * NQ, &d_sup_corr))) return fail(rc);
@@ -2254,43 +2319,26 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
             return fail(RV_E_DEVICE);         \
         }                                     \
     } while (0)
-    // ---- staging (one copy each instead of one per repetition): opened player keys (online.rs:101-113) and the
-    //      online commitments the preprocessing slots carry over from the proof (preprocess.rs:55-57)
     const size_t DW = (size_t)R * 8;
-    std::vector<uint8_t> hkeys((size_t)R * 128, 0), hco((size_t)R * 32, 0), hkeys64, hco64((size_t)R * 32, 0);
-    if (has64) hkeys64.assign((size_t)R * 128, 0);
-    for (uint32_t r = 0; r < R; r++) {
-        if (omit[r] < 8) {
-            memcpy(&hkeys[(size_t)r * 128], proof + P.gf2.on[slot_begin + r].keys, 128);
-            if (has64 && omit64[r] < 8) memcpy(&hkeys64[(size_t)r * 128], proof + P.z64.on[slot_begin + r].keys, 128);
-        } else {
-            const uint32_t k = slot_begin + r - RV_ONLINE_REPS;
-            memcpy(&hco[(size_t)r * 32], proof + P.gf2.pre[k].comm_online, 32);
-            memcpy(&hco64[(size_t)r * 32], proof + P.z64.pre[k].comm_online, 32);
-        }
-    }
-    uint8_t *d_hkeys = nullptr, *d_hco = nullptr, *d_hkeys64 = nullptr, *d_hco64 = nullptr;
-    if ((rc = dalloc(ctx, hkeys.size(), &d_hkeys))) return fail(rc);
-    track(d_hkeys);
-    if ((rc = dalloc(ctx, hco.size(), &d_hco))) return fail(rc);
-    track(d_hco);
-    if ((rc = dalloc(ctx, hco64.size(), &d_hco64))) return fail(rc);
-    track(d_hco64);
     if (has64) {
         if ((rc = dalloc(ctx, hkeys64.size(), &d_hkeys64))) return fail(rc);
         track(d_hkeys64);
     }
     // ---- stream 1: everything the mask generator needs, then the masks themselves
-    HC(hipMemcpyAsync(s->d_seeds, seeds.data(), seeds.size(), hipMemcpyHostToDevice, ctx->stream));
-    HC(hipMemcpyAsync(s->d_omit, omit.data(), omit.size(), hipMemcpyHostToDevice, ctx->stream));
-    HC(hipMemcpyAsync(d_keep, keep.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
-    HC(hipMemcpyAsync(d_onm, onm.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (!on_quads.empty()) HC(hipMemcpyAsync(d_on_quads, on_quads.data(), on_quads.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (blob) {
+        HC(hipMemcpyAsync(s->d_seeds, ctx->h_in, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        HC(hipMemcpyAsync(s->d_seeds, seeds.data(), seeds.size(), hipMemcpyHostToDevice, ctx->stream));
+        HC(hipMemcpyAsync(s->d_omit, omit.data(), omit.size(), hipMemcpyHostToDevice, ctx->stream));
+        HC(hipMemcpyAsync(d_keep, keep.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
+        HC(hipMemcpyAsync(d_onm, onm.data(), NQ * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!on_quads.empty()) HC(hipMemcpyAsync(d_on_quads, on_quads.data(), on_quads.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HC(hipMemcpyAsync(d_hkeys, hkeys.data(), hkeys.size(), hipMemcpyHostToDevice, ctx->stream));
+        HC(hipMemcpyAsync(d_hco, hco.data(), hco.size(), hipMemcpyHostToDevice, ctx->stream));
+        HC(hipMemcpyAsync(d_hco64, hco64.data(), hco64.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
     s->d_on_quads = d_on_quads;
     s->n_on_quads = (uint32_t)on_quads.size();
-    HC(hipMemcpyAsync(d_hkeys, hkeys.data(), hkeys.size(), hipMemcpyHostToDevice, ctx->stream));
-    HC(hipMemcpyAsync(d_hco, hco.data(), hco.size(), hipMemcpyHostToDevice, ctx->stream));
-    HC(hipMemcpyAsync(d_hco64, hco64.data(), hco64.size(), hipMemcpyHostToDevice, ctx->stream));
     ctx->phase(RV_PH_SETUP);
     ctx->count(2);
     launch_expand_seeds(ctx->stream, s->d_seeds, R, s->d_keys);
@@ -2309,8 +2357,10 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     // ---- the interpreter's stream: the proof itself (tens of MB from pageable memory: the host blocks in this
     //      copy while the mask kernels above already run) and the supplied-value rows unpacked from it
     hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
-    HC(hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, sb));
-    HC(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, sb));
+    if (!blob) {
+        HC(hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, sb));
+        HC(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, sb));
+    }
     if (s->ev_setup && ctx->pipeline) HC(hipStreamWaitEvent(sb, s->ev_setup, 0));  // d_omit / d_omit64 come from stream 1
     launch_unpack_bits(sb, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
     launch_unpack_bits(sb, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr);
@@ -2340,7 +2390,6 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     // the digests and the flag word leave through the mapped staging buffer (one small kernel instead of two copy-engine
     // operations of ~25 us each; see rv_prove_impl), unless it could not be had
     uint8_t* stage_dev = nullptr;
-    static const bool small_stage = !(getenv("RV_SMALL_STAGE") && atoi(getenv("RV_SMALL_STAGE")) == 0);
     if (small_stage && !g_recorder) {
         if (!ctx->h_stage && hipHostMalloc((void**)&ctx->h_stage, rv_ctx::STAGE_BYTES, hipHostMallocMapped) != hipSuccess) {
             (void)hipGetLastError();
