@@ -790,10 +790,6 @@ struct rv_shard {
     std::vector<std::pair<uint64_t, hipEvent_t>> mask_chunks;  // (AES blocks complete, event)
     hipEvent_t ev_setup = nullptr;
     std::vector<hipEvent_t> misc_events;
-    // transcript digests inside the level launches (shard_run of a whole prover; internal.h: HashPlan)
-    bool fuse_hash = false;
-    uint32_t avail_on[HS_STAGES + 1] = {}, avail_pre[HS_STAGES + 1] = {};  // complete chunks at the last launches, newest first
-    uint32_t* d_cv_x = nullptr;  // the tree reduction's second buffer (a quarter of a cv array)
 
     void destroy() {
         for (auto& c : mask_chunks) ctx->sync_pool.push_back(c.second);
@@ -804,8 +800,7 @@ struct rv_shard {
         ev_setup = nullptr;
         void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk,    d_masks,  d_wires,   d_on,     d_pre,    d_wit,  d_cv[0],
                       d_cv[1], d_dig,  d_h,       d_err,   d_omit,   d_offs,    d_out,    d_masks64, d_wmask64,
-                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr,
-                      d_cv_x};
+                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr};
         for (void* p : ps) ctx->release(p);
         for (void* p : extra) ctx->release(p);
     }
@@ -884,7 +879,6 @@ static int shard_run_alloc(rv_shard* s, InterpParams& p, Interp64Params& p64) {
     if (!s->d_err && (rc = dalloc(ctx, 1, &s->d_err))) return rc;  // (rv_prove_batch hands every proof a slot of one array)
     const size_t cvw = b3_stream_scratch_words(std::max({cc.n_on, cc.n_pre, cc.on_words64 * 8, cc.pre_words64 * 8}), s->R);
     if ((rc = dalloc(ctx, cvw, &s->d_cv[0])) || (rc = dalloc(ctx, cvw, &s->d_cv[1]))) return rc;
-    if (s->fuse_hash && (rc = dalloc(ctx, cvw / 4 + (size_t)s->R * 8, &s->d_cv_x))) return rc;
     if ((rc = dalloc(ctx, (size_t)4 * s->R * 8, &s->d_dig))) return rc;
     if (!s->d_h && (rc = dalloc(ctx, (size_t)s->R * 32, &s->d_h))) return rc;  // (rv_verify_batch: a slot of one array)
     const bool has64 = !cc.gates64.empty();
@@ -980,27 +974,7 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
             const LevelRange* next = (l + 1 < n_levels && (s->c->run_of_level[l + 1] < 0 || mode == MODE_PROVE_V) && cc.level_start[l + 2] > cc.level_start[l + 1])
                                          ? &cc.level_range[l + 1]
                                          : nullptr;
-            static const bool fuse_levels = !(getenv("RV_FUSE_HASH") && atoi(getenv("RV_FUSE_HASH")) == 2);
-            if (s->fuse_hash && fuse_levels) {
-                // chunks complete before this launch (everything earlier on the stream has finished): a chunk enters stage 0
-                // in the first launch after its last event and moves one stage per launch
-                HashPlan hp{};
-                const uint32_t done_on = l ? cc.level_done_on[l - 1] / 1024 : 0, done_pre = l ? cc.level_done_pre[l - 1] / 1024 : 0;
-                for (uint32_t k = HS_STAGES; k > 0; k--) s->avail_on[k] = s->avail_on[k - 1], s->avail_pre[k] = s->avail_pre[k - 1];
-                s->avail_on[0] = done_on;
-                s->avail_pre[0] = done_pre;
-                for (uint32_t k = 0; k < HS_STAGES; k++) {
-                    hp.on[k] = HashRange{s->avail_on[k + 1], s->avail_on[k] - s->avail_on[k + 1]};
-                    hp.pre[k] = HashRange{s->avail_pre[k + 1], s->avail_pre[k] - s->avail_pre[k + 1]};
-                    hp.n_wg += hp.on[k].n + hp.pre[k].n;
-                }
-                hp.n_wg = (hp.n_wg + 7) & ~7u;
-                hp.cv_on = s->d_cv[1];
-                hp.cv_pre = s->d_cv[0];
-                launch_interp_hash(sb, mode, s->c->d_gates, cc.level_range[l], p, next, hp);
-            } else {
-                launch_interp(sb, mode, s->c->d_gates, cc.level_range[l], p, next);
-            }
+            launch_interp(sb, mode, s->c->d_gates, cc.level_range[l], p, next);
             ctx->count();
         }
         if (has64 && cc.level_start64[l + 1] > cc.level_start64[l]) {
@@ -1026,24 +1000,7 @@ static int shard_run_hash(rv_shard* s) {
     const size_t DW = (size_t)s->R * 8;
     uint32_t n_launch;
     static const bool pair_on = !(getenv("RV_B3_PAIR") && atoi(getenv("RV_B3_PAIR")) == 0);
-    if (s->fuse_hash) {
-        // the level launches hashed most blocks already: finish the chunks in flight and the ones after them, then the trees
-        HashTail t_on{}, t_pre{};
-        auto tail = [](const uint32_t avail[HS_STAGES + 1], uint64_t n_events, HashTail& t) {
-            const uint32_t n_chunks = (uint32_t)((n_events + 1023) / 1024);
-            for (uint32_t k = 0; k + 1 < HS_STAGES; k++) {  // stage k of the last launch left these with (k + 1) * HS_BLOCKS blocks done
-                t.r[k] = HashRange{avail[k + 1], avail[k] - avail[k + 1]};
-                t.b0[k] = (k + 1) * HS_BLOCKS;
-            }
-            t.r[HS_STAGES - 1] = HashRange{avail[0], n_chunks - avail[0]};  // untouched
-            t.b0[HS_STAGES - 1] = 0;
-        };
-        tail(s->avail_on, cc.n_on, t_on);
-        tail(s->avail_pre, cc.n_pre, t_pre);
-        launch_b3_span_tail(ctx->stream, s->d_on, cc.n_on, t_on, s->d_cv[1], s->d_pre, cc.n_pre, t_pre, s->d_cv[0], s->NQ);
-        n_launch = 1 + b3_reduce_tree(ctx->stream, s->d_cv[0], s->d_cv_x, (cc.n_pre + 1023) / 1024, s->R, dig + 0 * DW);
-        n_launch += b3_reduce_tree(ctx->stream, s->d_cv[1], s->d_cv_x, (cc.n_on + 1023) / 1024, s->R, dig + 1 * DW);
-    } else if (pair_on && launch_b3_pair_small(ctx->stream, s->d_pre, cc.n_pre, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW, dig + 1 * DW,
+    if (pair_on && launch_b3_pair_small(ctx->stream, s->d_pre, cc.n_pre, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW, dig + 1 * DW,
                                         s->d_on_quads, s->n_on_quads)) {
         n_launch = 2;  // short transcripts (small circuits): both streams in the same two launches
     } else {
@@ -1071,17 +1028,8 @@ static int shard_run_hash(rv_shard* s) {
     return RV_OK;
 }
 
-// RV_FUSE_HASH=0: the two GF(2) transcript digests as kernels of their own after the level loop (the path of every other caller)
-static bool fuse_hash_wanted(const rv_shard* s, int mode) {
-    static const bool on = !(getenv("RV_FUSE_HASH") && atoi(getenv("RV_FUSE_HASH")) == 0);
-    const Compiled& cc = s->c->cc;
-    return on && (mode == MODE_PROVE || mode == MODE_PROVE_V) && s->NQ == 64 && !s->ctx->pipeline && !g_recorder &&
-           cc.n_on >= 64 * 1024 && cc.n_pre >= 64 * 1024;
-}
-
 static int shard_run(rv_shard* s, int mode, InterpParams& p, Interp64Params& p64) {
     int rc;
-    s->fuse_hash = fuse_hash_wanted(s, mode);
     if ((rc = shard_run_alloc(s, p, p64)) || (rc = shard_run_levels(s, mode, p, p64)) || (rc = shard_run_hash(s))) return rc;
     return RV_OK;
 }

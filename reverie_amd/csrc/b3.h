@@ -136,66 +136,6 @@ RV_HD void compress_n(uint32_t cv[N][8], const uint32_t m[N][16], uint64_t t, ui
         for (int k = 0; k < 8; k++) cv[i][k] = v[i][k] ^ v[i][k + 8];
 }
 
-// One compression with the four G functions of a half round written step by step side by side: a wavefront that has a
-// SIMD (almost) to itself -- the digest workgroups inside the interpreter's launches -- issues a dependent VALU
-// instruction only every ~10 cycles, an independent one every ~5, and the compiler keeps the source order of the chains.
-#define B3_G4(a0, b0, c0, d0, x0, y0, a1, b1, c1, d1, x1, y1, a2, b2, c2, d2, x2, y2, a3, b3_, c3, d3, x3, y3) \
-    a0 = a0 + b0 + (x0);                                                                                        \
-    a1 = a1 + b1 + (x1);                                                                                        \
-    a2 = a2 + b2 + (x2);                                                                                        \
-    a3 = a3 + b3_ + (x3);                                                                                       \
-    d0 = rotr(d0 ^ a0, 16);                                                                                     \
-    d1 = rotr(d1 ^ a1, 16);                                                                                     \
-    d2 = rotr(d2 ^ a2, 16);                                                                                     \
-    d3 = rotr(d3 ^ a3, 16);                                                                                     \
-    c0 = c0 + d0;                                                                                               \
-    c1 = c1 + d1;                                                                                               \
-    c2 = c2 + d2;                                                                                               \
-    c3 = c3 + d3;                                                                                               \
-    b0 = rotr(b0 ^ c0, 12);                                                                                     \
-    b1 = rotr(b1 ^ c1, 12);                                                                                     \
-    b2 = rotr(b2 ^ c2, 12);                                                                                     \
-    b3_ = rotr(b3_ ^ c3, 12);                                                                                   \
-    a0 = a0 + b0 + (y0);                                                                                        \
-    a1 = a1 + b1 + (y1);                                                                                        \
-    a2 = a2 + b2 + (y2);                                                                                        \
-    a3 = a3 + b3_ + (y3);                                                                                       \
-    d0 = rotr(d0 ^ a0, 8);                                                                                      \
-    d1 = rotr(d1 ^ a1, 8);                                                                                      \
-    d2 = rotr(d2 ^ a2, 8);                                                                                      \
-    d3 = rotr(d3 ^ a3, 8);                                                                                      \
-    c0 = c0 + d0;                                                                                               \
-    c1 = c1 + d1;                                                                                               \
-    c2 = c2 + d2;                                                                                               \
-    c3 = c3 + d3;                                                                                               \
-    b0 = rotr(b0 ^ c0, 7);                                                                                      \
-    b1 = rotr(b1 ^ c1, 7);                                                                                      \
-    b2 = rotr(b2 ^ c2, 7);                                                                                      \
-    b3_ = rotr(b3_ ^ c3, 7);
-#define B3_ROUND4(m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11, m12, m13, m14, m15)                                              \
-    B3_G4(v0, v4, v8, v12, m0, m1, v1, v5, v9, v13, m2, m3, v2, v6, v10, v14, m4, m5, v3, v7, v11, v15, m6, m7)                      \
-    B3_G4(v0, v5, v10, v15, m8, m9, v1, v6, v11, v12, m10, m11, v2, v7, v8, v13, m12, m13, v3, v4, v9, v14, m14, m15)
-RV_HD void compress_ilp(uint32_t cv[8], const uint32_t m[16], uint64_t t, uint32_t blen, uint32_t flags) {
-    uint32_t v0 = cv[0], v1 = cv[1], v2 = cv[2], v3 = cv[3], v4 = cv[4], v5 = cv[5], v6 = cv[6], v7 = cv[7];
-    uint32_t v8 = B3_IV0, v9 = B3_IV1, v10 = B3_IV2, v11 = B3_IV3;
-    uint32_t v12 = (uint32_t)t, v13 = (uint32_t)(t >> 32), v14 = blen, v15 = flags;
-    B3_ROUND4(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15])
-    B3_ROUND4(m[2], m[6], m[3], m[10], m[7], m[0], m[4], m[13], m[1], m[11], m[12], m[5], m[9], m[14], m[15], m[8])
-    B3_ROUND4(m[3], m[4], m[10], m[12], m[13], m[2], m[7], m[14], m[6], m[5], m[9], m[0], m[11], m[15], m[8], m[1])
-    B3_ROUND4(m[10], m[7], m[12], m[9], m[14], m[3], m[13], m[15], m[4], m[0], m[11], m[2], m[5], m[8], m[1], m[6])
-    B3_ROUND4(m[12], m[13], m[9], m[11], m[15], m[10], m[14], m[8], m[7], m[2], m[5], m[3], m[0], m[1], m[6], m[4])
-    B3_ROUND4(m[9], m[14], m[11], m[5], m[8], m[12], m[15], m[1], m[13], m[3], m[0], m[10], m[2], m[6], m[4], m[7])
-    B3_ROUND4(m[11], m[15], m[5], m[0], m[1], m[9], m[8], m[6], m[14], m[10], m[2], m[12], m[3], m[4], m[7], m[13])
-    cv[0] = v0 ^ v8;
-    cv[1] = v1 ^ v9;
-    cv[2] = v2 ^ v10;
-    cv[3] = v3 ^ v11;
-    cv[4] = v4 ^ v12;
-    cv[5] = v5 ^ v13;
-    cv[6] = v6 ^ v14;
-    cv[7] = v7 ^ v15;
-}
-
 RV_HD void iv(uint32_t cv[8]) {
     cv[0] = B3_IV0;
     cv[1] = B3_IV1;

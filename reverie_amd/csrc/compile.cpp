@@ -579,7 +579,6 @@ void relocate_chunk(Compiled& cc, uint64_t on0, uint64_t pre0, uint64_t on_words
         for (uint32_t& r : cc.rec_rows) r += (uint32_t)on0;
         for (uint32_t& r : cc.in_rows) r += (uint32_t)on0;
         for (uint32_t& r : cc.level_done_on) r += (uint32_t)on0;
-        for (uint32_t& r : cc.level_done_pre) r += (uint32_t)pre0;
         cc.n_on += on0;
         cc.n_pre += pre0;
     }
@@ -683,9 +682,8 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
     // pipelining tables
     out.level_need_blocks.assign(n_levels, 0);
     out.level_done_on.assign(n_levels, 0);
-    out.level_done_pre.assign(n_levels, 0);
     {
-        std::vector<uint32_t> row_level(out.n_on, 0), row_level_pre(out.n_pre, 0);
+        std::vector<uint32_t> row_level(out.n_on, 0);
         for (uint32_t l = 0; l < n_levels; l++) {
             uint32_t need = l ? out.level_need_blocks[l - 1] : 0;
             for (uint32_t i = out.level_start[l]; i < out.level_start[l + 1]; i++) {
@@ -701,7 +699,6 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                     uses = false;
                 if (uses) need = std::max(need, last / 128 + 1);
                 if (op == G_MUL || op == G_INPUT || op == G_ASSERT || op == G_RECON) row_level[g.eo] = l;
-                if (op == G_MUL) row_level_pre[g.ep] = l;
             }
             out.level_need_blocks[l] = need;
         }
@@ -715,15 +712,6 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
                 e++;
             }
             out.level_done_on[l] = (uint32_t)e;
-        }
-        e = 0;
-        run = 0;
-        for (uint32_t l = 0; l < n_levels; l++) {
-            while (e < out.n_pre && std::max(run, row_level_pre[e]) <= l) {
-                run = std::max(run, row_level_pre[e]);
-                e++;
-            }
-            out.level_done_pre[l] = (uint32_t)e;
         }
     }
     out.n_ssa = b.n_ssa;

@@ -32,7 +32,6 @@ struct Compiled {
     // pipelining aids (both monotone in l):
     std::vector<uint32_t> level_need_blocks;  // AES blocks (128 masks) that levels 0..l read
     std::vector<uint32_t> level_done_on;      // leading online-transcript rows complete once level l has run
-    std::vector<uint32_t> level_done_pre;     // the same for the preprocessing transcript (one row per Mul)
     std::vector<uint32_t> rec_rows;     // reconstruction ordinal -> online transcript row
     std::vector<uint32_t> in_rows;      // input ordinal -> online transcript row
     uint64_t n_ssa = 1;                 // SSA wires incl. the zero wire

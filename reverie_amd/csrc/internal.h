@@ -129,32 +129,6 @@ struct InterpParams {
     int* err;                 // device flag: RV_E_WITNESS_INVALID
 };
 
-// ---- transcript digests inside the interpreter's level launches (whole prover, 256 repetitions; kernels.hip) ----
-// A level launch carries extra workgroups at the front of its grid that hash BLAKE3 blocks of transcript chunks the
-// EARLIER launches completed: a chunk (1 024 events) is hashed in HS_STAGES consecutive launches, HS_BLOCKS blocks each,
-// its chaining value resting in the chunk's slot of the cv array in between.  One workgroup = one chunk's span for all
-// 256 repetitions (a lane per repetition).
-#ifndef RV_HS_BLOCKS
-#define RV_HS_BLOCKS 4
-#endif
-constexpr uint32_t HS_BLOCKS = RV_HS_BLOCKS, HS_STAGES = 16 / HS_BLOCKS;  // HS_STAGES * HS_BLOCKS = 16 blocks = one chunk
-struct HashRange {
-    uint32_t c0, n;  // chunks [c0, c0 + n)
-};
-struct HashPlan {
-    uint32_t n_wg;              // hash workgroups at the front of the grid (a multiple of 8: the XCD of the others is kept)
-    HashRange on[HS_STAGES];    // stage k: blocks [k * HS_BLOCKS, (k + 1) * HS_BLOCKS) of these chunks
-    HashRange pre[HS_STAGES];
-    uint32_t* cv_on;            // [n_chunks][256][8]
-    uint32_t* cv_pre;
-};
-struct HashTail {  // what is left after the last level: chunks [c0, c0 + n) from block b0 to their end
-    HashRange r[HS_STAGES + 1];
-    uint32_t b0[HS_STAGES + 1];
-};
-void launch_b3_span_tail(hipStream_t st, const uint32_t* d_on, uint64_t n_on, const HashTail& t_on, uint32_t* d_cv_on, const uint8_t* d_pre,
-                         uint64_t n_pre, const HashTail& t_pre, uint32_t* d_cv_pre, uint32_t NQ);
-
 // ---- launchers (implemented in the .hip files) ----
 void launch_expand_seeds(hipStream_t st, const uint8_t* d_seeds, uint32_t n_reps, uint8_t* d_keys /*[n][8][16]*/);
 // Per AES key: the 11 round keys (176 bytes) followed by 32 bytes of first-round constants (k_key_schedule):
@@ -182,8 +156,6 @@ struct LevelRange {
 // its first gate records
 void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p,
                    const LevelRange* next = nullptr);
-void launch_interp_hash(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p, const LevelRange* next,
-                        const HashPlan& hp);
 // levels [l0, l1) (all narrow, GF(2) only) in one launch by a single workgroup
 // tiny: plain per-gate loop (one gate per wavefront) instead of the 4-way unrolled class loops
 void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const LevelRange* d_level_range, uint32_t l0, uint32_t l1,

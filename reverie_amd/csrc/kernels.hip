@@ -839,147 +839,6 @@ __global__ __launch_bounds__(256) void k_b3_chunks_bits1(const uint8_t* __restri
     B_k_b3_chunks_bits<1>{}(stream, n_events, NQ, n_chunks, cvs, chunk_base, root_ok);
 }
 
-// ---- BLAKE3 spans: blocks [b0, b0 + nb) of chunk c, one lane per repetition (tid = 4 * quad + repetition in the quad);
-// the chaining value rests in the chunk's slot of `cvs` between spans.  FULL: the span is known to hold whole 64-event
-// blocks of a whole chunk (no guards).  Never ROOT: callers use spans only for transcripts of many chunks.
-template <bool BITS, bool FULL>
-__device__ __forceinline__ void b3_span(const void* __restrict__ stream_, uint64_t n_events, uint32_t NQ, uint64_t c, uint32_t b0, uint32_t nb,
-                                        uint32_t* __restrict__ cvs, uint32_t tid) {
-    const uint32_t q = tid >> 2, sub = tid & 3, R = NQ * 4;
-    const uint64_t ev0 = c * 1024;
-    uint64_t len = 1024;
-    uint32_t nblk = 16;
-    if (!FULL) {
-        if (ev0 > n_events || (ev0 == n_events && c != 0)) return;
-        len = (n_events - ev0 < 1024) ? (n_events - ev0) : 1024;
-        nblk = len == 0 ? 1 : (uint32_t)((len + 63) / 64);
-    }
-    const uint32_t b1 = (b0 + nb < nblk) ? b0 + nb : nblk;
-    if (b0 >= b1) return;
-    uint32_t cv[1][8];
-    uint4* dst = (uint4*)(cvs + ((size_t)c * R + 4 * q + sub) * 8);
-    if (b0 == 0) {
-        b3::iv(cv[0]);
-    } else {
-        const uint4 lo = dst[0], hi = dst[1];
-        cv[0][0] = lo.x, cv[0][1] = lo.y, cv[0][2] = lo.z, cv[0][3] = lo.w;
-        cv[0][4] = hi.x, cv[0][5] = hi.y, cv[0][6] = hi.z, cv[0][7] = hi.w;
-    }
-    // The four lanes of a quad word split the 64 rows of a block: lane `sub` loads rows 4k + sub (its own word of each: 16
-    // loads per block, all distinct) and a 4 x 4 byte transpose across the four lanes -- two DPP exchanges + two v_perm per
-    // message word -- hands every lane the byte of ITS repetition from rows 4k .. 4k + 3.  Repetition `sub` owns byte
-    // 3 - sub of a quad word; a preprocessing nibble is first spread to one 0 / 1 byte per repetition and smeared to the
-    // 0x00 / 0xFF bytes the reference feeds its hasher (gf2/recon.rs:314-321) after the transpose.
-    const uint32_t h = NQ >> 1, o = q >> 1, nsh = 4 * (q & 1);
-    const uint32_t cs = 3 - sub, cp = 3 - (sub ^ 2);  // the column this lane ends up with, and its stage-2 partner's
-    const uint32_t sel1 = (sub & 1) ? ((4 + cs) | (cs << 8) | ((4 + cp) << 16) | (cp << 24)) : (cs | ((4 + cs) << 8) | (cp << 16) | ((4 + cp) << 24));
-    const uint32_t sel2 = (sub & 2) ? 0x01000706u : 0x07060100u;
-    uint32_t wn[16];
-    auto load_block = [&](uint32_t b) {
-        const uint64_t e0 = ev0 + 64ull * b + sub;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint64_t ev = e0 + 4 * k;
-            if (BITS)
-                wn[k] = (FULL || ev < n_events) ? (uint32_t)((const uint8_t*)stream_)[ev * h + o] : 0u;
-            else
-                wn[k] = (FULL || ev < n_events) ? ((const uint32_t*)stream_)[ev * NQ + q] : 0u;
-        }
-    };
-    load_block(b0);
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t blen = (FULL || b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
-        const uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
-        uint32_t m[1][16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            uint32_t x = wn[k];
-            if (BITS) x = __umul24((x >> nsh) & 0xFu, 0x204081u) & 0x01010101u;  // nibble bit c -> byte c (0 / 1)
-            const uint32_t t1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // lane ^ 1
-            const uint32_t z = __builtin_amdgcn_perm(t1, x, sel1);
-            const uint32_t t2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)z, 0x4E, 0xF, 0xF, true);  // lane ^ 2
-            const uint32_t y = __builtin_amdgcn_perm(t2, z, sel2);
-            m[0][k] = BITS ? smear01(y) : y;
-        }
-        if (b + 1 < b1) load_block(b + 1);  // in flight during the compression
-        b3::compress_ilp(cv[0], m[0], c, blen, flags);
-    }
-    dst[0] = make_uint4(cv[0][0], cv[0][1], cv[0][2], cv[0][3]);
-    dst[1] = make_uint4(cv[0][4], cv[0][5], cv[0][6], cv[0][7]);
-}
-
-// A level launch of the whole prover whose first hp.n_wg workgroups hash transcript spans (internal.h: HashPlan); the
-// others run the level exactly as k_interp_full does.  The digest work is pure VALU work on data of earlier launches and
-// fills issue slots the row gathers leave idle.
-template <int MODE, bool GENERAL>
-__global__ __launch_bounds__(256, 6) void k_interp_hash(const Gate* __restrict__ gates, LevelRange r, InterpParams p, PfPlan pf, HashPlan hp) {
-    if (blockIdx.x < hp.n_wg) {
-        uint32_t t = blockIdx.x;
-#pragma unroll
-        for (int k = 0; k < (int)HS_STAGES; k++) {
-            if (t < hp.on[k].n) return b3_span<false, true>(p.on, 0, 64, hp.on[k].c0 + t, k * HS_BLOCKS, HS_BLOCKS, hp.cv_on, threadIdx.x);
-            t -= hp.on[k].n;
-        }
-#pragma unroll
-        for (int k = 0; k < (int)HS_STAGES; k++) {
-            if (t < hp.pre[k].n) return b3_span<true, true>(p.pre, 0, 64, hp.pre[k].c0 + t, k * HS_BLOCKS, HS_BLOCKS, hp.cv_pre, threadIdx.x);
-            t -= hp.pre[k].n;
-        }
-        return;  // padding
-    }
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(((blockIdx.x - hp.n_wg) * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t n_waves = (gridDim.x - hp.n_wg) * (blockDim.x >> 6);
-    run_level<MODE, 64, true, GENERAL, true>(gates, r, p, wave, n_waves, lane, 0u, gates, &pf);
-}
-
-void launch_interp_hash(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p, const LevelRange* next,
-                        const HashPlan& hp) {
-    const bool general = level_is_general(r);
-    const PfPlan pf = make_pf_plan<64>(r, next);
-    const uint32_t u = (uint32_t)interp_unroll(64, general);
-    uint64_t waves = ((uint64_t)(r.hi - r.lo) + u - 1) / u;
-    uint64_t blocks = (waves + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    const dim3 grid((unsigned)(blocks + hp.n_wg));
-    if (mode == MODE_PROVE_V) {
-        if (general)
-            hipLaunchKernelGGL((k_interp_hash<MODE_PROVE_V, true>), grid, dim3(256), 0, st, d_gates, r, p, pf, hp);
-        else
-            hipLaunchKernelGGL((k_interp_hash<MODE_PROVE_V, false>), grid, dim3(256), 0, st, d_gates, r, p, pf, hp);
-    } else {
-        if (general)
-            hipLaunchKernelGGL((k_interp_hash<MODE_PROVE, true>), grid, dim3(256), 0, st, d_gates, r, p, pf, hp);
-        else
-            hipLaunchKernelGGL((k_interp_hash<MODE_PROVE, false>), grid, dim3(256), 0, st, d_gates, r, p, pf, hp);
-    }
-}
-
-// what the level launches left: one workgroup per unfinished chunk, from its first missing block to its end
-__global__ __launch_bounds__(256) void k_b3_span_tail(const uint32_t* __restrict__ on, uint64_t n_on, HashTail t_on, uint32_t* __restrict__ cv_on,
-                                                      const uint8_t* __restrict__ pre, uint64_t n_pre, HashTail t_pre, uint32_t* __restrict__ cv_pre,
-                                                      uint32_t NQ) {
-    uint32_t t = blockIdx.x;
-#pragma unroll
-    for (int k = 0; k <= (int)HS_STAGES; k++) {
-        if (t < t_on.r[k].n) return b3_span<false, false>(on, n_on, NQ, t_on.r[k].c0 + t, t_on.b0[k], 16, cv_on, threadIdx.x);
-        t -= t_on.r[k].n;
-    }
-#pragma unroll
-    for (int k = 0; k <= (int)HS_STAGES; k++) {
-        if (t < t_pre.r[k].n) return b3_span<true, false>(pre, n_pre, NQ, t_pre.r[k].c0 + t, t_pre.b0[k], 16, cv_pre, threadIdx.x);
-        t -= t_pre.r[k].n;
-    }
-}
-void launch_b3_span_tail(hipStream_t st, const uint32_t* d_on, uint64_t n_on, const HashTail& t_on, uint32_t* d_cv_on, const uint8_t* d_pre,
-                         uint64_t n_pre, const HashTail& t_pre, uint32_t* d_cv_pre, uint32_t NQ) {
-    uint32_t n = 0;
-    for (uint32_t k = 0; k <= HS_STAGES; k++) n += t_on.r[k].n + t_pre.r[k].n;
-    if (!n) return;
-    hipLaunchKernelGGL(k_b3_span_tail, dim3(n), dim3(256), 0, st, d_on, n_on, t_on, d_cv_on, d_pre, n_pre, t_pre, d_cv_pre, NQ);
-}
-
 // LG tree levels per launch: thread = (group of G = 2^LG consecutive nodes, repetition).  One level is
 // out[i] = parent(in[2i], in[2i+1]) with an odd last node promoted unchanged; groups are aligned to G, so
 // reducing a group locally level by level gives exactly the nodes LG global levels would (the ragged
