@@ -357,10 +357,23 @@ __device__ __forceinline__ void rounds_0_to_9(uint64_t j, uint32_t* s, uint32_t*
 // 0 and 1 hold the first-round constants (global areas 11 and 12), not rk0 / rk1 (see rounds_0_to_9)
 template <int QW>
 __device__ __forceinline__ void stage_round_keys(const uint32_t* __restrict__ rk, uint32_t NQ, uint32_t qg, uint32_t* lds_rk) {
-    for (uint32_t i = threadIdx.x; i < 11 * 128 * QW; i += blockDim.x) {
-        const uint32_t area = i / (128 * QW), w = i % (128 * QW);
-        const uint32_t ga = area == 0 ? 11u : (area == 1 ? 12u : area);
-        lds_rk[i] = rk[(size_t)(ga * 128 + w / QW) * NQ + qg * QW + (w % QW)];
+    // several loads in flight per thread before the first LDS store: one load, one store at a time is 44 dependent L2
+    // round trips for a 512-thread workgroup at QW = 16
+    constexpr uint32_t N = 11 * 128 * QW, B = 11;
+    for (uint32_t i0 = threadIdx.x; i0 < N; i0 += B * blockDim.x) {
+        uint32_t v[B];
+#pragma unroll
+        for (uint32_t k = 0; k < B; k++) {
+            const uint32_t i = i0 + k * blockDim.x;
+            const uint32_t area = i / (128 * QW), w = i % (128 * QW);
+            const uint32_t ga = area == 0 ? 11u : (area == 1 ? 12u : area);
+            v[k] = i < N ? rk[(size_t)(ga * 128 + w / QW) * NQ + qg * QW + (w % QW)] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < B; k++) {
+            const uint32_t i = i0 + k * blockDim.x;
+            if (i < N) lds_rk[i] = v[k];
+        }
     }
     __syncthreads();
 }
