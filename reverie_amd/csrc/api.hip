@@ -78,6 +78,12 @@ struct rv_ctx {
     // ... and the seeds and the GF(2) witness of a whole proof enter through this one (one copy instead of two pageable ones)
     static constexpr size_t IN_STAGE_BYTES = (size_t)1 << 20;
     uint8_t* h_in = nullptr;
+    // page-locked staging of a compiled circuit's arrays on their way to HBM (circuit_upload; grown on demand up to
+    // UP_STAGE_MAX): a pageable hipMemcpyAsync pins and unpins the source pages inside the call -- 3.6 ms for a 35 MB
+    // chunk of the streaming prover at best, 9 - 22 ms when the kernel's address-space lock is busy
+    static constexpr size_t UP_STAGE_MAX = (size_t)192 << 20;
+    uint8_t* h_up = nullptr;
+    size_t h_up_cap = 0;
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
         if (!sync_pool.empty()) {
@@ -234,6 +240,7 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+    if (ctx->h_up) (void)hipHostFree(ctx->h_up);
     for (rv_ctx* w : ctx->workers) rv_ctx_destroy(w);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
@@ -488,10 +495,34 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
     int rc;
     HIPCHK(hipSetDevice(ctx->device));
     const Compiled& cc = c->cc;
+    // everything below goes through one page-locked buffer when it fits (the function waits for the stream before it
+    // returns, so the buffer is free again for the next circuit)
+    size_t stage_need = (size_t)1 << 20;  // (+ the LDS-run records, built further down: they fall back to a pageable copy when they do not fit)
+    for (size_t b : {cc.gates.size() * sizeof(Gate), cc.rec_rows.size() * 4, cc.in_rows.size() * 4, cc.gates64.size() * sizeof(Gate64),
+                     cc.rec_offs64.size() * 8, cc.in_offs64.size() * 8, cc.level_start.size() * 4, cc.level_range.size() * sizeof(LevelRange)})
+        stage_need += (b + 255) & ~(size_t)255;
+    static const bool stage_on = !(getenv("RV_UPLOAD_STAGE") && atoi(getenv("RV_UPLOAD_STAGE")) == 0);
+    if (stage_on && stage_need <= rv_ctx::UP_STAGE_MAX && stage_need > ctx->h_up_cap) {
+        if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+        ctx->h_up = nullptr;
+        ctx->h_up_cap = 0;
+        const size_t want = std::min(rv_ctx::UP_STAGE_MAX, std::max(stage_need + stage_need / 4, (size_t)8 << 20));
+        if (hipHostMalloc((void**)&ctx->h_up, want, hipHostMallocDefault) == hipSuccess)
+            ctx->h_up_cap = want;
+        else
+            (void)hipGetLastError();
+    }
+    size_t stage_off = 0;
     auto up = [&](const void* src, size_t bytes, void** dst) -> int {
         int r = ctx->alloc(bytes, dst);
         if (r) return r;
-        if (bytes) HIPCHK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (!bytes) return RV_OK;
+        if (stage_on && ctx->h_up && stage_off + bytes <= ctx->h_up_cap && stage_need <= rv_ctx::UP_STAGE_MAX) {
+            memcpy(ctx->h_up + stage_off, src, bytes);
+            src = ctx->h_up + stage_off;
+            stage_off += (bytes + 255) & ~(size_t)255;
+        }
+        HIPCHK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         return RV_OK;
     };
     if ((rc = up(cc.gates.data(), cc.gates.size() * sizeof(Gate), (void**)&c->d_gates)) ||
