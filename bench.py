@@ -495,13 +495,16 @@ def main():
             bs[0] = seeds
             bw = np.tile(np.asarray(wit, np.uint8), (B, 1))
             reverie_amd.Proof.new_batch(circuit, bw, seeds=bs)
-            t0 = time.perf_counter()
-            proofs = reverie_amd.Proof.new_batch(circuit, bw, seeds=bs)
-            d3 = time.perf_counter() - t0
+            d3s = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                proofs = reverie_amd.Proof.new_batch(circuit, bw, seeds=bs)
+                d3s.append(time.perf_counter() - t0)
+            d3 = statistics.median(d3s)
             result["prove_batch_host"] = {"value": n_and * B / d3, "unit": "AND gates/s", "ms_per_proof": d3 / B * 1e3, "proofs_per_call": B,
                                           "first_proof_bit_exact_vs_timed_proof": bytes(proofs[0]) == bytes(last),
                                           "last_proof_verifies_strict": bool(proofs[-1].verify(circuit)),
-                                          "note": "rv_prove_batch: witness bytes on the host -> B proofs' bytes on the host, one call"}
+                                          "note": "rv_prove_batch: witness bytes on the host -> B proofs' bytes on the host, one call (median of 3 calls)"}
             del proofs
     if world > 1:
         # informational, outside the timed region: the same N GPUs proving N INDEPENDENT statements, one whole proof
