@@ -2389,8 +2389,18 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     //      copy while the mask kernels above already run) and the supplied-value rows unpacked from it
     hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
     if (!blob) {
-        HC(hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, sb));
-        HC(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, sb));
+        // on ONE stream the copy would queue up behind the mask kernels; from the second stream it runs beside them
+        // (copy engine next to compute) and the unpack kernels wait for its event
+        static const bool side = !(getenv("RV_VERIFY_SIDE_COPY") && atoi(getenv("RV_VERIFY_SIDE_COPY")) == 0);
+        hipStream_t sc = (side && !ctx->pipeline && !g_recorder && proof_len >= ((size_t)4 << 20)) ? ctx->stream2 : sb;
+        HC(hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, sc));
+        HC(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, sc));
+        if (sc != sb) {
+            hipEvent_t e = ctx->get_sync_event();
+            s->misc_events.push_back(e);
+            HC(hipEventRecord(e, sc));
+            HC(hipStreamWaitEvent(sb, e, 0));
+        }
     }
     if (s->ev_setup && ctx->pipeline) HC(hipStreamWaitEvent(sb, s->ev_setup, 0));  // d_omit / d_omit64 come from stream 1
     launch_unpack_bits(sb, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
