@@ -426,6 +426,12 @@ int rv_hook_sharegen_z64(rv_ctx *ctx, const uint8_t *keys, const uint32_t omit[8
  * on its own with the ShareGen phases predicted from the ops before it adds up to the whole (RV_E_DEVICE if not). */
 int rv_hook_compile_info(const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, size_t chunk_ops,
                          rv_circuit_info *info);
+/* The two gate-stream compilers against each other (host only): the program is compiled by the sequential compiler and by the
+ * parallel one with `threads` host threads (>= 2), whatever its size, and the results are compared field by field.
+ * *diff = 0: identical; > 0: a number naming the first differing table (csrc/compile_par.cpp, compiled_diff); -1: the parallel
+ * compiler declined the program (B2A gates, an error in the op list) -- the sequential result is what rv_circuit_compile uses.
+ * Returns the sequential compiler's status (RV_OK or the error the reference raises while stepping, single.rs:106-156). */
+int rv_hook_compile_compare(const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, int threads, int *diff);
 /* DomainGF2::reconstruct (gf2/domain.rs:47-63) on n packed u64 shares (bit 63 - (8*rep + player)) -> n ReconGF2 words
  * (one 0x00/0xFF byte per repetition), through the interpreter's own device function */
 int rv_hook_gf2_reconstruct(rv_ctx *ctx, const uint64_t *shares, size_t n, uint64_t *out);

@@ -733,6 +733,26 @@ extern "C" int rv_hook_compile_info(const rv_op* ops, size_t n_ops, size_t z64_w
     }
 }
 
+extern "C" int rv_hook_compile_compare(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, int threads, int* diff) {
+    if (!diff || (n_ops && !ops) || (flags & ~RV_COMPILE_WHOLE_PROVER) || threads < 2) return RV_E_ARG;
+    try {
+        const int k = ((flags & RV_COMPILE_WHOLE_PROVER) && !getenv("RV_LAZY_K")) ? RV_LIN_K : 0;
+        Compiled a, b;
+        const int rc = compile_ops_seq(ops, n_ops, z64_wires, gf2_wires, a, nullptr, k);
+        const int rp = compile_ops_par(ops, n_ops, z64_wires, gf2_wires, b, k, threads);
+        if (rp == RV_COMPILE_FALLBACK)
+            *diff = -1;
+        else if (rp != rc)
+            *diff = 100;
+        else
+            *diff = rc == RV_OK ? compiled_diff(a, b) : 0;
+        return rc;
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
+}
+
 extern "C" int rv_circuit_get_info(const rv_circuit* c, rv_circuit_info* info) {
     if (!c || !info) return RV_E_ARG;
     *info = c->cc.info;

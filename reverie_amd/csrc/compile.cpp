@@ -595,6 +595,23 @@ void relocate_chunk(Compiled& cc, uint64_t on0, uint64_t pre0, uint64_t on_words
 }
 
 int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk, int force_lazy_k) {
+    const size_t par_min = getenv("RV_COMPILE_PAR_MIN") ? (size_t)atoll(getenv("RV_COMPILE_PAR_MIN")) : 200000;
+    const bool seq = getenv("RV_COMPILE_SEQ") && atoi(getenv("RV_COMPILE_SEQ")) != 0;
+    if (!chunk && !seq && n_ops >= par_min) {
+        const int nt = compile_threads();
+        if (nt > 1) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = compile_ops_par(ops, n_ops, z64_wires, gf2_wires, out, force_lazy_k, nt);
+            if (getenv("RV_COMPILE_STATS"))
+                fprintf(stderr, "[rv compile] parallel compiler (%d threads) returned %d after %.3f s\n", nt, rc,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            if (rc != RV_COMPILE_FALLBACK) return rc;
+        }
+    }
+    return compile_ops_seq(ops, n_ops, z64_wires, gf2_wires, out, chunk, force_lazy_k);
+}
+
+int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk, int force_lazy_k) {
     const auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (getenv("RV_COMPILE_STATS"))

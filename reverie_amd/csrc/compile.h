@@ -18,14 +18,48 @@
 #pragma once
 #include <stdint.h>
 
+#include <new>
+#include <utility>
 #include <vector>
 
 #include "internal.h"
 
 namespace rv {
 
+// Large host arrays of the compilers (hundreds of MB for a 10^7-gate circuit): anonymous mappings with transparent huge
+// pages requested (a 4 KiB first-touch fault per page was a third of the parallel compiler's time), zero-filled by the
+// kernel, never value-initialised a second time by the container.
+void* big_alloc(size_t bytes);  // nullptr when out of memory; contents are zero
+void big_free(void* p, size_t bytes);
+template <class T>
+struct BigAlloc {
+    using value_type = T;
+    BigAlloc() = default;
+    template <class U>
+    BigAlloc(const BigAlloc<U>&) {}
+    T* allocate(size_t n) {
+        void* p = big_alloc(n * sizeof(T));
+        if (!p) throw std::bad_alloc();
+        return (T*)p;
+    }
+    void deallocate(T* p, size_t n) { big_free(p, n * sizeof(T)); }
+    // default-initialisation instead of value-initialisation: resize() does not write the (already zero) pages
+    template <class U>
+    void construct(U* p) {
+        ::new ((void*)p) U;
+    }
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+    template <class U>
+    bool operator==(const BigAlloc<U>&) const { return true; }
+    template <class U>
+    bool operator!=(const BigAlloc<U>&) const { return false; }
+};
+
 struct Compiled {
-    std::vector<Gate> gates;            // sorted by level, program order inside a level
+    std::vector<Gate, BigAlloc<Gate>> gates;  // sorted by level, program order inside a level
     std::vector<uint32_t> level_start;  // gates of level l = [level_start[l], level_start[l+1])
     // inside a level gates are grouped by class (see LevelRange)
     std::vector<LevelRange> level_range;
@@ -71,7 +105,19 @@ void relocate_chunk(Compiled& cc, uint64_t on0, uint64_t pre0, uint64_t on_words
 
 // returns RV_OK or RV_E_*
 // force_lazy_k: 0 = choose (RV_LAZY_K / circuit shape), 1..RV_LIN_K = that many base rows per wire at most
+// Whole programs of RV_COMPILE_PAR_MIN ops and more (default 200 000) without B2A gates are compiled by several host threads
+// (compile_par.cpp; RV_COMPILE_THREADS, default min(32, hardware threads); RV_COMPILE_SEQ=1 turns it off); everything else,
+// and every program with an error in it, by the sequential compiler.  The result is the same bit for bit.
 int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr,
                 int force_lazy_k = 0);
+// the sequential compiler (one thread; the reference implementation of the gate stream, the error path, streaming chunks)
+int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr,
+                    int force_lazy_k = 0);
+// the parallel compiler: RV_OK, or RV_COMPILE_FALLBACK when the program is one it leaves to compile_ops_seq
+constexpr int RV_COMPILE_FALLBACK = -1;
+int compile_ops_par(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, int force_lazy_k, int n_threads);
+int compile_threads();
+// 0 when the two compiled circuits are identical field by field, else a number naming the first difference (test hook)
+int compiled_diff(const Compiled& a, const Compiled& b);
 
 }  // namespace rv

@@ -119,3 +119,111 @@ def test_streaming_pieces_add_up(L, seed):
         prog, _, wc = circuits.random_gf2(rng, n_in=int(rng.integers(1, 100)), n_gates=int(rng.integers(500, 5000)), n_wires=int(rng.integers(4, 300)))
     for chunk in (1, 7, 64, 129, 1000, len(prog) - 1, len(prog) + 5):
         assert compile_info(L, prog, wc, chunk_ops=max(chunk, 1))[0] == 0, chunk
+
+
+# ---- the parallel compiler (csrc/compile_par.cpp) against the sequential one: identical tables, field by field ----
+def compile_compare(L, prog, wc, flags=0, threads=4):
+    prog = np.ascontiguousarray(prog)
+    d = C.c_int(-7)
+    rc = L.rv_hook_compile_compare(prog.ctypes.data_as(C.c_void_p), C.c_size_t(len(prog)), C.c_size_t(int(wc[0])), C.c_size_t(int(wc[1])),
+                                   C.c_uint32(flags), C.c_int(threads), C.byref(d))
+    return rc, d.value
+
+
+def long_random_program(rng, n_ops, n_wires2=400, n_wires64=60, old2=32, p_z64=0.25):
+    """A long op list built with numpy (no B2A): recycled wires (a read usually sees a recent write), `old2` GF(2) wires
+    written once at the start and read everywhere (reads that see a write made many thread ranges earlier), wires that are
+    never written (they read as the zero wire, interpreter/single.rs:16), SizeHints in the middle that enlarge the wire
+    vectors, and every opcode of both rings."""
+    from reverie_amd.ops import OP_DTYPE
+
+    DOM_SIZEHINT = 3
+    prog = np.zeros(n_ops, OP_DTYPE)
+    dom = (rng.random(n_ops) < p_z64).astype(np.uint8)  # 0 = GF2, 1 = Z64
+    opc = rng.choice(np.arange(10, dtype=np.uint8), n_ops, p=[0.04, 0.03, 0.22, 0.06, 0.10, 0.04, 0.30, 0.05, 0.06, 0.10])
+    prog["domain"], prog["opcode"] = dom, opc
+    nw = np.where(dom == 0, n_wires2, n_wires64)
+    prog["dst"] = (rng.integers(0, 1 << 30, n_ops) % (nw - (dom == 0) * old2)) + (dom == 0) * old2   # never overwrite the old wires
+    prog["a"] = rng.integers(0, 1 << 30, n_ops) % (nw + 3)
+    prog["b"] = rng.integers(0, 1 << 30, n_ops) % (nw + 3)
+    prog["a"] = np.minimum(prog["a"], nw - 1)
+    prog["b"] = np.minimum(prog["b"], nw - 1)
+    far = (rng.random(n_ops) < 0.1) & (dom == 0)
+    prog["a"][far] = rng.integers(0, old2, int(far.sum()))
+    prog["imm"] = rng.integers(0, 1 << 62, n_ops, dtype=np.uint64)
+    # the old wires: inputs at the very start
+    prog["domain"][:old2], prog["opcode"][:old2], prog["dst"][:old2] = 0, OP_INPUT, np.arange(old2)
+    # two SizeHints: the last quarter of the program may use 50 more wires of each ring
+    q = 3 * n_ops // 4
+    late = np.arange(q + 1, n_ops)
+    grow = late[rng.random(len(late)) < 0.05]
+    prog["dst"][grow] = np.where(prog["domain"][grow] == 0, n_wires2, n_wires64) + rng.integers(0, 50, len(grow))
+    for at, (z, g) in ((n_ops // 3, (n_wires64 // 2, n_wires2 // 2)), (q, (n_wires64 + 50, n_wires2 + 50))):
+        prog[at] = (DOM_SIZEHINT, 0, 0, 0, z, g, 0)
+    return prog, (n_wires64, n_wires2)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_parallel_compiler_random_programs(L, seed):
+    rng = np.random.default_rng(900 + seed)
+    prog, _, _, wc = circuits.random_mixed(rng, n_gates=int(rng.integers(200, 3000)))
+    with_b2a = compile_compare(L, prog, wc)
+    assert with_b2a == (0, -1)                 # B2A gates: left to the sequential compiler
+    prog = prog[prog["domain"] != DOM_B2A]
+    for flags in (0, 1):
+        for threads in (2, 3, 8):
+            assert compile_compare(L, prog, wc, flags, threads) == (0, 0)
+
+
+@pytest.mark.parametrize("seed,n_ops,threads", [(1, 70_000, 8), (2, 120_000, 16), (3, 33_000, 5), (4, 260_000, 8)])
+def test_parallel_compiler_long_programs_with_far_reads(L, seed, n_ops, threads):
+    rng = np.random.default_rng(seed)
+    prog, wc = long_random_program(rng, n_ops)
+    for flags in (0, 1):
+        assert compile_compare(L, prog, wc, flags, threads) == (0, 0)
+    # the same ops as ONE dependency chain per ring (every op reads the previous result): the data-flow pass degenerates to
+    # the sequential order, blocks handed from thread to thread
+    chain = prog.copy()
+    body = np.arange(40, len(chain))
+    body = body[chain["domain"][body] <= 1]
+    chain["a"][body] = np.where(chain["domain"][body] == 0, 399, 59)
+    chain["dst"][body] = np.where(chain["opcode"][body] != OP_ASSERTZERO, chain["a"][body], chain["dst"][body])
+    assert compile_compare(L, chain, wc, 1, threads) == (0, 0)
+
+
+def test_parallel_compiler_layered_and_recycled(L):
+    for kw in (dict(n_in=256, width=2048, layers=12), dict(n_in=100, width=128, layers=300, p_and=0.3), dict(n_in=128, width=1024, layers=20, recycle=True)):
+        prog, wit, wc, st = circuits.layered_gf2(**kw)
+        for flags in (0, 1):
+            assert compile_compare(L, prog, wc, flags, 7) == (0, 0)
+    for recycle in (False, True):
+        prog, wit, wc, st = circuits.layered_z64(n_in=64, width=512, n_mul=20000, recycle=recycle)
+        assert compile_compare(L, prog, wc, 0, 6) == (0, 0)
+
+
+def test_parallel_compiler_leaves_errors_to_the_sequential_one(L):
+    rng = np.random.default_rng(5)
+    prog, wc = long_random_program(rng, 50_000)
+    bad = prog.copy()
+    bad["a"][40_000] = 10_000                  # wire out of range late in the program (a GF(2) / Z64 op with operands)
+    bad["opcode"][40_000] = OP_MUL
+    assert compile_compare(L, bad, wc) == (3, -1)
+    bad = prog.copy()
+    bad["opcode"][123] = 77
+    assert compile_compare(L, bad, wc) == (5, -1)
+    # a wire the SizeHint only allows LATER is out of range before it
+    bad = prog.copy()
+    q = 3 * len(prog) // 4
+    first_late = int(np.nonzero((bad["dst"] >= wc[1]) & (bad["domain"] == 0))[0][0])
+    bad[[q, first_late]] = bad[[first_late, q]]
+    assert compile_compare(L, bad, wc)[0] == 3
+
+
+def test_compile_dispatch_takes_the_parallel_compiler_for_large_programs(L, monkeypatch):
+    prog, wit, wc, st = circuits.layered_gf2(n_in=512, width=16384, layers=14)
+    assert len(prog) > 200_000
+    monkeypatch.setenv("RV_COMPILE_THREADS", "4")
+    rc, par = compile_info(L, prog, wc, flags=1)
+    monkeypatch.setenv("RV_COMPILE_SEQ", "1")
+    rc2, seq = compile_info(L, prog, wc, flags=1)
+    assert rc == 0 and rc2 == 0 and par == seq
