@@ -173,6 +173,17 @@ int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
 int rv_prove(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64,
              size_t n_z64, const uint8_t *seeds, uint8_t **proof, size_t *proof_len);
 
+/* ---- Proof::new / Proof::verify on the raw op list (SURVEY 8(b)'s signature) ------------------------------
+ * What the reference's own entry points take (proof/mod.rs:119-125,224-232: the op list, the witness, (z64, gf2) wire
+ * counts): compile (RV_COMPILE_WHOLE_PROVER for the prover) + prove / verify + release, in one call -- the form a drop-in for
+ * a single Proof::new uses.  The compile runs on several host threads (csrc/compile_par.cpp): a circuit the library has not
+ * seen costs ~0.1 s per 10^7 gates before its first proof; callers that prove one circuit many times compile it once
+ * (rv_circuit_compile_ex) and call rv_prove.  flags of rv_verify_ops: as rv_verify_ex. */
+int rv_prove_ops(rv_ctx *ctx, const rv_op *ops, size_t n_ops, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64, size_t n_z64,
+                 size_t z64_wires, size_t gf2_wires, const uint8_t *seeds, uint8_t **proof, size_t *proof_len);
+int rv_verify_ops(rv_ctx *ctx, const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, const uint8_t *proof, size_t proof_len,
+                  uint32_t flags, int *ok);
+
 /* ---- Proof::new with the openings left in device memory ------------------------------------
  * The whole prover (commit, Fiat-Shamir, openings) with ONE host synchronisation, for callers that keep working on
  * the GPU (bench.py's HBM-resident metric): writes [gf2 online | gf2 preprocessing | z64 online | z64 preprocessing]

@@ -41,9 +41,10 @@ static int hip_fail(hipError_t e, const char* what, const char* file, int line) 
     } while (0)
 
 extern "C" const char* rv_last_error(void) { return g_last_error.c_str(); }
-extern "C" uint32_t rv_abi_version(void) { return 4; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
+extern "C" uint32_t rv_abi_version(void) { return 5; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
                                                         //    streaming prover, rv_prove_multi, reconstruct hooks
                                                         // 4: rv_circuit_compile_ex (a pure addition)
+                                                        // 5: rv_prove_ops / rv_verify_ops, rv_hook_compile_compare (pure additions)
 
 extern "C" const char* rv_strerror(int code) {
     switch (code) {
@@ -485,6 +486,8 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
                     c->rp.n_levels, c->rp.segs.size(), c->rp.lds_slots, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     }
     if ((rc = circuit_upload(ctx, c))) return rc;  // (destroys c on failure)
+    if (getenv("RV_COMPILE_STATS"))
+        fprintf(stderr, "[rv circuit] compiled + uploaded after %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     *out = c;
     return RV_OK;
 }
@@ -610,7 +613,9 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         for (size_t l = 0; l < n_levels && !any; l++) any = c->run_of_level[l] >= 0;
         if (lds_on && any && !cc.row_prg_base) {
             LdsRunScratch scratch;
-            scratch.init(cc);
+            size_t first_narrow = 0;
+            while (first_narrow < n_levels && c->run_of_level[first_narrow] < 0) first_narrow++;
+            scratch.init(cc, (uint32_t)first_narrow);
             std::vector<LdsRec> recs;
             auto narrow = [&](size_t i) {
                 const bool no64 = cc.level_start64.empty() || cc.level_start64[i + 1] == cc.level_start64[i];
@@ -668,12 +673,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         for (const auto& r : c->narrow_runs) narrow_levels += r.second - r.first;
         c->vclr_ok = cc.gates64.empty() && narrow_levels <= 16 && !cc.row_prg_base;
     }
-    if (c->vclr_ok)
-        for (const Gate& g : cc.gates)
-            if (g_op(g) == G_RANDOM || g_op(g) == G_RECON) {
-                c->vclr_ok = false;
-                break;
-            }
+    if (cc.n_random_or_recon) c->vclr_ok = false;  // (values that differ between repetitions)
     return RV_OK;
 }
 
@@ -2543,6 +2543,29 @@ extern "C" int rv_verify_ex(rv_ctx* ctx, const rv_circuit* c, const uint8_t* pro
         g_last_error = "out of host memory";
         return RV_E_NOMEM;
     }
+}
+
+// Proof::new / Proof::verify on the raw op list (proof/mod.rs:119-125,224-232): compile + prove / verify + release
+extern "C" int rv_prove_ops(rv_ctx* ctx, const rv_op* ops, size_t n_ops, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64, size_t n_z64,
+                            size_t z64_wires, size_t gf2_wires, const uint8_t* seeds, uint8_t** proof, size_t* proof_len) {
+    if (!proof || !proof_len) return RV_E_ARG;
+    rv_circuit* c = nullptr;
+    int rc = rv_circuit_compile_ex(ctx, ops, n_ops, z64_wires, gf2_wires, RV_COMPILE_WHOLE_PROVER, &c);
+    if (rc) return rc;
+    rc = rv_prove(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, proof, proof_len);
+    rv_circuit_destroy(c);
+    return rc;
+}
+
+extern "C" int rv_verify_ops(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, const uint8_t* proof, size_t proof_len,
+                             uint32_t flags, int* ok) {
+    if (!ok) return RV_E_ARG;
+    rv_circuit* c = nullptr;
+    int rc = rv_circuit_compile_ex(ctx, ops, n_ops, z64_wires, gf2_wires, 0, &c);
+    if (rc) return rc;
+    rc = rv_verify_ex(ctx, c, proof, proof_len, flags, ok);
+    rv_circuit_destroy(c);
+    return rc;
 }
 
 extern "C" int rv_verify(rv_ctx* ctx, const rv_circuit* c, const uint8_t* proof, size_t proof_len, int* ok) {

@@ -249,6 +249,7 @@ struct Builder {
         set_prg_level(m, 0);
         emit(g, 0);
         out.info.gf2_linear++;
+        out.n_random_or_recon++;
         return new_ssa(base(m));
     }
     uint32_t g_input() {
@@ -282,6 +283,7 @@ struct Builder {
         uint32_t res = 0;
         if (recon) {
             g.dst = COMP | n_comp++;  // {mask 0, corr = revealed value}
+            out.n_random_or_recon++;
             lvl_comp.push_back(lvl);
             res = new_ssa(base(g.dst));
         }

@@ -31,6 +31,7 @@ namespace rv {
 // kernel, never value-initialised a second time by the container.
 void* big_alloc(size_t bytes);  // nullptr when out of memory; contents are zero
 void big_free(void* p, size_t bytes);
+void big_free_later(void* p, size_t bytes);  // the same from a background thread (nobody waits for an unmap)
 template <class T>
 struct BigAlloc {
     using value_type = T;
@@ -42,7 +43,7 @@ struct BigAlloc {
         if (!p) throw std::bad_alloc();
         return (T*)p;
     }
-    void deallocate(T* p, size_t n) { big_free(p, n * sizeof(T)); }
+    void deallocate(T* p, size_t n) { big_free_later(p, n * sizeof(T)); }
     // default-initialisation instead of value-initialisation: resize() does not write the (already zero) pages
     template <class U>
     void construct(U* p) {
@@ -72,6 +73,7 @@ struct Compiled {
     uint64_t n_masks_pad = 0;           // PRG mask rows, padded to whole AES blocks (128)
     uint64_t n_rows = 1;                // share rows: n_masks_pad + computed rows (first computed = zero row)
     uint64_t n_masks = 0, n_on = 0, n_pre = 0, n_in = 0, n_rec = 0;
+    uint64_t n_random_or_recon = 0;     // G_RANDOM + G_RECON gates (wire values that differ between repetitions: no MODE_PROVE_V)
     // Z64 domain (gates64 share the level numbering: level l = [level_start64[l], level_start64[l+1]))
     std::vector<Gate64> gates64;
     std::vector<uint32_t> level_start64;
@@ -106,7 +108,7 @@ void relocate_chunk(Compiled& cc, uint64_t on0, uint64_t pre0, uint64_t on_words
 // returns RV_OK or RV_E_*
 // force_lazy_k: 0 = choose (RV_LAZY_K / circuit shape), 1..RV_LIN_K = that many base rows per wire at most
 // Whole programs of RV_COMPILE_PAR_MIN ops and more (default 200 000) without B2A gates are compiled by several host threads
-// (compile_par.cpp; RV_COMPILE_THREADS, default min(32, hardware threads); RV_COMPILE_SEQ=1 turns it off); everything else,
+// (compile_par.cpp; RV_COMPILE_THREADS, default min(16, hardware threads); RV_COMPILE_SEQ=1 turns it off); everything else,
 // and every program with an error in it, by the sequential compiler.  The result is the same bit for bit.
 int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr,
                 int force_lazy_k = 0);

@@ -20,6 +20,9 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
+#include <new>
+
 #include <vector>
 
 #include "compile.h"
@@ -61,11 +64,31 @@ inline size_t lds_run_bytes(uint32_t QS, uint32_t n_slots) {
     return ring + (size_t)n_slots * QS * 8 + 64;
 }
 
+// uint32 array whose elements all start as 0xFFFFFFFF (= -1) without being written: the values are kept plus one in
+// zero pages from the kernel (three arrays of n_rows entries are 144 MB for the 10^7-gate circuit, and filling them took
+// longer than building the run they serve)
+struct MinusOneArray {
+    uint32_t* p = nullptr;
+    size_t bytes = 0;
+    MinusOneArray() = default;
+    MinusOneArray(const MinusOneArray&) = delete;
+    MinusOneArray& operator=(const MinusOneArray&) = delete;
+    ~MinusOneArray() { big_free(p, bytes); }
+    void init(size_t n) {
+        big_free(p, bytes);
+        bytes = std::max<size_t>(n, 1) * 4;
+        p = (uint32_t*)big_alloc(bytes);
+        if (!p) throw std::bad_alloc();
+    }
+    uint32_t get(size_t i) const { return p[i] - 1u; }
+    int32_t geti(size_t i) const { return (int32_t)(p[i] - 1u); }
+    void set(size_t i, uint32_t v) { p[i] = v + 1u; }
+};
 struct LdsRunScratch {  // per circuit, sized n_rows, shared by all runs
-    std::vector<int32_t> last_use_level;  // last level that reads the row (-1: never)
-    std::vector<uint32_t> slot_of;        // row -> slot during a build (0xFFFFFFFF otherwise)
-    std::vector<int32_t> last_step;
-    void init(const Compiled& cc);
+    MinusOneArray last_use_level;  // last level that reads the row (-1: never; only levels from the first narrow stretch on are looked at)
+    MinusOneArray slot_of;         // row -> slot during a build (0xFFFFFFFF otherwise)
+    MinusOneArray last_step;
+    void init(const Compiled& cc, uint32_t first_level);
 };
 
 // Appends the run's records to `recs`.  false: the live wires do not fit `max_slots` (nothing appended).

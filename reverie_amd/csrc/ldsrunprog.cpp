@@ -22,26 +22,28 @@ LdsRec nop_rec() {
 }
 }  // namespace
 
-void LdsRunScratch::init(const Compiled& cc) {
-    last_use_level.assign(cc.n_rows, -1);
-    slot_of.assign(cc.n_rows, UNSET);
-    last_step.assign(cc.n_rows, -1);
+// first_level: the first level of the circuit's first narrow stretch -- a row's readers before that level cannot be "later
+// readers" of any run, so the scan starts there (for a wide circuit with a narrow tail that is a few thousand of 10^7 gates)
+void LdsRunScratch::init(const Compiled& cc, uint32_t first_level) {
+    last_use_level.init(cc.n_rows);
+    slot_of.init(cc.n_rows);
+    last_step.init(cc.n_rows);
     const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
-    for (size_t l = 0; l < n_levels; l++)
+    for (size_t l = first_level; l < n_levels; l++)
         for (uint32_t i = cc.level_start[l]; i < cc.level_start[l + 1]; i++) {
             const Gate& g = cc.gates[i];
             for (int k = 0; k < RV_LIN_K; k++) {
-                last_use_level[g.a[k]] = (int32_t)l;
-                last_use_level[g.b[k]] = (int32_t)l;
+                last_use_level.set(g.a[k], (uint32_t)l);
+                last_use_level.set(g.b[k], (uint32_t)l);
             }
         }
     // B2A reads 64 consecutive GF(2) wires' rows from the Z64 interpreter: those rows must stay in global memory
-    for (size_t l = 0; l + 1 < cc.level_start64.size(); l++)
+    for (size_t l = first_level; l + 1 < cc.level_start64.size(); l++)
         for (uint32_t i = cc.level_start64[l]; i < cc.level_start64[l + 1]; i++) {
             const Gate64& g = cc.gates64[i];
             if (g.op != G64_B2A) continue;
             for (uint32_t k = 0; k < 64; k++)
-                if ((uint64_t)g.a + k < cc.n_rows) last_use_level[g.a + k] = std::max(last_use_level[g.a + k], (int32_t)l);
+                if ((uint64_t)g.a + k < cc.n_rows) last_use_level.set(g.a + k, (uint32_t)std::max(last_use_level.geti(g.a + k), (int32_t)l));
         }
 }
 
@@ -52,13 +54,13 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
     std::vector<uint32_t> touched, live_in;
     auto reset = [&] {
         for (uint32_t r : touched) {
-            S.slot_of[r] = UNSET;
-            S.last_step[r] = -1;
+            S.slot_of.set(r, UNSET);
+            S.last_step.set(r, UNSET);
         }
     };
     auto touch = [&](uint32_t r, uint32_t mark) {
-        if (S.slot_of[r] == UNSET) {
-            S.slot_of[r] = mark;
+        if (S.slot_of.get(r) == UNSET) {
+            S.slot_of.set(r, mark);
             touched.push_back(r);
         }
     };
@@ -67,7 +69,7 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
         const Gate& g = cc.gates[i];
         for (int k = 0; k < 2 * RV_LIN_K; k++) {
             const uint32_t r = k < RV_LIN_K ? g.a[k] : g.b[k - RV_LIN_K];
-            if (r == zero || S.slot_of[r] != UNSET) continue;
+            if (r == zero || S.slot_of.get(r) != UNSET) continue;
             touch(r, LIVE_IN);
             live_in.push_back(r);
         }
@@ -89,8 +91,8 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
             const Gate& g = cc.gates[i];
             const int32_t st = (int32_t)(level_step0[l - l0] + (i - cc.level_start[l]) / GPS);
             for (int k = 0; k < RV_LIN_K; k++) {
-                if (g.a[k] != zero) S.last_step[g.a[k]] = st;
-                if (g.b[k] != zero) S.last_step[g.b[k]] = st;
+                if (g.a[k] != zero) S.last_step.set(g.a[k], (uint32_t)st);
+                if (g.b[k] != zero) S.last_step.set(g.b[k], (uint32_t)st);
             }
         }
     // ---- pass 3: slots by liveness (lowest free slot first, so the high-water mark stays small) and the records
@@ -113,13 +115,13 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
     const size_t rec_base = recs.size();
     recs.resize(rec_base + (size_t)n_steps_pad * GPS, nop_rec());
     auto define = [&](uint32_t row, uint32_t step) -> uint16_t {  // slot for a row written at `step` (LR_NONE if nothing here reads it)
-        if (S.last_step[row] < 0) {
-            S.slot_of[row] = DEFINED;
+        if (S.last_step.geti(row) < 0) {
+            S.slot_of.set(row, DEFINED);
             return (uint16_t)LR_NONE;
         }
         const uint32_t s = take();
-        S.slot_of[row] = s;
-        dies[(size_t)S.last_step[row]].push_back(s);
+        S.slot_of.set(row, s);
+        dies[(size_t)S.last_step.geti(row)].push_back(s);
         (void)step;
         return (uint16_t)s;
     };
@@ -145,8 +147,8 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
             LdsRec& r = recs[rec_base + (size_t)step * GPS + (i - lo) % GPS];
             const uint32_t op = g_op(g);
             for (int k = 0; k < RV_LIN_K; k++) {
-                r.a[k] = g.a[k] == zero ? 0 : (uint16_t)S.slot_of[g.a[k]];
-                r.b[k] = g.b[k] == zero ? 0 : (uint16_t)S.slot_of[g.b[k]];
+                r.a[k] = g.a[k] == zero ? 0 : (uint16_t)S.slot_of.get(g.a[k]);
+                r.b[k] = g.b[k] == zero ? 0 : (uint16_t)S.slot_of.get(g.b[k]);
             }
             uint32_t flags = (g_ca(g) ? LF_CA : 0u) | (g_cb(g) ? LF_CB : 0u);
             if (op == G_INPUT || op == G_MUL || op == G_ASSERT || op == G_RECON) {
@@ -164,7 +166,7 @@ bool build_lds_run(const Compiled& cc, uint32_t l0, uint32_t l1, uint32_t QS, ui
             r.m = (op == G_XORK || op == G_RECON) ? g.dst : g.m;
             if (op != G_ASSERT) {
                 r.dst = define(g.dst, step);
-                if (S.last_use_level[g.dst] >= (int32_t)l1) flags |= LF_OUT;
+                if (S.last_use_level.geti(g.dst) >= (int32_t)l1) flags |= LF_OUT;
             }
             r.op = op_word(op, flags);
             if ((i - lo) % GPS == GPS - 1 || i + 1 == hi) release(step);

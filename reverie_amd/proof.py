@@ -149,7 +149,6 @@ class Proof:
             seeds: Union[None, bytes, np.ndarray] = None, ctx: Optional[Context] = None) -> "Proof":
         """Proof::new.  `seeds` (256x16 bytes) injects the per-repetition seeds the reference
         draws from OsRng; None draws them from the OS."""
-        c = _as_circuit(circuit, wire_counts, ctx, whole_prover=True)  # (a program compiled for this one whole proof)
         g, z = _witness(wit_gf2, wit_z64)
         s = None
         if seeds is not None:
@@ -157,8 +156,17 @@ class Proof:
                                      else np.asarray(seeds, dtype=np.uint8)).reshape(TOTAL_REPS, 16)
         out = C.c_void_p()
         n = C.c_size_t()
-        _lib.check(_lib.lib().rv_prove(c.ctx.handle, c.handle, _ptr(g), C.c_size_t(len(g)), _ptr(z), C.c_size_t(len(z)),
-                                       _ptr(s), C.byref(out), C.byref(n)))
+        if isinstance(circuit, Circuit):
+            c = _as_circuit(circuit, wire_counts, ctx)
+            _lib.check(_lib.lib().rv_prove(c.ctx.handle, c.handle, _ptr(g), C.c_size_t(len(g)), _ptr(z), C.c_size_t(len(z)),
+                                           _ptr(s), C.byref(out), C.byref(n)))
+        else:
+            # the reference's own call shape (proof/mod.rs:119-125): the raw op list, compiled for this one proof
+            ops = program(circuit) if len(circuit) else np.zeros(0, OP_DTYPE)
+            cx = ctx or Context.default()
+            _lib.check(_lib.lib().rv_prove_ops(cx.handle, ops.ctypes.data_as(C.c_void_p), C.c_size_t(len(ops)), _ptr(g), C.c_size_t(len(g)),
+                                               _ptr(z), C.c_size_t(len(z)), C.c_size_t(int(wire_counts[0])), C.c_size_t(int(wire_counts[1])),
+                                               _ptr(s), C.byref(out), C.byref(n)))
         return Proof(_owned=(C.c_void_p(out.value), n.value))
 
     @staticmethod
@@ -190,11 +198,17 @@ class Proof:
         AssertZero gates must hold and the records' `omit` must match the challenge -- both of which the reference
         leaves unchecked, so that it accepts proofs of false statements.  strict=False is
         RV_VERIFY_REFERENCE_COMPAT: exactly the reference's answer (compatibility tests only)."""
-        c = _as_circuit(circuit, wire_counts, ctx)
         ok = C.c_int()
         buf, n = self._buffer()
         flags = 0 if strict else _lib.RV_VERIFY_REFERENCE_COMPAT
-        _lib.check(_lib.lib().rv_verify_ex(c.ctx.handle, c.handle, buf, C.c_size_t(n), C.c_uint32(flags), C.byref(ok)))
+        if isinstance(circuit, Circuit):
+            c = _as_circuit(circuit, wire_counts, ctx)
+            _lib.check(_lib.lib().rv_verify_ex(c.ctx.handle, c.handle, buf, C.c_size_t(n), C.c_uint32(flags), C.byref(ok)))
+        else:
+            ops = program(circuit) if len(circuit) else np.zeros(0, OP_DTYPE)
+            cx = ctx or Context.default()
+            _lib.check(_lib.lib().rv_verify_ops(cx.handle, ops.ctypes.data_as(C.c_void_p), C.c_size_t(len(ops)), C.c_size_t(int(wire_counts[0])),
+                                                C.c_size_t(int(wire_counts[1])), buf, C.c_size_t(n), C.c_uint32(flags), C.byref(ok)))
         return bool(ok.value)
 
 
