@@ -68,6 +68,7 @@ extern "C" const char* rv_strerror(int code) {
 // ------------------------------------------------------------------------------------
 struct rv_ctx {
     int device = 0;
+    size_t lds_bytes = 0;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     hipStream_t stream = nullptr;   // setup, AES masks, hashing, openings (VALU-heavy work)
     hipStream_t stream2 = nullptr;  // the interpreter (HBM-bound), pipelined against the mask generator
     std::vector<rv_ctx*> workers;            // rv_prove_batch on large circuits: one worker context per host thread
@@ -219,6 +220,17 @@ extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
     HIPCHK(hipSetDevice(device_ordinal));
     rv_ctx* c = new rv_ctx();
     c->device = device_ordinal;
+    {
+        // LDS a workgroup may have (160 KiB on gfx950): the LDS-run and rep-sliced paths size their wire stores by it and are
+        // left out when it is too small for them (a build for another part must fall back to the row interpreter, not fail at launch)
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_ordinal) != hipSuccess) {
+            (void)hipGetLastError();
+            lds = 64 * 1024;
+        }
+        c->lds_bytes = (size_t)std::max(lds, 0);
+        set_device_lds_limit(c->lds_bytes);
+    }
     if (const char* e = getenv("RV_PIPELINE")) c->pipeline = atoi(e) != 0;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
@@ -403,12 +415,13 @@ struct rv_circuit {
 };
 
 // LDS the rep-sliced interpreter may use for wire slots (a workgroup owns the CU: 160 KiB minus a little headroom)
-static uint32_t rep_lds_budget() {
+static uint32_t rep_lds_budget(const rv_ctx* ctx) {
     static const uint32_t v = [] {
         const char* e = getenv("RV_REP_LDS");
         return e ? (uint32_t)atoi(e) : 156u * 1024u;
     }();
-    return v;
+    const size_t dev = ctx->lds_bytes > 4096 ? ctx->lds_bytes - 4096 : 0;
+    return (uint32_t)std::min<size_t>(v, dev);
 }
 // RV_REP: 0 (default) = the row path everywhere; 1 = the rep-sliced path for whole proofs (all 256 repetitions on this
 // GPU) of circuits it accepts; 2 = for shards too.  Read at every call (tests switch it).  Off by default: measured on
@@ -476,10 +489,10 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
     // keeps one base row per wire, else from a second compile that does
     if (rep_mode() && c->cc.gates64.empty() && !c->cc.gates.empty()) {
         const char* why = "";
-        c->rep_ok = build_rep_program(c->cc, rep_lds_budget(), c->rp, &why);
+        c->rep_ok = build_rep_program(c->cc, rep_lds_budget(ctx), c->rp, &why);
         if (!c->rep_ok && strstr(why, "base")) {
             Compiled one;
-            if (compile_ops(ops, n_ops, z64_wires, gf2_wires, one, nullptr, 1) == RV_OK) c->rep_ok = build_rep_program(one, rep_lds_budget(), c->rp, &why);
+            if (compile_ops(ops, n_ops, z64_wires, gf2_wires, one, nullptr, 1) == RV_OK) c->rep_ok = build_rep_program(one, rep_lds_budget(ctx), c->rp, &why);
         }
         if (getenv("RV_COMPILE_STATS"))
             fprintf(stderr, "[rv circuit] rep-sliced path: %s%s (%u levels, %zu segments, %u LDS slots) at %.3f s\n", c->rep_ok ? "yes" : "no: ", why,
@@ -496,7 +509,17 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
 static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
     const auto t_compiled = std::chrono::steady_clock::now();
     int rc;
-    HIPCHK(hipSetDevice(ctx->device));
+// (c is destroyed on EVERY failure: the callers rely on it)
+#define UPCHK(x)                                                        \
+    do {                                                                \
+        hipError_t e_ = (x);                                            \
+        if (e_ != hipSuccess) {                                         \
+            const int code_ = hip_fail(e_, #x, __FILE__, __LINE__);     \
+            rv_circuit_destroy(c);                                      \
+            return code_;                                               \
+        }                                                               \
+    } while (0)
+    UPCHK(hipSetDevice(ctx->device));
     const Compiled& cc = c->cc;
     // everything below goes through one page-locked buffer when it fits (the function waits for the stream before it
     // returns, so the buffer is free again for the next circuit)
@@ -506,7 +529,10 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         stage_need += (b + 255) & ~(size_t)255;
     static const bool stage_on = !(getenv("RV_UPLOAD_STAGE") && atoi(getenv("RV_UPLOAD_STAGE")) == 0);
     if (stage_on && stage_need <= rv_ctx::UP_STAGE_MAX && stage_need > ctx->h_up_cap) {
-        if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+        if (ctx->h_up) {
+            (void)hipStreamSynchronize(ctx->stream);  // (no copy out of the old buffer may still be pending)
+            (void)hipHostFree(ctx->h_up);
+        }
         ctx->h_up = nullptr;
         ctx->h_up_cap = 0;
         const size_t want = std::min(rv_ctx::UP_STAGE_MAX, std::max(stage_need + stage_need / 4, (size_t)8 << 20));
@@ -547,7 +573,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
             return rc;
         }
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    UPCHK(hipStreamSynchronize(ctx->stream));
     if (c->rep_ok) {  // the device holds them now
         std::vector<RepRec>().swap(c->rp.recs);
         std::vector<RepSeg>().swap(c->rp.segs);
@@ -633,8 +659,12 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
                     // two quad words per slice: the fewest steps per level (64 / qs gates each) a pair of quads sharing
                     // a preprocessing byte allows, and the most workgroups; 4 only on request
                     const uint32_t qs = qs_env == 4 ? 4u : 2u;
-                    const size_t budget = 160 * 1024 - 1024;
+                    const size_t budget = std::min<size_t>(160 * 1024, ctx->lds_bytes) - 1024;
                     const size_t fixed = lds_run_bytes(qs, 0);
+                    if (budget < fixed + 64 * qs * 8) {  // not even a handful of wire slots next to the ring: the row interpreter's narrow runs
+                        l = e;
+                        continue;
+                    }
                     const uint32_t max_slots = (uint32_t)std::min<size_t>((budget - fixed) / (qs * 8), LR_NONE - 1);
                     rv_circuit::LdsPlan plan{};
                     plan.qs = qs;
@@ -650,7 +680,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
                     rv_circuit_destroy(c);
                     return rc;
                 }
-                HIPCHK(hipStreamSynchronize(ctx->stream));
+                UPCHK(hipStreamSynchronize(ctx->stream));
             }
             if (getenv("RV_COMPILE_STATS"))
                 for (const auto& pl : c->lds_runs)
@@ -675,6 +705,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
     }
     if (cc.n_random_or_recon) c->vclr_ok = false;  // (values that differ between repetitions)
     return RV_OK;
+#undef UPCHK
 }
 
 extern "C" void rv_circuit_destroy(rv_circuit* c) {
@@ -860,6 +891,9 @@ struct rv_shard {
 extern "C" void rv_shard_destroy(rv_shard* s) {
     if (!s) return;
     (void)hipStreamSynchronize(s->ctx->stream);
+    // work forked onto the second stream (the verifier's side copy of the proof, the two-stream pipeline): its buffers go back to
+    // the arena below and the caller's host buffers leave scope -- nothing of it may still be in flight
+    if (!s->misc_events.empty() || !s->mask_chunks.empty() || s->ev_setup) (void)hipStreamSynchronize(s->ctx->stream2);
     s->destroy();
     delete s;
 }
@@ -2255,6 +2289,7 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     };
     uint8_t* d_proof = nullptr;
     uint64_t* d_src = nullptr;
+    hipEvent_t ev_arena = nullptr;
     uint32_t *d_keep = nullptr, *d_onm = nullptr, *d_sup_in = nullptr, *d_sup_corr = nullptr, *d_sup_rec = nullptr;
     auto track = [&](void* p) { s->extra.push_back(p); };
     std::vector<uint32_t> on_quads;
@@ -2326,6 +2361,14 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         track(d_proof);
         if ((rc = dalloc(ctx, src.size(), &d_src))) return fail(rc);
         track(d_src);
+        // d_proof / d_src may be filled from the SECOND stream further down (beside the mask kernels).  The arena hands blocks out
+        // in the main stream's order, so the side stream first waits for everything the main stream holds NOW -- whatever used
+        // these blocks last -- and nothing of this call's own kernels (they are queued after this point)
+        if (!ctx->pipeline && !g_recorder && proof_len >= ((size_t)4 << 20)) {
+            ev_arena = ctx->get_sync_event();
+            s->misc_events.push_back(ev_arena);
+            if (hipEventRecord(ev_arena, ctx->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventRecord", __FILE__, __LINE__));
+        }
         if ((rc = dalloc(ctx, NQ, &d_keep))) return fail(rc);
         track(d_keep);
         if ((rc = dalloc(ctx, NQ, &d_onm))) return fail(rc);
@@ -2412,7 +2455,8 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         // on ONE stream the copy would queue up behind the mask kernels; from the second stream it runs beside them
         // (copy engine next to compute) and the unpack kernels wait for its event
         static const bool side = !(getenv("RV_VERIFY_SIDE_COPY") && atoi(getenv("RV_VERIFY_SIDE_COPY")) == 0);
-        hipStream_t sc = (side && !ctx->pipeline && !g_recorder && proof_len >= ((size_t)4 << 20)) ? ctx->stream2 : sb;
+        hipStream_t sc = (side && ev_arena) ? ctx->stream2 : sb;
+        if (sc != sb) HC(hipStreamWaitEvent(sc, ev_arena, 0));
         HC(hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, sc));
         HC(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, sc));
         if (sc != sb) {
@@ -2784,13 +2828,22 @@ static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, 
         const size_t n_thr = B >= 32 ? std::min<size_t>({(size_t)8, B / 8, (size_t)std::max(1u, std::thread::hardware_concurrency())}) : 1;
         std::vector<int> rcs(std::max<size_t>(n_thr, 1), RV_OK);
         auto range = [&](size_t t, size_t k0, size_t k1) {
-            for (size_t k = k0; k < k1 && rcs[t] == RV_OK; k++) rcs[t] = fill(k);
+            try {  // (runs on a worker thread: nothing may escape it)
+                for (size_t k = k0; k < k1 && rcs[t] == RV_OK; k++) rcs[t] = fill(k);
+            } catch (...) {
+                rcs[t] = RV_E_NOMEM;
+            }
         };
         if (n_thr <= 1) {
             range(0, 0, B);
         } else {
             std::vector<std::thread> th;
-            for (size_t t = 0; t < n_thr; t++) th.emplace_back(range, t, B * t / n_thr, B * (t + 1) / n_thr);
+            th.reserve(n_thr);
+            try {
+                for (size_t t = 0; t < n_thr; t++) th.emplace_back(range, t, B * t / n_thr, B * (t + 1) / n_thr);
+            } catch (...) {  // a thread could not be started: the ranges without one are done here
+                for (size_t t = th.size(); t < n_thr; t++) range(t, B * t / n_thr, B * (t + 1) / n_thr);
+            }
             for (auto& x : th) x.join();
         }
         for (int r : rcs)

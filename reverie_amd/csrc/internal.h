@@ -129,6 +129,10 @@ struct InterpParams {
     int* err;                 // device flag: RV_E_WITNESS_INVALID
 };
 
+// LDS per workgroup of the device in use (set by rv_ctx_create): the dynamic-LDS kernels raise their limit to it, not beyond
+void set_device_lds_limit(size_t bytes);
+size_t device_lds_limit();
+
 // ---- launchers (implemented in the .hip files) ----
 void launch_expand_seeds(hipStream_t st, const uint8_t* d_seeds, uint32_t n_reps, uint8_t* d_keys /*[n][8][16]*/);
 // Per AES key: the 11 round keys (176 bytes) followed by 32 bytes of first-round constants (k_key_schedule):

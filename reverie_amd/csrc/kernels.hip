@@ -24,6 +24,11 @@
 
 namespace rv {
 
+static size_t g_device_lds_limit = 160 * 1024;
+void set_device_lds_limit(size_t bytes) { g_device_lds_limit = bytes; }
+size_t device_lds_limit() { return g_device_lds_limit; }
+
+
 // XOR of the n listed base rows / their corr bits.  Unused slots hold the zero row, so all
 // RV_LIN_K slots are loaded unconditionally with STATIC indices (a runtime-indexed id array would
 // push the gate record into scratch memory; a per-slot branch would serialise the loads).

@@ -289,11 +289,16 @@ template <int MODE, int QS>
 static void launch_lds_mq(hipStream_t st, const LdsRunParams& rp, size_t lds, uint32_t NQ, const InterpParams& p, const InterpParams* d_pp,
                           uint32_t batch) {
     static const bool attr = [] {
-        (void)hipFuncSetAttribute((const void*)k_interp_lds<MODE, QS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        (void)hipFuncSetAttribute((const void*)k_interp_lds<MODE, QS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        return true;
+        const int want = (int)std::min<size_t>(160 * 1024, device_lds_limit()) - 1024;
+        const hipError_t a = hipFuncSetAttribute((const void*)k_interp_lds<MODE, QS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        const hipError_t b = hipFuncSetAttribute((const void*)k_interp_lds<MODE, QS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        if (a != hipSuccess || b != hipSuccess) {
+            (void)hipGetLastError();
+            fprintf(stderr, "[reverie_amd] LDS runs: the device refused %d bytes of dynamic LDS per workgroup (%s)\n", want, hipGetErrorString(a != hipSuccess ? a : b));
+        }
+        return a == hipSuccess && b == hipSuccess;
     }();
-    (void)attr;
+    (void)attr;  // (circuit_upload planned the runs within the device's limit; a refusal shows up as a failed launch, reported by the caller's hipGetLastError)
     if (d_pp)
         hipLaunchKernelGGL((k_interp_lds<MODE, QS, true>), dim3(NQ / QS, batch), dim3(64 * (1 + LR_PRODUCERS)), lds, st, rp, InterpParams{}, d_pp);
     else

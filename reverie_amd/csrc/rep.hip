@@ -1,5 +1,11 @@
 // Rep-sliced prover kernels for gfx950: one workgroup = ONE repetition, live wires in LDS (repprog.h).
 //
+// STATUS: OPT-IN (RV_REP=1 / 2), NOT on the default path.  This is the layout BASELINE.json's north_star prescribes ("one lane
+// = one (repetition, player) slot, wire values staged in LDS"); it was built, is byte-identical to the oracle
+// (tests/test_gpu_parity.py::test_rep_sliced_path) and was REFUTED by measurement as a replacement for the row interpreter:
+// 9.9 ms of GPU time per proof of the 10^7-gate circuit against 5.4 ms ("Rep-sliced path").  It stays in
+// the tree as the evidence for that choice and as the layout a fused mask-generator + interpreter kernel would start from.
+//
 // Replaces, for the prover of a pure GF(2) circuit whose live wires fit the LDS (all under /root/reference/src/):
 //   interpreter/single.rs:25-157      Instance::step / op_mul
 //   transcript/prover.rs:181-232      ProverTranscript::{input, reconstruct, correction, zero_check}
@@ -262,8 +268,9 @@ __global__ __launch_bounds__(1024) void k_rep(RepParams P, uint32_t* __restrict_
 void launch_rep_clear(hipStream_t st, const RepLevel* d_levels, uint32_t n_levels, const RepSeg* d_segs, const RepRec* d_recs, const uint8_t* d_wit,
                       uint32_t* d_vbits, int* d_err, uint32_t lds_slots) {
     static bool attr = [] {
-        (void)hipFuncSetAttribute((const void*)k_rep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        (void)hipFuncSetAttribute((const void*)k_rep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        const int want = (int)std::min<size_t>(160 * 1024, device_lds_limit()) - 1024;
+        (void)hipFuncSetAttribute((const void*)k_rep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        (void)hipFuncSetAttribute((const void*)k_rep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
         return true;
     }();
     (void)attr;

@@ -43,6 +43,23 @@ def test_parse_errors():
             bristol.parse(bad)
 
 
+def test_wire_ids_beyond_u32_are_unsupported_not_malformed():
+    """The reference's wire ids are usize (interpreter/single.rs:14,109-155); rv_op carries u32.  A file that names a wire or a
+    count of 2^32 and more is answered RV_E_UNSUPPORTED (8): a stated ceiling, not a silent truncation and not "malformed" (5)."""
+    import reverie_amd
+
+    ok = "1 3\n2 1 1\n1 1\n\n2 1 0 1 2 XOR\n"
+    bristol.parse(ok)
+    for text in (ok.replace("2 1 0 1 2 XOR", "2 1 0 1 4294967296 XOR"), ok.replace("1 3\n", "1 4294967296\n"),
+                 ok.replace("2 1 0 1 2 XOR", "2 1 0 99999999999999999999999 2 XOR")):
+        with pytest.raises(reverie_amd.ReverieError) as e:
+            bristol.parse(text)
+        assert e.value.code == 8
+    with pytest.raises(reverie_amd.ReverieError) as e:
+        bristol.parse(ok.replace("2 1 0 1 2 XOR", "2 1 0 1 4294967295 XOR"))  # fits u32, but no such wire in a 3-wire circuit
+    assert e.value.code != 8
+
+
 def test_adder64_circuit():
     prog, info = bristol.parse(bristol_gen.adder64())
     assert info["n_and"] == 63 and info["n_inputs"] == 128

@@ -149,6 +149,43 @@ def test_stream_errors(rv, rule_seeds):
     sp.close()
 
 
+@pytest.mark.parametrize("threads", ["1", "4"])
+def test_stream_pass2_must_feed_pass1s_ops_and_witness(rv, rule_seeds, monkeypatch, threads):
+    """Pass 2 with the SAME cuts as pass 1 reuses pass 1's compiled chunks (the default cache): the ops actually fed are still
+    digested and compared -- a different program of the same length is RV_E_ARG at finish, not a proof of pass 1's program --
+    and so is a different witness (even one that satisfies the circuit)."""
+    from reverie_amd.stream import StreamingProver
+
+    monkeypatch.setenv("RV_STREAM_THREADS", threads)
+    rng = np.random.default_rng(11)
+    prog, wit, wc = circuits.random_gf2(rng, n_in=40, n_gates=3000, n_wires=120, p_assert=0.0)
+    # an unconstrained second witness: no AssertZero in the program, so every witness is valid
+    other_wit = [b ^ 1 if i % 3 == 0 else b for i, b in enumerate(wit)]
+    other = prog.copy()
+    k = int(np.nonzero(other["opcode"] == 6)[0][-1])        # the last Mul reads another operand: same length, same counters
+    other["a"][k] = (int(other["a"][k]) + 1) % wc[1]
+
+    def run(p2_prog, p2_wit):
+        # one feed per pass, cut by the library every 700 ops (threads > 1: the pieces are compiled / checked on worker threads)
+        sp = StreamingProver(wc, seeds=rule_seeds, max_chunk_ops=700)
+        try:
+            sp.feed(prog, wit, [])
+            sp.commit()
+            sp.feed(p2_prog, p2_wit, [])
+            return sp.finish()
+        finally:
+            sp.close()
+
+    good = run(prog, wit)
+    assert bytes(good) == bytes(rv.Proof.new(prog, wit, [], wc, seeds=rule_seeds))
+    with pytest.raises(rv.ReverieError) as e:
+        run(other, wit)
+    assert e.value.code == 9
+    with pytest.raises(rv.ReverieError) as e:
+        run(prog, other_wit)
+    assert e.value.code == 9
+
+
 def test_stream_layered_bounded_memory(rv, oracle, rule_seeds):
     """the layered workload at two depths with recycled wire indices: the same proof as rv_prove / the oracle, and a
     device footprint that does not move when the circuit gets four times longer"""
