@@ -572,6 +572,27 @@ void count_masks(const rv_op* ops, size_t n_ops, uint64_t* gf2_masks, uint64_t* 
     *z64_masks = m64;
 }
 
+// transcript events the ops make (per repetition): GF(2) online rows = inputs + reconstructions (Mul, AssertZero; B2A: 63 + 64),
+// preprocessing rows = Mul (B2A: 63); Z64 online words = inputs + 8 per Mul / AssertZero, preprocessing words = Mul + B2A
+void count_events(const rv_op* ops, size_t n_ops, StreamEvents* ev) {
+    StreamEvents e;
+    for (size_t i = 0; i < n_ops; i++) {
+        const rv_op& op = ops[i];
+        if (op.domain == RV_DOM_GF2) {
+            if (op.opcode == RV_OP_INPUT) e.in2++;
+            else if (op.opcode == RV_OP_MUL) e.rec2++, e.pre2++;
+            else if (op.opcode == RV_OP_ASSERTZERO) e.rec2++;
+        } else if (op.domain == RV_DOM_Z64) {
+            if (op.opcode == RV_OP_INPUT) e.on64 += 1;
+            else if (op.opcode == RV_OP_MUL) e.on64 += 8, e.pre64 += 1;
+            else if (op.opcode == RV_OP_ASSERTZERO) e.on64 += 8;
+        } else if (op.domain == RV_DOM_B2A) {
+            e.rec2 += 63 + 64, e.pre2 += 63, e.pre64 += 1;
+        }
+    }
+    *ev = e;
+}
+
 void relocate_chunk(Compiled& cc, uint64_t on0, uint64_t pre0, uint64_t on_words64_0, uint64_t pre_words64_0) {
     if (on0 || pre0) {
         for (Gate& g : cc.gates) {  // (eo / ep of gates without a transcript row are never read)

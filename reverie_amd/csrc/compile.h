@@ -101,6 +101,13 @@ struct ChunkStart {
 // ShareGen::next() calls the ops make (generator/share.rs:54-65 as a pure count over the op list: Input / Random 1, Mul 2,
 // B2A 64 + 63 x 2 GF(2) and one Z64) -- all a chunk compiled AHEAD of its predecessors needs to know about them
 void count_masks(const rv_op* ops, size_t n_ops, uint64_t* gf2_masks, uint64_t* z64_masks);
+// The transcript events the ops make -- what a chunk compiled AHEAD needs to know about the ops before it to predict the carried
+// events in front of its own (stream.inc): GF(2) inputs / reconstructions (both online rows) and preprocessing rows, Z64 online
+// and preprocessing words
+struct StreamEvents {
+    uint64_t in2 = 0, rec2 = 0, pre2 = 0, on64 = 0, pre64 = 0;
+};
+void count_events(const rv_op* ops, size_t n_ops, StreamEvents* ev);
 // A chunk compiled with zero transcript offsets, moved behind `on0` / `pre0` carried transcript rows and `on_words64_0` /
 // `pre_words64_0` carried Z64 words (they enter the compiled stream only as additive offsets)
 void relocate_chunk(Compiled& cc, uint64_t on0, uint64_t pre0, uint64_t on_words64_0, uint64_t pre_words64_0);

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 
-def streaming_record(ctx, prog, wit, wc, st, seeds, want: bytes, chunk_ops: int = 1 << 20, layers: int = 153, p_and: float = 0.5):
+def streaming_record(ctx, prog, wit, wc, st, seeds, want: bytes, chunk_ops: int = 1 << 18, layers: int = 153, p_and: float = 0.5):
     """config 4 through rv_prove_streaming.  The circuit is regenerated with recycled wire indices (the proof does not
     depend on wire numbering, the streaming prover's wire store does); `want` = rv_prove's proof of the same statement."""
     import circuits
@@ -27,9 +27,9 @@ def streaming_record(ctx, prog, wit, wc, st, seeds, want: bytes, chunk_ops: int 
            "gf2_wires": rwc[1], "bit_exact_vs_rv_prove": bytes(proof) == want,
            "device_bytes": {k: info[k] for k in ("wire_store_bytes", "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")},
            "note": "rv_prove_streaming, host ops in -> host proof bytes out, two passes over the op array; every chunk is compiled "
-                   "(levelised) on the host, on up to 6 worker threads ahead of the GPU, and kept for pass 2 while it fits "
-                   "RV_STREAM_CACHE_MB -- still most of the time (~0.1 s of one core per 10^6 ops); the resident prover keeps "
-                   "~6.4 GB for this circuit"}
+                   "(levelised) and moved to its transcript offsets on one of up to 12 worker threads ahead of the GPU, and kept for "
+                   "pass 2 while it fits RV_STREAM_CACHE_MB; a long feed starts with pieces of 1/8, 1/4 and 1/2 of the chunk size; "
+                   "the resident prover keeps ~6.4 GB for this circuit"}
     del proof
     return rec
 
