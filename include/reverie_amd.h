@@ -247,9 +247,10 @@ void rv_free(void *p);
  *     rv_stream_abort(s)                       releases the stream (also after a finish or an error)
  *
  * The pieces of pass 2 need not be cut where those of pass 1 were, but their concatenation must be the same op
- * list (checked at finish: RV_E_ARG).  wit_gf2 / wit_z64 of a feed are the witness elements its Input gates
+ * list and the same witness (both digested as they are fed, also when pass 1's compiled chunk is reused; checked at
+ * finish: RV_E_ARG).  wit_gf2 / wit_z64 of a feed are the witness elements its Input gates
  * consume, in order (more may be passed; RV_E_WITNESS_SHORT if fewer).  A feed longer than max_chunk_ops
- * (0 = 2^20) is cut into device chunks of that size.  SizeHint ops may not grow the wire counts given at begin
+ * (0 = 2^18) is cut into device chunks of that size (a long feed of chunks >= 2^16 ops starts with pieces of 1/8, 1/4, 1/2).  SizeHint ops may not grow the wire counts given at begin
  * (RV_E_UNSUPPORTED).  After an error the stream only accepts rv_stream_abort. */
 int rv_stream_begin(rv_ctx *ctx, size_t z64_wires, size_t gf2_wires, const uint8_t *seeds /* 256 x 16 or NULL */,
                     size_t max_chunk_ops, rv_stream **out);
