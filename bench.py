@@ -36,7 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PROFILE_TAG = "r02"    # profiles/<tag>_pmc_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r03"    # profiles/<tag>_pmc_traffic.json feeds roofline.traffic
 
 
 def rule_seeds():
@@ -214,8 +214,8 @@ def secondary_records(ctx, seeds, quick):
         rec["cpu_oracle_and_per_s"] = n_and * 3 / (time.perf_counter() - t0)
         out[name] = rec
         circ.close()
-    # config 5: Z64, 10^6 MUL (the full size on the GPU; the CPU oracle proves a 10^5-MUL sample of the same generator,
-    # which is also the bit-exactness check -- the full circuit needs ~20 GB and minutes on the host)
+    # config 5: Z64, 10^6 MUL (the full size on the GPU, byte-compared with the CPU oracle's proof of the same circuit once per run
+    # when the host has the memory for it; a 10^5-MUL sample of the same generator besides)
     n_mul = 100_000 if quick else 1_000_000
     prog, w64, wc, st = circuits.layered_z64(n_mul=n_mul)
     circ = reverie_amd.Circuit(prog, wc, ctx)
@@ -235,13 +235,33 @@ def secondary_records(ctx, seeds, quick):
                    "PMC traffic (k_interp64 moves ~150 GB per proof at ~5.5 TB/s, k_aes_z64_masks is VALU-bound: 2.05e9 "
                    "cipher blocks + the bit transposes)"}
     circ.close()
-    del p, data
+    del p
+    # the FULL circuit through the CPU oracle once (a 640 MB proof, ~20 GB of host memory, ~10 s on 32 threads): the byte-for-byte
+    # check of the timed configuration itself, and the CPU baseline on it; skipped (with the 10^5-MUL sample standing in) when the
+    # host is short of memory
+    mem_gb = 0.0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                mem_gb = int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    if not quick and mem_gb >= 64:
+        base, full = cpu_baseline(prog, [], w64, wc, seeds, st["mul"], "Z64 MUL gates/s", "the whole timed workload (10^6 MUL)", runs=1)
+        rec["full_size_bit_exact_vs_cpu"] = data == full
+        rec["cpu_baseline"] = base
+        del full
+    else:
+        rec["full_size_bit_exact_vs_cpu"] = None
+        rec["full_size_note"] = f"host has {mem_gb:.0f} GB available (or --quick): the oracle's full-size proof was not made"
+    del data
     sprog, sw64, swc, sst = circuits.layered_z64(n_mul=100_000)
     scirc = reverie_amd.Circuit(sprog, swc, ctx)
     dts, sdata = HostProver(scirc, [], sw64, seeds).run(1)
-    base, sproof = cpu_baseline(sprog, [], sw64, swc, seeds, sst["mul"], "Z64 MUL gates/s", "10^5-MUL sample of the same generator", runs=3)
+    sbase, sproof = cpu_baseline(sprog, [], sw64, swc, seeds, sst["mul"], "Z64 MUL gates/s", "10^5-MUL sample of the same generator", runs=3)
     rec["sample_1e5_bit_exact_vs_cpu"] = sdata == sproof
-    rec["cpu_baseline"] = base
+    rec.setdefault("cpu_baseline", sbase)
+    rec["cpu_baseline_1e5_sample"] = sbase
     scirc.close()
     out["z64"] = rec
     return out
@@ -424,6 +444,22 @@ def main():
             "phase_ms": phases, "phase_launches": launches, "algorithmic_bytes_per_proof": {k: int(v) for k, v in alg.items()},
             "gpu_ms_per_proof": sum(phases.values()),
         }
+        # SURVEY 8(d) names integer VALU throughput as the binding roofline of the mask and hash phases: instruction-issue
+        # fraction = wavefront-level VALU instructions per proof (SQ_INSTS_VALU of the profiled run, a property of the circuit)
+        # / this run's phase time / the chip's issue peak (1024 SIMDs x 1/2 instruction per clock x 2.4 GHz)
+        sq_path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_sq_counters.json")
+        if world == 1 and args.layers == 153 and args.p_and == 0.5 and os.path.exists(sq_path):
+            sk = json.load(open(sq_path))["kernels"]
+            peak_issue = 1024 * 0.5 * 2.4e9
+            valu = {"peak": peak_issue, "unit": "wavefront VALU instructions/s", "kernels": {}}
+            for phase, prefixes in (("masks", ("rv::k_aes_gf2_masks<",)), ("hash", ("rv::k_b3_chunks<", "rv::k_b3_chunks_bits", "rv::k_b3_reduce<", "rv::k_b3_tree_tail"))):
+                insts = sum(v.get("SQ_INSTS_VALU_per_proof", 0.0) for k, v in sk.items() if k.startswith(prefixes))
+                if insts and phases[phase] > 0:
+                    valu["kernels"][phase] = {"kernels": [k for k in sk if k.startswith(prefixes)], "valu_insts_per_proof": insts,
+                                              "phase_ms": phases[phase], "issue_frac": insts / (phases[phase] * 1e-3) / peak_issue}
+            valu["note"] = ("half of the BLAKE3 / bitsliced-AES instruction mix are 3-source VOP3 (v_bitop3, v_perm, v_add3, v_alignbit) "
+                            "that issue at a quarter of a wavefront per clock, not half: tools/mb/valu_mb.hip; DESIGN.md section 4")
+            roofline["valu"] = valu
         boundary = (("rv_prove_sharded (library communicator: RCCL all-gather of digests on the library's stream, ncclSend/ncclRecv of "
                      "the openings); rank 0 ends with bincode(Proof) bytes in host memory" if lib_comm is not None else
                      "sharded rv_shard_* + torch.distributed all-gather; rank 0 ends with bincode(Proof) bytes in host memory"

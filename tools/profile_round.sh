@@ -15,5 +15,6 @@ cd /root/repo
 python tools/prof_summary.py $(ls $out/trace/*/*_results.db | head -1) $N > $out/${tag}_bench_kernel_stats.txt
 python tools/pmc_summary.py $(ls $out/fetch/*/*_results.db | head -1) $(ls $out/write/*/*_results.db | head -1) $N $out/${tag}_pmc_traffic > /dev/null
 python tools/prof_summary.py $(ls $out/sq/*/*_results.db | head -1) $N | sed -n '/counters_collection/,$p' > $out/${tag}_sq_counters.txt
+python tools/sq_summary.py $(ls $out/sq/*/*_results.db | head -1) $N $out/${tag}_sq_counters.json > /dev/null
 rm -rf $out/trace $out/fetch $out/write $out/sq
 head -12 $out/${tag}_bench_kernel_stats.txt; head -12 $out/${tag}_pmc_traffic.txt
