@@ -277,6 +277,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="only the timed configuration (rocprofv3 runs whose summary should contain nothing else)")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="only the timed proofs and the parity check (tools/profile_round.sh: the kernel counts of a profiled run must "
+                         "be those of warmup + steps proofs)")
     ap.add_argument("--quick", action="store_true", help="fewer repetitions in the secondary records, Z64 at 10^5 MUL")
     ap.add_argument("--device-resident", action="store_true",
                     help="time rv_prove_device (openings left in HBM: round 1's headline) instead of the host-to-host rv_prove")
@@ -490,7 +493,7 @@ def main():
             single = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
             parity["sharded_proof_equals_single_gpu_proof"] = bytes(single) == bytes(last)
         result["parity"] = parity
-        if world == 1:
+        if world == 1 and not args.profile_run:
             # the first proof of a circuit the library has not seen: rv_prove_ops from the raw op list (the reference's
             # Proof::new walks the raw ops, proof/mod.rs:150-152) = compile on the host threads + upload + prove
             fp = []

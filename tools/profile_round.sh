@@ -6,7 +6,7 @@ out=/root/repo/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 W=2; K=6; N=$((W+K))
-B="python /root/repo/bench.py --no-secondary --no-cpu-baseline --steps $K --warmup $W"
+B="python /root/repo/bench.py --no-secondary --no-cpu-baseline --profile-run --steps $K --warmup $W"
 rocprofv3 --kernel-trace --stats -d $out/trace -- $B > $out/bench_trace.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/write -- $B > /dev/null 2>&1
