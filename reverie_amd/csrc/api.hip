@@ -747,6 +747,12 @@ extern "C" int rv_hook_compile_info(const rv_op* ops, size_t n_ops, size_t z64_w
                 uint64_t a = 0, b = 0;
                 count_masks(ops + at, n, &a, &b);
                 if (piece.n_masks - cs.mask_phase != a || piece.n_masks64 - cs.mask64_phase != b) return RV_E_DEVICE;
+                // ... and the transcript events count_events predicts (the workers place a piece at the offsets they imply)
+                StreamEvents ev;
+                count_events(ops + at, n, &ev);
+                if (piece.n_on != ev.in2 + ev.rec2 || piece.n_in != ev.in2 || piece.n_rec != ev.rec2 || piece.n_pre != ev.pre2 ||
+                    piece.on_words64 != ev.on64 || piece.pre_words64 != ev.pre64)
+                    return RV_E_DEVICE;
                 const uint64_t on_before = piece.n_on, pre_before = piece.n_pre;
                 relocate_chunk(piece, 7, 5, 3, 2);
                 if (piece.n_on != on_before + 7 || piece.n_pre != pre_before + 5) return RV_E_DEVICE;
