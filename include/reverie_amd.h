@@ -275,6 +275,23 @@ int rv_prove_streaming(rv_ctx *ctx, const rv_op *ops, size_t n_ops, size_t z64_w
                        size_t n_gf2, const uint64_t *wit_z64, size_t n_z64, const uint8_t *seeds, size_t max_chunk_ops,
                        uint8_t **proof, size_t *proof_len, rv_stream_info *info);
 
+/* ---- Proof::verify with bounded device memory (the streaming verifier) -----------------------------------------------
+ * The reference's verify walks the op list like its prover (proof/mod.rs:259-261,276-278); rv_verify keeps the whole compiled
+ * circuit and its rows resident (~6 GB for 10^7 GF(2) gates, ~90 GB for 10^6 Z64 multiplications).  Here the ops are fed in
+ * pieces, ONCE (the omitted players are in the proof), and device memory is the streaming prover's: wire store + one chunk +
+ * the proof.
+ *     rv_stream_verify_begin(ctx, z64_wires, gf2_wires, proof, proof_len, max_chunk_ops, &s)   (proof must outlive the stream)
+ *     rv_stream_feed(s, ops_0, n, NULL, 0, NULL, 0) ... rv_stream_feed(s, ops_k, ...)           (no witness)
+ *     rv_stream_verify_finish(s, flags, &ok)      flags as rv_verify_ex; ok = what rv_verify_ex answers for the same ops
+ *     rv_stream_abort(s)
+ * A proof with the wrong repetition counts gives ok = 0 (as rv_verify); a malformed one RV_E_PROOF_MALFORMED at begin. */
+int rv_stream_verify_begin(rv_ctx *ctx, size_t z64_wires, size_t gf2_wires, const uint8_t *proof, size_t proof_len, size_t max_chunk_ops,
+                           rv_stream **out);
+int rv_stream_verify_finish(rv_stream *s, uint32_t flags, int *ok);
+/* begin + one feed of an op array that already sits in host memory + finish; info (nullable): the stream's final figures */
+int rv_verify_streaming(rv_ctx *ctx, const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, const uint8_t *proof, size_t proof_len,
+                        uint32_t flags, size_t max_chunk_ops, int *ok, rv_stream_info *info);
+
 /* ---- sharded form (one process per GPU; repetitions [rep_begin, rep_begin+rep_count),
  * both multiples of 8).  rv_prove == commit(0,256) -> combine -> challenge -> open ->
  * assemble.  Between commit and open the caller exchanges the 32-byte per-repetition

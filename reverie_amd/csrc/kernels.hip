@@ -1649,8 +1649,11 @@ void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d
 // proof took 2.0 ms per vector on the headline circuit; this takes 0.3: the 1.28 GB of rows written are the cost.)
 constexpr uint32_t UNP_TB = 64;
 struct B_k_unpack_bits {
-    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out) const {
-    __shared__ uint8_t s_bytes[RV_ONLINE_REPS * UNP_TB];
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out, uint64_t first_item) const {
+    // first_item: the vectors' item the output starts at (the streaming verifier rebuilds a chunk's rows: any bit offset);
+    // a slot's staged bytes are UNP_TB + 1 so that the shifted window of the last items has its second byte
+    constexpr uint32_t SB = UNP_TB + 1;
+    __shared__ uint8_t s_bytes[RV_ONLINE_REPS * SB];
     __shared__ uint8_t s_slot[256];
     __shared__ uint64_t s_off[RV_ONLINE_REPS], s_len[RV_ONLINE_REPS];
     __shared__ uint32_t s_cnt[4];
@@ -1673,10 +1676,12 @@ struct B_k_unpack_bits {
     uint32_t n_slots = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     if (n_slots > RV_ONLINE_REPS) n_slots = RV_ONLINE_REPS;
     __syncthreads();
-    const uint64_t t0 = (uint64_t)blockIdx.x * UNP_TB;  // first source byte of this workgroup
-    for (uint32_t i = tid; i < n_slots * UNP_TB; i += 256) {
-        const uint32_t k = i / UNP_TB, t = i % UNP_TB;
-        s_bytes[i] = (t0 + t < s_len[k]) ? blob[s_off[k] + t0 + t] : (uint8_t)0;  // past the vector's end: zero
+    const uint64_t t0 = (uint64_t)blockIdx.x * UNP_TB;  // first output byte column of this workgroup
+    const uint64_t b0 = first_item / 8 + t0;              // ... and the source byte it starts in
+    const uint32_t sh = (uint32_t)(first_item & 7);       // output item il of the workgroup <-> source bit sh + il from byte b0
+    for (uint32_t i = tid; i < n_slots * SB; i += 256) {
+        const uint32_t k = i / SB, t = i % SB;
+        s_bytes[i] = (b0 + t < s_len[k]) ? blob[s_off[k] + b0 + t] : (uint8_t)0;  // past the vector's end: zero
     }
     __syncthreads();
     const uint64_t it0 = 8 * t0;
@@ -1708,7 +1713,7 @@ struct B_k_unpack_bits {
             uint32_t w = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (sl[i] != 0xFF && (((uint32_t)s_bytes[sl[i] * UNP_TB + (il >> 3)] >> (7 - (il & 7))) & 1u)) w |= val[i];
+                if (sl[i] != 0xFF && (((uint32_t)s_bytes[sl[i] * SB + ((sh + il) >> 3)] >> (7 - ((sh + il) & 7))) & 1u)) w |= val[i];
             rows_out[(it0 + il) * NQ + q] = w;
         }
         return;
@@ -1720,7 +1725,7 @@ struct B_k_unpack_bits {
         for (int i = 0; i < 4; i++) {
             const uint32_t sl = s_slot[4 * q + i];
             if (sl != 0xFF) {
-                const uint32_t bit = ((uint32_t)s_bytes[sl * UNP_TB + (il >> 3)] >> (7 - (il & 7))) & 1u;
+                const uint32_t bit = ((uint32_t)s_bytes[sl * SB + ((sh + il) >> 3)] >> (7 - ((sh + il) & 7))) & 1u;
                 if (bit) w |= (kind == 0) ? (1u << (31u - 8u * i - omit[4 * q + i])) : (0xFFu << (24 - 8 * i));
             }
         }
@@ -1728,16 +1733,16 @@ struct B_k_unpack_bits {
     }
 }
 };
-__global__ __launch_bounds__(256) void k_unpack_bits(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out) {
-    B_k_unpack_bits{}(blob, src_off, src_len, omit, n_items, NQ, kind, rows_out);
+__global__ __launch_bounds__(256) void k_unpack_bits(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out, uint64_t first_item) {
+    B_k_unpack_bits{}(blob, src_off, src_len, omit, n_items, NQ, kind, rows_out, first_item);
 }
 
 void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
-                        const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out) {
+                        const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out, uint64_t first_item) {
     if (!n_items) return;
     const uint64_t n_bytes = (n_items + 7) / 8;
     launch<B_k_unpack_bits, 256>(k_unpack_bits, st, dim3((unsigned)((n_bytes + UNP_TB - 1) / UNP_TB)), dim3(256), d_blob, d_src_off, d_src_len,
-                                 d_omit, n_items, NQ, kind, d_rows_out);
+                                 d_omit, n_items, NQ, kind, d_rows_out, first_item);
 }
 
 // Fixed-size parts of the openings.

@@ -85,3 +85,53 @@ def prove_streaming(ops, wit_gf2, wit_z64, wire_counts: Tuple[int, int], seeds=N
                                              C.c_size_t(int(wire_counts[1])), _ptr(g), C.c_size_t(len(g)), _ptr(z), C.c_size_t(len(z)), _ptr(s),
                                              C.c_size_t(max_chunk_ops), C.byref(out), C.byref(n), C.byref(si)))
     return Proof(_owned=(C.c_void_p(out.value), n.value)), {k: int(getattr(si, k)) for k, _ in si._fields_}
+
+
+class StreamingVerifier:
+    """Proof::verify with bounded device memory: the ops are fed in pieces, once (rv_stream_verify_begin / feed / finish).
+
+        sv = StreamingVerifier((z64_wires, gf2_wires), proof)
+        for ops in pieces: sv.feed(ops)
+        ok = sv.finish()            # == proof.verify(all ops, (z64_wires, gf2_wires))
+    """
+
+    def __init__(self, wire_counts: Tuple[int, int], proof, max_chunk_ops: int = 0, ctx: Optional[Context] = None):
+        self.ctx = ctx or Context.default()
+        self.handle = C.c_void_p()
+        self._proof = proof if isinstance(proof, Proof) else Proof(bytes(proof))  # (kept alive: the stream reads it until finish)
+        buf, n = self._proof._buffer()
+        _lib.check(_lib.lib().rv_stream_verify_begin(self.ctx.handle, C.c_size_t(int(wire_counts[0])), C.c_size_t(int(wire_counts[1])), buf,
+                                                     C.c_size_t(n), C.c_size_t(max_chunk_ops), C.byref(self.handle)))
+
+    def feed(self, ops):
+        ops = program(ops) if len(ops) else np.zeros(0, OP_DTYPE)
+        _lib.check(_lib.lib().rv_stream_feed(self.handle, _ptr(ops), C.c_size_t(len(ops)), None, C.c_size_t(0), None, C.c_size_t(0)))
+
+    def finish(self, strict: bool = True) -> bool:
+        ok = C.c_int()
+        _lib.check(_lib.lib().rv_stream_verify_finish(self.handle, C.c_uint32(0 if strict else _lib.RV_VERIFY_REFERENCE_COMPAT), C.byref(ok)))
+        return bool(ok.value)
+
+    info = StreamingProver.info
+    close = StreamingProver.close
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def verify_streaming(ops, wire_counts: Tuple[int, int], proof, strict: bool = True, max_chunk_ops: int = 0,
+                     ctx: Optional[Context] = None) -> Tuple[bool, dict]:
+    """rv_verify_streaming: one pass over an op array in host memory -> (ok, stream info)"""
+    ctx = ctx or Context.default()
+    ops = program(ops) if len(ops) else np.zeros(0, OP_DTYPE)
+    pr = proof if isinstance(proof, Proof) else Proof(bytes(proof))
+    buf, n = pr._buffer()
+    ok = C.c_int()
+    si = _lib.StreamInfo()
+    _lib.check(_lib.lib().rv_verify_streaming(ctx.handle, _ptr(ops), C.c_size_t(len(ops)), C.c_size_t(int(wire_counts[0])), C.c_size_t(int(wire_counts[1])),
+                                              buf, C.c_size_t(n), C.c_uint32(0 if strict else _lib.RV_VERIFY_REFERENCE_COMPAT), C.c_size_t(max_chunk_ops),
+                                              C.byref(ok), C.byref(si)))
+    return bool(ok.value), {k: int(getattr(si, k)) for k, _ in si._fields_}

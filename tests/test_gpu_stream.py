@@ -230,3 +230,125 @@ def test_stream_full_size_configs(rv, rule_seeds):
     assert bytes(proof) == bytes(want)
     assert proof.verify(c)
     c.close()
+
+
+# ---- the streaming verifier (rv_stream_verify_*): Proof::verify with the ops fed in pieces, bounded device memory ----
+def _verify_stream(proof, prog, wc, cuts, strict=True):
+    from reverie_amd.stream import StreamingVerifier
+
+    sv = StreamingVerifier(wc, proof)
+    edges = [0] + sorted(set(int(c) for c in cuts if 0 < c < len(prog))) + [len(prog)]
+    for a, b in zip(edges[:-1], edges[1:]):
+        sv.feed(prog[a:b])
+    try:
+        return sv.finish(strict=strict)
+    finally:
+        sv.close()
+
+
+@pytest.mark.parametrize("name", sorted(META))
+def test_stream_verify_golden(rv, name):
+    m = META[name]
+    prog = program([tuple(o) for o in m["ops"]]) if m["ops"] else np.zeros(0, OP_DTYPE)
+    gold = open(os.path.join(GOLDEN, f"proof_{name}.bin"), "rb").read()
+    wc = tuple(m["wire_counts"])
+    hint = prog[prog["domain"] == 3]
+    wc = (max([wc[0]] + [int(x) for x in hint["a"]]), max([wc[1]] + [int(x) for x in hint["b"]]))
+    n = len(prog)
+    for cuts in ([], [n // 2], list(range(1, n, 3)), list(range(7, n, 50))):
+        assert _verify_stream(gold, prog, wc, cuts) is True, (name, cuts[:4])
+    if n:
+        bad = bytearray(gold)
+        bad[len(bad) // 2] ^= 4
+        try:  # (a flipped length field is RV_E_PROOF_MALFORMED for both verifiers, anything else `false`)
+            want = rv.Proof(bytes(bad)).verify(prog, wc)
+        except rv.ReverieError as e:
+            want = e.code
+        try:
+            got = _verify_stream(bytes(bad), prog, wc, [n // 3])
+        except rv.ReverieError as e:
+            got = e.code
+        assert got == want and got is not True
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_stream_verify_matches_resident_verifier(rv, oracle, seed):
+    """random GF(2) + Z64 + B2A programs cut at random places: the streaming verifier answers what rv_verify_ex answers -- for
+    honest proofs, for proofs with a flipped byte anywhere (strict and reference-compatible), and for proofs whose supplied
+    vectors are short (exhausted iterators read as zero, online.rs:124,162,170)"""
+    rng = np.random.default_rng(7700 + seed)
+    prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=int(rng.integers(150, 600)))
+    hint = prog[prog["domain"] == 3]
+    wc = (max([wc[0]] + [int(x) for x in hint["a"]]), max([wc[1]] + [int(x) for x in hint["b"]]))
+    seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+    proof = rv.Proof.new(prog, w2, w64, wc, seeds=seeds)
+    n = len(prog)
+    for k in (0, 1, 5):
+        cuts = rng.integers(1, n, k) if k else []
+        assert _verify_stream(proof, prog, wc, cuts) is True
+        assert _verify_stream(proof, prog, wc, cuts, strict=False) is True
+    data = bytes(proof)
+    for _ in range(12):
+        bad = bytearray(data)
+        at = int(rng.integers(0, len(bad)))
+        bad[at] ^= 1 << int(rng.integers(0, 8))
+        for strict in (True, False):
+            try:
+                want = rv.Proof(bytes(bad)).verify(prog, wc, strict=strict)
+            except rv.ReverieError as e:
+                want = ("err", e.code)
+            try:
+                got = _verify_stream(bytes(bad), prog, wc, rng.integers(1, n, 3), strict=strict)
+            except rv.ReverieError as e:
+                got = ("err", e.code)
+            assert got == want, (seed, at, strict)
+    # the one-call form
+    from reverie_amd.stream import verify_streaming
+
+    ok, info = verify_streaming(prog, wc, proof, max_chunk_ops=1024)
+    assert ok and info["n_ops"] == n
+
+
+def test_stream_verify_long_transcripts_and_strict_checks(rv, oracle, rule_seeds):
+    """transcripts of several BLAKE3 chunks cut around the 1024-event marks and away from byte boundaries of the opening
+    vectors (a chunk's supplied values start at any bit); a proof of a FALSE statement that the reference-compatible check
+    lets through is refused by the strict streaming verifier exactly as by rv_verify"""
+    rng = np.random.default_rng(9)
+    ops = [GF2.Input(i) for i in range(8)] + [Z64.Input(i) for i in range(3)]
+    for i in range(5000):
+        a, b = int(rng.integers(0, 24)), int(rng.integers(0, 24))
+        d = int(rng.integers(8, 24))
+        ops.append(GF2.Mul(d, a, b) if i % 3 else GF2.Add(d, a, b))
+        if i % 11 == 0:
+            ops.append(Z64.Mul(int(rng.integers(3, 8)), int(rng.integers(0, 8)), int(rng.integers(0, 8))))
+    prog = program(ops)
+    w2 = rng.integers(0, 2, 8).tolist()
+    w64 = [int(x) for x in rng.integers(0, 1 << 63, 3, dtype=np.uint64)]
+    wc = (8, 24)
+    proof = rv.Proof.new(prog, w2, w64, wc, seeds=rule_seeds)
+    n = len(prog)
+    for cuts in ([1536 + 11], [1023, 1024, 1025, 2048, 3071], list(range(100, n, 137))):
+        assert _verify_stream(proof, prog, wc, cuts) is True
+    # a proof of C1 checked against C2 (same transcripts, failing AssertZero gates: tests/circuits.py): the reference-compatible
+    # check accepts, the strict one refuses -- the streaming verifier exactly as rv_verify
+    c1, c2, a2, a64, cwc = circuits.assert_circuits()
+    pf = rv.Proof.new(c1, a2, a64, cwc, seeds=rule_seeds)
+    for cprog, want in ((c1, (True, True)), (c2, (True, False))):
+        for cuts in ([], [3], [5, 8]):
+            assert (_verify_stream(pf, cprog, cwc, cuts, strict=False), _verify_stream(pf, cprog, cwc, cuts, strict=True)) == want
+
+
+def test_stream_verify_full_size_bounded_memory(rv, rule_seeds):
+    """BASELINE config 4 (10^7 gates, wire indices recycled): the streaming verifier accepts the prover's proof and refuses a
+    tampered one in well under a GB of device memory next to the proof (rv_verify keeps ~6 GB resident)"""
+    from reverie_amd.stream import verify_streaming
+
+    prog, wit, wc, st = circuits.layered_gf2(recycle=True)
+    proof = rv.Proof.new(prog, wit, [], wc, seeds=rule_seeds)
+    ok, info = verify_streaming(prog, wc, proof)
+    assert ok
+    assert info["wire_store_bytes"] + info["peak_chunk_bytes"] < (1 << 30)
+    bad = bytearray(bytes(proof))
+    bad[len(bad) // 3] ^= 0x10
+    ok, _ = verify_streaming(prog, wc, bytes(bad))
+    assert not ok

@@ -23,8 +23,15 @@ def streaming_record(ctx, prog, wit, wc, st, seeds, want: bytes, chunk_ops: int 
     t0 = time.perf_counter()
     proof, info = prove_streaming(rprog, rwit, [], rwc, seeds=seeds, max_chunk_ops=chunk_ops, ctx=ctx)
     dt = time.perf_counter() - t0
+    from reverie_amd.stream import verify_streaming
+
+    tv = time.perf_counter()
+    vok, vinfo = verify_streaming(rprog, rwc, proof, max_chunk_ops=chunk_ops, ctx=ctx)
+    tv = time.perf_counter() - tv
     rec = {"value": rst["and"] / dt, "unit": "AND gates/s", "ms": dt * 1e3, "chunk_ops": chunk_ops, "chunks": info["chunks"],
            "gf2_wires": rwc[1], "bit_exact_vs_rv_prove": bytes(proof) == want,
+           "verify_streaming": {"ms": tv * 1e3, "ok": vok, "device_bytes_beside_the_proof": vinfo["wire_store_bytes"] + vinfo["peak_chunk_bytes"] + vinfo["hash_state_bytes"],
+                                "note": "rv_verify_streaming (strict): one pass over the op array, chunks in verify mode against the proof"},
            "device_bytes": {k: info[k] for k in ("wire_store_bytes", "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")},
            "note": "rv_prove_streaming, host ops in -> host proof bytes out, two passes over the op array; every chunk is compiled "
                    "(levelised) and moved to its transcript offsets on one of up to 12 worker threads ahead of the GPU, and kept for "
@@ -43,9 +50,15 @@ def z64_record(ctx, seeds, n_mul=1_000_000, chunk_ops=1 << 16):
     t0 = time.perf_counter()
     proof, info = prove_streaming(prog, [], w64, wc, seeds=seeds, max_chunk_ops=chunk_ops, ctx=ctx)
     dt = time.perf_counter() - t0
+    from reverie_amd.stream import verify_streaming
+
+    tv = time.perf_counter()
+    vok, vinfo = verify_streaming(prog, wc, proof, max_chunk_ops=chunk_ops, ctx=ctx)
+    tv = time.perf_counter() - tv
     circ = reverie_amd.Circuit(prog, wc, ctx)
     want = reverie_amd.Proof.new(circ, [], w64, seeds=seeds)
     rec = {"value": st["mul"] / dt, "unit": "Z64 MUL gates/s", "ms": dt * 1e3, "chunk_ops": chunk_ops, "chunks": info["chunks"],
+           "verify_streaming": {"ms": tv * 1e3, "ok": vok, "device_bytes_beside_the_proof": vinfo["wire_store_bytes"] + vinfo["peak_chunk_bytes"] + vinfo["hash_state_bytes"]},
            "z64_wires": wc[0], "bit_exact_vs_rv_prove": bytes(proof) == bytes(want), "resident_prover_scratch_bytes": circ.info["scratch_bytes"],
            "device_bytes": {k: info[k] for k in ("wire_store_bytes", "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")}}
     circ.close()
