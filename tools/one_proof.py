@@ -1,0 +1,11 @@
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+import reverie_amd as rv
+import circuits
+prog, wit, wc, st = circuits.layered_gf2()
+c = rv.Circuit(prog, wc)
+seeds = bytes(range(256)) * 16
+for i in range(2):
+    p = rv.Proof.new(c, wit, [], seeds=seeds)
+print("done", len(p), file=sys.stderr)
