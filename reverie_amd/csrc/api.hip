@@ -2301,6 +2301,9 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     std::vector<uint32_t> on_quads;
     for (uint32_t q = 0; q < NQ; q++)
         if (onm[q]) on_quads.push_back(q);
+    // rows of the supplied values: sixteen quad words (two sectors, written whole) when the opened repetitions sit in the first
+    // sixteen -- the verifier's slot order puts them into the first ten -- instead of full share rows
+    const uint32_t sup_nq = (NQ > 16 && (on_quads.empty() || on_quads.back() < 16)) ? 16u : NQ;
     // ---- staging (one copy each instead of one per repetition): opened player keys (online.rs:101-113) and the
     //      online commitments the preprocessing slots carry over from the proof (preprocess.rs:55-57)
     std::vector<uint8_t> hkeys((size_t)R * 128, 0), hco((size_t)R * 32, 0), hkeys64, hco64((size_t)R * 32, 0);
@@ -2388,11 +2391,11 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         if ((rc = dalloc(ctx, hco64.size(), &d_hco64))) return fail(rc);
         track(d_hco64);
     }
-    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_in, 1) * NQ, &d_sup_in))) return fail(rc);
+    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_in, 1) * sup_nq, &d_sup_in))) return fail(rc);
     track(d_sup_in);
-    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * NQ, &d_sup_corr))) return fail(rc);
+    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_pre, 1) * sup_nq, &d_sup_corr))) return fail(rc);
     track(d_sup_corr);
-    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_rec, 1) * NQ, &d_sup_rec))) return fail(rc);
+    if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_rec, 1) * sup_nq, &d_sup_rec))) return fail(rc);
     track(d_sup_rec);
     uint64_t *d_src64 = nullptr, *d_sup_in64 = nullptr, *d_sup_corr64 = nullptr, *d_sup_rec64 = nullptr;
     uint32_t* d_keep64 = nullptr;
@@ -2473,9 +2476,9 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         }
     }
     if (s->ev_setup && ctx->pipeline) HC(hipStreamWaitEvent(sb, s->ev_setup, 0));  // d_omit / d_omit64 come from stream 1
-    launch_unpack_bits(sb, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
-    launch_unpack_bits(sb, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr);
-    launch_unpack_bits(sb, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec);
+    launch_unpack_bits(sb, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in, sup_nq);
+    launch_unpack_bits(sb, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr, sup_nq);
+    launch_unpack_bits(sb, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec, sup_nq);
     Interp64Params p64{};
     if (has64) {
         HC(hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, sb));
@@ -2492,6 +2495,7 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     p.sup_in = d_sup_in;
     p.sup_corr = d_sup_corr;
     p.sup_rec = d_sup_rec;
+    p.sup_nq = sup_nq;
     if ((rc = shard_run(s, MODE_VERIFY, p, p64))) return fail(rc);
     // preprocessing slots: the online commitment is the one carried by the proof (preprocess.rs:55-57)
     launch_overlay_rows(ctx->stream, s->d_dig + 1 * DW, (const uint32_t*)d_hco, s->d_omit, R, 8, 0);
@@ -2885,15 +2889,16 @@ static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, 
         launch_overlay_rows(ctx->stream, (uint32_t*)s->d_keys, (const uint32_t*)(d + L.hkeys), s->d_omit, R, 32, 1);
         if (!(rc = shard_setup_prg(s, (const uint32_t*)(d + L.keep)))) {
             const uint64_t* d_src = (const uint64_t*)(d + L.src);
-            launch_unpack_bits(ctx->stream, d, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in);
-            launch_unpack_bits(ctx->stream, d, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr);
-            launch_unpack_bits(ctx->stream, d, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec);
+            launch_unpack_bits(ctx->stream, d, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in, NQ);
+            launch_unpack_bits(ctx->stream, d, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr, NQ);
+            launch_unpack_bits(ctx->stream, d, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec, NQ);
             Interp64Params p64{};
             pp[k] = InterpParams{};
             pp[k].on_mask = (const uint32_t*)(d + L.onm);
             pp[k].sup_in = d_sup_in;
             pp[k].sup_corr = d_sup_corr;
             pp[k].sup_rec = d_sup_rec;
+            pp[k].sup_nq = NQ;
             rc = shard_run_alloc(s, pp[k], p64);
         }
         g_recorder = nullptr;

@@ -126,6 +126,7 @@ struct InterpParams {
     const uint32_t* sup_in;   // verify: [n_inputs][NQ] supplied masked inputs (smeared)
     const uint32_t* sup_corr; // verify: [n_mul][NQ] supplied corrections (smeared)
     const uint32_t* sup_rec;  // verify: [n_rec][NQ] supplied broadcast bit of the omitted player
+    uint32_t sup_nq;          // verify: quad words per row of the three sup_* arrays (NQ, or 16 when every opened repetition sits in the first sixteen)
     int* err;                 // device flag: RV_E_WITNESS_INVALID
 };
 
@@ -242,7 +243,7 @@ void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, 
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,
                          uint32_t NQ, int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
 void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
-                        const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out,
+                        const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out, uint32_t out_nq /* row stride in quad words */,
                         uint64_t first_item = 0 /* the vectors' item row 0 of the output is */);
 void launch_shard_init(hipStream_t st, int* d_err, uint32_t* d_zero_mask, uint32_t n_mask_words /* <= 64 */, uint8_t* d_zero_corr,
                        uint32_t n_corr_bytes /* <= 32 */);

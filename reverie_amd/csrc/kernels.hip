@@ -66,7 +66,7 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
             const uint32_t w = p.wit[g.x] ? 0xFFFFFFFFu : 0u;
             corr = w ^ recon32(lam);
         } else {
-            corr = onm ? (p.sup_in[(size_t)g.x * NQ + q] & onm) : 0u;  // (rows of quads without an opened repetition are never written)
+            corr = onm ? (p.sup_in[(size_t)g.x * p.sup_nq + q] & onm) : 0u;  // (rows of quads without an opened repetition are never written)
         }
         if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = corr;
         if (MODE == MODE_PROVE_V) {
@@ -116,8 +116,8 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         } else {
             // online-verified reps: supplied correction, add the unopened player's broadcast
             if (onm) {
-                delta = (p.sup_corr[(size_t)g.ep * NQ + q] & onm) | (delta & ~onm);
-                s ^= p.sup_rec[(size_t)g.x * NQ + q];
+                delta = (p.sup_corr[(size_t)g.ep * p.sup_nq + q] & onm) | (delta & ~onm);
+                s ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
             }
             r = recon32(s) & onm;  // preprocessing-verified reps: reconstruct() returns zero
         }
@@ -136,7 +136,7 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     case G_RECON: {
         // B2A's recorded reconstruction (combine.rs:181-183): value = reconstruct(mask) + corr
         uint32_t m = gather_rows(p.rows, g.a, NQ, q);
-        if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * NQ + q];
+        if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
         if (MODE == MODE_PROVE || onm) p.on[(size_t)g.eo * NQ + q] = m;
         uint32_t r = recon32(m);
         if (MODE == MODE_VERIFY) r &= onm;
@@ -147,7 +147,7 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     }
     case G_ASSERT: {
         uint32_t m = gather_rows(p.rows, g.a, NQ, q);
-        if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * NQ + q];
+        if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
         if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = m;
         if (MODE == MODE_PROVE_V) {
             // the wire's value itself must be zero (prover.rs:221-228), the same in every repetition
@@ -256,6 +256,10 @@ template <int MODE, int NQ, int U, int KA, int KB>
 __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
                                      uint32_t onm, const Gate* pf = nullptr) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
+    // verifier: the online rows are stored in whole 32-byte sectors (the quads of the opened repetitions are a sector and a
+    // quarter in its slot order, and a partially written sector is a read-modify-write at the memory side; the digests read
+    // the opened quads only, so what the others hold does not matter)
+    const bool on_wr = MODE != MODE_VERIFY || ((__ballot(onm != 0) >> ((sub * NQ + q) & ~7u)) & 0xFFull) != 0;
     Gate g[U];
 #pragma unroll
     for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
@@ -292,8 +296,8 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
         if (MODE == MODE_VERIFY) {
             sc[u] = sr[u] = 0;
             if (onm) {  // supplied values exist (and are stored) only for quads with an opened repetition
-                sc[u] = p.sup_corr[(size_t)g[u].ep * NQ + q];
-                sr[u] = p.sup_rec[(size_t)g[u].x * NQ + q];
+                sc[u] = p.sup_corr[(size_t)g[u].ep * p.sup_nq + q];
+                sr[u] = p.sup_rec[(size_t)g[u].x * p.sup_nq + q];
             }
         }
     }
@@ -337,7 +341,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
             s ^= sr[u];
             r = recon32(s) & onm;
         }
-        if (MODE != MODE_VERIFY || onm) __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
+        if (MODE != MODE_VERIFY || on_wr) __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
         store_bits(p.pre, g[u].ep, NQ, q, delta);
         if (MODE == MODE_PROVE_V) {
             if (q == 0) p.vclr[g[u].dst] = (uint8_t)(vx & vy);
@@ -1672,12 +1676,15 @@ void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d
 // proof took 2.0 ms per vector on the headline circuit; this takes 0.3: the 1.28 GB of rows written are the cost.)
 constexpr uint32_t UNP_TB = 64;
 struct B_k_unpack_bits {
-    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out, uint64_t first_item) const {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out, uint32_t out_nq, uint64_t first_item) const {
     // first_item: the vectors' item the output starts at (the streaming verifier rebuilds a chunk's rows: any bit offset);
-    // a slot's staged bytes are UNP_TB + 1 so that the shifted window of the last items has its second byte
-    constexpr uint32_t SB = UNP_TB + 1;
-    __shared__ uint8_t s_bytes[RV_ONLINE_REPS * SB];
+    // a slot's staged bytes are UNP_TB + 1 so that the shifted window of the last items has its second byte.  The bytes
+    // arrive as ALIGNED 32-bit loads (a slot's window starts at any byte of the proof: up to 3 bytes of slack in front,
+    // `s_mis`), bytes outside the vector zeroed -- bytewise loads from 40 streams made the staging the longest part
+    constexpr uint32_t SB = UNP_TB + 1, SW = (SB + 3 + 3) / 4, SBP = 4 * SW;  // words / padded bytes per slot
+    __shared__ __attribute__((aligned(4))) uint8_t s_bytes[RV_ONLINE_REPS * SBP];
     __shared__ uint8_t s_slot[256];
+    __shared__ uint8_t s_mis[RV_ONLINE_REPS];
     __shared__ uint64_t s_off[RV_ONLINE_REPS], s_len[RV_ONLINE_REPS];
     __shared__ uint32_t s_cnt[4];
     const uint32_t R = 4 * NQ;
@@ -1702,45 +1709,77 @@ struct B_k_unpack_bits {
     const uint64_t t0 = (uint64_t)blockIdx.x * UNP_TB;  // first output byte column of this workgroup
     const uint64_t b0 = first_item / 8 + t0;              // ... and the source byte it starts in
     const uint32_t sh = (uint32_t)(first_item & 7);       // output item il of the workgroup <-> source bit sh + il from byte b0
-    for (uint32_t i = tid; i < n_slots * SB; i += 256) {
-        const uint32_t k = i / SB, t = i % SB;
-        s_bytes[i] = (b0 + t < s_len[k]) ? blob[s_off[k] + b0 + t] : (uint8_t)0;  // past the vector's end: zero
+    for (uint32_t i = tid; i < n_slots * SW; i += 256) {
+        const uint32_t k = i / SW, j = i % SW;
+        const uint64_t len = s_len[k];
+        const uintptr_t start = (uintptr_t)blob + s_off[k] + b0;  // first wanted byte; the vector ends at vend (past it: zero)
+        const uintptr_t vend = (uintptr_t)blob + s_off[k] + (len < b0 + SB ? len : b0 + SB);
+        const uintptr_t a = (start & ~(uintptr_t)3) + 4 * j;
+        uint32_t v = 0;
+        if (b0 < len && a + 4 > start && a < vend) {
+            v = *(const uint32_t*)a;  // (inside the proof's allocation: it contains a byte of the vector, and the arena rounds to 256)
+            const uint32_t lo = start > a ? (uint32_t)(start - a) : 0u, hi = vend < a + 4 ? (uint32_t)(vend - a) : 4u;
+            const uint32_t m = (hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u)) & ~((1u << (8 * lo)) - 1u);
+            v &= m;
+        }
+        ((uint32_t*)s_bytes)[k * SW + j] = v;
+        if (j == 0) s_mis[k] = (uint8_t)(start & 3);
     }
     __syncthreads();
     const uint64_t it0 = 8 * t0;
     const uint64_t n_here = (n_items - it0 < 8ull * UNP_TB) ? n_items - it0 : 8ull * UNP_TB;
     if (256 % NQ == 0) {
-        // a thread keeps its quad for the whole loop: which of its four repetitions are opened, their slots and the
-        // word each contributes stay in registers (per-word slot lookups made this kernel compute-bound: 483 us per
-        // vector); only the quads that hold an opened repetition are written at all -- the interpreter reads no others
-        // -- and the threads are dealt over exactly those quads (in the verifier's slot order: the first ten)
+        // a thread keeps its quad for the whole loop: which of its four repetitions are opened, where their bytes start in
+        // LDS and the word each contributes stay in registers; only the quads that hold an opened repetition are written at
+        // all -- the interpreter reads no others -- and the threads are dealt over exactly those quads (in the verifier's
+        // slot order: the first ten).  A step takes one source byte column: two LDS bytes per repetition give eight items.
         __shared__ uint8_t s_quads[64];
         __shared__ uint32_t s_nq;
-        if (tid == 0) {
-            uint32_t n = 0;
-            for (uint32_t qq = 0; qq < NQ; qq++)
-                if ((s_slot[4 * qq] & s_slot[4 * qq + 1] & s_slot[4 * qq + 2] & s_slot[4 * qq + 3]) != 0xFF) s_quads[n++] = (uint8_t)qq;
-            s_nq = n;
+        if (tid < 64) {
+            const bool has = tid < NQ && (s_slot[4 * tid] & s_slot[4 * tid + 1] & s_slot[4 * tid + 2] & s_slot[4 * tid + 3]) != 0xFF;
+            // ... rounded to whole 32-byte sectors (eight quads; the others get zeros): a row's ten quads are a full sector and
+            // a quarter of the next, and partial-sector writes cost the memory side a read-modify-write each
+            const unsigned long long bh = __ballot(has);
+            const bool wr = tid < NQ && ((bh >> (tid & ~7u)) & 0xFFull) != 0;
+            const unsigned long long bq = __ballot(wr);
+            if (wr) s_quads[__popcll(bq & ((1ull << tid) - 1ull))] = (uint8_t)tid;
+            if (tid == 0) s_nq = (uint32_t)__popcll(bq);
         }
         __syncthreads();
         const uint32_t nq = s_nq;
         if (!nq || tid >= nq * (256 / nq)) return;
         const uint32_t q = s_quads[tid % nq], step = 256 / nq;
-        uint32_t sl[4], val[4];
+        uint32_t at[4], val[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            sl[i] = s_slot[4 * q + i];
+            const uint32_t sl = s_slot[4 * q + i];
+            at[i] = sl == 0xFF ? 0xFFFFFFFFu : sl * SBP + s_mis[sl];
             val[i] = (kind == 0) ? (1u << (31u - 8u * i - (omit[4 * q + i] & 7u))) : (0xFFu << (24 - 8 * i));
         }
-        for (uint32_t il = tid / nq; il < n_here; il += step) {
-            uint32_t w = 0;
+        for (uint32_t t = tid / nq; 8 * t < n_here; t += step) {
+            uint32_t bits[4];  // item j of the column <-> bit 7 - j
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (sl[i] != 0xFF && (((uint32_t)s_bytes[sl[i] * SB + ((sh + il) >> 3)] >> (7 - ((sh + il) & 7))) & 1u)) w |= val[i];
-            rows_out[(it0 + il) * NQ + q] = w;
+            for (int i = 0; i < 4; i++) {
+                bits[i] = 0;
+                if (at[i] != 0xFFFFFFFFu)
+                    bits[i] = ((((uint32_t)s_bytes[at[i] + t] << 8) | (uint32_t)s_bytes[at[i] + t + 1]) >> (8 - sh)) & 0xFFu;
+            }
+            const uint32_t nj = n_here - 8 * t < 8 ? (uint32_t)(n_here - 8 * t) : 8u;
+            uint32_t* dst = rows_out + (it0 + 8 * t) * out_nq + q;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) w |= ((bits[i] >> (7 - j)) & 1u) ? val[i] : 0u;
+                if (j < nj) dst[(size_t)j * out_nq] = w;
+            }
         }
         return;
     }
+    // (odd row widths: the plain loop)
+    auto src_bit = [&](uint32_t sl, uint32_t il) {
+        return ((uint32_t)s_bytes[sl * SBP + s_mis[sl] + ((sh + il) >> 3)] >> (7 - ((sh + il) & 7))) & 1u;
+    };
     for (uint32_t idx = tid; idx < n_here * NQ; idx += 256) {
         const uint32_t il = idx / NQ, q = idx % NQ;
         uint32_t w = 0;
@@ -1748,24 +1787,24 @@ struct B_k_unpack_bits {
         for (int i = 0; i < 4; i++) {
             const uint32_t sl = s_slot[4 * q + i];
             if (sl != 0xFF) {
-                const uint32_t bit = ((uint32_t)s_bytes[sl * SB + ((sh + il) >> 3)] >> (7 - ((sh + il) & 7))) & 1u;
+                const uint32_t bit = src_bit(sl, il);
                 if (bit) w |= (kind == 0) ? (1u << (31u - 8u * i - omit[4 * q + i])) : (0xFFu << (24 - 8 * i));
             }
         }
-        rows_out[(it0 + il) * NQ + q] = w;
+        if (q < out_nq) rows_out[(it0 + il) * out_nq + q] = w;
     }
 }
 };
-__global__ __launch_bounds__(256) void k_unpack_bits(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out, uint64_t first_item) {
-    B_k_unpack_bits{}(blob, src_off, src_len, omit, n_items, NQ, kind, rows_out, first_item);
+__global__ __launch_bounds__(256) void k_unpack_bits(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* __restrict__ rows_out, uint32_t out_nq, uint64_t first_item) {
+    B_k_unpack_bits{}(blob, src_off, src_len, omit, n_items, NQ, kind, rows_out, out_nq, first_item);
 }
 
 void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
-                        const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out, uint64_t first_item) {
+                        const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out, uint32_t out_nq, uint64_t first_item) {
     if (!n_items) return;
     const uint64_t n_bytes = (n_items + 7) / 8;
     launch<B_k_unpack_bits, 256>(k_unpack_bits, st, dim3((unsigned)((n_bytes + UNP_TB - 1) / UNP_TB)), dim3(256), d_blob, d_src_off, d_src_len,
-                                 d_omit, n_items, NQ, kind, d_rows_out, first_item);
+                                 d_omit, n_items, NQ, kind, d_rows_out, out_nq, first_item);
 }
 
 // Fixed-size parts of the openings.

@@ -79,8 +79,10 @@ __device__ __forceinline__ void lr_load_vals(const LrRecs& R, const InterpParams
             V.v0[s] = *(kind == G_INPUT ? p.wit + x : safe8);
             V.v1[s] = 0;
         } else {
-            V.v0[s] = *(kind == G_INPUT ? p.sup_in + (size_t)x * NQ + q : kind == G_MUL ? p.sup_corr + (size_t)ep * NQ + q : safe32);
-            V.v1[s] = *((kind == G_MUL || kind == G_ASSERT || kind == G_RECON) ? p.sup_rec + (size_t)x * NQ + q : safe32);
+            // (supplied rows hold sup_nq quad words -- the ones with opened repetitions; the others' values are masked out anyway)
+            const bool sq = q < p.sup_nq;
+            V.v0[s] = *(sq && kind == G_INPUT ? p.sup_in + (size_t)x * p.sup_nq + q : sq && kind == G_MUL ? p.sup_corr + (size_t)ep * p.sup_nq + q : safe32);
+            V.v1[s] = *((sq && (kind == G_MUL || kind == G_ASSERT || kind == G_RECON)) ? p.sup_rec + (size_t)x * p.sup_nq + q : safe32);
         }
     }
 }
