@@ -2304,6 +2304,12 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     // rows of the supplied values: sixteen quad words (two sectors, written whole) when the opened repetitions sit in the first
     // sixteen -- the verifier's slot order puts them into the first ten -- instead of full share rows
     const uint32_t sup_nq = (NQ > 16 && (on_quads.empty() || on_quads.back() < 16)) ? 16u : NQ;
+    uint32_t sup_r = R;  // ... and the Z64 ones: the first 64 repetitions when no other is opened there
+    if (R > 64) {
+        sup_r = 64;
+        for (uint32_t r = 64; r < R; r++)
+            if (omit64[r] < 8) sup_r = R;
+    }
     // ---- staging (one copy each instead of one per repetition): opened player keys (online.rs:101-113) and the
     //      online commitments the preprocessing slots carry over from the proof (preprocess.rs:55-57)
     std::vector<uint8_t> hkeys((size_t)R * 128, 0), hco((size_t)R * 32, 0), hkeys64, hco64((size_t)R * 32, 0);
@@ -2408,11 +2414,11 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         track(d_src64);
         if ((rc = dalloc(ctx, NQ, &d_keep64))) return fail(rc);
         track(d_keep64);
-        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_in64, 1) * R, &d_sup_in64))) return fail(rc);
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_in64, 1) * sup_r, &d_sup_in64))) return fail(rc);
         track(d_sup_in64);
-        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_corr64, 1) * R, &d_sup_corr64))) return fail(rc);
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_corr64, 1) * sup_r, &d_sup_corr64))) return fail(rc);
         track(d_sup_corr64);
-        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_rec64, 1) * R, &d_sup_rec64))) return fail(rc);
+        if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.n_rec64, 1) * sup_r, &d_sup_rec64))) return fail(rc);
         track(d_sup_rec64);
     }
 #define HC(x)                                 \
@@ -2482,13 +2488,14 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     Interp64Params p64{};
     if (has64) {
         HC(hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, sb));
-        launch_unpack64(sb, d_proof, d_src64 + 4 * R, d_src64 + 5 * R, s->d_omit64, cc.n_in64, R, d_sup_in64);
-        launch_unpack64(sb, d_proof, d_src64 + 2 * R, d_src64 + 3 * R, s->d_omit64, cc.n_corr64, R, d_sup_corr64);
-        launch_unpack64(sb, d_proof, d_src64 + 0 * R, d_src64 + 1 * R, s->d_omit64, cc.n_rec64, R, d_sup_rec64);
+        launch_unpack64(sb, d_proof, d_src64 + 4 * R, d_src64 + 5 * R, s->d_omit64, cc.n_in64, R, d_sup_in64, sup_r);
+        launch_unpack64(sb, d_proof, d_src64 + 2 * R, d_src64 + 3 * R, s->d_omit64, cc.n_corr64, R, d_sup_corr64, sup_r);
+        launch_unpack64(sb, d_proof, d_src64 + 0 * R, d_src64 + 1 * R, s->d_omit64, cc.n_rec64, R, d_sup_rec64, sup_r);
         p64.omit = s->d_omit64;
         p64.sup_in = d_sup_in64;
         p64.sup_corr = d_sup_corr64;
         p64.sup_rec = d_sup_rec64;
+        p64.sup_r = sup_r;
     }
     InterpParams p{};
     p.on_mask = d_onm;

@@ -97,6 +97,7 @@ struct Interp64Params {
     const uint64_t* sup_in;   // verify: [n_in64][R]
     const uint64_t* sup_corr; // verify: [n_corr64][R]
     const uint64_t* sup_rec;  // verify: [n_rec64][R] share of the omitted player
+    uint32_t sup_r;           // verify: repetitions per row of the three sup_* arrays (R, or 64 when the opened ones are the first 64 at most)
     // gf2 side, for B2A
     const uint8_t* corr2;     // compact gf2 corr rows
     const uint32_t* masks2;   // gf2 share rows (PRG part)
@@ -189,7 +190,7 @@ uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_
 void launch_extract64(hipStream_t st, const uint64_t* d_stream, uint64_t stride_words, const uint64_t* d_offs /*[n_items]*/,
                       uint64_t n_items, int add_omit, uint32_t R, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
 void launch_unpack64(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
-                     const uint8_t* d_omit, uint64_t n_items, uint32_t R, uint64_t* d_out);
+                     const uint8_t* d_omit, uint64_t n_items, uint32_t R, uint64_t* d_out, uint32_t out_r /* repetitions per output row (<= R) */);
 // BLAKE3 over a row-format transcript: digests[R][8] words
 // d_quads / n_quads (nullable): hash only the listed quad words (the verifier's opened repetitions)
 uint32_t launch_b3_stream(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv_a,

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
             if (MODE == MODE_PROVE)
                 corr = p.wit[g.x] - sum8(lam);
             else
-                corr = online ? p.sup_in[(size_t)g.x * p.R + r] : 0;
+                corr = online ? p.sup_in[(size_t)g.x * p.sup_r + r] : 0;
             if (pk == 0) {
                 *dc = corr;
                 p.on[(size_t)r * p.on_words + g.eo] = corr;
@@ -139,9 +139,9 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
             uint64_t delta = a * b - c;
             U2 s{ly.x * cx + lx.x * cy + lab.x - lnew.x, ly.y * cx + lx.y * cy + lab.y - lnew.y};
             if (MODE == MODE_VERIFY && online) {
-                delta = p.sup_corr[(size_t)g.xc * p.R + r];
+                delta = p.sup_corr[(size_t)g.xc * p.sup_r + r];
                 if (mine) {
-                    const uint64_t sup = p.sup_rec[(size_t)g.x * p.R + r];
+                    const uint64_t sup = p.sup_rec[(size_t)g.x * p.sup_r + r];
                     if (om & 1) s.y += sup; else s.x += sup;
                 }
             }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
         case G64_ASSERT: {
             U2 m = ld2(am);
             if (MODE == MODE_VERIFY && online && mine) {
-                const uint64_t sup = p.sup_rec[(size_t)g.x * p.R + r];
+                const uint64_t sup = p.sup_rec[(size_t)g.x * p.sup_r + r];
                 if (om & 1) m.y += sup; else m.x += sup;
             }
             st2_unaligned(p.on + (size_t)r * p.on_words + g.eo + 2 * pk, m);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
             }
             const U2 mu = ld2(p.masks + (size_t)g.m * S + 2 * l);
             uint64_t kappa = zval - sum8(mu);
-            if (MODE == MODE_VERIFY && online) kappa = p.sup_corr[(size_t)g.xc * p.R + r];
+            if (MODE == MODE_VERIFY && online) kappa = p.sup_corr[(size_t)g.xc * p.sup_r + r];
             st2(dm, U2{0 - mu.x, 0 - mu.y});
             if (pk == 0) {
                 p.pre[(size_t)r * p.pre_words + g.ep] = kappa;
@@ -327,14 +327,15 @@ void launch_extract64(hipStream_t st, const uint64_t* d_stream, uint64_t stride_
                        n_items, add_omit, R, d_omit, d_dst_off, d_out);
 }
 
-// verifier: proof vectors -> dense [item][R] u64; items past a vector's end read as zero
+// verifier: proof vectors -> dense [item][out_r] u64 (out_r = R, or the first 64 repetitions when no other is opened -- the
+// verifier's slot order: a quarter of the bytes); items past a vector's end read as zero
 // (z64/recon.rs:96-104, z64/share.rs:78-88 `unwrap_or([0u8; 8])`)
 __global__ void k_unpack64(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ src_off,
-                           const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t R,
+                           const uint64_t* __restrict__ src_len, const uint8_t* __restrict__ omit, uint64_t n_items, uint32_t out_r,
                            uint64_t* __restrict__ out) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t it = tid / R;
-    const uint32_t r = (uint32_t)(tid % R);
+    const uint64_t it = tid / out_r;
+    const uint32_t r = (uint32_t)(tid % out_r);
     if (it >= n_items) return;
     uint64_t v = 0;
     if (omit[r] < 8 && (it + 1) * 8 <= src_len[r]) {
@@ -342,15 +343,16 @@ __global__ void k_unpack64(const uint8_t* __restrict__ blob, const uint64_t* __r
 #pragma unroll
         for (int i = 0; i < 8; i++) v |= (uint64_t)s[i] << (8 * i);
     }
-    out[it * R + r] = v;
+    out[it * out_r + r] = v;
 }
 
 void launch_unpack64(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
-                     const uint8_t* d_omit, uint64_t n_items, uint32_t R, uint64_t* d_out) {
+                     const uint8_t* d_omit, uint64_t n_items, uint32_t R, uint64_t* d_out, uint32_t out_r) {
     if (!n_items) return;
-    const uint64_t threads = n_items * R;
+    (void)R;
+    const uint64_t threads = n_items * out_r;
     hipLaunchKernelGGL(k_unpack64, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_blob, d_src_off, d_src_len, d_omit,
-                       n_items, R, d_out);
+                       n_items, out_r, d_out);
 }
 
 }  // namespace rv
