@@ -110,6 +110,7 @@ struct rv_ctx {
         uint64_t launches;
     };
     std::vector<Mark> marks;
+    std::map<hipEvent_t, int> ev_refs;  // events of the marks not yet collected
     int cur_phase = -1;
     hipEvent_t cur_start = nullptr;
     hipStream_t cur_stream = nullptr;
@@ -131,17 +132,27 @@ struct rv_ctx {
         // (not while a batch is being recorded: the launches happen later, and a thousand event markers queued between
         // two phases of a batch kept the GPU idle for 7 ms)
         if (!profiling || g_recorder) return;
+        // ONE marker per boundary: the event that ends a phase also starts the next one on the same stream (every marker
+        // in the queue costs the proof ~5 us of idle GPU, and the bench's timed region runs with the phases on)
+        hipStream_t next = p >= 0 ? (st ? st : stream) : nullptr;
+        hipEvent_t e = nullptr;
         if (cur_phase >= 0) {
-            hipEvent_t e = get_event();
+            e = get_event();
             (void)hipEventRecord(e, cur_stream);
             marks.push_back({cur_phase, cur_start, e, cur_launches});
+            ++ev_refs[e];
         }
         cur_phase = p;
         cur_launches = 0;
         if (p >= 0) {
-            cur_stream = st ? st : stream;
-            cur_start = get_event();
-            (void)hipEventRecord(cur_start, cur_stream);
+            if (e && next == cur_stream) {
+                cur_start = e;
+            } else {
+                cur_start = get_event();
+                (void)hipEventRecord(cur_start, next);
+            }
+            ++ev_refs[cur_start];
+            cur_stream = next;
         }
     }
     void count(uint64_t n = 1) { cur_launches += n; }
@@ -153,9 +164,9 @@ struct rv_ctx {
             float ms = 0;
             if (hipEventElapsedTime(&ms, m.a, m.b) == hipSuccess) prof.ms[m.phase] += ms;
             prof.launches[m.phase] += m.launches;
-            ev_pool.push_back(m.a);
-            ev_pool.push_back(m.b);
         }
+        for (auto& kv : ev_refs) ev_pool.push_back(kv.first);  // (an event may be the end of one mark and the start of the next)
+        ev_refs.clear();
         marks.clear();
     }
 

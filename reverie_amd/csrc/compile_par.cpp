@@ -245,11 +245,20 @@ void* big_alloc(size_t bytes) {
 }
 // Unmapping hundreds of MB takes tens of milliseconds and nobody waits for its result: blocks of 4 MiB and more released through
 // big_free_later go to one process-wide background thread (started on first use, joined when the library is unloaded).
+// munmap holds the address-space lock that every page fault and many driver calls need, so the thread stays out of the way:
+// it frees nothing while a compile is running (compile_busy) and not before the releases have been quiet for a while -- the
+// upload and the first proof follow a compile at once, and a loop of compiles would otherwise fault its fresh pages
+// against the previous round's unmapping (20 - 30 ms per compile on the 10^7-gate circuit).  Above a cap it frees at once.
 namespace {
 struct Reaper {
+    static constexpr size_t CAP_BYTES = (size_t)6 << 30;
+    static constexpr int QUIET_MS = 250;
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::pair<void*, size_t>> q;
+    size_t queued = 0;
+    int busy = 0;
+    std::chrono::steady_clock::time_point last_push;
     bool stop = false;
     std::thread th;
     void loop() {
@@ -257,8 +266,12 @@ struct Reaper {
         for (;;) {
             cv.wait(lk, [&] { return stop || !q.empty(); });
             if (q.empty() && stop) return;
+            while (!stop && queued <= CAP_BYTES &&
+                   (busy > 0 || std::chrono::steady_clock::now() - last_push < std::chrono::milliseconds(QUIET_MS)))
+                cv.wait_for(lk, std::chrono::milliseconds(50));
             std::vector<std::pair<void*, size_t>> take;
             take.swap(q);
+            queued = 0;
             lk.unlock();
             for (auto& e : take) big_free(e.first, e.second);
             lk.lock();
@@ -268,7 +281,13 @@ struct Reaper {
         std::lock_guard<std::mutex> g(mu);
         if (!th.joinable()) th = std::thread([this] { loop(); });
         q.emplace_back(p, bytes);
+        queued += bytes;
+        last_push = std::chrono::steady_clock::now();
         cv.notify_one();
+    }
+    void set_busy(int d) {
+        std::lock_guard<std::mutex> g(mu);
+        busy += d;
     }
     ~Reaper() {
         {
@@ -283,6 +302,10 @@ Reaper& reaper() {
     static Reaper r;
     return r;
 }
+struct CompileBusy {  // while one lives, the background thread unmaps nothing
+    CompileBusy() { reaper().set_busy(+1); }
+    ~CompileBusy() { reaper().set_busy(-1); }
+};
 }  // namespace
 void big_free_later(void* p, size_t bytes) {
     if (!p) return;
@@ -318,6 +341,7 @@ int compile_ops_par(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
     };
     if (n_ops == 0 || n_ops > (1u << 30) || n_threads < 2) return RV_COMPILE_FALLBACK;
     const int T = n_threads;
+    CompileBusy busy_guard;
     Pool pool(T);
     const size_t n_blk = (n_ops + BLK - 1) / BLK;
     out = Compiled();
