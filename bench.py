@@ -518,12 +518,15 @@ def main():
             host_proof = reverie_amd.Proof.new(circuit, wit, [], seeds=seeds)
             vcirc = reverie_amd.Circuit(prog, wc, ctx)
             host_proof.verify(vcirc)
-            tp = time.perf_counter()
-            okp = bool(host_proof.verify(vcirc))
-            tp = time.perf_counter() - tp
+            tps, okp = [], True
+            for _ in range(5):
+                tp = time.perf_counter()
+                okp = bool(host_proof.verify(vcirc)) and okp
+                tps.append(time.perf_counter() - tp)
+            tp = sorted(tps)[2]
             vcirc.close()
-            result["verifier"] = {"value": n_and / tp, "unit": "AND gates/s", "ms": tp * 1e3, "strict_ok": okp,
-                                  "note": "rv_verify (strict), host proof bytes (page-locked, as rv_prove returned them) in, one call; "
+            result["verifier"] = {"value": n_and / tp, "unit": "AND gates/s", "ms": tp * 1e3, "ms_min_max": [min(tps) * 1e3, max(tps) * 1e3], "strict_ok": okp,
+                                  "note": "rv_verify (strict), host proof bytes (page-locked, as rv_prove returned them) in, median of 5 calls after a first one; "
                                           "circuit compiled by rv_circuit_compile (the prover's has the RV_COMPILE_WHOLE_PROVER hint)"}
             parity["rv_prove_is_deterministic"] = bytes(host_proof) == bytes(last)
             del host_proof

@@ -20,17 +20,21 @@ def streaming_record(ctx, prog, wit, wc, st, seeds, want: bytes, chunk_ops: int 
     from reverie_amd.stream import prove_streaming
 
     rprog, rwit, rwc, rst = circuits.layered_gf2(layers=layers, p_and=p_and, recycle=True)
-    t0 = time.perf_counter()
-    proof, info = prove_streaming(rprog, rwit, [], rwc, seeds=seeds, max_chunk_ops=chunk_ops, ctx=ctx)
-    dt = time.perf_counter() - t0
     from reverie_amd.stream import verify_streaming
 
-    tv = time.perf_counter()
-    vok, vinfo = verify_streaming(rprog, rwc, proof, max_chunk_ops=chunk_ops, ctx=ctx)
-    tv = time.perf_counter() - tv
-    rec = {"value": rst["and"] / dt, "unit": "AND gates/s", "ms": dt * 1e3, "chunk_ops": chunk_ops, "chunks": info["chunks"],
+    # median of three calls (the first one also sizes the context's staging buffers and starts the worker threads)
+    dts, tvs = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        proof, info = prove_streaming(rprog, rwit, [], rwc, seeds=seeds, max_chunk_ops=chunk_ops, ctx=ctx)
+        dts.append(time.perf_counter() - t0)
+        tv = time.perf_counter()
+        vok, vinfo = verify_streaming(rprog, rwc, proof, max_chunk_ops=chunk_ops, ctx=ctx)
+        tvs.append(time.perf_counter() - tv)
+    dt, tv = sorted(dts)[1], sorted(tvs)[1]
+    rec = {"value": rst["and"] / dt, "unit": "AND gates/s", "ms": dt * 1e3, "first_call_ms": dts[0] * 1e3, "chunk_ops": chunk_ops, "chunks": info["chunks"],
            "gf2_wires": rwc[1], "bit_exact_vs_rv_prove": bytes(proof) == want,
-           "verify_streaming": {"ms": tv * 1e3, "ok": vok, "device_bytes_beside_the_proof": vinfo["wire_store_bytes"] + vinfo["peak_chunk_bytes"] + vinfo["hash_state_bytes"],
+           "verify_streaming": {"ms": tv * 1e3, "first_call_ms": tvs[0] * 1e3, "ok": vok, "device_bytes_beside_the_proof": vinfo["wire_store_bytes"] + vinfo["peak_chunk_bytes"] + vinfo["hash_state_bytes"],
                                 "note": "rv_verify_streaming (strict): one pass over the op array, chunks in verify mode against the proof"},
            "device_bytes": {k: info[k] for k in ("wire_store_bytes", "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")},
            "note": "rv_prove_streaming, host ops in -> host proof bytes out, two passes over the op array; every chunk is compiled "
