@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import circuits, oracle_lib, reverie_amd
-from reverie_amd.stream import prove_streaming
+from reverie_amd.stream import prove_streaming, verify_streaming
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -32,5 +32,19 @@ for case in range(n_cases):
     if bytes(proof) != want:
         bad += 1
         print("MISMATCH case", case, "ops", len(prog), "chunks", info["chunks"], "threads", os.environ["RV_STREAM_THREADS"], flush=True)
+    # the streaming verifier (other chunk cuts than the prover's) against the resident one: the proof, and the proof with a flipped byte
+    flip = bytearray(want)
+    flip[int(rng.integers(0, len(flip)))] ^= 1 << int(rng.integers(0, 8))
+    for pb in (want, bytes(flip)):
+        def run(f):
+            try:
+                return f()
+            except reverie_amd.ReverieError as e:
+                return ("error", e.code)
+        a = run(lambda: verify_streaming(prog, wc, pb, max_chunk_ops=int(rng.integers(700, 3000)), ctx=ctx)[0])
+        b = run(lambda: reverie_amd.Proof(pb).verify(prog, wc, ctx=ctx))
+        if a != b or (pb is want and a is not True):
+            bad += 1
+            print("VERIFY MISMATCH case", case, "streaming", a, "resident", b, flush=True)
 print(f"{done} cases run, {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
