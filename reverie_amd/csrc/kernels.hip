@@ -1088,6 +1088,16 @@ size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R) {
     return (size_t)n_chunks * R * 8;  // per ping-pong buffer
 }
 
+// (chunk, quad word) lanes below which a lane takes ONE repetition instead of four: four times the wavefronts, each a quarter as
+// long -- for transcripts that would not fill the chip's wavefront slots otherwise (RV_B3_RPL1_LANES: an experiment knob)
+static uint64_t b3_rpl1_lanes() {
+    static const uint64_t v = [] {
+        const char* e = getenv("RV_B3_RPL1_LANES");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)128 * 1024;  // (64-repetition shards of the 10^7-gate circuit: digests 0.47 -> 0.38 ms)
+    }();
+    return v;
+}
+
 // chunk chaining values only ([n_chunks][R][8] into d_cv); chunk_base / root_ok: see B_k_b3_chunks
 void launch_b3_stream_chunks(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv, const uint32_t* d_quads,
                              uint32_t n_quads, uint64_t chunk_base, uint32_t root_ok) {
@@ -1097,7 +1107,7 @@ void launch_b3_stream_chunks(hipStream_t st, const uint32_t* d_stream, uint64_t 
     const uint64_t threads = n * (d_quads ? n_quads : NQ);
     // few lanes (a quarter of the row or less in the verifier; a transcript of a few chunks, i.e. a small circuit):
     // one repetition per lane gives four times the wavefronts, each a quarter as long
-    if ((d_quads && n_quads * 4 <= NQ) || threads * (g_recorder ? g_recorder->batch : 1u) < 64 * 1024)
+    if ((d_quads && n_quads * 4 <= NQ) || threads * (g_recorder ? g_recorder->batch : 1u) < b3_rpl1_lanes())
         launch<B_k_b3_chunks<1>, 256>(k_b3_chunks<1>, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv, d_quads, n_quads, chunk_base, root_ok);
     else
         launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv, d_quads, n_quads, chunk_base, root_ok);
@@ -1117,7 +1127,7 @@ void launch_b3_stream_bits_chunks(hipStream_t st, const uint8_t* d_stream, uint6
     const uint64_t n = n_events == 0 ? 1 : (n_events + 1023) / 1024;
     const uint64_t threads = n * NQ;
     // a transcript of a few chunks (small circuit, and no batch to supply the wavefronts): one repetition per lane
-    if (threads * (g_recorder ? g_recorder->batch : 1u) < 64 * 1024)
+    if (threads * (g_recorder ? g_recorder->batch : 1u) < b3_rpl1_lanes())
         launch<B_k_b3_chunks_bits<1>, 256>(k_b3_chunks_bits1, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
                                            d_cv, chunk_base, root_ok);
     else
