@@ -674,7 +674,7 @@ int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
             return rc;
         }
         const uint64_t n_levels_now = bp->any ? (uint64_t)bp->max_level + 1 : 0;
-        const bool deep_narrow = n_levels_now > 256 && bp->gates.size() / n_levels_now < 64 && bp->gates.size() < 5000000;
+        const bool deep_narrow = n_levels_now && lazy_forms_pay(n_levels_now, bp->gates.size());
         if (forced || lazy_k != 1 || !deep_narrow) break;
         if (chunk) break;  // (a chunk's counters were seeded from ChunkStart; one attempt)
         lazy_k = K;

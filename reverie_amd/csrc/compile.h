@@ -120,6 +120,12 @@ void relocate_chunk(Compiled& cc, uint64_t on0, uint64_t pre0, uint64_t on_words
 int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr,
                 int force_lazy_k = 0);
 // the sequential compiler (one thread; the reference implementation of the gate stream, the error path, streaming chunks)
+// Does keeping XORs of up to RV_LIN_K rows symbolic pay for this circuit?  Decided from its K = 1 compile: deep circuits whose
+// levels fit the narrow-run kernels (at most 256 gates on average) are bound by the number of dependency levels and of
+// 32-gate steps, not by row traffic -- SHA-256: 5 386 -> 4 291 levels; AES-128 (95 gates per level): 1 096 -> 624 LDS-run steps,
+// 0.46 -> 0.36 ms per proof, verify 0.49 -> 0.38 ms.  Wide circuits run fastest with every XOR materialised.
+inline bool lazy_forms_pay(uint64_t n_levels, uint64_t n_gates) { return n_levels > 64 && n_gates / n_levels < 256 && n_gates < 5000000; }
+
 int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr,
                     int force_lazy_k = 0);
 // the parallel compiler: RV_OK, or RV_COMPILE_FALLBACK when the program is one it leaves to compile_ops_seq

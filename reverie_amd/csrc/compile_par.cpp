@@ -813,7 +813,7 @@ int compile_ops_par(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
         if (max_level >= MAX_LEVEL) return RV_COMPILE_FALLBACK;  // (levels share a word with the row count in LinP)
         n_levels = any ? max_level + 1 : 0;
         // deep, narrow circuits: keep XORs of up to K rows symbolic (compile.cpp, compile_ops_seq: the same rule)
-        const bool deep_narrow = n_levels > 256 && n_gates2 / n_levels < 64 && n_gates2 < 5000000;
+        const bool deep_narrow = n_levels && lazy_forms_pay(n_levels, n_gates2);
         if (forced || lazy_k != 1 || !deep_narrow) break;
         lazy_k = K;
     }
