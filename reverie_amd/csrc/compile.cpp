@@ -27,6 +27,7 @@ struct Builder {
     Compiled& out;
     bool counting;  // pass 1: only number the SSA wires and count how often each is read
     int lazy_k = 1; // largest base set a wire may keep symbolically (1 = aliases and constants only)
+    uint32_t lazy_slack = 1;  // extra row reads a symbolic wire may cost over materialising it (f readers x (n - 1) rows vs n + 1)
     // GF(2)
     std::vector<Gate> gates;      // program order
     std::vector<uint32_t> level;  // per gate
@@ -183,8 +184,8 @@ struct Builder {
         const uint32_t f = uses[n_ssa];  // how often the result will be read
         // keep it symbolic when that costs no more row traffic than materialising it:
         // f readers x (n - 1) extra rows  vs  n reads + 1 write
-        static const uint32_t slack = getenv("RV_LAZY_SLACK") ? (uint32_t)atoi(getenv("RV_LAZY_SLACK")) : 1u;
-        const bool lazy = n <= 1 || (n <= lazy_k && (uint64_t)f * (uint32_t)(n - 1) <= (uint32_t)(n + slack));
+        // (lazy_slack: no such limit for the circuits that are bound by their dependency levels, see compile_ops_seq)
+        const bool lazy = n <= 1 || (n <= lazy_k && (uint64_t)f * (uint32_t)(n - 1) <= (uint64_t)n + lazy_slack);
         // a linear gate nobody reads has no effect on the proof (no transcript entry, no mask consumed): drop it
         // (13.5 % of the XOR gates of the random layered workload have fan-out zero)
         if (f == 0) return new_ssa(Lin());
@@ -668,6 +669,7 @@ int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
         delete bp;
         bp = new Builder(out, false, uses);
         bp->lazy_k = lazy_k;
+        bp->lazy_slack = lazy_slack_for(lazy_k, forced);
         int rc = run_pass(ops, n_ops, z64_wires, gf2_wires, *bp, chunk);
         if (rc) {
             delete bp;

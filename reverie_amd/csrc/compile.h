@@ -16,6 +16,7 @@
 //   * reconstruction / input ordinals for the opening vectors (prover.rs:29-31)
 //   * bounds errors the reference raises while stepping (Vec index panics)
 #pragma once
+#include <stdlib.h>
 #include <stdint.h>
 
 #include <new>
@@ -124,6 +125,13 @@ int compile_ops(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wir
 // levels fit the narrow-run kernels (at most 256 gates on average) are bound by the number of dependency levels and of
 // 32-gate steps, not by row traffic -- SHA-256: 5 386 -> 4 291 levels; AES-128 (95 gates per level): 1 096 -> 624 LDS-run steps,
 // 0.46 -> 0.36 ms per proof, verify 0.49 -> 0.38 ms.  Wide circuits run fastest with every XOR materialised.
+// ... and then traffic is no argument against a symbolic wire either: with the fan-out limit of the wide circuits lifted SHA-256
+// has 3 717 levels instead of 4 291 (3 944 steps instead of 4 368, 1.39 -> 1.28 ms per proof).  RV_LAZY_SLACK overrides.
+inline uint32_t lazy_slack_for(int lazy_k, bool forced) {
+    static const int env = getenv("RV_LAZY_SLACK") ? atoi(getenv("RV_LAZY_SLACK")) : -1;
+    if (env >= 0) return (uint32_t)env;
+    return (lazy_k > 1 && !forced) ? (1u << 30) : 1u;
+}
 inline bool lazy_forms_pay(uint64_t n_levels, uint64_t n_gates) { return n_levels > 64 && n_gates / n_levels < 256 && n_gates < 5000000; }
 
 int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr,

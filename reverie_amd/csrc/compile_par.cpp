@@ -603,7 +603,6 @@ int compile_ops_par(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
     static_assert(K == 3, "LinP packs n into two bits");
     lvl64[0] = -1;
     row64[0] = 0;
-    static const uint32_t slack = getenv("RV_LAZY_SLACK") ? (uint32_t)atoi(getenv("RV_LAZY_SLACK")) : 1u;
     int lazy_k = 1;
     bool forced = false;
     if (force_lazy_k) {
@@ -630,6 +629,7 @@ int compile_ops_par(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
             acc[(size_t)t] = Acc();
         }
         const int lk = lazy_k;
+        const uint32_t slack = lazy_slack_for(lazy_k, forced);
         pool.run([&](int t) {
             Acc a;
             uint32_t safe2 = 0, safe64 = 0;  // SSA ids below these are final
@@ -698,7 +698,7 @@ int compile_ops_par(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
                             const int n = sym_diff(A, B, rows);
                             const uint32_t cc = l_c(A) ^ l_c(B);
                             const uint32_t f = uses[s];
-                            const bool lazy = n <= 1 || (n <= lk && (uint64_t)f * (uint32_t)(n - 1) <= (uint32_t)(n + slack));
+                            const bool lazy = n <= 1 || (n <= lk && (uint64_t)f * (uint32_t)(n - 1) <= (uint64_t)n + slack);
                             if (f == 0) {
                                 lin[s] = lin_zero();  // nobody reads it: no gate, no transcript entry, no mask
                                 break;
