@@ -667,9 +667,10 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
                 size_t e = l;
                 while (e < n_levels && narrow(e)) e++;
                 if (e - l >= 3) {
-                    // two quad words per slice: the fewest steps per level (64 / qs gates each) a pair of quads sharing
-                    // a preprocessing byte allows, and the most workgroups; 4 only on request
-                    const uint32_t qs = qs_env == 4 ? 4u : 2u;
+                    // one quad word per slice: 64 gates per step, the fewest steps per level, and the most workgroups (the two
+                    // quads sharing a byte of a bit-packed row then sit in different workgroups: lr_put_nibble, ldsrun.hip);
+                    // 2 or 4 on request
+                    const uint32_t qs = qs_env == 4 ? 4u : qs_env == 2 ? 2u : 1u;
                     const size_t budget = std::min<size_t>(160 * 1024, ctx->lds_bytes) - 1024;
                     const size_t fixed = lds_run_bytes(qs, 0);
                     if (budget < fixed + 64 * qs * 8) {  // not even a handful of wire slots next to the ring: the row interpreter's narrow runs
@@ -1021,6 +1022,9 @@ static int shard_run_alloc(rv_shard* s, InterpParams& p, Interp64Params& p64) {
 // Batched proofs: an LDS run takes NQ / qs workgroups per proof, each alone on a compute unit and mostly waiting on its
 // own dependency chain -- better than one workgroup per proof (k_interp_narrow_b, ~3x slower per proof) only while the
 // whole batch still finds room on the chip at once or nearly so (RV_LDS_BATCH_WGS overrides the limit)
+// one-quad slices update nibbles of the bit-packed rows through aligned 32-bit words: rows of at least four bytes (32 repetitions)
+static bool lds_run_fits_rows(uint32_t qs, uint32_t NQ) { return NQ % qs == 0 && (qs > 1 || NQ % 8 == 0); }
+
 static bool lds_run_for_batch(const rv_circuit* c, size_t level, size_t batch) {
     if (c->lds_run_of_level[level] < 0) return false;
     const auto& pl = c->lds_runs[(size_t)c->lds_run_of_level[level]];
@@ -1042,7 +1046,7 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
             HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
             waited++;
         }
-        if (mode != MODE_PROVE_V && s->c->lds_run_of_level[l] >= 0 && p.NQ % s->c->lds_runs[(size_t)s->c->lds_run_of_level[l]].qs == 0) {
+        if (mode != MODE_PROVE_V && s->c->lds_run_of_level[l] >= 0 && lds_run_fits_rows(s->c->lds_runs[(size_t)s->c->lds_run_of_level[l]].qs, p.NQ)) {
             // a narrow stretch with its live wires in LDS: one launch, NQ / qs workgroups
             const auto& pl = s->c->lds_runs[(size_t)s->c->lds_run_of_level[l]];
             if (l == pl.run.l0) {

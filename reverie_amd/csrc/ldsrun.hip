@@ -141,15 +141,29 @@ struct LrPending {
     uint32_t op = 0, on_val = 0, delta = 0, on_off = 0, pre_off = 0, drow = 0, dcorr = 0, bad = 0, grow = 0;
 };
 
-template <int MODE>
+// QS = 1 (a slice is ONE quad word, 64 gates per step): the quad's nibble of a bit-packed row shares its byte with the
+// neighbouring slice's, i.e. another workgroup's -- the nibble is cleared and set with two fire-and-forget atomics on the
+// aligned word (same lane, same address: applied in program order) instead of one byte store per pair of lanes
+__device__ __forceinline__ void lr_put_nibble(uint8_t* base, size_t byte_off, uint32_t q, uint32_t n) {
+    uint32_t* wp = (uint32_t*)(base + (byte_off & ~(size_t)3));
+    const uint32_t sh = (((uint32_t)byte_off & 3u) << 3) | ((q & 1u) << 2);
+    (void)__hip_atomic_fetch_and(wp, ~(0xFu << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_or(wp, n << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int MODE, int QS>
 __device__ __forceinline__ void lr_flush(const LrPending& w, uint8_t* on_base, uint8_t* pre_base, const InterpParams& p, uint32_t NQ,
                                          uint32_t q, uint32_t onm) {
     const uint32_t op = w.op;
     if ((op & LF_ON) && (MODE != MODE_VERIFY || onm)) *(uint32_t*)(on_base + (size_t)w.on_off) = w.on_val;
     if (op & (1u << LB_MUL)) {
         const uint32_t n = compress4(w.delta);
-        const uint32_t other = pair_swap(n);
-        if (!(q & 1)) pre_base[(size_t)w.pre_off] = (uint8_t)(n | (other << 4));
+        if (QS == 1) {
+            lr_put_nibble(pre_base, (size_t)w.pre_off, q, n);
+        } else {
+            const uint32_t other = pair_swap(n);
+            if (!(q & 1)) pre_base[(size_t)w.pre_off] = (uint8_t)(n | (other << 4));
+        }
     }
     if (op & (LF_OUT | (1u << LB_ASSERT))) {  // the rare ones
         if (op & (1u << LB_ASSERT)) {
@@ -158,12 +172,15 @@ __device__ __forceinline__ void lr_flush(const LrPending& w, uint8_t* on_base, u
         }
         if (op & LF_OUT) {  // read again after the run: the row interpreter's layout in global memory
             if (op & ((1u << LB_XOR) | (1u << LB_RECON))) p.rows[(size_t)w.grow * NQ + q] = w.drow;
-            store_bits(p.corr, w.grow, NQ, q, w.dcorr);
+            if (QS == 1)
+                lr_put_nibble(p.corr, (size_t)w.grow * (NQ >> 1) + (q >> 1), q, compress4(w.dcorr));
+            else
+                store_bits(p.corr, w.grow, NQ, q, w.dcorr);
         }
     }
 }
 
-template <int MODE>
+template <int MODE, int QS>
 __device__ __forceinline__ void lr_step(const uint4 f0, const uint4 f1, const uint4 v, const uint4 f3, LrPending& pend, uint8_t* on_base,
                                         uint8_t* pre_base, const InterpParams& p, uint32_t NQ, uint32_t q, uint32_t onm) {
     const uint32_t op = f1.w;
@@ -171,7 +188,7 @@ __device__ __forceinline__ void lr_step(const uint4 f0, const uint4 f1, const ui
     const uint2 A0 = lds_get(f0.x), A1 = lds_get(f0.y), A2 = lds_get(f0.z);
     const uint2 B0 = lds_get(f0.w), B1 = lds_get(f1.x), B2 = lds_get(f1.y);
     __builtin_amdgcn_sched_barrier(0);
-    lr_flush<MODE>(pend, on_base, pre_base, p, NQ, q, onm);  // the previous step's stores, while the gathers are in flight
+    lr_flush<MODE, QS>(pend, on_base, pre_base, p, NQ, q, onm);  // the previous step's stores, while the gathers are in flight
     __builtin_amdgcn_sched_barrier(0);
     // 0 / ~0 masks (one v_bfe_i32 each): operand constants, the gate's kind
     const uint32_t ca = (uint32_t)((int32_t)(op << 27) >> 31), cb = (uint32_t)((int32_t)(op << 26) >> 31);
@@ -252,11 +269,11 @@ __global__ __launch_bounds__(64 * (1 + LR_PRODUCERS)) void k_interp_lds(LdsRunPa
                     n2 = f[(s + 1) * 256 + 128];
                     n3 = f[(s + 1) * 256 + 192];
                 }
-                lr_step<MODE>(c0, c1, c2, c3, pend, on_base, pre_base, p, NQ, q, onm);
+                lr_step<MODE, QS>(c0, c1, c2, c3, pend, on_base, pre_base, p, NQ, q, onm);
             }
             lr_barrier();
         }
-        lr_flush<MODE>(pend, on_base, pre_base, p, NQ, q, onm);
+        lr_flush<MODE, QS>(pend, on_base, pre_base, p, NQ, q, onm);
     } else {
         // ---- producers, three chunks deep: while the consumer works on chunk c a producer writes chunk c + 1 into the
         // other buffer from operands it requested one iteration ago, requests the operands of chunk c + 2 with records
@@ -316,6 +333,11 @@ void launch_interp_lds(hipStream_t st, int mode, uint32_t QS, uint32_t NQ, const
             launch_lds_mq<MODE_VERIFY, 4>(st, rp, lds, NQ, p, d_pp, batch);
         else
             launch_lds_mq<MODE_PROVE, 4>(st, rp, lds, NQ, p, d_pp, batch);
+    } else if (QS == 1) {
+        if (mode == MODE_VERIFY)
+            launch_lds_mq<MODE_VERIFY, 1>(st, rp, lds, NQ, p, d_pp, batch);
+        else
+            launch_lds_mq<MODE_PROVE, 1>(st, rp, lds, NQ, p, d_pp, batch);
     } else {
         if (mode == MODE_VERIFY)
             launch_lds_mq<MODE_VERIFY, 2>(st, rp, lds, NQ, p, d_pp, batch);

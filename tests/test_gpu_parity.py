@@ -1091,7 +1091,7 @@ def _hourglass(seed=5):
     return np.ascontiguousarray(np.concatenate([prog, wide] + tail + [t])), wit, (0, nxt)
 
 
-@pytest.mark.parametrize("qs", ["0", "2", "4"])
+@pytest.mark.parametrize("qs", ["0", "1", "2", "4"])
 def test_lds_runs(rv, oracle, rule_seeds, monkeypatch, qs):
     """Narrow stretches with the live wires in LDS (csrc/ldsrun.*; slice width RV_LDS_QS): prover and verifier must agree
     with the oracle byte for byte -- random narrow programs with every op kind (Random gates, constants, wire reuse,

@@ -13,7 +13,7 @@ ctx = reverie_amd.Context(0)
 t0 = time.time()
 bad = 0
 for case in range(n_cases):
-    os.environ["RV_LDS_QS"] = str(int(rng.choice([0, 2, 4])))
+    os.environ["RV_LDS_QS"] = str(int(rng.choice([0, 1, 2, 4])))
     if rng.random() < 0.8:
         prog, w2, wc = circuits.random_gf2(rng, n_in=int(rng.integers(1, 300)), n_gates=int(rng.integers(20, 6000)),
                                            n_wires=int(rng.integers(4, 600)), p_assert=float(rng.choice([0.0, 0.05, 0.2])))
