@@ -28,6 +28,10 @@ struct Builder {
     bool counting;  // pass 1: only number the SSA wires and count how often each is read
     int lazy_k = 1; // largest base set a wire may keep symbolically (1 = aliases and constants only)
     uint32_t lazy_slack = 1;  // extra row reads a symbolic wire may cost over materialising it (f readers x (n - 1) rows vs n + 1)
+    // deep narrow circuits: when a sum outgrows lazy_k rows, up to `balance` of its LATEST rows stay symbolic and only the strictly
+    // earlier ones are summed into a computed row -- that row is ready before the late ones are, so the sum costs its consumer
+    // no extra dependency level (0: the whole sum becomes one row, a level behind its latest base)
+    int balance = 0;
     // GF(2)
     std::vector<Gate> gates;      // program order
     std::vector<uint32_t> level;  // per gate
@@ -194,10 +198,33 @@ struct Builder {
             L.n = (uint8_t)n;
             L.c = c;
             for (int k = 0; k < n; k++) L.b[k] = rows[k];
-        } else {
+        } else if (!balanced_sum(rows, n, c, L)) {
             L = base(materialise(rows, n, c));
         }
         return new_ssa(L);
+    }
+    // see `balance`; false: no split with strictly earlier rows exists (or the mode is off)
+    bool balanced_sum(const uint32_t* rows, int n, uint8_t c, Lin& L) {
+        if (balance <= 0 || n <= lazy_k || lazy_k < 2) return false;
+        uint32_t srt[2 * K];
+        for (int k = 0; k < n; k++) srt[k] = rows[k];
+        std::stable_sort(srt, srt + n, [&](uint32_t x, uint32_t y) { return row_level(x) < row_level(y); });
+        for (int keep = std::min(lazy_k - 1, balance); keep >= 1; keep--) {
+            const int ne = n - keep;
+            if (ne < 1 || row_level(srt[ne - 1]) >= row_level(srt[ne])) continue;
+            uint32_t early[2 * K];
+            for (int k = 0; k < ne; k++) early[k] = srt[k];
+            std::sort(early, early + ne);
+            uint32_t all[K];
+            all[0] = ne == 1 ? early[0] : materialise(early, ne, 0);  // (the constant stays with the form)
+            for (int k = 0; k < keep; k++) all[1 + k] = srt[ne + k];
+            std::sort(all, all + keep + 1);
+            L.n = (uint8_t)(keep + 1);
+            L.c = c;
+            for (int k = 0; k <= keep; k++) L.b[k] = all[k];
+            return true;
+        }
+        return false;
     }
     uint32_t g_xorc(uint32_t a, uint32_t cbit) {  // AddConst / SubConst: free
         use(a);
@@ -664,22 +691,53 @@ int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
         forced = true;
     }
     Builder* bp = nullptr;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    // a deep narrow circuit runs as steps of up to 64 gates of one level (LDS runs, ldsrun.h): what counts is their number
+    auto steps64 = [](const Builder& b) {
+        std::vector<uint32_t> per((size_t)b.max_level + 1, 0);
+        for (uint32_t l : b.level) per[l]++;
+        uint64_t steps = 0;
+        for (uint32_t g : per) steps += (g + 63) / 64;
+        return steps;
+    };
+    static const int balance_env = getenv("RV_LAZY_BALANCE") ? atoi(getenv("RV_LAZY_BALANCE")) : -1;
+    int balance = 0, best_balance = 0, phase = 0;  // phase 0: K = 1; 1: K rows, balance 0 .. K - 1 tried in turn; 2: the best one again
+    uint64_t best_steps = ~0ull;
+    for (;;) {
         out = Compiled();
         delete bp;
         bp = new Builder(out, false, uses);
         bp->lazy_k = lazy_k;
         bp->lazy_slack = lazy_slack_for(lazy_k, forced);
+        bp->balance = balance;
         int rc = run_pass(ops, n_ops, z64_wires, gf2_wires, *bp, chunk);
         if (rc) {
             delete bp;
             return rc;
         }
-        const uint64_t n_levels_now = bp->any ? (uint64_t)bp->max_level + 1 : 0;
-        const bool deep_narrow = n_levels_now && lazy_forms_pay(n_levels_now, bp->gates.size());
-        if (forced || lazy_k != 1 || !deep_narrow) break;
-        if (chunk) break;  // (a chunk's counters were seeded from ChunkStart; one attempt)
-        lazy_k = K;
+        if (phase == 0) {
+            const uint64_t n_levels_now = bp->any ? (uint64_t)bp->max_level + 1 : 0;
+            const bool deep_narrow = n_levels_now && lazy_forms_pay(n_levels_now, bp->gates.size());
+            if (forced || lazy_k != 1 || !deep_narrow) break;
+            if (chunk) break;  // (a chunk's counters were seeded from ChunkStart; one attempt)
+            lazy_k = K;
+            phase = 1;
+            if (balance_env >= 0) {  // (an experiment knob: no search)
+                balance = std::min(balance_env, K - 1);
+                phase = 2;
+            }
+            continue;
+        }
+        if (phase == 2) break;
+        // phase 1: how many steps does this variant take?  (the search costs three more passes: small circuits only)
+        const uint64_t st = steps64(*bp);
+        if (st < best_steps) best_steps = st, best_balance = balance;
+        if (balance + 1 <= K - 1 && bp->gates.size() < 1000000) {
+            balance++;
+            continue;
+        }
+        if (best_balance == balance) break;  // the variant just built is the one to keep
+        balance = best_balance;
+        phase = 2;
     }
     lap("pass 2 (gates) done");
     Builder& b = *bp;

@@ -132,7 +132,7 @@ inline uint32_t lazy_slack_for(int lazy_k, bool forced) {
     if (env >= 0) return (uint32_t)env;
     return (lazy_k > 1 && !forced) ? (1u << 30) : 1u;
 }
-inline bool lazy_forms_pay(uint64_t n_levels, uint64_t n_gates) { return n_levels > 64 && n_gates / n_levels < 256 && n_gates < 5000000; }
+inline bool lazy_forms_pay(uint64_t n_levels, uint64_t n_gates) { return n_gates && n_levels > 64 && n_gates / n_levels < 256 && n_gates < 5000000; }
 
 int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, const ChunkStart* chunk = nullptr,
                     int force_lazy_k = 0);

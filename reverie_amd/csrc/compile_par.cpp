@@ -815,7 +815,8 @@ int compile_ops_par(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
         // deep, narrow circuits: keep XORs of up to K rows symbolic (compile.cpp, compile_ops_seq: the same rule)
         const bool deep_narrow = n_levels && lazy_forms_pay(n_levels, n_gates2);
         if (forced || lazy_k != 1 || !deep_narrow) break;
-        lazy_k = K;
+        // deep narrow circuits: the sequential compiler searches over the ways of splitting a sum (compile.cpp, `balance`)
+        return RV_COMPILE_FALLBACK;
     }
     lap("pass 2a (linear forms, levels)");
 

@@ -130,6 +130,13 @@ def compile_compare(L, prog, wc, flags=0, threads=4):
     return rc, d.value
 
 
+def same_tables(L, prog, wc, flags, threads):
+    """identical tables -- or, without the prover's hint, a deep narrow circuit left to the sequential compiler (which then
+    searches over the ways of splitting long sums, compile.cpp `balance`)"""
+    got = compile_compare(L, prog, wc, flags, threads)
+    return got == (0, 0) or (flags == 0 and got == (0, -1))
+
+
 def long_random_program(rng, n_ops, n_wires2=400, n_wires64=60, old2=32, p_z64=0.25):
     """A long op list built with numpy (no B2A): recycled wires (a read usually sees a recent write), `old2` GF(2) wires
     written once at the start and read everywhere (reads that see a write made many thread ranges earlier), wires that are
@@ -172,7 +179,7 @@ def test_parallel_compiler_random_programs(L, seed):
     prog = prog[prog["domain"] != DOM_B2A]
     for flags in (0, 1):
         for threads in (2, 3, 8):
-            assert compile_compare(L, prog, wc, flags, threads) == (0, 0)
+            assert same_tables(L, prog, wc, flags, threads)
 
 
 @pytest.mark.parametrize("seed,n_ops,threads", [(1, 70_000, 8), (2, 120_000, 16), (3, 33_000, 5), (4, 260_000, 8)])
@@ -180,7 +187,7 @@ def test_parallel_compiler_long_programs_with_far_reads(L, seed, n_ops, threads)
     rng = np.random.default_rng(seed)
     prog, wc = long_random_program(rng, n_ops)
     for flags in (0, 1):
-        assert compile_compare(L, prog, wc, flags, threads) == (0, 0)
+        assert same_tables(L, prog, wc, flags, threads)
     # the same ops as ONE dependency chain per ring (every op reads the previous result): the data-flow pass degenerates to
     # the sequential order, blocks handed from thread to thread
     chain = prog.copy()
@@ -195,7 +202,8 @@ def test_parallel_compiler_layered_and_recycled(L):
     for kw in (dict(n_in=256, width=2048, layers=12), dict(n_in=100, width=128, layers=300, p_and=0.3), dict(n_in=128, width=1024, layers=20, recycle=True)):
         prog, wit, wc, st = circuits.layered_gf2(**kw)
         for flags in (0, 1):
-            assert compile_compare(L, prog, wc, flags, 7) == (0, 0)
+            assert same_tables(L, prog, wc, flags, 7)
+    assert compile_compare(L, *circuits.layered_gf2(n_in=256, width=2048, layers=12)[0:3:2], 0, 7) == (0, 0)  # (wide: never left)
     for recycle in (False, True):
         prog, wit, wc, st = circuits.layered_z64(n_in=64, width=512, n_mul=20000, recycle=recycle)
         assert compile_compare(L, prog, wc, 0, 6) == (0, 0)
