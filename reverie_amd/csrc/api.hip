@@ -86,6 +86,10 @@ struct rv_ctx {
     static constexpr size_t UP_STAGE_MAX = (size_t)192 << 20;
     uint8_t* h_up = nullptr;
     size_t h_up_cap = 0;
+    // ... and the streaming feeds' ring of page-locked slots: a worker thread copies a compiled piece's arrays into a slot
+    // ahead of the main thread (circuit_stage), which then only issues the copies (stream.inc)
+    std::vector<uint8_t*> h_ring;
+    size_t h_ring_cap = 0;
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
         if (!sync_pool.empty()) {
@@ -265,6 +269,7 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+    for (uint8_t* p : ctx->h_ring) (void)hipHostFree(p);
     for (rv_ctx* w : ctx->workers) rv_ctx_destroy(w);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
@@ -389,6 +394,8 @@ extern "C" int rv_ctx_profile(rv_ctx* ctx, int enable, int reset, rv_profile* ou
 // ------------------------------------------------------------------------------------
 struct rv_circuit {
     rv_ctx* ctx = nullptr;
+    const uint8_t* staged = nullptr;  // circuit_stage: the arrays circuit_upload sends first, already in page-locked memory
+    size_t staged_bytes = 0;
     Compiled cc;  // gates kept on the host too (level table, counts)
     Gate* d_gates = nullptr;
     uint32_t* d_rec_rows = nullptr;
@@ -516,6 +523,34 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
     return RV_OK;
 }
 
+// The arrays circuit_upload sends first, in its order, each rounded up to 256 bytes: their size, and a copy of them into `dst`
+// (page-locked; any thread, no HIP call) that circuit_upload then sends from instead of going through the context's staging buffer
+template <class F>
+static void circuit_stage_each(const Compiled& cc, F f) {
+    f(cc.gates.data(), cc.gates.size() * sizeof(Gate));
+    f(cc.rec_rows.data(), cc.rec_rows.size() * 4);
+    f(cc.in_rows.data(), cc.in_rows.size() * 4);
+    f(cc.gates64.data(), cc.gates64.size() * sizeof(Gate64));
+    f(cc.rec_offs64.data(), cc.rec_offs64.size() * 8);
+    f(cc.in_offs64.data(), cc.in_offs64.size() * 8);
+    f(cc.level_start.data(), cc.level_start.size() * 4);
+    f(cc.level_range.data(), cc.level_range.size() * sizeof(LevelRange));
+}
+static size_t circuit_stage_bytes(const Compiled& cc) {
+    size_t n = 0;
+    circuit_stage_each(cc, [&](const void*, size_t b) { n += (b + 255) & ~(size_t)255; });
+    return n;
+}
+static void circuit_stage(rv_circuit* c, uint8_t* dst) {
+    size_t off = 0;
+    circuit_stage_each(c->cc, [&](const void* p, size_t b) {
+        if (b) memcpy(dst + off, p, b);
+        off += (b + 255) & ~(size_t)255;
+    });
+    c->staged = dst;
+    c->staged_bytes = off;
+}
+
 // the compiled gate stream (c->cc) to HBM + the narrow-run plan; c is destroyed on failure
 static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
     const auto t_compiled = std::chrono::steady_clock::now();
@@ -557,7 +592,10 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         int r = ctx->alloc(bytes, dst);
         if (r) return r;
         if (!bytes) return RV_OK;
-        if (stage_on && ctx->h_up && stage_off + bytes <= ctx->h_up_cap && stage_need <= rv_ctx::UP_STAGE_MAX) {
+        if (c->staged && stage_off + bytes <= c->staged_bytes) {  // (a streaming piece: copied here by a worker thread)
+            src = c->staged + stage_off;
+            stage_off += (bytes + 255) & ~(size_t)255;
+        } else if (stage_on && ctx->h_up && stage_off + bytes <= ctx->h_up_cap && stage_need <= rv_ctx::UP_STAGE_MAX) {
             memcpy(ctx->h_up + stage_off, src, bytes);
             src = ctx->h_up + stage_off;
             stage_off += (bytes + 255) & ~(size_t)255;
@@ -585,6 +623,8 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         }
     }
     UPCHK(hipStreamSynchronize(ctx->stream));
+    c->staged = nullptr;  // (the slot belongs to the next piece from here on)
+    c->staged_bytes = 0;
     if (c->rep_ok) {  // the device holds them now
         std::vector<RepRec>().swap(c->rp.recs);
         std::vector<RepSeg>().swap(c->rp.segs);
