@@ -471,6 +471,11 @@ int rv_hook_z64_reconstruct(rv_ctx *ctx, const uint64_t *shares /* n x 64 */, si
 int rv_hook_blake3(rv_ctx *ctx, const uint8_t *data, size_t n_streams, size_t len, uint8_t *out /* n x 32 */);
 /* per-stream digests of a committed shard: rep_count x 4 x 32 = H_pre(gf2), H_on(gf2), H_pre(z64), H_on(z64) */
 int rv_hook_shard_stream_digests(rv_shard *s, uint8_t *out);
+/* Proofs this process has produced through rv_prove's early-corrections path (csrc/api.hip, rv_prove_impl: for large GF(2)
+ * circuits the corrections vectors of all repetitions -- Pack of ReconGF2, gf2/recon.rs:189-239, half of what
+ * ProverTranscript::extract returns, prover.rs:57-175 -- cross PCIe before the challenge exists).  The bytes are the same
+ * either way; the tests use the counter to know which path they compared.  RV_EARLY=0 turns the path off. */
+uint64_t rv_hook_early_proofs(void);
 
 #ifdef __cplusplus
 }

@@ -8,8 +8,10 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <map>
 #include <string>
 #include <mutex>
@@ -63,6 +65,66 @@ extern "C" const char* rv_strerror(int code) {
 }
 
 // ------------------------------------------------------------------------------------
+// Helper threads of the early-corrections path (rv_prove_impl): a handful of sleeping threads that copy the opened
+// repetitions' corrections from the staging buffer into the proof while the GPU extracts the other half.
+// ------------------------------------------------------------------------------------
+struct HelperPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t gen = 0;
+    bool stop = false;
+    const std::function<void(int)>* job = nullptr;  // null again once the caller's own share is done: a helper that wakes up after that stays out
+    std::atomic<int> running{0};
+    explicit HelperPool(int n) {
+        for (int i = 1; i < n; i++)
+            th.emplace_back([this, i] {
+                uint64_t seen = 0;
+                for (;;) {
+                    const std::function<void(int)>* f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        f = job;
+                        if (f) running.fetch_add(1, std::memory_order_relaxed);  // (under the lock: run() cannot miss it)
+                    }
+                    if (f) {
+                        (*f)(i);
+                        running.fetch_sub(1, std::memory_order_release);
+                    }
+                }
+            });
+    }
+    int size() const { return (int)th.size() + 1; }
+    // f(0) on the calling thread, f(1 ..) on the helpers that wake up in time; f must hand out its work dynamically (whoever
+    // shows up takes the next piece) and return when nothing is left to take.  Returns when every thread that entered f has left it.
+    void run(const std::function<void(int)>& f) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = &f;
+            gen++;
+        }
+        cv.notify_all();
+        f(0);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = nullptr;
+        }
+        while (running.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+    }
+    ~HelperPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
+// ------------------------------------------------------------------------------------
 // context: one device, one stream, a caching arena (hipMalloc of GB-sized buffers costs
 // milliseconds; proofs over the same circuit reuse the same sizes)
 // ------------------------------------------------------------------------------------
@@ -90,6 +152,15 @@ struct rv_ctx {
     // ahead of the main thread (circuit_stage), which then only issues the copies (stream.inc)
     std::vector<uint8_t*> h_ring;
     size_t h_ring_cap = 0;
+    // early corrections (rv_prove_impl): page-locked staging for EVERY repetition's corrections vector, the mapped
+    // mailbox the challenge arrives in ([0] = sequence number, from word 16 on the data), the helper threads
+    uint8_t* h_ec = nullptr;
+    size_t h_ec_cap = 0;
+    uint8_t* d_ec = nullptr;  // the device side of the staging (outside the arena: the proof's other buffers keep the places they have without it)
+    size_t d_ec_cap = 0;
+    uint32_t* h_fs = nullptr;
+    uint32_t fs_seq = 0;
+    HelperPool* ec_pool = nullptr;
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
         if (!sync_pool.empty()) {
@@ -270,6 +341,10 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     if (ctx->h_up) (void)hipHostFree(ctx->h_up);
     for (uint8_t* p : ctx->h_ring) (void)hipHostFree(p);
+    if (ctx->h_ec) (void)hipHostFree(ctx->h_ec);
+    if (ctx->d_ec) (void)hipFree(ctx->d_ec);
+    if (ctx->h_fs) (void)hipHostFree(ctx->h_fs);
+    delete ctx->ec_pool;
     for (rv_ctx* w : ctx->workers) rv_ctx_destroy(w);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
@@ -392,6 +467,19 @@ extern "C" int rv_ctx_profile(rv_ctx* ctx, int enable, int reset, rv_profile* ou
 // ------------------------------------------------------------------------------------
 // circuit
 // ------------------------------------------------------------------------------------
+// Early corrections (rv_prove_impl; kernels.hip "Early corrections"): which byte ranges of the repetitions' corrections
+// vectors leave for the host after which level.  A pure function of the compiled circuit, computed on first use.
+struct EarlyPlan {
+    bool ok = false;
+    struct Chunk {
+        uint64_t byte0, nbytes, pitch;  // bytes [byte0, byte0 + nbytes) of every repetition's vector; row stride in the staging block
+        size_t off;                     // the chunk's [256][pitch] block in the staging buffers (device and host alike)
+        uint32_t ready_level;           // its preprocessing rows are final once levels 0 .. ready_level have run
+    };
+    std::vector<Chunk> chunks;
+    size_t bytes = 0;
+};
+
 struct rv_circuit {
     rv_ctx* ctx = nullptr;
     const uint8_t* staged = nullptr;  // circuit_stage: the arrays circuit_upload sends first, already in page-locked memory
@@ -430,6 +518,8 @@ struct rv_circuit {
     std::vector<LdsPlan> lds_runs;
     std::vector<int32_t> lds_run_of_level;  // index into lds_runs or -1
     LdsRec* d_lds_recs = nullptr;
+    mutable std::once_flag ec_once;
+    mutable EarlyPlan ec_plan;
 };
 
 // LDS the rep-sliced interpreter may use for wire slots (a workgroup owns the CU: 160 KiB minus a little headroom)
@@ -885,6 +975,30 @@ extern "C" int rv_challenge(const uint8_t comm[RV_HASH_SIZE], uint8_t omit[RV_TO
 // ------------------------------------------------------------------------------------
 // shard
 // ------------------------------------------------------------------------------------
+// one proof's early corrections: the plan, the device / host staging blocks, the chunks queued so far and the events that
+// say a chunk has arrived on the host (owned by the shard's misc_events)
+struct EarlyRun {
+    const EarlyPlan* plan = nullptr;
+    uint8_t* d_ec = nullptr;
+    uint8_t* h_ec = nullptr;
+    size_t next = 0;                 // chunks whose "ready" stamp is in the interpreter's stream
+    size_t pumped = 0;               // chunks whose copy has been handed to the second stream
+    std::vector<uint8_t> packed;     // per chunk: already packed when its stamp appears
+    // progress stamps in the context's host-mapped mailbox (no HIP events: their status reached the host late, and the
+    // host must see a chunk the moment it is ready): word 1 = (seq << 8 | chunks ready), word 2 = (seq << 8 | chunks copied)
+    uint32_t* box_dev = nullptr;
+    volatile uint32_t* box = nullptr;
+    uint32_t seq = 0;
+    bool ready(size_t k) const {
+        const uint32_t v = __atomic_load_n(&box[1], __ATOMIC_ACQUIRE);
+        return (v >> 8) == (seq & 0xFFFFFFu) && (v & 0xFFu) > k;
+    }
+    bool copied(size_t k) const {
+        const uint32_t v = __atomic_load_n(&box[2], __ATOMIC_ACQUIRE);
+        return (v >> 8) == (seq & 0xFFFFFFu) && (v & 0xFFu) > k;
+    }
+};
+
 struct rv_shard {
     rv_ctx* ctx = nullptr;
     const rv_circuit* c = nullptr;
@@ -930,6 +1044,7 @@ struct rv_shard {
     std::vector<std::pair<uint64_t, hipEvent_t>> mask_chunks;  // (AES blocks complete, event)
     hipEvent_t ev_setup = nullptr;
     std::vector<hipEvent_t> misc_events;
+    struct EarlyRun* ec = nullptr;  // early corrections of this proof (not owned)
 
     void destroy() {
         for (auto& c : mask_chunks) ctx->sync_pool.push_back(c.second);
@@ -951,7 +1066,7 @@ extern "C" void rv_shard_destroy(rv_shard* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     // work forked onto the second stream (the verifier's side copy of the proof, the two-stream pipeline): its buffers go back to
     // the arena below and the caller's host buffers leave scope -- nothing of it may still be in flight
-    if (!s->misc_events.empty() || !s->mask_chunks.empty() || s->ev_setup) (void)hipStreamSynchronize(s->ctx->stream2);
+    if (!s->misc_events.empty() || !s->mask_chunks.empty() || s->ev_setup || s->ec) (void)hipStreamSynchronize(s->ctx->stream2);
     s->destroy();
     delete s;
 }
@@ -1072,6 +1187,139 @@ static bool lds_run_for_batch(const rv_circuit* c, size_t level, size_t batch) {
     return batch * (RV_TOTAL_REPS / 4 / pl.qs) <= limit;
 }
 
+// The early-corrections plan of a circuit: per level the smallest preprocessing row any LATER level still writes (a
+// Mul's row number g.ep; everything below it is final), the corrections vector cut into RV_EARLY_CHUNKS (default 10)
+// byte ranges, each with the level it is complete after.  Only for pure GF(2) circuits with at least RV_EARLY_MIN
+// (default 2^21) Mul gates whose preprocessing rows complete roughly in step with the levels (a layered circuit; a
+// circuit whose first rows are written by its last level gains nothing and keeps the plain path).
+static std::atomic<uint64_t> g_early_proofs{0};
+extern "C" uint64_t rv_hook_early_proofs(void) { return g_early_proofs.load(std::memory_order_relaxed); }
+
+static const EarlyPlan* early_plan(const rv_circuit* c) {
+    std::call_once(c->ec_once, [c] {
+        EarlyPlan& P = c->ec_plan;
+        const Compiled& cc = c->cc;
+        // (read per circuit, not once per process: the tests lower them)
+        const uint64_t min_events = getenv("RV_EARLY_MIN") ? (uint64_t)atoll(getenv("RV_EARLY_MIN")) : (1ull << 21);
+        const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? atoi(getenv("RV_EARLY_CHUNKS")) : 10;
+        const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+        if (!cc.gates64.empty() || cc.row_prg_base || cc.n_pre < min_events || !n_levels || n_chunks_env < 1) return;
+        // smallest row written per level, on a few threads (10^7 gate records are 0.4 GB)
+        std::vector<uint64_t> lo(n_levels, UINT64_MAX);
+        const int T = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
+        auto scan = [&](size_t l0, size_t l1) {
+            for (size_t l = l0; l < l1; l++) {
+                uint64_t m = UINT64_MAX;
+                for (uint32_t i = cc.level_start[l]; i < cc.level_start[l + 1]; i++)
+                    if (g_op(cc.gates[i]) == G_MUL) m = std::min<uint64_t>(m, cc.gates[i].ep);
+                lo[l] = m;
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            size_t l0 = 0;
+            for (int t = 0; t < T; t++) {
+                // levels dealt by gate count
+                const uint32_t want = (uint32_t)((uint64_t)cc.gates.size() * (t + 1) / T);
+                size_t l1 = t + 1 == T ? n_levels : (size_t)(std::lower_bound(cc.level_start.begin(), cc.level_start.end(), want) - cc.level_start.begin());
+                l1 = std::min(std::max(l1, l0), n_levels);
+                if (l1 > l0) {
+                    if (t + 1 == T) scan(l0, l1); else th.emplace_back(scan, l0, l1);
+                }
+                l0 = l1;
+            }
+            for (auto& t : th) t.join();
+        }
+        // done[l] = rows final once levels 0 .. l have run
+        std::vector<uint64_t> done(n_levels);
+        uint64_t m = cc.n_pre;
+        for (size_t l = n_levels; l-- > 0;) {
+            done[l] = m;
+            m = std::min(m, lo[l]);
+        }
+        const uint64_t l2c = cc.n_pre / 8 + 1;
+        const uint64_t K = (uint64_t)n_chunks_env;
+        const uint64_t per = ((l2c + K - 1) / K + 127) & ~127ull;
+        size_t off = 0;
+        for (uint64_t b0 = 0; b0 < l2c; b0 += per) {
+            EarlyPlan::Chunk ch{};
+            ch.byte0 = b0;
+            ch.nbytes = std::min(per, l2c - b0);
+            ch.pitch = (ch.nbytes + 127) & ~127ull;
+            ch.off = off;
+            off += (size_t)256 * ch.pitch;
+            const uint64_t need = std::min<uint64_t>(8 * (ch.byte0 + ch.nbytes), cc.n_pre);
+            ch.ready_level = (uint32_t)(std::lower_bound(done.begin(), done.end(), need) - done.begin());
+            if (ch.ready_level >= n_levels) return;  // (cannot happen: done[last] = n_pre)
+            const uint64_t k = P.chunks.size();
+            if (ch.ready_level > n_levels * (k + 1) / K + n_levels / 4) return;  // completes too late to be worth sending ahead
+            P.chunks.push_back(ch);
+        }
+        P.bytes = off;
+        P.ok = true;
+    });
+    return &c->ec_plan;
+}
+
+// Early corrections, device side.  early_flush (called by the level loop) puts, behind the level that completes a chunk, the
+// packing kernel and a stamp kernel into the interpreter's own stream; the host -- idle once a proof is queued -- sees the
+// stamp in the mapped mailbox and hands the chunk's copy to the second stream (early_pump), which therefore only ever
+// holds copy-engine work and the "arrived" stamps.  Measured on the 10^7-gate circuit (tools/early_ab.py, gpurun_out/e*.log):
+//  * packing kernels on the second stream are not dispatched while the first stream issues its short level launches back
+//    to back (kernel trace: the first one starts when the hash kernels do), so the copies piled up behind the challenge;
+//    in the interpreter's stream they cost 6 x 26 us (RV_EARLY_PACK_STREAM=0 / 2: the old placements);
+//  * HIP events instead of stamps (hipEventRecord + hipStreamWaitEvent, or hipEventQuery from the host) were no cheaper;
+//  * the copy-engine transfers themselves slow the interpreter beside them by ~0.2 ms (2.08 -> 2.26 ms with the packing
+//    kernels but no copies, 2.40 - 2.45 with them): 163 dependent launches, each boundary a little dearer while the
+//    engine is busy.  The hash kernels (few, long) do not notice.
+static int early_flush(rv_shard* s, size_t levels_queued) {
+    EarlyRun* e = s->ec;
+    rv_ctx* ctx = s->ctx;
+    const auto& chunks = e->plan->chunks;
+    if (e->next >= chunks.size() || chunks[e->next].ready_level >= levels_queued) return RV_OK;
+    static const int pack_stream = getenv("RV_EARLY_PACK_STREAM") ? atoi(getenv("RV_EARLY_PACK_STREAM")) : 1;  // 1: every chunk in-stream, 0: the last one, 2: none
+    const size_t first = e->next;
+    size_t last = first;
+    while (last < chunks.size() && chunks[last].ready_level < levels_queued) last++;
+    for (size_t k = first; k < last; k++) {
+        const bool in_stream = pack_stream == 1 || (pack_stream != 2 && k + 1 == chunks.size());
+        const auto& ch = chunks[k];
+        if (in_stream) {
+            launch_pack_corr_all(ctx->stream, s->d_pre, s->c->cc.n_pre, ch.byte0, ch.nbytes, ch.pitch, e->d_ec + ch.off);
+            ctx->count();
+        }
+        e->packed.push_back(in_stream ? 1 : 0);
+    }
+    launch_publish(ctx->stream, nullptr, 0, nullptr, e->box_dev + 1, (e->seq << 8) | (uint32_t)last);
+    ctx->count();
+    e->next = last;
+    return RV_OK;
+}
+
+// host side: waits for every chunk's stamp in turn and queues its packing kernel (unless done), its copy to the host and the
+// stamp that says it has arrived
+static int early_pump(rv_shard* s) {
+    EarlyRun* e = s->ec;
+    rv_ctx* ctx = s->ctx;
+    const auto& chunks = e->plan->chunks;
+    for (; e->pumped < chunks.size(); e->pumped++) {
+        const size_t k = e->pumped;
+        if (k >= e->packed.size()) return RV_E_DEVICE;
+        for (uint64_t spins = 0; !e->ready(k); spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFF) == 0xFFFF) {
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q != hipErrorNotReady && !e->ready(k)) return q == hipSuccess ? RV_E_DEVICE : hip_fail(q, "early corrections (pump)", __FILE__, __LINE__);
+            }
+        }
+        const auto& ch = chunks[k];
+        if (!e->packed[k]) launch_pack_corr_all(ctx->stream2, s->d_pre, s->c->cc.n_pre, ch.byte0, ch.nbytes, ch.pitch, e->d_ec + ch.off);
+        HIPCHK(hipMemcpyAsync(e->h_ec + ch.off, e->d_ec + ch.off, (size_t)256 * ch.pitch, hipMemcpyDeviceToHost, ctx->stream2));
+        launch_publish(ctx->stream2, nullptr, 0, nullptr, e->box_dev + 2, (e->seq << 8) | (uint32_t)(k + 1));
+    }
+    return RV_OK;
+}
+
 static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const Interp64Params& p64) {
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
@@ -1080,7 +1328,9 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
     const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
     ctx->phase(RV_PH_INTERP, sb);
     size_t waited = 0;  // mask chunks already waited for
+    int rc_ec;
     for (size_t l = 0; l < n_levels; l++) {
+        if (s->ec && (rc_ec = early_flush(s, l))) return rc_ec;
         while (waited < s->mask_chunks.size() &&
                (waited == 0 ? 0 : s->mask_chunks[waited - 1].first) < cc.level_need_blocks[l]) {
             HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
@@ -1128,6 +1378,7 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
             ctx->count();
         }
     }
+    if (s->ec && (rc_ec = early_flush(s, n_levels))) return rc_ec;
     return RV_OK;
 }
 
@@ -1267,7 +1518,7 @@ static int shard_commit_rep(rv_shard* s) {
 // the commitment and checks s->d_err itself after its own synchronisation
 static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
                                size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out,
-                               bool defer_sync = false);
+                               bool defer_sync = false, EarlyRun* ec = nullptr);
 
 extern "C" int rv_shard_commit(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
                                size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out) {
@@ -1281,7 +1532,7 @@ extern "C" int rv_shard_commit(rv_ctx* ctx, const rv_circuit* c, const uint8_t* 
 
 static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
                                size_t n_z64, const uint8_t* seeds, uint32_t rep_begin, uint32_t rep_count, rv_shard** out,
-                               bool defer_sync) {
+                               bool defer_sync, EarlyRun* ec) {
     if (!ctx || !c || !out || !seeds) return RV_E_ARG;
     if (rep_count == 0 || rep_count % 8 || rep_begin % 8 || rep_begin + rep_count > RV_TOTAL_REPS) return RV_E_ARG;
     *out = nullptr;
@@ -1331,6 +1582,7 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         if ((rc = shard_commit_rep(s))) return fail(rc);
     } else {
         if ((rc = shard_setup_prg(s, nullptr))) return fail(rc);
+        if (ec) s->ec = ec;  // (the caller made sure this path is taken: no rep-sliced prover, one stream)
         InterpParams p{};
         p.wit = s->d_wit;
         Interp64Params p64{};
@@ -1453,9 +1705,13 @@ extern "C" int rv_shard_open_size(const rv_shard* s, const uint8_t omit[RV_TOTAL
     return RV_OK;
 }
 
+// fs_mailbox (host-mapped, nullable; device Fiat-Shamir only): the challenge is also published there -- sequence number fs_seq
+// in word 0 once comm[32], the opening map [256] and {n_on, n_pre} stand from word 16 on --, and the corrections vectors are
+// NOT extracted (early corrections: the host has them already, rv_prove_impl)
 static int shard_open_impl(rv_shard* s, const uint8_t* omit /* NULL: device Fiat-Shamir */, void* dst, void** dptr, size_t lens[4],
                            bool framed = false, uint8_t* comm_out = nullptr, uint8_t* omit_out = nullptr, bool no_sync = false,
-                           const uint8_t* d_all_h = nullptr /* device: all 256 digests (sharded proofs after the all-gather) */);
+                           const uint8_t* d_all_h = nullptr /* device: all 256 digests (sharded proofs after the all-gather) */,
+                           uint32_t* fs_mailbox = nullptr, uint32_t fs_seq = 0);
 
 extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void** dptr, size_t lens[4]) {
     if (!omit) return RV_E_ARG;
@@ -1471,8 +1727,9 @@ extern "C" int rv_shard_open_into(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS]
 // `omit` == NULL: Fiat-Shamir on the device (k_fs_challenge) from the shard's own digests; only for a shard that
 // holds all 256 repetitions.  comm_out / omit_out (nullable) then receive comm and the opening map.
 static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** dptr, size_t lens[4], bool framed, uint8_t* comm_out,
-                           uint8_t* omit_out, bool no_sync, const uint8_t* d_all_h) {
+                           uint8_t* omit_out, bool no_sync, const uint8_t* d_all_h, uint32_t* fs_mailbox, uint32_t fs_seq) {
     if (!s || !dptr || !lens) return RV_E_ARG;
+    if (fs_mailbox && (omit || s->rep)) return RV_E_ARG;
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     HIPCHK(hipSetDevice(ctx->device));
@@ -1546,6 +1803,10 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
         launch_fs_challenge(ctx->stream, d_all_h ? d_all_h : s->d_h, F, s->rep_begin, s->R, s->d_omit + s->R, s->d_omit,
                             s->d_omit + s->R + 32, s->d_offs, (OnlineList*)d_ol, (uint32_t*)(s->d_omit + s->R + 32 + RV_TOTAL_REPS));
         ctx->count();
+        if (fs_mailbox) {
+            launch_publish(ctx->stream, (const uint32_t*)(s->d_omit + s->R), (uint32_t)(FS_TAIL / 4), fs_mailbox + 16, fs_mailbox, fs_seq);
+            ctx->count();
+        }
     } else {
         HIPCHK(hipMemcpyAsync(s->d_omit, om, s->R, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(s->d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1561,7 +1822,7 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
         launch_rep_open(ctx->stream, s->d_on_rep, s->on_stride, s->c->d_in_rows, cc.n_in, 1, d_ol, s->d_omit, s->d_offs + 4 * s->R, d_out);
     } else if (any_on) {
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
-        launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out);
+        if (!fs_mailbox) launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out);
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
         launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_rec_offs64, cc.n_rec64, 1, s->R, s->d_omit,
                          s->d_offs + 5 * s->R, d_out);
@@ -1685,9 +1946,11 @@ extern "C" int rv_assemble_proof(const uint8_t comm[RV_HASH_SIZE], const rv_shar
 
 // dst (nullable): page-locked destination of at least dst_cap bytes supplied by the caller (rv_prove_batch hands every
 // proof a slice of one buffer); otherwise the proof gets a buffer of its own
+// allow_early: the early-corrections path may be taken (a one-shot rv_prove_ops does without: its staging buffer is 3x the proof
+// of page-locked memory, tens of milliseconds to map for a gain of half a millisecond)
 static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
                         size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len, uint8_t* dst = nullptr,
-                        size_t dst_cap = 0);
+                        size_t dst_cap = 0, bool allow_early = true);
 
 extern "C" int rv_prove(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
                         size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len) {
@@ -1700,7 +1963,7 @@ extern "C" int rv_prove(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2
 }
 
 static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64,
-                        size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len, uint8_t* dst, size_t dst_cap) {
+                        size_t n_z64, const uint8_t* seeds, uint8_t** proof, size_t* proof_len, uint8_t* dst, size_t dst_cap, bool allow_early) {
     if (!ctx || !c || !proof || !proof_len) return RV_E_ARG;
     *proof = nullptr;
     *proof_len = 0;
@@ -1715,10 +1978,196 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         seeds = os_seeds;
     }
     rv_shard* s = nullptr;
-    int rc = rv_shard_commit_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, 0, RV_TOTAL_REPS, &s, /*defer_sync=*/true);
-    if (rc) return rc;
     uint8_t* out = nullptr;
-    do {
+    // Early corrections (kernels.hip): half of a large GF(2) proof -- the corrections vectors -- does not depend on the
+    // challenge beyond the choice of repetitions.  Every repetition's vector goes to a page-locked staging buffer through
+    // the copy engine while the interpreter and the hash kernels run; once the challenge is known (published into a mapped
+    // mailbox the host polls, no stream synchronisation) helper threads copy the 40 opened ones into the proof while the GPU
+    // extracts the other half, which a kernel then writes around them into the same buffer.  RV_EARLY=0 turns it off.
+    EarlyRun er;
+    bool early = false;
+    const bool early_stats = getenv("RV_EARLY_STATS") && atoi(getenv("RV_EARLY_STATS"));
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    double t_queued = 0, t_chal = 0, t_copied = 0, t_sync = 0;
+    std::vector<double> t_chunk;
+    uint8_t* out_dev = nullptr;
+    uint32_t* fs_dev = nullptr;
+    OpenLayout EL{};
+    const bool early_on = !(getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 0);
+    if (early_on && allow_early && !dst && !g_recorder && !ctx->pipeline && rep_mode() == 0 && c->cc.gates64.empty()) {
+        const EarlyPlan* pl = early_plan(c);
+        if (pl->ok) {
+            HIPCHK(hipSetDevice(ctx->device));
+            uint8_t canon[RV_TOTAL_REPS];
+            for (uint32_t r = 0; r < RV_TOTAL_REPS; r++) canon[r] = r < RV_ONLINE_REPS ? 0 : RV_PLAYERS;
+            EL = open_layout(c->cc, canon, RV_TOTAL_REPS, true);
+            bool ok = true;
+            if (ctx->h_ec_cap < pl->bytes) {
+                if (ctx->h_ec) (void)hipHostFree(ctx->h_ec);
+                ctx->h_ec = nullptr;
+                ctx->h_ec_cap = 0;
+                if (hipHostMalloc((void**)&ctx->h_ec, pl->bytes, hipHostMallocDefault) == hipSuccess)
+                    ctx->h_ec_cap = pl->bytes;
+                else
+                    ok = false;
+            }
+            if (ok && ctx->d_ec_cap < pl->bytes) {
+                if (ctx->d_ec) (void)hipFree(ctx->d_ec);
+                ctx->d_ec = nullptr;
+                ctx->d_ec_cap = 0;
+                if (hipMalloc((void**)&ctx->d_ec, pl->bytes) == hipSuccess)
+                    ctx->d_ec_cap = pl->bytes;
+                else
+                    ok = false;
+            }
+            if (ok && !ctx->h_fs) {
+                if (hipHostMalloc((void**)&ctx->h_fs, 4096, hipHostMallocMapped) == hipSuccess)
+                    memset(ctx->h_fs, 0, 4096);
+                else
+                    ok = false;
+            }
+            if (ok && hipHostGetDevicePointer((void**)&fs_dev, ctx->h_fs, 0) != hipSuccess) ok = false;
+            if (ok && !(out = (uint8_t*)out_alloc(EL.total))) ok = false;
+            if (ok && (hipHostGetDevicePointer((void**)&out_dev, out, 0) != hipSuccess || ((uintptr_t)out_dev & 15))) ok = false;
+            if (!ok) {
+                (void)hipGetLastError();
+                rv_free(out);
+                out = nullptr;
+            }
+            if (ok && !ctx->ec_pool) {
+                static const int n_helpers = getenv("RV_EARLY_THREADS") ? std::max(2, atoi(getenv("RV_EARLY_THREADS")) + 1) : 9;
+                ctx->ec_pool = new HelperPool(n_helpers);
+            }
+            // (test knob: the staging buffer starts every proof as garbage, so that bytes copied out of it before they arrived show)
+            if (ok && getenv("RV_EARLY_POISON") && atoi(getenv("RV_EARLY_POISON"))) memset(ctx->h_ec, 0x5A, pl->bytes);
+            if (ok) {
+                early = true;
+                er.plan = pl;
+                er.h_ec = ctx->h_ec;
+                er.d_ec = ctx->d_ec;
+                er.box_dev = fs_dev;
+                er.box = ctx->h_fs;
+                ctx->fs_seq = (ctx->fs_seq + 1) & 0xFFFFFFu;  // a fresh number even after a proof that failed half-way: its stamps must never match
+                if (!ctx->fs_seq) ctx->fs_seq = 1;
+                er.seq = ctx->fs_seq;
+            }
+        }
+    }
+    int rc = rv_shard_commit_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, 0, RV_TOTAL_REPS, &s, /*defer_sync=*/true, early ? &er : nullptr);
+    if (rc) {
+        rv_free(out);
+        return rc;
+    }
+    if (early) do {
+        void* d = nullptr;
+        size_t lens[4];
+        const uint32_t seq = er.seq;
+        if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, nullptr, nullptr, /*no_sync=*/true, nullptr, fs_dev, seq))) break;
+        const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
+        if (total != EL.total || er.packed.size() != er.plan->chunks.size() || er.plan->chunks.size() > 255) {
+            rc = RV_E_DEVICE;
+            break;
+        }
+        // the image without the corrections vectors, then the error word (mailbox word 8)
+        const uint64_t corr_at = 145 + EL.l2r;
+        launch_copy_gaps(ctx->stream, (const uint8_t*)d, out_dev, total, EL.base[0], EL.sz2, corr_at, EL.l2c, RV_ONLINE_REPS);
+        launch_store_word(ctx->stream, s->d_err, (int*)(fs_dev + 8));
+        if (hipGetLastError() != hipSuccess) {
+            rc = RV_E_DEVICE;
+            break;
+        }
+        t_queued = since();
+        if ((rc = early_pump(s))) break;
+        // the challenge: poll the mailbox (now and then make sure the stream is still alive)
+        volatile uint32_t* box = ctx->h_fs;
+        for (uint64_t spins = 0; __atomic_load_n(&box[0], __ATOMIC_ACQUIRE) != seq; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFF) == 0xFFFF) {
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q != hipErrorNotReady && __atomic_load_n(&box[0], __ATOMIC_ACQUIRE) != seq) {
+                    rc = q == hipSuccess ? RV_E_DEVICE : hip_fail(q, "early corrections", __FILE__, __LINE__);
+                    break;
+                }
+            }
+        }
+        if (rc) break;
+        t_chal = since();
+        const uint8_t* omit_all = (const uint8_t*)(ctx->h_fs + 16) + 32;
+        uint32_t opened[RV_ONLINE_REPS], n_open = 0;
+        for (uint32_t r = 0; r < RV_TOTAL_REPS; r++)
+            if (omit_all[r] < RV_PLAYERS && n_open < RV_ONLINE_REPS) opened[n_open++] = r;
+        // every thread (this one included) claims (chunk, opened repetition) pieces from one counter, chunk by chunk as the
+        // chunks' stamps appear: a helper that wakes up late takes fewer pieces instead of holding its share back
+        {
+            const auto& chunks = er.plan->chunks;
+            std::atomic<size_t> next_piece{0};
+            std::atomic<int> bad{0};
+            const size_t n_pieces = chunks.size() * n_open;
+            const std::function<void(int)> job = [&](int id) {
+                size_t seen = 0;  // chunks this thread knows to have arrived
+                for (;;) {
+                    const size_t t = next_piece.fetch_add(1, std::memory_order_relaxed);
+                    if (t >= n_pieces) return;
+                    const size_t k = t / n_open, j = t % n_open;
+                    for (uint64_t spins = 0; seen <= k; spins++) {
+                        if (er.copied(k)) {
+                            seen = k + 1;
+                            if (early_stats && id == 0 && t_chunk.size() <= k) t_chunk.resize(k + 1, since());
+                            break;
+                        }
+                        if (bad.load(std::memory_order_relaxed)) return;
+                        __builtin_ia32_pause();
+                        if (id == 0 && (spins & 0xFFFF) == 0xFFFF) {
+                            const hipError_t q = hipStreamQuery(ctx->stream2);
+                            if (q != hipErrorNotReady && !er.copied(k)) {
+                                bad.store(1);
+                                return;
+                            }
+                        }
+                    }
+                    const auto& ch = chunks[k];
+                    memcpy(out + EL.base[0] + j * EL.sz2 + corr_at + ch.byte0, er.h_ec + ch.off + (size_t)opened[j] * ch.pitch, ch.nbytes);
+                }
+            };
+            ctx->ec_pool->run(job);
+            t_copied = since();
+            if (bad.load()) {
+                rc = hip_fail(hipGetLastError(), "early corrections (copy)", __FILE__, __LINE__);
+                break;
+            }
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            rc = hip_fail(hipGetLastError(), "proof (early corrections)", __FILE__, __LINE__);
+            break;
+        }
+        t_sync = since();
+        if (early_stats) {
+            fprintf(stderr, "early: queued %.3f  challenge %.3f  chunks", t_queued, t_chal);
+            for (double t : t_chunk) fprintf(stderr, " %.3f", t);
+            fprintf(stderr, "  copied %.3f  stream done %.3f ms\n", t_copied, t_sync);
+        }
+        ctx->collect();
+        if (n_open != RV_ONLINE_REPS) {
+            rc = RV_E_DEVICE;
+            break;
+        }
+        if ((int)ctx->h_fs[8]) {
+            rc = RV_E_WITNESS_INVALID;
+            break;
+        }
+        size_t off = 32;
+        const uint64_t counts[4] = {RV_ONLINE_REPS, RV_PREPROCESSING_REPS, RV_ONLINE_REPS, RV_PREPROCESSING_REPS};
+        for (int k = 0; k < 4; k++) {
+            put_le64(out + off, counts[k]);
+            off += 8 + lens[k];
+        }
+        *proof = out;
+        *proof_len = total;
+        out = nullptr;
+        g_early_proofs.fetch_add(1, std::memory_order_relaxed);
+    } while (0);
+    else do {
         // commitment, challenge and openings all on the device (k_fs_challenge); the whole proof is laid out there
         // in its final bincode form (comm included) and leaves in ONE copy; the host waits for the device once
         void* d = nullptr;
@@ -1789,8 +2238,8 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         *proof_len = total;
         out = nullptr;
     } while (0);
+    rv_shard_destroy(s);  // (waits for both streams: nothing writes into `out` any more)
     if (!dst) rv_free(out);
-    rv_shard_destroy(s);
     return rc;
 }
 
@@ -2668,7 +3117,12 @@ extern "C" int rv_prove_ops(rv_ctx* ctx, const rv_op* ops, size_t n_ops, const u
     rv_circuit* c = nullptr;
     int rc = rv_circuit_compile_ex(ctx, ops, n_ops, z64_wires, gf2_wires, RV_COMPILE_WHOLE_PROVER, &c);
     if (rc) return rc;
-    rc = rv_prove(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, proof, proof_len);
+    try {  // (one proof of a circuit nobody keeps: without the early-corrections staging)
+        rc = rv_prove_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, proof, proof_len, nullptr, 0, /*allow_early=*/false);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        rc = RV_E_NOMEM;
+    }
     rv_circuit_destroy(c);
     return rc;
 }

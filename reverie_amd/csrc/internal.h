@@ -173,6 +173,11 @@ void launch_interp_batched(hipStream_t st, const Gate* d_gates, const LevelRange
 bool launch_b3_pair_small(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, const uint32_t* d_on, uint64_t n_on, uint32_t NQ, uint32_t* d_cv_a,
                           uint32_t* d_cv_b, uint32_t* d_dig_pre, uint32_t* d_dig_on, const uint32_t* d_quads = nullptr, uint32_t n_quads = 0);
 void launch_store_word(hipStream_t st, const int* d_src, int* dst_mapped);
+// early corrections (kernels.hip, api.hip: rv_prove on large GF(2) circuits)
+void launch_pack_corr_all(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint64_t byte0, uint64_t n_bytes, uint64_t pitch, uint8_t* d_out);
+void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
+                      uint64_t corr_len, uint32_t n_rec);
+void launch_publish(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, uint32_t* flag_mapped, uint32_t seq);
 void launch_store_words(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, const int* d_err, int* dst_err_mapped);
 // a narrow stretch with its live wires in LDS (ldsrun.h); d_pp != null: `batch` proofs, parameters from the device array
 struct LdsRec;

@@ -1878,4 +1878,122 @@ void launch_store_words(hipStream_t st, const uint32_t* d_src, uint32_t n_words,
     hipLaunchKernelGGL(k_store_words, dim3((n_words + 255) / 256), dim3(256), 0, st, d_src, n_words, dst_mapped, d_err, dst_err_mapped);
 }
 
+// ------------------------------------------------------------------------------------
+// Early corrections (api.hip, rv_prove on large GF(2) circuits).  The corrections vector of an opened repetition
+// (Pack of ReconGF2, gf2/recon.rs:189-239: one bit per Mul, 8 per byte MSB-first, n/8 + 1 bytes) depends on the
+// challenge only through WHICH repetitions open, and it is half of the proof.  So the packed vector of EVERY repetition
+// is produced while the interpreter still runs -- a range of the preprocessing rows at a time, as soon as the levels that
+// write them are done -- and leaves for the host through the copy engine before the challenge exists; after the
+// challenge the host copies the 40 it needs into the proof and only the other half crosses PCIe behind the last kernel.
+//
+// k_pack_corr_all: workgroup = PC_TB output bytes (8 * PC_TB rows of 32 bytes, contiguous) of all 256 repetitions,
+// thread = repetition.  The rows are staged in LDS transposed ([byte column][row]: a thread's eight rows are one
+// 64-bit LDS read), the packed bytes collected per repetition and written out as whole 128-byte lines.
+// out: [256][pitch], pitch a multiple of 128; byte0 = first byte of the chunk within a repetition's vector.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t PC_TB = 128;
+constexpr uint32_t PC_OSTRIDE = PC_TB + 4;  // bytes per repetition in the LDS output tile: 33 dwords
+constexpr uint32_t PC_STRIDE = 8 * PC_TB + 8;  // bytes per LDS column: 258 dwords, so the 8 columns of a wavefront fall on different banks
+__global__ __launch_bounds__(256) void k_pack_corr_all(const uint8_t* __restrict__ bits /*[n_items][32]*/, uint64_t n_items, uint64_t byte0,
+                                                       uint64_t n_bytes, uint64_t pitch, uint8_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[32 * PC_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[256 * PC_OSTRIDE];
+    const uint64_t t0 = (uint64_t)blockIdx.x * PC_TB;
+    const uint32_t nb = (uint32_t)((n_bytes - t0 < PC_TB) ? n_bytes - t0 : PC_TB);
+    const uint64_t r0 = 8 * (byte0 + t0);
+    const uint32_t n_rows = (uint32_t)(r0 >= n_items ? 0 : (n_items - r0 < 8ull * nb ? n_items - r0 : 8ull * nb));  // rows past the end are zero bits
+    const uint8_t* src = bits + r0 * 32;
+    // item = (four consecutive rows, four byte columns): four 32-bit loads, a 4 x 4 byte transpose, four 32-bit LDS stores.
+    // All of a thread's 32 loads are issued before the first transpose (eight dependent round trips per workgroup otherwise:
+    // the kernel was latency-bound at 1.9 TB/s).
+    constexpr int ITEMS = 2 * PC_TB * 8 / 256;
+    uint32_t w[ITEMS][4];
+#pragma unroll
+    for (int n = 0; n < ITEMS; n++) {
+        const uint32_t it = threadIdx.x + 256 * n, cq = it & 7, g = it >> 3;
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[n][j] = (4 * g + j < n_rows) ? *(const uint32_t*)(src + (size_t)(4 * g + j) * 32 + 4 * cq) : 0u;
+    }
+#pragma unroll
+    for (int n = 0; n < ITEMS; n++) {
+        const uint32_t it = threadIdx.x + 256 * n, cq = it & 7, g = it >> 3;
+        if (4 * g >= 8 * nb) continue;
+        const uint32_t a = __builtin_amdgcn_perm(w[n][1], w[n][0], 0x05010400u), b = __builtin_amdgcn_perm(w[n][1], w[n][0], 0x07030602u);
+        const uint32_t c = __builtin_amdgcn_perm(w[n][3], w[n][2], 0x05010400u), d = __builtin_amdgcn_perm(w[n][3], w[n][2], 0x07030602u);
+        *(uint32_t*)(s_t + (4 * cq + 0) * PC_STRIDE + 4 * g) = __builtin_amdgcn_perm(c, a, 0x05040100u);
+        *(uint32_t*)(s_t + (4 * cq + 1) * PC_STRIDE + 4 * g) = __builtin_amdgcn_perm(c, a, 0x07060302u);
+        *(uint32_t*)(s_t + (4 * cq + 2) * PC_STRIDE + 4 * g) = __builtin_amdgcn_perm(d, b, 0x05040100u);
+        *(uint32_t*)(s_t + (4 * cq + 3) * PC_STRIDE + 4 * g) = __builtin_amdgcn_perm(d, b, 0x07060302u);
+    }
+    __syncthreads();
+    {
+        // nibble bit k of quad q <-> repetition 4q + 3 - k (as k_extract_from_bits): byte r / 8, bit 4 * (r / 4 % 2) + 3 - r % 4
+        const uint32_t r = threadIdx.x, bit = 4 * ((r >> 2) & 1) + 3 - (r & 3);
+        const uint8_t* col = s_t + (r >> 3) * PC_STRIDE;
+        // sixteen output bytes per step: the sixteen 64-bit LDS reads are in flight together (one at a time the loop was bound by
+        // the LDS latency: 128 dependent reads per thread, ~26 us per 27 MB chunk); bytes past nb inside the last step are padding
+        for (uint32_t t16 = 0; t16 < nb; t16 += 16) {
+            uint2 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = *(const uint2*)(col + 8 * (t16 + k));
+            uint32_t word[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                // row j of the eight -> output bit 7 - j: the four low bits of a word's bytes gathered by one multiplication
+                const uint32_t lo = (v[k].x >> bit) & 0x01010101u, hi = (v[k].y >> bit) & 0x01010101u;
+                word[k >> 2] |= ((((lo * 0x80402010u) >> 28) << 4) | ((hi * 0x80402010u) >> 28)) << (8 * (k & 3));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) *(uint32_t*)(s_out + r * PC_OSTRIDE + t16 + 4 * k) = word[k];
+        }
+    }
+    __syncthreads();
+    // 16 bytes per thread and step, eight threads per repetition: whole lines
+    for (uint32_t i = threadIdx.x; i < 256 * (PC_TB / 16); i += 256) {
+        const uint32_t r = i / (PC_TB / 16), k = i % (PC_TB / 16);
+        if (16 * k < nb) {  // (the bytes past nb inside the last 16 are pitch padding)
+            const uint32_t* sp = (const uint32_t*)(s_out + r * PC_OSTRIDE + 16 * k);
+            *(uint4*)(out + (size_t)r * pitch + t0 + 16 * k) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+        }
+    }
+}
+void launch_pack_corr_all(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint64_t byte0, uint64_t n_bytes, uint64_t pitch, uint8_t* d_out) {
+    if (!n_bytes) return;
+    hipLaunchKernelGGL(k_pack_corr_all, dim3((unsigned)((n_bytes + PC_TB - 1) / PC_TB)), dim3(256), 0, st, d_bits, n_items, byte0, n_bytes, pitch, d_out);
+}
+
+// The proof image in HBM to the page-locked proof buffer WITHOUT the corrections vectors of its n_rec online records
+// (record j: image bytes [first + j * rec, ...), its corrections at [+ corr_at, + corr_at + corr_len)): piece j runs from
+// the end of record j - 1's corrections to the start of record j's, the last piece to the end of the image.  Source and
+// destination offsets are equal, both bases 16-byte aligned.
+__global__ __launch_bounds__(256) void k_copy_gaps(const uint8_t* __restrict__ img, uint8_t* __restrict__ dst_mapped, uint64_t total, uint64_t first,
+                                                   uint64_t rec, uint64_t corr_at, uint64_t corr_len, uint32_t n_rec) {
+    const uint32_t j = blockIdx.y;
+    const uint64_t a = j == 0 ? 0 : first + (uint64_t)(j - 1) * rec + corr_at + corr_len;
+    const uint64_t b = j == n_rec ? total : first + (uint64_t)j * rec + corr_at;
+    if (b <= a) return;
+    uint64_t a16 = (a + 15) & ~15ull, b16 = b & ~15ull;
+    if (a16 > b16) a16 = b16 = b;  // shorter than one aligned word: bytes only
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = a + tid; i < a16; i += nth) dst_mapped[i] = img[i];
+    for (uint64_t i = a16 + 16 * tid; i < b16; i += 16 * nth) *(uint4*)(dst_mapped + i) = *(const uint4*)(img + i);
+    for (uint64_t i = b16 + tid; i < b; i += nth) dst_mapped[i] = img[i];
+}
+void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
+                      uint64_t corr_len, uint32_t n_rec) {
+    hipLaunchKernelGGL(k_copy_gaps, dim3(8, n_rec + 1), dim3(256), 0, st, d_img, dst_mapped, total, first, rec, corr_at, corr_len, n_rec);
+}
+
+// n_words of device memory into host-mapped memory, then (ordered behind them at system scope) a sequence number the
+// host polls: how the host learns the challenge in the middle of a proof without a stream synchronisation
+__global__ __launch_bounds__(256) void k_publish(const uint32_t* __restrict__ src, uint32_t n_words, uint32_t* __restrict__ dst_mapped, uint32_t* __restrict__ flag_mapped, uint32_t seq) {
+    for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst_mapped[i] = src[i];  // (n_words = 0: a progress stamp only)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag_mapped, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_publish(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, uint32_t* flag_mapped, uint32_t seq) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(n_words ? 256 : 64), 0, st, d_src, n_words, dst_mapped, flag_mapped, seq);
+}
+
 }  // namespace rv

@@ -1208,3 +1208,46 @@ def test_compile_hint_whole_prover(rv, oracle, rule_seeds):
     prog, w2, wc = cases[0]
     if not os.environ.get("RV_LAZY_K"):
         assert rv.Circuit(prog, wc, whole_prover=True).info["gf2_rows_written"] < rv.Circuit(prog, wc).info["gf2_rows_written"]
+
+
+def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
+    """rv_prove's early-corrections path (the corrections vectors of ALL repetitions cross PCIe before the challenge
+    exists, the host copies the 40 opened ones into the proof, a kernel writes the rest around them: csrc/api.hip) on
+    circuits small enough for the oracle, with the size threshold lowered: the oracle's bytes for every chunk count,
+    Mul counts that are and are not multiples of 8 (the always-present last byte), the plain path's bytes with
+    RV_EARLY=0, an invalid witness reported, and the path really taken (rv_hook_early_proofs)."""
+    from reverie_amd import _lib
+
+    L = _lib.lib()
+    monkeypatch.setenv("RV_EARLY_MIN", "1000")
+    # (the last case is mostly XOR: its outputs still depend on the inputs after 80 layers, so a flipped witness bit is caught)
+    cases = [(64, 8192, 40, 0.5, "10", 16), (37, 4736, 70, 0.6, "3", 37), (64, 8192, 36, 1.0, "1", 16), (128, 16384, 24, 0.5, "16", 16),
+             (64, 16384, 80, 0.1, "4", 16)]
+    for n_in, width, layers, p_and, chunks, fold_to in cases:
+        monkeypatch.setenv("RV_EARLY_CHUNKS", chunks)
+        monkeypatch.setenv("RV_EARLY", "1")
+        prog, wit, wc, st = circuits.layered_gf2(n_in=n_in, width=width, layers=layers, p_and=p_and, fold_to=fold_to)
+        want = oracle.prove(prog, wit, [], wc, rule_seeds, threads=4)
+        assert len(want) > (1 << 20), "the case must be large enough for a page-locked proof buffer"
+        c = rv.Circuit(prog, wc)
+        n0 = L.rv_hook_early_proofs()
+        got = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+        assert L.rv_hook_early_proofs() == n0 + 1, "the early-corrections path was not taken"
+        assert bytes(got) == want, (width, layers, chunks, st["and"] % 8)
+        again = rv.Proof.new(c, wit, [], seeds=rule_seeds)  # the staging buffers and the mailbox are reused
+        assert bytes(again) == want
+        assert got.verify(c)
+        monkeypatch.setenv("RV_EARLY", "0")
+        plain = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+        assert L.rv_hook_early_proofs() == n0 + 2
+        assert bytes(plain) == want
+        monkeypatch.setenv("RV_EARLY", "1")
+        if p_and < 0.2:
+            bad = wit.copy()
+            bad[0] ^= 1
+            with pytest.raises(rv.ReverieError) as e:
+                rv.Proof.new(c, bad, [], seeds=rule_seeds)
+            assert e.value.code == 1
+            assert L.rv_hook_early_proofs() == n0 + 2
+            assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == want  # ... and the context is fine afterwards
+        c.close()
