@@ -113,6 +113,7 @@ enum {
     RV_PH_HASH = 3,   /* k_b3_chunks(_bits,_contig) + k_b3_reduce + k_b3_tree_tail: transcript BLAKE3 */
     RV_PH_JOIN = 4,   /* k_join                                                        */
     RV_PH_OPEN = 5,   /* k_fs_challenge + k_open_headers + k_extract_rows / k_extract_from_bits / k_extract64 */
+    RV_PH_EARLY = 6,  /* launches only (their time is inside RV_PH_INTERP): k_pack_corr_all + k_publish of rv_prove's early-corrections path */
     RV_PH_COUNT = 8
 };
 typedef struct rv_profile {

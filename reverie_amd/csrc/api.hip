@@ -1188,7 +1188,8 @@ static bool lds_run_for_batch(const rv_circuit* c, size_t level, size_t batch) {
 }
 
 // The early-corrections plan of a circuit: per level the smallest preprocessing row any LATER level still writes (a
-// Mul's row number g.ep; everything below it is final), the corrections vector cut into RV_EARLY_CHUNKS (default 10)
+// Mul's row number g.ep; everything below it is final), the corrections vector cut into RV_EARLY_CHUNKS (default 6:
+// 4 .. 10 give the same proof time, and every chunk costs a ~27 us packing kernel)
 // byte ranges, each with the level it is complete after.  Only for pure GF(2) circuits with at least RV_EARLY_MIN
 // (default 2^21) Mul gates whose preprocessing rows complete roughly in step with the levels (a layered circuit; a
 // circuit whose first rows are written by its last level gains nothing and keeps the plain path).
@@ -1201,7 +1202,7 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
         const Compiled& cc = c->cc;
         // (read per circuit, not once per process: the tests lower them)
         const uint64_t min_events = getenv("RV_EARLY_MIN") ? (uint64_t)atoll(getenv("RV_EARLY_MIN")) : (1ull << 21);
-        const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? atoi(getenv("RV_EARLY_CHUNKS")) : 10;
+        const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? atoi(getenv("RV_EARLY_CHUNKS")) : 6;
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
         if (!cc.gates64.empty() || cc.row_prg_base || cc.n_pre < min_events || !n_levels || n_chunks_env < 1) return;
         // smallest row written per level, on a few threads (10^7 gate records are 0.4 GB)
@@ -1268,7 +1269,12 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
 //  * packing kernels on the second stream are not dispatched while the first stream issues its short level launches back
 //    to back (kernel trace: the first one starts when the hash kernels do), so the copies piled up behind the challenge;
 //    in the interpreter's stream they cost 6 x 26 us (RV_EARLY_PACK_STREAM=0 / 2: the old placements);
-//  * HIP events instead of stamps (hipEventRecord + hipStreamWaitEvent, or hipEventQuery from the host) were no cheaper;
+//  * HIP events instead of stamps (hipEventRecord + hipStreamWaitEvent, or hipEventQuery from the host) were no cheaper, and
+//    neither was a second stream of the highest priority;
+//  * the packing kernel takes ~27 us per 27 MB chunk whatever its instruction count (a lane per repetition with multiplications,
+//    or the 8 x 8 bit transposes it has now: 2 300 vs 700 instructions per thread): one generation of workgroups that all
+//    load, then all store; its tiles as extra workgroups at the end of the level launches' grids (k_interp_full with a packing
+//    branch, built and measured: byte-identical) cost the interpreter the same ~0.15 ms -- it has no idle issue slots to give;
 //  * the copy-engine transfers themselves slow the interpreter beside them by ~0.2 ms (2.08 -> 2.26 ms with the packing
 //    kernels but no copies, 2.40 - 2.45 with them): 163 dependent launches, each boundary a little dearer while the
 //    engine is busy.  The hash kernels (few, long) do not notice.
@@ -1284,14 +1290,15 @@ static int early_flush(rv_shard* s, size_t levels_queued) {
     for (size_t k = first; k < last; k++) {
         const bool in_stream = pack_stream == 1 || (pack_stream != 2 && k + 1 == chunks.size());
         const auto& ch = chunks[k];
+        // (these launches sit inside the interpreter's phase but are not level launches: rv_profile counts them in slot 6)
         if (in_stream) {
             launch_pack_corr_all(ctx->stream, s->d_pre, s->c->cc.n_pre, ch.byte0, ch.nbytes, ch.pitch, e->d_ec + ch.off);
-            ctx->count();
+            if (ctx->profiling) ctx->prof.launches[RV_PH_EARLY]++;
         }
         e->packed.push_back(in_stream ? 1 : 0);
     }
     launch_publish(ctx->stream, nullptr, 0, nullptr, e->box_dev + 1, (e->seq << 8) | (uint32_t)last);
-    ctx->count();
+    if (ctx->profiling) ctx->prof.launches[RV_PH_EARLY]++;
     e->next = last;
     return RV_OK;
 }

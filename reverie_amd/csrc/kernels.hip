@@ -1886,65 +1886,67 @@ void launch_store_words(hipStream_t st, const uint32_t* d_src, uint32_t n_words,
 // write them are done -- and leaves for the host through the copy engine before the challenge exists; after the
 // challenge the host copies the 40 it needs into the proof and only the other half crosses PCIe behind the last kernel.
 //
-// k_pack_corr_all: workgroup = PC_TB output bytes (8 * PC_TB rows of 32 bytes, contiguous) of all 256 repetitions,
-// thread = repetition.  The rows are staged in LDS transposed ([byte column][row]: a thread's eight rows are one
-// 64-bit LDS read), the packed bytes collected per repetition and written out as whole 128-byte lines.
+// k_pack_corr_all: workgroup = PC_TB output bytes (8 * PC_TB rows of 32 bytes, contiguous) of all 256 repetitions.
+// A thread takes eight consecutive rows x four byte columns at a time: eight 32-bit loads, byte transposes (v_perm) into
+// four words pairs with a row per byte, and for each column the 8 x 8 bit transpose of Hacker's Delight (transpose8rS32)
+// -- eight output bytes, one per repetition of the column's byte, for ~5 instructions each (a lane per repetition
+// picking one bit out of each of its eight rows took 14 and two quarter-rate multiplications).  The bytes are collected
+// per repetition in LDS and written out as whole 128-byte lines.
 // out: [256][pitch], pitch a multiple of 128; byte0 = first byte of the chunk within a repetition's vector.
 // ------------------------------------------------------------------------------------
 constexpr uint32_t PC_TB = 128;
 constexpr uint32_t PC_OSTRIDE = PC_TB + 4;  // bytes per repetition in the LDS output tile: 33 dwords
-constexpr uint32_t PC_STRIDE = 8 * PC_TB + 8;  // bytes per LDS column: 258 dwords, so the 8 columns of a wavefront fall on different banks
 __global__ __launch_bounds__(256) void k_pack_corr_all(const uint8_t* __restrict__ bits /*[n_items][32]*/, uint64_t n_items, uint64_t byte0,
                                                        uint64_t n_bytes, uint64_t pitch, uint8_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_t[32 * PC_STRIDE];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[256 * PC_OSTRIDE];
     const uint64_t t0 = (uint64_t)blockIdx.x * PC_TB;
     const uint32_t nb = (uint32_t)((n_bytes - t0 < PC_TB) ? n_bytes - t0 : PC_TB);
     const uint64_t r0 = 8 * (byte0 + t0);
     const uint32_t n_rows = (uint32_t)(r0 >= n_items ? 0 : (n_items - r0 < 8ull * nb ? n_items - r0 : 8ull * nb));  // rows past the end are zero bits
     const uint8_t* src = bits + r0 * 32;
-    // item = (four consecutive rows, four byte columns): four 32-bit loads, a 4 x 4 byte transpose, four 32-bit LDS stores.
-    // All of a thread's 32 loads are issued before the first transpose (eight dependent round trips per workgroup otherwise:
-    // the kernel was latency-bound at 1.9 TB/s).
-    constexpr int ITEMS = 2 * PC_TB * 8 / 256;
-    uint32_t w[ITEMS][4];
+    // item = (output byte tl, column quad cq): rows 8 tl .. 8 tl + 7, byte columns 4 cq .. 4 cq + 3; a wavefront's 64 items
+    // cover 64 consecutive rows.  All of a thread's 32 loads are issued before the first transpose.
+    constexpr int ITEMS = PC_TB * 8 / 256;
+    uint32_t w[ITEMS][8];
 #pragma unroll
     for (int n = 0; n < ITEMS; n++) {
-        const uint32_t it = threadIdx.x + 256 * n, cq = it & 7, g = it >> 3;
+        const uint32_t it = threadIdx.x + 256 * n, cq = it & 7, tl = it >> 3;
 #pragma unroll
-        for (int j = 0; j < 4; j++) w[n][j] = (4 * g + j < n_rows) ? *(const uint32_t*)(src + (size_t)(4 * g + j) * 32 + 4 * cq) : 0u;
+        for (int j = 0; j < 8; j++) w[n][j] = (8 * tl + j < n_rows) ? *(const uint32_t*)(src + (size_t)(8 * tl + j) * 32 + 4 * cq) : 0u;
     }
 #pragma unroll
     for (int n = 0; n < ITEMS; n++) {
-        const uint32_t it = threadIdx.x + 256 * n, cq = it & 7, g = it >> 3;
-        if (4 * g >= 8 * nb) continue;
-        const uint32_t a = __builtin_amdgcn_perm(w[n][1], w[n][0], 0x05010400u), b = __builtin_amdgcn_perm(w[n][1], w[n][0], 0x07030602u);
-        const uint32_t c = __builtin_amdgcn_perm(w[n][3], w[n][2], 0x05010400u), d = __builtin_amdgcn_perm(w[n][3], w[n][2], 0x07030602u);
-        *(uint32_t*)(s_t + (4 * cq + 0) * PC_STRIDE + 4 * g) = __builtin_amdgcn_perm(c, a, 0x05040100u);
-        *(uint32_t*)(s_t + (4 * cq + 1) * PC_STRIDE + 4 * g) = __builtin_amdgcn_perm(c, a, 0x07060302u);
-        *(uint32_t*)(s_t + (4 * cq + 2) * PC_STRIDE + 4 * g) = __builtin_amdgcn_perm(d, b, 0x05040100u);
-        *(uint32_t*)(s_t + (4 * cq + 3) * PC_STRIDE + 4 * g) = __builtin_amdgcn_perm(d, b, 0x07060302u);
-    }
-    __syncthreads();
-    {
-        // nibble bit k of quad q <-> repetition 4q + 3 - k (as k_extract_from_bits): byte r / 8, bit 4 * (r / 4 % 2) + 3 - r % 4
-        const uint32_t r = threadIdx.x, bit = 4 * ((r >> 2) & 1) + 3 - (r & 3);
-        const uint8_t* col = s_t + (r >> 3) * PC_STRIDE;
-        // sixteen output bytes per step: the sixteen 64-bit LDS reads are in flight together (one at a time the loop was bound by
-        // the LDS latency: 128 dependent reads per thread, ~26 us per 27 MB chunk); bytes past nb inside the last step are padding
-        for (uint32_t t16 = 0; t16 < nb; t16 += 16) {
-            uint2 v[16];
+        const uint32_t it = threadIdx.x + 256 * n, cq = it & 7, tl = it >> 3;
+        if (tl >= nb) continue;
+        // xs[k] = rows 0..3 of column 4 cq + k, row 0 in the top byte; ys[k] = rows 4..7
+        uint32_t xs[4], ys[4];
+        {
+            const uint32_t a = __builtin_amdgcn_perm(w[n][2], w[n][3], 0x05010400u), b = __builtin_amdgcn_perm(w[n][2], w[n][3], 0x07030602u);
+            const uint32_t c = __builtin_amdgcn_perm(w[n][0], w[n][1], 0x05010400u), d = __builtin_amdgcn_perm(w[n][0], w[n][1], 0x07030602u);
+            xs[0] = __builtin_amdgcn_perm(c, a, 0x05040100u), xs[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+            xs[2] = __builtin_amdgcn_perm(d, b, 0x05040100u), xs[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+        }
+        {
+            const uint32_t a = __builtin_amdgcn_perm(w[n][6], w[n][7], 0x05010400u), b = __builtin_amdgcn_perm(w[n][6], w[n][7], 0x07030602u);
+            const uint32_t c = __builtin_amdgcn_perm(w[n][4], w[n][5], 0x05010400u), d = __builtin_amdgcn_perm(w[n][4], w[n][5], 0x07030602u);
+            ys[0] = __builtin_amdgcn_perm(c, a, 0x05040100u), ys[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+            ys[2] = __builtin_amdgcn_perm(d, b, 0x05040100u), ys[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+        }
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = *(const uint2*)(col + 8 * (t16 + k));
-            uint32_t word[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                // row j of the eight -> output bit 7 - j: the four low bits of a word's bytes gathered by one multiplication
-                const uint32_t lo = (v[k].x >> bit) & 0x01010101u, hi = (v[k].y >> bit) & 0x01010101u;
-                word[k >> 2] |= ((((lo * 0x80402010u) >> 28) << 4) | ((hi * 0x80402010u) >> 28)) << (8 * (k & 3));
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) *(uint32_t*)(s_out + r * PC_OSTRIDE + t16 + 4 * k) = word[k];
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = xs[k], y = ys[k], t;
+            t = (x ^ (x >> 7)) & 0x00AA00AAu, x = x ^ t ^ (t << 7);
+            t = (y ^ (y >> 7)) & 0x00AA00AAu, y = y ^ t ^ (t << 7);
+            t = (x ^ (x >> 14)) & 0x0000CCCCu, x = x ^ t ^ (t << 14);
+            t = (y ^ (y >> 14)) & 0x0000CCCCu, y = y ^ t ^ (t << 14);
+            t = (x & 0xF0F0F0F0u) | ((y >> 4) & 0x0F0F0F0Fu);
+            y = ((x << 4) & 0xF0F0F0F0u) | (y & 0x0F0F0F0Fu);
+            x = t;
+            // byte i of (x, y) from the top = input bit 7 - i of every row, row j at output bit 7 - j.  Nibble bit p of a byte
+            // <-> repetition 8 c + 3 - p (p < 4), 8 c + 11 - p (p >= 4), as k_extract_from_bits: x = repetitions 8 c + 4 .. + 7, y = 8 c .. + 3
+            uint8_t* o = s_out + (size_t)(8 * (4 * cq + k)) * PC_OSTRIDE + tl;
+            o[4 * PC_OSTRIDE] = (uint8_t)(x >> 24), o[5 * PC_OSTRIDE] = (uint8_t)(x >> 16), o[6 * PC_OSTRIDE] = (uint8_t)(x >> 8), o[7 * PC_OSTRIDE] = (uint8_t)x;
+            o[0 * PC_OSTRIDE] = (uint8_t)(y >> 24), o[1 * PC_OSTRIDE] = (uint8_t)(y >> 16), o[2 * PC_OSTRIDE] = (uint8_t)(y >> 8), o[3 * PC_OSTRIDE] = (uint8_t)y;
         }
     }
     __syncthreads();
