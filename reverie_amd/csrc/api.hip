@@ -1205,6 +1205,15 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
         const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? atoi(getenv("RV_EARLY_CHUNKS")) : 6;
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
         if (!cc.gates64.empty() || cc.row_prg_base || cc.n_pre < min_events || !n_levels || n_chunks_env < 1) return;
+        // All repetitions' vectors (32 bytes per Mul) must cross PCIe (~55 GB/s) while the interpreter and the hash kernels run, or
+        // the copies pile up behind the challenge and the proof gets SLOWER: measured on the all-AND variant of the 10^7-gate circuit
+        // (320 MB against ~4.6 ms: 10.9 -> 11.0 - 11.6 ms), while the mixed circuit (160 MB against ~3.2 ms) gains.  Estimated from
+        // the benchmark circuits' rates: a level launch >= 13 us and ~0.25 ns per gate, the hashes ~0.21 ns per Mul.  RV_EARLY=2 skips the test.
+        if (!(getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2)) {
+            const double t_pcie = 32.0 * (double)cc.n_pre / 55e9;
+            const double t_window = std::max((double)n_levels * 13e-6, (double)cc.gates.size() * 0.25e-9) + (double)cc.n_pre * 0.21e-9 + 0.3e-3;
+            if (t_pcie > 0.95 * t_window) return;
+        }
         // smallest row written per level, on a few threads (10^7 gate records are 0.4 GB)
         std::vector<uint64_t> lo(n_levels, UINT64_MAX);
         const int T = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));

@@ -1225,7 +1225,7 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
              (64, 16384, 80, 0.1, "4", 16)]
     for n_in, width, layers, p_and, chunks, fold_to in cases:
         monkeypatch.setenv("RV_EARLY_CHUNKS", chunks)
-        monkeypatch.setenv("RV_EARLY", "1")
+        monkeypatch.setenv("RV_EARLY", "2")
         prog, wit, wc, st = circuits.layered_gf2(n_in=n_in, width=width, layers=layers, p_and=p_and, fold_to=fold_to)
         want = oracle.prove(prog, wit, [], wc, rule_seeds, threads=4)
         assert len(want) > (1 << 20), "the case must be large enough for a page-locked proof buffer"
@@ -1241,7 +1241,7 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
         plain = rv.Proof.new(c, wit, [], seeds=rule_seeds)
         assert L.rv_hook_early_proofs() == n0 + 2
         assert bytes(plain) == want
-        monkeypatch.setenv("RV_EARLY", "1")
+        monkeypatch.setenv("RV_EARLY", "2")
         if p_and < 0.2:
             bad = wit.copy()
             bad[0] ^= 1
