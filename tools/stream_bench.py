@@ -82,6 +82,11 @@ if __name__ == "__main__":
     circ = reverie_amd.Circuit(prog, wc, ctx)
     want = bytes(reverie_amd.Proof.new(circ, wit, [], seeds=seeds))
     circ.close()
+    if "--bench-record" in sys.argv:  # bench.py's `streaming` record: the default chunk size only, one JSON line
+        rec = streaming_record(ctx, prog, wit, wc, st, seeds, want, chunk_ops=1 << 18, layers=layers)
+        rec["note"] += "; measured in a process of its own (tools/stream_bench.py --bench-record): inside bench.py's process -- 20+ GB of host arrays, the oracle's and torch's thread pools -- the host-side compile of the chunks runs ~1.5x slower (0.18 s)"
+        print(json.dumps(rec))
+        sys.exit(0)
     for chunk in (1 << 20, 1 << 18):
         print(json.dumps(streaming_record(ctx, prog, wit, wc, st, seeds, want, chunk_ops=chunk, layers=layers)))
     print(json.dumps(z64_record(ctx, seeds, n_mul=int(os.environ.get("Z64_MULS", "1000000")))))
