@@ -1841,11 +1841,11 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
         if (!fs_mailbox) launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out);
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
         launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_rec_offs64, cc.n_rec64, 1, s->R, s->d_omit,
-                         s->d_offs + 5 * s->R, d_out);
+                         s->d_offs + 5 * s->R, d_out, d_ol);
         launch_extract64(ctx->stream, s->d_pre64, cc.pre_words64, nullptr, cc.n_corr64, 0, s->R, s->d_omit, s->d_offs + 6 * s->R,
-                         d_out);
+                         d_out, d_ol);
         launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_in_offs64, cc.n_in64, 0, s->R, s->d_omit,
-                         s->d_offs + 7 * s->R, d_out);
+                         s->d_offs + 7 * s->R, d_out, d_ol);
     }
     HIPCHK(hipGetLastError());
     ctx->phase(-1);

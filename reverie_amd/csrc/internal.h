@@ -193,7 +193,8 @@ void launch_aes_z64_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* 
 uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
                       uint32_t* d_digest);
 void launch_extract64(hipStream_t st, const uint64_t* d_stream, uint64_t stride_words, const uint64_t* d_offs /*[n_items]*/,
-                      uint64_t n_items, int add_omit, uint32_t R, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
+                      uint64_t n_items, int add_omit, uint32_t R, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out,
+                      const struct OnlineList* d_ol = nullptr /* device: the shard's opened repetitions; given, only those get threads */);
 void launch_unpack64(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
                      const uint8_t* d_omit, uint64_t n_items, uint32_t R, uint64_t* d_out, uint32_t out_r /* repetitions per output row (<= R) */);
 // BLAKE3 over a row-format transcript: digests[R][8] words
