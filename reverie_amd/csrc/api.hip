@@ -478,6 +478,12 @@ struct EarlyPlan {
     };
     std::vector<Chunk> chunks;
     size_t bytes = 0;
+    // Z64 circuits (pure Z64, no B2A): a repetition's corrections vector IS its preprocessing transcript ([R][words] in HBM), so
+    // there is nothing to pack -- a chunk is a word range of the first r_spec repetitions' rows, copied as one 2-D transfer into
+    // staging rows of `pitch` bytes.  r_spec < 256 when all repetitions' vectors would not fit through PCIe beside the proof's
+    // kernels: the opened repetitions beyond it are extracted and copied the plain way.
+    bool z64 = false;
+    uint32_t r_spec = RV_TOTAL_REPS;
 };
 
 struct rv_circuit {
@@ -1204,7 +1210,59 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
         const uint64_t min_events = getenv("RV_EARLY_MIN") ? (uint64_t)atoll(getenv("RV_EARLY_MIN")) : (1ull << 21);
         const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? atoi(getenv("RV_EARLY_CHUNKS")) : 6;
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
-        if (!cc.gates64.empty() || cc.row_prg_base || cc.n_pre < min_events || !n_levels || n_chunks_env < 1) return;
+        if (!cc.gates64.empty()) {
+            // ---- Z64 ----
+            const size_t n_lv64 = cc.level_start64.empty() ? 0 : cc.level_start64.size() - 1;
+            const uint64_t min64 = getenv("RV_EARLY_MIN") ? min_events : (1ull << 17);
+            if (cc.row_prg_base || cc.n_pre || cc.pre_words64 != cc.n_corr64 || cc.n_corr64 < min64 || (cc.n_corr64 & 1) || !n_lv64 || n_chunks_env < 1) return;
+            std::vector<uint64_t> lo(n_lv64, UINT64_MAX);
+            for (size_t l = 0; l < n_lv64; l++)
+                for (uint32_t i = cc.level_start64[l]; i < cc.level_start64[l + 1]; i++) {
+                    const uint32_t op = cc.gates64[i].op;
+                    if (op == G64_B2A) return;
+                    if (op == G64_MUL) lo[l] = std::min<uint64_t>(lo[l], cc.gates64[i].ep);
+                }
+            std::vector<uint64_t> done(n_lv64);
+            uint64_t m = cc.pre_words64;
+            for (size_t l = n_lv64; l-- > 0;) {
+                done[l] = m;
+                m = std::min(m, lo[l]);
+            }
+            // how many repetitions' vectors fit through PCIe while the interpreter and the hashes run (rates of the 10^6-MUL
+            // benchmark circuit: ~10 ns per gate, ~6 ns per Mul of hashing); RV_EARLY=2: RV_EARLY_REPS (default 128) whatever the estimate
+            const uint64_t vec_bytes = 8 * cc.n_corr64;
+            uint32_t r_spec;
+            if (getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2) {
+                r_spec = getenv("RV_EARLY_REPS") ? (uint32_t)atoi(getenv("RV_EARLY_REPS")) : 128;
+            } else {
+                const double t_window = (double)cc.gates64.size() * 10e-9 + (double)cc.n_corr64 * 6e-9;
+                r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.85 * t_window * 55e9 / (double)vec_bytes);
+            }
+            r_spec = std::min<uint32_t>(r_spec, RV_TOTAL_REPS) & ~7u;
+            if (r_spec < 64) return;
+            const uint64_t pitch = (vec_bytes + 127) & ~127ull;
+            const uint64_t K = (uint64_t)n_chunks_env;
+            const uint64_t per = ((vec_bytes + K - 1) / K + 127) & ~127ull;
+            for (uint64_t b0 = 0; b0 < vec_bytes; b0 += per) {
+                EarlyPlan::Chunk ch{};
+                ch.byte0 = b0;
+                ch.nbytes = std::min(per, vec_bytes - b0);
+                ch.pitch = pitch;
+                ch.off = 0;
+                const uint64_t need = (ch.byte0 + ch.nbytes) / 8;
+                ch.ready_level = (uint32_t)(std::lower_bound(done.begin(), done.end(), need) - done.begin());
+                if (ch.ready_level >= n_lv64) return;
+                const uint64_t k = P.chunks.size();
+                if (ch.ready_level > n_lv64 * (k + 1) / K + n_lv64 / 4) return;
+                P.chunks.push_back(ch);
+            }
+            P.bytes = (size_t)r_spec * pitch;
+            P.z64 = true;
+            P.r_spec = r_spec;
+            P.ok = true;
+            return;
+        }
+        if (cc.row_prg_base || cc.n_pre < min_events || !n_levels || n_chunks_env < 1) return;
         // All repetitions' vectors (32 bytes per Mul) must cross PCIe (~55 GB/s) while the interpreter and the hash kernels run, or
         // the copies pile up behind the challenge and the proof gets SLOWER: measured on the all-AND variant of the 10^7-gate circuit
         // (320 MB against ~4.6 ms: 10.9 -> 11.0 - 11.6 ms), while the mixed circuit (160 MB against ~3.2 ms) gains.  Estimated from
@@ -1300,6 +1358,10 @@ static int early_flush(rv_shard* s, size_t levels_queued) {
         const bool in_stream = pack_stream == 1 || (pack_stream != 2 && k + 1 == chunks.size());
         const auto& ch = chunks[k];
         // (these launches sit inside the interpreter's phase but are not level launches: rv_profile counts them in slot 6)
+        if (e->plan->z64) {
+            e->packed.push_back(1);  // nothing to pack: the rows are the vectors
+            continue;
+        }
         if (in_stream) {
             launch_pack_corr_all(ctx->stream, s->d_pre, s->c->cc.n_pre, ch.byte0, ch.nbytes, ch.pitch, e->d_ec + ch.off);
             if (ctx->profiling) ctx->prof.launches[RV_PH_EARLY]++;
@@ -1329,8 +1391,15 @@ static int early_pump(rv_shard* s) {
             }
         }
         const auto& ch = chunks[k];
-        if (!e->packed[k]) launch_pack_corr_all(ctx->stream2, s->d_pre, s->c->cc.n_pre, ch.byte0, ch.nbytes, ch.pitch, e->d_ec + ch.off);
-        HIPCHK(hipMemcpyAsync(e->h_ec + ch.off, e->d_ec + ch.off, (size_t)256 * ch.pitch, hipMemcpyDeviceToHost, ctx->stream2));
+        if (e->plan->z64) {
+            // word range [byte0, byte0 + nbytes) of the first r_spec repetitions' preprocessing rows (16-byte multiples on both
+            // sides: the copy engine's fast 2-D path)
+            HIPCHK(hipMemcpy2DAsync(e->h_ec + ch.byte0, ch.pitch, (const uint8_t*)s->d_pre64 + ch.byte0, (size_t)s->c->cc.pre_words64 * 8, ch.nbytes,
+                                    e->plan->r_spec, hipMemcpyDeviceToHost, ctx->stream2));
+        } else {
+            if (!e->packed[k]) launch_pack_corr_all(ctx->stream2, s->d_pre, s->c->cc.n_pre, ch.byte0, ch.nbytes, ch.pitch, e->d_ec + ch.off);
+            HIPCHK(hipMemcpyAsync(e->h_ec + ch.off, e->d_ec + ch.off, (size_t)256 * ch.pitch, hipMemcpyDeviceToHost, ctx->stream2));
+        }
         launch_publish(ctx->stream2, nullptr, 0, nullptr, e->box_dev + 2, (e->seq << 8) | (uint32_t)(k + 1));
     }
     return RV_OK;
@@ -1727,7 +1796,8 @@ extern "C" int rv_shard_open_size(const rv_shard* s, const uint8_t omit[RV_TOTAL
 static int shard_open_impl(rv_shard* s, const uint8_t* omit /* NULL: device Fiat-Shamir */, void* dst, void** dptr, size_t lens[4],
                            bool framed = false, uint8_t* comm_out = nullptr, uint8_t* omit_out = nullptr, bool no_sync = false,
                            const uint8_t* d_all_h = nullptr /* device: all 256 digests (sharded proofs after the all-gather) */,
-                           uint32_t* fs_mailbox = nullptr, uint32_t fs_seq = 0);
+                           uint32_t* fs_mailbox = nullptr, uint32_t fs_seq = 0, uint32_t corr64_rep_min = 0 /* Z64 early corrections: the Z64
+                           corrections vectors of repetitions below this one are not extracted either (GF(2) ones are then, as always) */);
 
 extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void** dptr, size_t lens[4]) {
     if (!omit) return RV_E_ARG;
@@ -1743,7 +1813,7 @@ extern "C" int rv_shard_open_into(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS]
 // `omit` == NULL: Fiat-Shamir on the device (k_fs_challenge) from the shard's own digests; only for a shard that
 // holds all 256 repetitions.  comm_out / omit_out (nullable) then receive comm and the opening map.
 static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** dptr, size_t lens[4], bool framed, uint8_t* comm_out,
-                           uint8_t* omit_out, bool no_sync, const uint8_t* d_all_h, uint32_t* fs_mailbox, uint32_t fs_seq) {
+                           uint8_t* omit_out, bool no_sync, const uint8_t* d_all_h, uint32_t* fs_mailbox, uint32_t fs_seq, uint32_t corr64_rep_min) {
     if (!s || !dptr || !lens) return RV_E_ARG;
     if (fs_mailbox && (omit || s->rep)) return RV_E_ARG;
     rv_ctx* ctx = s->ctx;
@@ -1838,12 +1908,12 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
         launch_rep_open(ctx->stream, s->d_on_rep, s->on_stride, s->c->d_in_rows, cc.n_in, 1, d_ol, s->d_omit, s->d_offs + 4 * s->R, d_out);
     } else if (any_on) {
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
-        if (!fs_mailbox) launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out);
+        if (!fs_mailbox || corr64_rep_min) launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out);
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
         launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_rec_offs64, cc.n_rec64, 1, s->R, s->d_omit,
                          s->d_offs + 5 * s->R, d_out, d_ol);
         launch_extract64(ctx->stream, s->d_pre64, cc.pre_words64, nullptr, cc.n_corr64, 0, s->R, s->d_omit, s->d_offs + 6 * s->R,
-                         d_out, d_ol);
+                         d_out, d_ol, corr64_rep_min);
         launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_in_offs64, cc.n_in64, 0, s->R, s->d_omit,
                          s->d_offs + 7 * s->R, d_out, d_ol);
     }
@@ -2011,7 +2081,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
     uint32_t* fs_dev = nullptr;
     OpenLayout EL{};
     const bool early_on = !(getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 0);
-    if (early_on && allow_early && !dst && !g_recorder && !ctx->pipeline && rep_mode() == 0 && c->cc.gates64.empty()) {
+    if (early_on && allow_early && !dst && !g_recorder && !ctx->pipeline && rep_mode() == 0) {
         const EarlyPlan* pl = early_plan(c);
         if (pl->ok) {
             HIPCHK(hipSetDevice(ctx->device));
@@ -2028,7 +2098,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
                 else
                     ok = false;
             }
-            if (ok && ctx->d_ec_cap < pl->bytes) {
+            if (ok && !pl->z64 && ctx->d_ec_cap < pl->bytes) {
                 if (ctx->d_ec) (void)hipFree(ctx->d_ec);
                 ctx->d_ec = nullptr;
                 ctx->d_ec_cap = 0;
@@ -2044,13 +2114,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
                     ok = false;
             }
             if (ok && hipHostGetDevicePointer((void**)&fs_dev, ctx->h_fs, 0) != hipSuccess) ok = false;
-            if (ok && !(out = (uint8_t*)out_alloc(EL.total))) ok = false;
-            if (ok && (hipHostGetDevicePointer((void**)&out_dev, out, 0) != hipSuccess || ((uintptr_t)out_dev & 15))) ok = false;
-            if (!ok) {
-                (void)hipGetLastError();
-                rv_free(out);
-                out = nullptr;
-            }
+            if (!ok) (void)hipGetLastError();
             if (ok && !ctx->ec_pool) {
                 static const int n_helpers = getenv("RV_EARLY_THREADS") ? std::max(2, atoi(getenv("RV_EARLY_THREADS")) + 1) : 9;
                 ctx->ec_pool = new HelperPool(n_helpers);
@@ -2071,23 +2135,35 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         }
     }
     int rc = rv_shard_commit_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, 0, RV_TOTAL_REPS, &s, /*defer_sync=*/true, early ? &er : nullptr);
-    if (rc) {
-        rv_free(out);
-        return rc;
+    if (rc) return rc;
+    if (early) {
+        // the proof's buffer, now that the GPU is busy (a fresh page-locked buffer of a 640 MB proof takes 45 ms to map).  Without it
+        // the plain path below still works: the stamps in the stream are harmless, nothing was handed to the second stream yet
+        if (!(out = (uint8_t*)out_alloc(EL.total)) || hipHostGetDevicePointer((void**)&out_dev, out, 0) != hipSuccess || ((uintptr_t)out_dev & 15)) {
+            (void)hipGetLastError();
+            rv_free(out);
+            out = nullptr;
+            early = false;
+            s->ec = nullptr;
+        }
     }
     if (early) do {
         void* d = nullptr;
         size_t lens[4];
         const uint32_t seq = er.seq;
-        if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, nullptr, nullptr, /*no_sync=*/true, nullptr, fs_dev, seq))) break;
+        const bool z64 = er.plan->z64;
+        if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, nullptr, nullptr, /*no_sync=*/true, nullptr, fs_dev, seq, z64 ? er.plan->r_spec : 0))) break;
         const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
         if (total != EL.total || er.packed.size() != er.plan->chunks.size() || er.plan->chunks.size() > 255) {
             rc = RV_E_DEVICE;
             break;
         }
         // the image without the corrections vectors, then the error word (mailbox word 8)
-        const uint64_t corr_at = 145 + EL.l2r;
-        launch_copy_gaps(ctx->stream, (const uint8_t*)d, out_dev, total, EL.base[0], EL.sz2, corr_at, EL.l2c, RV_ONLINE_REPS);
+        // (Z64: only the records of the opened repetitions below r_spec -- the kernel counts them -- go without their vectors)
+        const uint64_t corr_at = 145 + (z64 ? EL.l64r : EL.l2r);
+        const uint64_t rec_first = z64 ? EL.base[2] : EL.base[0], rec_size = z64 ? EL.sz64 : EL.sz2, corr_len = z64 ? EL.l64c : EL.l2c;
+        launch_copy_gaps(ctx->stream, (const uint8_t*)d, out_dev, total, rec_first, rec_size, corr_at, corr_len, RV_ONLINE_REPS, s->d_omit,
+                         z64 ? er.plan->r_spec : RV_TOTAL_REPS);
         launch_store_word(ctx->stream, s->d_err, (int*)(fs_dev + 8));
         if (hipGetLastError() != hipSuccess) {
             rc = RV_E_DEVICE;
@@ -2119,13 +2195,17 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
             const auto& chunks = er.plan->chunks;
             std::atomic<size_t> next_piece{0};
             std::atomic<int> bad{0};
-            const size_t n_pieces = chunks.size() * n_open;
+            // (Z64: the staging buffer holds the first r_spec repetitions; the opened ones among them are the first n_staged ranks)
+        uint32_t n_staged = 0;
+        for (uint32_t j = 0; j < n_open; j++)
+            if (opened[j] < er.plan->r_spec) n_staged = j + 1;
+        const size_t n_pieces = chunks.size() * n_staged;
             const std::function<void(int)> job = [&](int id) {
                 size_t seen = 0;  // chunks this thread knows to have arrived
                 for (;;) {
                     const size_t t = next_piece.fetch_add(1, std::memory_order_relaxed);
                     if (t >= n_pieces) return;
-                    const size_t k = t / n_open, j = t % n_open;
+                    const size_t k = t / n_staged, j = t % n_staged;
                     for (uint64_t spins = 0; seen <= k; spins++) {
                         if (er.copied(k)) {
                             seen = k + 1;
@@ -2143,7 +2223,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
                         }
                     }
                     const auto& ch = chunks[k];
-                    memcpy(out + EL.base[0] + j * EL.sz2 + corr_at + ch.byte0, er.h_ec + ch.off + (size_t)opened[j] * ch.pitch, ch.nbytes);
+                    memcpy(out + rec_first + j * rec_size + corr_at + ch.byte0, er.h_ec + ch.off + (size_t)opened[j] * ch.pitch + (z64 ? ch.byte0 : 0), ch.nbytes);
                 }
             };
             ctx->ec_pool->run(job);

@@ -176,7 +176,7 @@ void launch_store_word(hipStream_t st, const int* d_src, int* dst_mapped);
 // early corrections (kernels.hip, api.hip: rv_prove on large GF(2) circuits)
 void launch_pack_corr_all(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint64_t byte0, uint64_t n_bytes, uint64_t pitch, uint8_t* d_out);
 void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
-                      uint64_t corr_len, uint32_t n_rec);
+                      uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit /*[256]*/, uint32_t rep_limit);
 void launch_publish(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, uint32_t* flag_mapped, uint32_t seq);
 void launch_store_words(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, const int* d_err, int* dst_err_mapped);
 // a narrow stretch with its live wires in LDS (ldsrun.h); d_pp != null: `batch` proofs, parameters from the device array
@@ -194,7 +194,8 @@ uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_
                       uint32_t* d_digest);
 void launch_extract64(hipStream_t st, const uint64_t* d_stream, uint64_t stride_words, const uint64_t* d_offs /*[n_items]*/,
                       uint64_t n_items, int add_omit, uint32_t R, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out,
-                      const struct OnlineList* d_ol = nullptr /* device: the shard's opened repetitions; given, only those get threads */);
+                      const struct OnlineList* d_ol = nullptr /* device: the shard's opened repetitions; given, only those get threads */,
+                      uint32_t rep_min = 0 /* with d_ol: repetitions below this one are left out */);
 void launch_unpack64(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
                      const uint8_t* d_omit, uint64_t n_items, uint32_t R, uint64_t* d_out, uint32_t out_r /* repetitions per output row (<= R) */);
 // BLAKE3 over a row-format transcript: digests[R][8] words

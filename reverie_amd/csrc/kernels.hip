@@ -1964,15 +1964,26 @@ void launch_pack_corr_all(hipStream_t st, const uint8_t* d_bits, uint64_t n_item
     hipLaunchKernelGGL(k_pack_corr_all, dim3((unsigned)((n_bytes + PC_TB - 1) / PC_TB)), dim3(256), 0, st, d_bits, n_items, byte0, n_bytes, pitch, d_out);
 }
 
-// The proof image in HBM to the page-locked proof buffer WITHOUT the corrections vectors of its n_rec online records
-// (record j: image bytes [first + j * rec, ...), its corrections at [+ corr_at, + corr_at + corr_len)): piece j runs from
-// the end of record j - 1's corrections to the start of record j's, the last piece to the end of the image.  Source and
-// destination offsets are equal, both bases 16-byte aligned.
+// The proof image in HBM to the page-locked proof buffer WITHOUT the corrections vectors of its first m online records, m =
+// the opened repetitions below rep_limit (omit[r] < 8; all n_rec of them when rep_limit = 256).  Record j: image bytes
+// [first + j * rec, ...), its corrections at [+ corr_at, + corr_at + corr_len).  Piece j (blockIdx.y) runs from the end of record
+// j - 1's corrections to the start of record j's, piece m to the end of the image.  Source and destination offsets are equal,
+// both bases 16-byte aligned.
 __global__ __launch_bounds__(256) void k_copy_gaps(const uint8_t* __restrict__ img, uint8_t* __restrict__ dst_mapped, uint64_t total, uint64_t first,
-                                                   uint64_t rec, uint64_t corr_at, uint64_t corr_len, uint32_t n_rec) {
-    const uint32_t j = blockIdx.y;
+                                                   uint64_t rec, uint64_t corr_at, uint64_t corr_len, uint32_t n_rec, const uint8_t* __restrict__ omit,
+                                                   uint32_t rep_limit) {
+    __shared__ uint32_t s_m;
+    if (threadIdx.x < 64) {
+        uint32_t cnt = 0;
+        for (uint32_t r = threadIdx.x; r < rep_limit && r < RV_TOTAL_REPS; r += 64) cnt += omit[r] < 8 ? 1u : 0u;
+        for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (threadIdx.x == 0) s_m = cnt < n_rec ? cnt : n_rec;
+    }
+    __syncthreads();
+    const uint32_t m = s_m, j = blockIdx.y;
+    if (j > m) return;
     const uint64_t a = j == 0 ? 0 : first + (uint64_t)(j - 1) * rec + corr_at + corr_len;
-    const uint64_t b = j == n_rec ? total : first + (uint64_t)j * rec + corr_at;
+    const uint64_t b = j == m ? total : first + (uint64_t)j * rec + corr_at;
     if (b <= a) return;
     uint64_t a16 = (a + 15) & ~15ull, b16 = b & ~15ull;
     if (a16 > b16) a16 = b16 = b;  // shorter than one aligned word: bytes only
@@ -1982,8 +1993,10 @@ __global__ __launch_bounds__(256) void k_copy_gaps(const uint8_t* __restrict__ i
     for (uint64_t i = b16 + tid; i < b; i += nth) dst_mapped[i] = img[i];
 }
 void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
-                      uint64_t corr_len, uint32_t n_rec) {
-    hipLaunchKernelGGL(k_copy_gaps, dim3(8, n_rec + 1), dim3(256), 0, st, d_img, dst_mapped, total, first, rec, corr_at, corr_len, n_rec);
+                      uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit, uint32_t rep_limit) {
+    // (the last piece may be most of the image -- Z64 with few staged repetitions --: enough workgroups per piece to fill PCIe alone)
+    hipLaunchKernelGGL(k_copy_gaps, dim3(rep_limit < RV_TOTAL_REPS ? 64 : 8, n_rec + 1), dim3(256), 0, st, d_img, dst_mapped, total, first, rec, corr_at, corr_len,
+                       n_rec, d_omit, rep_limit);
 }
 
 // n_words of device memory into host-mapped memory, then (ordered behind them at system scope) a sequence number the

@@ -323,12 +323,13 @@ __global__ void k_extract64(const uint64_t* __restrict__ stream, uint64_t stride
 // 40 x n_items threads instead of R x n_items of which 216 in 256 returned at once (10^6-MUL circuit: opening phase 1.06 -> 0.75 ms)
 __global__ void k_extract64_ol(const uint64_t* __restrict__ stream, uint64_t stride_words, const uint64_t* __restrict__ offs,
                                uint64_t n_items, int add_omit, const OnlineList* __restrict__ ol, const uint8_t* __restrict__ omit,
-                               const uint64_t* __restrict__ dst_off, uint8_t* __restrict__ out) {
+                               const uint64_t* __restrict__ dst_off, uint8_t* __restrict__ out, uint32_t rep_min) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t it = tid % n_items;
     const uint32_t k = (uint32_t)(tid / n_items);
     if (k >= ol->n || k >= RV_ONLINE_REPS) return;
     const uint32_t r = ol->rep[k];
+    if (r < rep_min) return;  // (Z64 early corrections: the host has this repetition's vector already)
     const uint32_t om = omit[r];
     const uint64_t off = (offs ? offs[it] : it) + (add_omit ? om : 0);
     const uint64_t v = stream[(size_t)r * stride_words + off];
@@ -338,12 +339,12 @@ __global__ void k_extract64_ol(const uint64_t* __restrict__ stream, uint64_t str
 }
 
 void launch_extract64(hipStream_t st, const uint64_t* d_stream, uint64_t stride_words, const uint64_t* d_offs, uint64_t n_items,
-                      int add_omit, uint32_t R, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out, const OnlineList* d_ol) {
+                      int add_omit, uint32_t R, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out, const OnlineList* d_ol, uint32_t rep_min) {
     if (!n_items) return;
     if (d_ol) {
         const uint64_t threads = n_items * RV_ONLINE_REPS;
         hipLaunchKernelGGL(k_extract64_ol, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_stream, stride_words, d_offs,
-                           n_items, add_omit, d_ol, d_omit, d_dst_off, d_out);
+                           n_items, add_omit, d_ol, d_omit, d_dst_off, d_out, rep_min);
         return;
     }
     const uint64_t threads = n_items * R;

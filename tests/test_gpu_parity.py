@@ -1251,3 +1251,40 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
             assert L.rv_hook_early_proofs() == n0 + 2
             assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == want  # ... and the context is fine afterwards
         c.close()
+
+
+@pytest.mark.parametrize("reps", ["64", "128", "256"])
+def test_early_corrections_path_z64(rv, oracle, rule_seeds, monkeypatch, reps):
+    """The Z64 form of the early-corrections path (a repetition's corrections vector is its preprocessing transcript: word
+    ranges of the first r_spec repetitions' rows cross PCIe as 2-D copies before the challenge; the opened repetitions
+    beyond r_spec are extracted the plain way): the oracle's bytes with 64 / 128 / 256 staged repetitions, the plain
+    path's bytes, an invalid witness reported."""
+    from reverie_amd import _lib
+
+    L = _lib.lib()
+    monkeypatch.setenv("RV_EARLY_MIN", "1000")
+    monkeypatch.setenv("RV_EARLY", "2")
+    monkeypatch.setenv("RV_EARLY_REPS", reps)
+    monkeypatch.setenv("RV_EARLY_CHUNKS", "5")
+    prog, w64, wc, st = circuits.layered_z64(n_in=64, width=2048, n_mul=24000)
+    assert st["mul"] % 2 == 0
+    want = oracle.prove(prog, [], w64, wc, rule_seeds, threads=4)
+    assert len(want) > (1 << 20)
+    c = rv.Circuit(prog, wc)
+    n0 = L.rv_hook_early_proofs()
+    got = rv.Proof.new(c, [], w64, seeds=rule_seeds)
+    assert L.rv_hook_early_proofs() == n0 + 1, "the early-corrections path was not taken"
+    assert bytes(got) == want
+    assert bytes(rv.Proof.new(c, [], w64, seeds=rule_seeds)) == want
+    assert got.verify(c)
+    monkeypatch.setenv("RV_EARLY", "0")
+    assert bytes(rv.Proof.new(c, [], w64, seeds=rule_seeds)) == want
+    assert L.rv_hook_early_proofs() == n0 + 2
+    monkeypatch.setenv("RV_EARLY", "2")
+    bad = list(w64)
+    bad[0] ^= 1
+    with pytest.raises(rv.ReverieError) as e:
+        rv.Proof.new(c, [], bad, seeds=rule_seeds)
+    assert e.value.code == 1
+    assert bytes(rv.Proof.new(c, [], w64, seeds=rule_seeds)) == want
+    c.close()
