@@ -232,7 +232,7 @@ def secondary_records(ctx, seeds, quick):
            "mul_per_s": st["mul"] * steps / dt, "verifies_strict": ok, "verify_ms": tv * 1e3,
            "phase_ms": phase_ms(ctx, lambda: hp.run(2), 2),
            "note": "host to host; the 640 MB proof alone is ~11 ms of PCIe, of which the early-corrections path (the corrections vectors of the first "
-                   "168 repetitions cross PCIe while the kernels run: csrc/api.hip) hides ~3; profiles/r02_z64_* hold the kernel trace and the "
+                   "128 repetitions cross PCIe while the kernels run: csrc/api.hip) hides ~2.5; profiles/r02_z64_* hold the kernel trace and the "
                    "PMC traffic (k_interp64 moves ~150 GB per proof at ~5.5 TB/s, k_aes_z64_masks is VALU-bound: 2.05e9 "
                    "cipher blocks + the bit transposes)"}
     circ.close()

@@ -1236,7 +1236,9 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
                 r_spec = getenv("RV_EARLY_REPS") ? (uint32_t)atoi(getenv("RV_EARLY_REPS")) : 128;
             } else {
                 const double t_window = (double)cc.gates64.size() * 10e-9 + (double)cc.n_corr64 * 6e-9;
-                r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.85 * t_window * 55e9 / (double)vec_bytes);
+                // (0.65 of what the window could carry: 112 .. 176 staged repetitions of the benchmark circuit give the same proof time,
+                // 67.3 - 69.3 ms against 70.8 plain, 192 make it slower, 73.6 -- so the smaller buffer: 128 repetitions, 1.0 GB)
+                r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.65 * t_window * 55e9 / (double)vec_bytes);
             }
             r_spec = std::min<uint32_t>(r_spec, RV_TOTAL_REPS) & ~7u;
             if (r_spec < 64) return;
