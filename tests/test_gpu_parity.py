@@ -1288,3 +1288,28 @@ def test_early_corrections_path_z64(rv, oracle, rule_seeds, monkeypatch, reps):
     assert e.value.code == 1
     assert bytes(rv.Proof.new(c, [], w64, seeds=rule_seeds)) == want
     c.close()
+
+
+def test_early_corrections_two_circuits_one_context(rv, oracle, rule_seeds, monkeypatch):
+    """The early-corrections staging buffers belong to the context: proofs of two circuits of different sizes alternate on it
+    (the buffers grow once), a GF(2) and a Z64 one, with OS-drawn seeds too (those proofs must verify)."""
+    monkeypatch.setenv("RV_EARLY_MIN", "1000")
+    monkeypatch.setenv("RV_EARLY", "2")
+    monkeypatch.setenv("RV_EARLY_CHUNKS", "4")
+    pa, wa, wca, _ = circuits.layered_gf2(n_in=64, width=8192, layers=30, p_and=0.5, fold_to=16)
+    pb, wb, wcb, _ = circuits.layered_gf2(n_in=64, width=16384, layers=40, p_and=0.6, fold_to=16)
+    pz, wz, wcz, _ = circuits.layered_z64(n_in=64, width=2048, n_mul=20000)
+    ca, cb, cz = rv.Circuit(pa, wca), rv.Circuit(pb, wcb), rv.Circuit(pz, wcz)
+    want_a = oracle.prove(pa, wa, [], wca, rule_seeds, threads=4)
+    want_b = oracle.prove(pb, wb, [], wcb, rule_seeds, threads=4)
+    want_z = oracle.prove(pz, [], wz, wcz, rule_seeds, threads=4)
+    for _ in range(2):
+        assert bytes(rv.Proof.new(ca, wa, [], seeds=rule_seeds)) == want_a
+        assert bytes(rv.Proof.new(cz, [], wz, seeds=rule_seeds)) == want_z
+        assert bytes(rv.Proof.new(cb, wb, [], seeds=rule_seeds)) == want_b
+    for c, w2, w64 in ((ca, wa, []), (cb, wb, []), (cz, [], wz)):
+        p = rv.Proof.new(c, w2, w64)  # seeds from the OS
+        assert p.verify(c)
+        assert oracle.verify(pa if c is ca else pb if c is cb else pz, wca if c is ca else wcb if c is cb else wcz, bytes(p))
+    for c in (ca, cb, cz):
+        c.close()
