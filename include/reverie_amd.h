@@ -477,6 +477,13 @@ int rv_hook_shard_stream_digests(rv_shard *s, uint8_t *out);
  * ProverTranscript::extract returns, prover.rs:57-175 -- cross PCIe before the challenge exists).  The bytes are the same
  * either way; the tests use the counter to know which path they compared.  RV_EARLY=0 turns the path off. */
 uint64_t rv_hook_early_proofs(void);
+/* The early-corrections plan of a program (host only, no device): the ops are compiled as rv_circuit_compile_ex(flags) would and
+ * the plan rv_prove would use is built and checked against the compiled gate records.  out[0] = a plan exists (0 / 1: the circuit
+ * is pure GF(2) with >= 2^21 Mul gates -- RV_EARLY_MIN -- or pure Z64, its preprocessing rows complete in step with the levels
+ * and fit the PCIe window), [1] = Z64 form, [2] = repetitions staged, [3] = chunks, [4] = staging bytes, [5] = 1 when no level
+ * after a chunk's ready level writes one of its rows and the ready level itself does, [6 + k] = chunk k's ready level (k < 16).
+ * Returns the compiler's status. */
+int rv_hook_early_plan(const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, uint64_t out[22]);
 
 #ifdef __cplusplus
 }

@@ -1331,6 +1331,59 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
     return &c->ec_plan;
 }
 
+// Host-only view of the plan (tests): compiles the ops as rv_circuit_compile_ex would, builds the early-corrections plan and checks
+// it against the gate records one by one -- no gate of a level after a chunk's ready_level may write a preprocessing row of the chunk,
+// and some gate of the ready_level itself must (else the chunk could have left a level earlier).  out[0] = plan taken (0 / 1),
+// [1] = Z64 form, [2] = staged repetitions, [3] = chunks, [4] = staging bytes, [5] = the check (1 = consistent), [6 + k] = chunk k's
+// ready_level (k < 16).
+extern "C" int rv_hook_early_plan(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, uint64_t out[22]) {
+    if (!out || (n_ops && !ops) || (flags & ~RV_COMPILE_WHOLE_PROVER)) return RV_E_ARG;
+    try {
+        rv_circuit tmp;
+        int rc = compile_ops(ops, n_ops, z64_wires, gf2_wires, tmp.cc, nullptr, ((flags & RV_COMPILE_WHOLE_PROVER) && !getenv("RV_LAZY_K")) ? RV_LIN_K : 0);
+        if (rc) return rc;
+        const EarlyPlan* P = early_plan(&tmp);
+        for (int i = 0; i < 22; i++) out[i] = 0;
+        out[0] = P->ok, out[1] = P->z64, out[2] = P->r_spec, out[3] = P->chunks.size(), out[4] = P->bytes;
+        if (!P->ok) return RV_OK;
+        const Compiled& cc = tmp.cc;
+        bool good = true;
+        for (size_t k = 0; k < P->chunks.size(); k++) {
+            const auto& ch = P->chunks[k];
+            if (k < 16) out[6 + k] = ch.ready_level;
+            // rows (GF(2): 8 per byte; Z64: one word per 8 bytes) of the chunk
+            const uint64_t row0 = P->z64 ? ch.byte0 / 8 : ch.byte0 * 8;
+            const uint64_t row1 = P->z64 ? (ch.byte0 + ch.nbytes) / 8 : std::min<uint64_t>((ch.byte0 + ch.nbytes) * 8, cc.n_pre);
+            bool at_ready = row1 <= row0;  // (the pad byte behind the last row belongs to no gate)
+            const size_t n_levels = (P->z64 ? cc.level_start64.size() : cc.level_start.size()) - 1;
+            for (size_t l = 0; l < n_levels; l++) {
+                const uint32_t a = P->z64 ? cc.level_start64[l] : cc.level_start[l], b = P->z64 ? cc.level_start64[l + 1] : cc.level_start[l + 1];
+                for (uint32_t i = a; i < b; i++) {
+                    uint64_t ep;
+                    if (P->z64) {
+                        if (cc.gates64[i].op != G64_MUL) continue;
+                        ep = cc.gates64[i].ep;
+                    } else {
+                        if (g_op(cc.gates[i]) != G_MUL) continue;
+                        ep = cc.gates[i].ep;
+                    }
+                    if (ep < row1 && l > ch.ready_level) good = false;  // (rows below the chunk count too: chunks leave in order)
+                    if (ep >= row0 && ep < row1 && l == ch.ready_level) at_ready = true;
+                }
+            }
+            // (a chunk whose own last writer is earlier than a previous chunk's inherits that chunk's level: in-order delivery)
+            if (!at_ready && !(k && ch.ready_level == P->chunks[k - 1].ready_level)) good = false;
+            if (k && ch.ready_level < P->chunks[k - 1].ready_level) good = false;
+            if (k && ch.byte0 != P->chunks[k - 1].byte0 + P->chunks[k - 1].nbytes) good = false;
+        }
+        out[5] = good;
+        return RV_OK;
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
+}
+
 // Early corrections, device side.  early_flush (called by the level loop) puts, behind the level that completes a chunk, the
 // packing kernel and a stamp kernel into the interpreter's own stream; the host -- idle once a proof is queued -- sees the
 // stamp in the mapped mailbox and hands the chunk's copy to the second stream (early_pump), which therefore only ever

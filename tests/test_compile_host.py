@@ -235,3 +235,79 @@ def test_compile_dispatch_takes_the_parallel_compiler_for_large_programs(L, monk
     monkeypatch.setenv("RV_COMPILE_SEQ", "1")
     rc2, seq = compile_info(L, prog, wc, flags=1)
     assert rc == 0 and rc2 == 0 and par == seq
+
+
+# ---- the early-corrections plan (rv_prove, csrc/api.hip: early_plan), host side only ----
+def early_plan(L, prog, wc, flags=1):
+    prog = np.ascontiguousarray(prog)
+    out = (C.c_uint64 * 22)()
+    rc = L.rv_hook_early_plan(prog.ctypes.data_as(C.c_void_p), C.c_size_t(len(prog)), C.c_size_t(int(wc[0])), C.c_size_t(int(wc[1])), C.c_uint32(flags), out)
+    assert rc == 0
+    o = [int(x) for x in out]
+    return {"ok": o[0], "z64": o[1], "reps": o[2], "chunks": o[3], "bytes": o[4], "check": o[5], "ready": o[6:6 + min(o[3], 16)]}
+
+
+def chains_program(n_chains, depth, chain_major):
+    """n_chains independent chains of `depth` dependent Mul gates; program order chain by chain (every level then writes
+    preprocessing rows spread over the whole transcript) or round by round (the rows complete in step with the levels)"""
+    ops = [GF2.Input(i) for i in range(n_chains + 1)]
+    wire = n_chains + 1
+    cur = list(range(n_chains))
+    order = [(c, r) for c in range(n_chains) for r in range(depth)] if chain_major else [(c, r) for r in range(depth) for c in range(n_chains)]
+    for c, _ in order:
+        ops.append(GF2.Mul(wire, cur[c], n_chains))
+        cur[c] = wire
+        wire += 1
+    return program(ops), (0, wire)
+
+
+def test_early_plan_host(L, monkeypatch):
+    """The plan rv_prove's early-corrections path follows, on the host alone: taken for layered GF(2) and Z64 circuits with every
+    chunk's ready level checked against the compiled gates (no later level writes its rows, its own level does), refused when the
+    rows do not complete in step with the levels, for programs with both domains, below the size threshold, and when all
+    repetitions' vectors would not fit through PCIe beside the kernels."""
+    monkeypatch.setenv("RV_EARLY_MIN", "1000")
+    for chunks in ("1", "4", "9"):
+        monkeypatch.setenv("RV_EARLY_CHUNKS", chunks)
+        prog, _, wc, st = circuits.layered_gf2(n_in=64, width=4096, layers=24, p_and=0.5, fold_to=16)
+        for flags in (0, 1):
+            p = early_plan(L, prog, wc, flags)
+            assert p["ok"] and not p["z64"] and p["check"] and p["reps"] == 256, p
+            assert p["chunks"] == int(chunks) and p["ready"] == sorted(p["ready"]), p
+            assert p["bytes"] >= 256 * (st["and"] // 8 + 1), p
+    monkeypatch.setenv("RV_EARLY_CHUNKS", "4")
+    # rows in step with the levels / spread over the transcript
+    prog, wc = chains_program(64, 48, chain_major=False)
+    p = early_plan(L, prog, wc)
+    assert p["ok"] and p["check"], p
+    prog, wc = chains_program(64, 48, chain_major=True)
+    assert not early_plan(L, prog, wc)["ok"]
+    # Z64: the staged repetitions follow the PCIe estimate, or RV_EARLY_REPS under RV_EARLY=2
+    prog, _, wc, st = circuits.layered_z64(n_in=64, width=1024, n_mul=6000)
+    p = early_plan(L, prog, wc)
+    assert p["ok"] and p["z64"] and p["check"] and 64 <= p["reps"] <= 256 and p["reps"] % 8 == 0, p
+    assert p["bytes"] >= p["reps"] * 8 * st["mul"], p
+    monkeypatch.setenv("RV_EARLY", "2")
+    monkeypatch.setenv("RV_EARLY_REPS", "200")
+    p = early_plan(L, prog, wc)
+    assert p["ok"] and p["reps"] == 200 and p["check"], p
+    monkeypatch.delenv("RV_EARLY")
+    # both domains in one program: no plan
+    prog, _, _, _ = circuits.random_mixed(np.random.default_rng(5), n_gates=3000)
+    assert not early_plan(L, prog, (12, 90))["ok"]
+    # below the threshold
+    monkeypatch.delenv("RV_EARLY_MIN")
+    prog, _, wc, _ = circuits.layered_gf2(n_in=64, width=4096, layers=24, p_and=0.5, fold_to=16)
+    assert not early_plan(L, prog, wc)["ok"]
+
+
+def test_early_plan_pcie_window(L, monkeypatch):
+    """A few very wide all-AND levels: 32 bytes per Mul for all repetitions do not fit through PCIe in the time the levels and the
+    hashes are estimated to take -- the plan is refused (RV_EARLY=2 takes it regardless)."""
+    monkeypatch.setenv("RV_EARLY_MIN", "1000")
+    prog, _, wc, st = circuits.layered_gf2(n_in=64, width=1 << 20, layers=4, p_and=1.0, fold_to=16)
+    assert st["and"] == 4 << 20
+    assert not early_plan(L, prog, wc)["ok"]
+    monkeypatch.setenv("RV_EARLY", "2")
+    p = early_plan(L, prog, wc)
+    assert p["ok"] and p["check"], p
