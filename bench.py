@@ -481,8 +481,8 @@ def main():
             "algorithmic_bytes_per_launch": alg[dom] / n_l,
             "early_corrections": {"kernels_in_phase": early_launches, "kernel_alone": kernel_alone,
                                   "note": "the timed proofs take rv_prove's early-corrections path: the interpreter's phase also holds this many small kernels "
-                                          "(k_pack_corr_all ~27 us + k_publish ~5 us per chunk of the corrections vectors, not counted in launches_per_proof) and the "
-                                          "copy engine moves 160 MB to the host beside the levels, which costs them ~0.2 ms per proof; achieved / frac above are "
+                                          "(k_pack_corr_all ~25 us + k_publish ~5 us per chunk of the corrections vectors, not counted in launches_per_proof) while the "
+                                          "copy engine moves 160 MB to the host beside the levels; achieved / frac above are "
                                           "the whole phase over the level launches, kernel_alone is the same kernel without the path"} if early_launches else None,
             "phase_ms": phases, "phase_launches": launches, "algorithmic_bytes_per_proof": {k: int(v) for k, v in alg.items()},
             "gpu_ms_per_proof": sum(phases.values()),

@@ -991,16 +991,12 @@ struct EarlyRun {
     size_t pumped = 0;               // chunks whose copy has been handed to the second stream
     std::vector<uint8_t> packed;     // per chunk: already packed when its stamp appears
     // progress stamps in the context's host-mapped mailbox (no HIP events: their status reached the host late, and the
-    // host must see a chunk the moment it is ready): word 1 = (seq << 8 | chunks ready), word 2 = (seq << 8 | chunks copied)
+    // host must see a chunk the moment it is ready): word 1 = (seq << 8 | chunks ready)
     uint32_t* box_dev = nullptr;
     volatile uint32_t* box = nullptr;
     uint32_t seq = 0;
     bool ready(size_t k) const {
         const uint32_t v = __atomic_load_n(&box[1], __ATOMIC_ACQUIRE);
-        return (v >> 8) == (seq & 0xFFFFFFu) && (v & 0xFFu) > k;
-    }
-    bool copied(size_t k) const {
-        const uint32_t v = __atomic_load_n(&box[2], __ATOMIC_ACQUIRE);
         return (v >> 8) == (seq & 0xFFFFFFu) && (v & 0xFFu) > k;
     }
 };
@@ -1194,8 +1190,8 @@ static bool lds_run_for_batch(const rv_circuit* c, size_t level, size_t batch) {
 }
 
 // The early-corrections plan of a circuit: per level the smallest preprocessing row any LATER level still writes (a
-// Mul's row number g.ep; everything below it is final), the corrections vector cut into RV_EARLY_CHUNKS (default 6:
-// 4 .. 10 give the same proof time, and every chunk costs a ~27 us packing kernel)
+// Mul's row number g.ep; everything below it is final), the corrections vector cut into RV_EARLY_CHUNKS (default 4:
+// 4 and 5 give the same proof time, 3 and 6 .. 10 a longer one; every chunk costs a ~25 us packing kernel)
 // byte ranges, each with the level it is complete after.  Only for pure GF(2) circuits with at least RV_EARLY_MIN
 // (default 2^21) Mul gates whose preprocessing rows complete roughly in step with the levels (a layered circuit; a
 // circuit whose first rows are written by its last level gains nothing and keeps the plain path).
@@ -1208,7 +1204,7 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
         const Compiled& cc = c->cc;
         // (read per circuit, not once per process: the tests lower them)
         const uint64_t min_events = getenv("RV_EARLY_MIN") ? (uint64_t)atoll(getenv("RV_EARLY_MIN")) : (1ull << 21);
-        const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? atoi(getenv("RV_EARLY_CHUNKS")) : 6;
+        const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? atoi(getenv("RV_EARLY_CHUNKS")) : 4;
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
         if (!cc.gates64.empty()) {
             // ---- Z64 ----
@@ -1397,9 +1393,11 @@ extern "C" int rv_hook_early_plan(const rv_op* ops, size_t n_ops, size_t z64_wir
 //    or the 8 x 8 bit transposes it has now: 2 300 vs 700 instructions per thread): one generation of workgroups that all
 //    load, then all store; its tiles as extra workgroups at the end of the level launches' grids (k_interp_full with a packing
 //    branch, built and measured: byte-identical) cost the interpreter the same ~0.15 ms -- it has no idle issue slots to give;
-//  * the copy-engine transfers themselves slow the interpreter beside them by ~0.2 ms (2.08 -> 2.26 ms with the packing
-//    kernels but no copies, 2.40 - 2.45 with them): 163 dependent launches, each boundary a little dearer while the
-//    engine is busy.  The hash kernels (few, long) do not notice.
+//  * NOTHING may wait on the second stream.  Its copies were first followed by an "arrived" stamp kernel each (before that by an
+//    event): a packet that waits for the copy engine's signal at the head of another hardware queue is polled by the command
+//    processor between the first queue's level launches, and the 163 launches paid 0.2 ms for it (interpreter phase 2.40 - 2.45 ms
+//    against 2.17 - 2.2 now; tools/copy_beside.py: copy-engine transfers alone beside the levels cost 0.03 ms).  The host waits for
+//    the stream itself after the challenge -- a signal wait on the host side, no packet.
 static int early_flush(rv_shard* s, size_t levels_queued) {
     EarlyRun* e = s->ec;
     rv_ctx* ctx = s->ctx;
@@ -1455,7 +1453,9 @@ static int early_pump(rv_shard* s) {
             if (!e->packed[k]) launch_pack_corr_all(ctx->stream2, s->d_pre, s->c->cc.n_pre, ch.byte0, ch.nbytes, ch.pitch, e->d_ec + ch.off);
             HIPCHK(hipMemcpyAsync(e->h_ec + ch.off, e->d_ec + ch.off, (size_t)256 * ch.pitch, hipMemcpyDeviceToHost, ctx->stream2));
         }
-        launch_publish(ctx->stream2, nullptr, 0, nullptr, e->box_dev + 2, (e->seq << 8) | (uint32_t)(k + 1));
+        // (NO kernel or event behind the copy: a packet that waits for the copy engine's signal at the head of the second queue is
+        // polled by the command processor between the first queue's level launches and costs the interpreter 0.15 - 0.2 ms per proof --
+        // tools/copy_beside.py: copies alone beside the levels cost 0.03.  The host waits for the stream instead, after the challenge.)
     }
     return RV_OK;
 }
@@ -2244,39 +2244,28 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         uint32_t opened[RV_ONLINE_REPS], n_open = 0;
         for (uint32_t r = 0; r < RV_TOTAL_REPS; r++)
             if (omit_all[r] < RV_PLAYERS && n_open < RV_ONLINE_REPS) opened[n_open++] = r;
-        // every thread (this one included) claims (chunk, opened repetition) pieces from one counter, chunk by chunk as the
-        // chunks' stamps appear: a helper that wakes up late takes fewer pieces instead of holding its share back
+        // the copies of the chunks: normally long done; the host waits for the second stream (its copies complete in order), then every
+        // thread (this one included) claims (chunk, opened repetition) pieces from one counter: a helper that wakes up late takes fewer
+        // pieces instead of holding its share back
+        if (hipStreamSynchronize(ctx->stream2) != hipSuccess) {
+            rc = hip_fail(hipGetLastError(), "early corrections (copies)", __FILE__, __LINE__);
+            break;
+        }
+        if (early_stats) t_chunk.push_back(since());
         {
             const auto& chunks = er.plan->chunks;
             std::atomic<size_t> next_piece{0};
             std::atomic<int> bad{0};
             // (Z64: the staging buffer holds the first r_spec repetitions; the opened ones among them are the first n_staged ranks)
-        uint32_t n_staged = 0;
-        for (uint32_t j = 0; j < n_open; j++)
-            if (opened[j] < er.plan->r_spec) n_staged = j + 1;
-        const size_t n_pieces = chunks.size() * n_staged;
-            const std::function<void(int)> job = [&](int id) {
-                size_t seen = 0;  // chunks this thread knows to have arrived
+            uint32_t n_staged = 0;
+            for (uint32_t j = 0; j < n_open; j++)
+                if (opened[j] < er.plan->r_spec) n_staged = j + 1;
+            const size_t n_pieces = chunks.size() * n_staged;
+            const std::function<void(int)> job = [&](int) {
                 for (;;) {
                     const size_t t = next_piece.fetch_add(1, std::memory_order_relaxed);
                     if (t >= n_pieces) return;
                     const size_t k = t / n_staged, j = t % n_staged;
-                    for (uint64_t spins = 0; seen <= k; spins++) {
-                        if (er.copied(k)) {
-                            seen = k + 1;
-                            if (early_stats && id == 0 && t_chunk.size() <= k) t_chunk.resize(k + 1, since());
-                            break;
-                        }
-                        if (bad.load(std::memory_order_relaxed)) return;
-                        __builtin_ia32_pause();
-                        if (id == 0 && (spins & 0xFFFF) == 0xFFFF) {
-                            const hipError_t q = hipStreamQuery(ctx->stream2);
-                            if (q != hipErrorNotReady && !er.copied(k)) {
-                                bad.store(1);
-                                return;
-                            }
-                        }
-                    }
                     const auto& ch = chunks[k];
                     memcpy(out + rec_first + j * rec_size + corr_at + ch.byte0, er.h_ec + ch.off + (size_t)opened[j] * ch.pitch + (z64 ? ch.byte0 : 0), ch.nbytes);
                 }
