@@ -1261,15 +1261,20 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
             return;
         }
         if (cc.row_prg_base || cc.n_pre < min_events || !n_levels || n_chunks_env < 1) return;
-        // All repetitions' vectors (32 bytes per Mul) must cross PCIe (~55 GB/s) while the interpreter and the hash kernels run, or
-        // the copies pile up behind the challenge and the proof gets SLOWER: measured on the all-AND variant of the 10^7-gate circuit
-        // (320 MB against ~4.6 ms: 10.9 -> 11.0 - 11.6 ms), while the mixed circuit (160 MB against ~3.2 ms) gains.  Estimated from
-        // the benchmark circuits' rates: a level launch >= 13 us and ~0.25 ns per gate, the hashes ~0.21 ns per Mul.  RV_EARLY=2 skips the test.
-        if (!(getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2)) {
-            const double t_pcie = 32.0 * (double)cc.n_pre / 55e9;
+        // The staged repetitions' vectors (1/8 byte per Mul each) must cross PCIe (~55 GB/s) while the interpreter and the hash kernels
+        // run, or the copies pile up behind the challenge and the proof gets SLOWER (all 256 on the all-AND variant of the 10^7-gate
+        // circuit, 320 MB against ~4.6 ms: 10.9 -> 11.0 - 11.6 ms).  So only as many repetitions as fit 0.9 of the estimated window
+        // (the benchmark circuits' rates: a level launch >= 13 us and ~0.25 ns per gate, the hashes ~0.21 ns per Mul); the opened
+        // repetitions beyond them are extracted and copied the plain way.  RV_EARLY=2: all of them (RV_EARLY_REPS overrides).
+        uint32_t r_spec = RV_TOTAL_REPS;
+        if (getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2) {
+            if (getenv("RV_EARLY_REPS")) r_spec = (uint32_t)atoi(getenv("RV_EARLY_REPS"));
+        } else {
             const double t_window = std::max((double)n_levels * 13e-6, (double)cc.gates.size() * 0.25e-9) + (double)cc.n_pre * 0.21e-9 + 0.3e-3;
-            if (t_pcie > 0.95 * t_window) return;
+            r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.9 * t_window * 55e9 / ((double)cc.n_pre / 8.0));
         }
+        r_spec = std::min<uint32_t>(r_spec, RV_TOTAL_REPS) & ~7u;
+        if (r_spec < 64) return;
         // smallest row written per level, on a few threads (10^7 gate records are 0.4 GB)
         std::vector<uint64_t> lo(n_levels, UINT64_MAX);
         const int T = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
@@ -1322,6 +1327,7 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
             P.chunks.push_back(ch);
         }
         P.bytes = off;
+        P.r_spec = r_spec;
         P.ok = true;
     });
     return &c->ec_plan;
@@ -1451,7 +1457,7 @@ static int early_pump(rv_shard* s) {
                                     e->plan->r_spec, hipMemcpyDeviceToHost, ctx->stream2));
         } else {
             if (!e->packed[k]) launch_pack_corr_all(ctx->stream2, s->d_pre, s->c->cc.n_pre, ch.byte0, ch.nbytes, ch.pitch, e->d_ec + ch.off);
-            HIPCHK(hipMemcpyAsync(e->h_ec + ch.off, e->d_ec + ch.off, (size_t)256 * ch.pitch, hipMemcpyDeviceToHost, ctx->stream2));
+            HIPCHK(hipMemcpyAsync(e->h_ec + ch.off, e->d_ec + ch.off, (size_t)e->plan->r_spec * ch.pitch, hipMemcpyDeviceToHost, ctx->stream2));
         }
         // (NO kernel or event behind the copy: a packet that waits for the copy engine's signal at the head of the second queue is
         // polled by the command processor between the first queue's level launches and costs the interpreter 0.15 - 0.2 ms per proof --
@@ -1851,8 +1857,8 @@ extern "C" int rv_shard_open_size(const rv_shard* s, const uint8_t omit[RV_TOTAL
 static int shard_open_impl(rv_shard* s, const uint8_t* omit /* NULL: device Fiat-Shamir */, void* dst, void** dptr, size_t lens[4],
                            bool framed = false, uint8_t* comm_out = nullptr, uint8_t* omit_out = nullptr, bool no_sync = false,
                            const uint8_t* d_all_h = nullptr /* device: all 256 digests (sharded proofs after the all-gather) */,
-                           uint32_t* fs_mailbox = nullptr, uint32_t fs_seq = 0, uint32_t corr64_rep_min = 0 /* Z64 early corrections: the Z64
-                           corrections vectors of repetitions below this one are not extracted either (GF(2) ones are then, as always) */);
+                           uint32_t* fs_mailbox = nullptr, uint32_t fs_seq = 0, uint32_t corr2_rep_min = 0, uint32_t corr64_rep_min = 0 /* early
+                           corrections: the GF(2) / Z64 corrections vectors of the repetitions below these are not extracted */);
 
 extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void** dptr, size_t lens[4]) {
     if (!omit) return RV_E_ARG;
@@ -1868,7 +1874,8 @@ extern "C" int rv_shard_open_into(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS]
 // `omit` == NULL: Fiat-Shamir on the device (k_fs_challenge) from the shard's own digests; only for a shard that
 // holds all 256 repetitions.  comm_out / omit_out (nullable) then receive comm and the opening map.
 static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** dptr, size_t lens[4], bool framed, uint8_t* comm_out,
-                           uint8_t* omit_out, bool no_sync, const uint8_t* d_all_h, uint32_t* fs_mailbox, uint32_t fs_seq, uint32_t corr64_rep_min) {
+                           uint8_t* omit_out, bool no_sync, const uint8_t* d_all_h, uint32_t* fs_mailbox, uint32_t fs_seq, uint32_t corr2_rep_min,
+                           uint32_t corr64_rep_min) {
     if (!s || !dptr || !lens) return RV_E_ARG;
     if (fs_mailbox && (omit || s->rep)) return RV_E_ARG;
     rv_ctx* ctx = s->ctx;
@@ -1963,7 +1970,7 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
         launch_rep_open(ctx->stream, s->d_on_rep, s->on_stride, s->c->d_in_rows, cc.n_in, 1, d_ol, s->d_omit, s->d_offs + 4 * s->R, d_out);
     } else if (any_on) {
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
-        if (!fs_mailbox || corr64_rep_min) launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out);
+        if (corr2_rep_min < s->R) launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out, corr2_rep_min);
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
         launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_rec_offs64, cc.n_rec64, 1, s->R, s->d_omit,
                          s->d_offs + 5 * s->R, d_out, d_ol);
@@ -2207,7 +2214,9 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         size_t lens[4];
         const uint32_t seq = er.seq;
         const bool z64 = er.plan->z64;
-        if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, nullptr, nullptr, /*no_sync=*/true, nullptr, fs_dev, seq, z64 ? er.plan->r_spec : 0))) break;
+        if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, nullptr, nullptr, /*no_sync=*/true, nullptr, fs_dev, seq, z64 ? 0 : er.plan->r_spec,
+                                  z64 ? er.plan->r_spec : 0)))
+            break;
         const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
         if (total != EL.total || er.packed.size() != er.plan->chunks.size() || er.plan->chunks.size() > 255) {
             rc = RV_E_DEVICE;
@@ -2217,8 +2226,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         // (Z64: only the records of the opened repetitions below r_spec -- the kernel counts them -- go without their vectors)
         const uint64_t corr_at = 145 + (z64 ? EL.l64r : EL.l2r);
         const uint64_t rec_first = z64 ? EL.base[2] : EL.base[0], rec_size = z64 ? EL.sz64 : EL.sz2, corr_len = z64 ? EL.l64c : EL.l2c;
-        launch_copy_gaps(ctx->stream, (const uint8_t*)d, out_dev, total, rec_first, rec_size, corr_at, corr_len, RV_ONLINE_REPS, s->d_omit,
-                         z64 ? er.plan->r_spec : RV_TOTAL_REPS);
+        launch_copy_gaps(ctx->stream, (const uint8_t*)d, out_dev, total, rec_first, rec_size, corr_at, corr_len, RV_ONLINE_REPS, s->d_omit, er.plan->r_spec);
         launch_store_word(ctx->stream, s->d_err, (int*)(fs_dev + 8));
         if (hipGetLastError() != hipSuccess) {
             rc = RV_E_DEVICE;

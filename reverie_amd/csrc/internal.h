@@ -232,7 +232,7 @@ struct OnlineList {
     uint64_t dst[RV_ONLINE_REPS];
 };
 void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint32_t NQ,
-                              const OnlineList* d_ol /* device */, uint8_t* d_out);
+                              const OnlineList* d_ol /* device */, uint8_t* d_out, uint32_t rep_min = 0 /* repetitions below it are left out */);
 // Fiat-Shamir on the device for a shard that holds all 256 repetitions (proof/mod.rs:68-108,158-175):
 // comm = BLAKE3(h[0..256)), the challenge map, and from it everything the opening kernels consume
 // (omit[256], the 8 x 256 output offsets, the OnlineList) without a host round trip.

@@ -1335,7 +1335,7 @@ __device__ __forceinline__ void ex_flush(const uint8_t* s_buf, const uint64_t* s
                                          uint8_t* __restrict__ out, uint32_t k0 = 0) {
     for (uint32_t idx = threadIdx.x + k0 * EX_TB; idx < n_slots * EX_TB; idx += blockDim.x) {
         const uint32_t k = idx / EX_TB, i = idx % EX_TB;
-        if (i < nb) out[s_dst[k] + t0 + i] = s_buf[k * EX_TB + i];
+        if (i < nb && s_dst[k] != ~0ull) out[s_dst[k] + t0 + i] = s_buf[k * EX_TB + i];  // (~0: a slot that is left out)
     }
 }
 
@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict
 // the workgroup's 8*tb rows are contiguous in HBM and are copied to LDS in one coalesced pass; thread =
 // (output byte, opened repetition) then picks its 8 bits out of LDS.
 struct B_k_extract_from_bits {
-    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const OnlineList* __restrict__ olp, uint8_t* __restrict__ out) const {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const OnlineList* __restrict__ olp, uint8_t* __restrict__ out, uint32_t rep_min) const {
     __shared__ uint8_t s_buf[RV_ONLINE_REPS * EX_TB];
     __shared__ uint64_t s_dst[RV_ONLINE_REPS];
     __shared__ uint32_t s_pos[RV_ONLINE_REPS];  // byte in the row << 3 | bit in the byte
@@ -1449,7 +1449,7 @@ struct B_k_extract_from_bits {
     }
     if (threadIdx.x < n_ol) {
         const uint32_t r = olp->rep[threadIdx.x];
-        s_dst[threadIdx.x] = olp->dst[threadIdx.x];
+        s_dst[threadIdx.x] = r < rep_min ? ~0ull : olp->dst[threadIdx.x];  // (early corrections: the host has the vectors of the repetitions below rep_min)
         s_pos[threadIdx.x] = ((r >> 3) << 3) | (4 * ((r >> 2) & 1) + 3 - (r & 3));
     }
     __syncthreads();
@@ -1479,8 +1479,8 @@ struct B_k_extract_from_bits {
     ex_flush(s_buf, s_dst, n_ol, t0, nb, out);
 }
 };
-__global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const OnlineList* __restrict__ olp, uint8_t* __restrict__ out) {
-    B_k_extract_from_bits{}(bits, n_items, NQ, tb, olp, out);
+__global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const OnlineList* __restrict__ olp, uint8_t* __restrict__ out, uint32_t rep_min) {
+    B_k_extract_from_bits{}(bits, n_items, NQ, tb, olp, out, rep_min);
 }
 
 static uint32_t ex_tb_for(uint64_t n_bytes) {
@@ -1492,11 +1492,11 @@ static uint32_t ex_tb_for(uint64_t n_bytes) {
 }
 
 void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint32_t NQ, const OnlineList* d_ol,
-                              uint8_t* d_out) {
+                              uint8_t* d_out, uint32_t rep_min) {
     const uint64_t n_bytes = n_items / 8 + 1;
     const uint32_t tb = ex_tb_for(n_bytes);
     launch<B_k_extract_from_bits, 256>(k_extract_from_bits, st, dim3((unsigned)((n_bytes + tb - 1) / tb)), dim3(256), d_bits, n_items, NQ, tb, d_ol,
-                       d_out);
+                       d_out, rep_min);
 }
 
 // ------------------------------------------------------------------------------------

@@ -303,11 +303,14 @@ def test_early_plan_host(L, monkeypatch):
 
 def test_early_plan_pcie_window(L, monkeypatch):
     """A few very wide all-AND levels: 32 bytes per Mul for all repetitions do not fit through PCIe in the time the levels and the
-    hashes are estimated to take -- the plan is refused (RV_EARLY=2 takes it regardless)."""
+    hashes are estimated to take -- the plan stages fewer repetitions (RV_EARLY=2 takes all, or RV_EARLY_REPS)."""
     monkeypatch.setenv("RV_EARLY_MIN", "1000")
     prog, _, wc, st = circuits.layered_gf2(n_in=64, width=1 << 20, layers=4, p_and=1.0, fold_to=16)
     assert st["and"] == 4 << 20
-    assert not early_plan(L, prog, wc)["ok"]
+    p = early_plan(L, prog, wc)
+    assert p["ok"] and p["check"] and 64 <= p["reps"] < 256 and p["reps"] % 8 == 0, p
     monkeypatch.setenv("RV_EARLY", "2")
     p = early_plan(L, prog, wc)
-    assert p["ok"] and p["check"], p
+    assert p["ok"] and p["check"] and p["reps"] == 256, p
+    monkeypatch.setenv("RV_EARLY_REPS", "96")
+    assert early_plan(L, prog, wc)["reps"] == 96

@@ -1223,8 +1223,13 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
     # (the last case is mostly XOR: its outputs still depend on the inputs after 80 layers, so a flipped witness bit is caught)
     cases = [(64, 8192, 40, 0.5, "10", 16), (37, 4736, 70, 0.6, "3", 37), (64, 8192, 36, 1.0, "1", 16), (128, 16384, 24, 0.5, "16", 16),
              (64, 16384, 80, 0.1, "4", 16)]
-    for n_in, width, layers, p_and, chunks, fold_to in cases:
+    for case_no, (n_in, width, layers, p_and, chunks, fold_to) in enumerate(cases):
         monkeypatch.setenv("RV_EARLY_CHUNKS", chunks)
+        # (cases 1 and 3: only the first 96 / 200 repetitions are staged, the opened ones beyond them take the plain way)
+        if case_no in (1, 3):
+            monkeypatch.setenv("RV_EARLY_REPS", "96" if case_no == 1 else "200")
+        else:
+            monkeypatch.delenv("RV_EARLY_REPS", raising=False)
         monkeypatch.setenv("RV_EARLY", "2")
         prog, wit, wc, st = circuits.layered_gf2(n_in=n_in, width=width, layers=layers, p_and=p_and, fold_to=fold_to)
         want = oracle.prove(prog, wit, [], wc, rule_seeds, threads=4)
