@@ -495,7 +495,7 @@ def main():
             sk = json.load(open(sq_path))["kernels"]
             peak_issue = 1024 * 0.5 * 2.4e9
             valu = {"peak": peak_issue, "unit": "wavefront VALU instructions/s", "kernels": {}}
-            for phase, prefixes in (("masks", ("rv::k_aes_gf2_masks<",)), ("hash", ("rv::k_b3_chunks<", "rv::k_b3_chunks_bits", "rv::k_b3_reduce<", "rv::k_b3_tree_tail"))):
+            for phase, prefixes in (("masks", ("rv::k_aes_gf2_masks<",)), ("hash", ("rv::k_b3_chunks<", "rv::k_b3_chunks_uni", "rv::k_b3_chunks_bits", "rv::k_b3_reduce<", "rv::k_b3_tree_tail"))):
                 insts = sum(v.get("SQ_INSTS_VALU_per_proof", 0.0) for k, v in sk.items() if k.startswith(prefixes))
                 if insts and phases[phase] > 0:
                     valu["kernels"][phase] = {"kernels": [k for k in sk if k.startswith(prefixes)], "valu_insts_per_proof": insts,

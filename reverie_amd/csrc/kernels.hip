@@ -716,7 +716,10 @@ void launch_interp_narrow_batched(hipStream_t st, const Gate* d_gates, const Lev
 // RPL = repetitions per lane (4: one lane per quad word; 1: four lanes share a quad word).  Fewer
 // repetitions per lane = more, lighter wavefronts: 4 900 chunks x 64 lanes is only 1.6 rounds of the
 // chip at 3 waves/SIMD (40 % of the time is tail), RPL = 1 gives 19 600 waves at 7+ waves/SIMD.
-template <int RPL>
+// UNI (RPL = 4, full-width rows, no quad list: the prover's whole proofs): a chunk per wavefront, lane = quad word.  The chunk index
+// is then wave-uniform BY CONSTRUCTION, so a block's 64 row loads take a scalar base and one shared 32-bit lane offset instead of
+// 64 vector address computations (128 of ~3 200 VALU instructions per block).
+template <int RPL, bool UNI = false>
 struct B_k_b3_chunks {
     // quads (nullable) / n_quads: only these quad words are hashed -- the verifier needs the online digest of the 40
     // opened repetitions alone (the other 216 carry theirs in the proof), i.e. of at most 40 of the 64 quads
@@ -727,10 +730,12 @@ struct B_k_b3_chunks {
     }
     static __device__ __forceinline__ void run(uint64_t tid, const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, const uint32_t* __restrict__ quads, uint32_t n_quads, uint64_t chunk_base, uint32_t root_ok) {
     constexpr uint32_t SUBS = 4 / RPL;
-    const uint32_t lanes_per_chunk = (quads ? n_quads : NQ) * SUBS;
-    const uint64_t c = tid / lanes_per_chunk;
+    static_assert(!UNI || RPL == 4, "a chunk per wavefront needs one lane per quad word");
+    const uint32_t lanes_per_chunk = UNI ? 64u : (quads ? n_quads : NQ) * SUBS;
+    uint64_t c = tid / lanes_per_chunk;
+    if (UNI) c = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)c) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32);
     const uint32_t ql = (uint32_t)(tid % lanes_per_chunk);
-    const uint32_t q = quads ? quads[ql / SUBS] : ql / SUBS, sub = ql % SUBS;
+    const uint32_t q = UNI ? ql : (quads ? quads[ql / SUBS] : ql / SUBS), sub = ql % SUBS;
     if (c >= n_chunks) return;
     const uint64_t ev0 = c * 1024;
     const uint64_t len = (n_events - ev0 < 1024) ? (n_events - ev0) : 1024;
@@ -747,8 +752,15 @@ struct B_k_b3_chunks {
         if (blen == 64) {
             // unguarded: a per-element "load or zero" select makes hipcc branch around every load and
             // wait for it (64 dependent round trips per block)
+            if (UNI) {
+                const char* rb = (const char*)(stream + e0 * 64);
+                const uint32_t qoff = q * 4u;
 #pragma unroll
-            for (int e = 0; e < 64; e++) w[e] = stream[(e0 + e) * NQ + q];
+                for (int e = 0; e < 64; e++) w[e] = *(const uint32_t*)(rb + e * 256 + qoff);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 64; e++) w[e] = stream[(e0 + e) * NQ + q];
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 64; e++) w[e] = (e0 + e < n_events) ? stream[(e0 + e) * NQ + q] : 0u;
@@ -781,19 +793,25 @@ template <int RPL>
 __global__ __launch_bounds__(256) void k_b3_chunks(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/, const uint32_t* __restrict__ quads, uint32_t n_quads, uint64_t chunk_base, uint32_t root_ok) {
     B_k_b3_chunks<RPL>{}(stream, n_events, NQ, n_chunks, cvs, quads, n_quads, chunk_base, root_ok);
 }
+__global__ __launch_bounds__(256) void k_b3_chunks_uni(const uint32_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs /*[n_chunks][R][8]*/, const uint32_t* __restrict__ quads, uint32_t n_quads, uint64_t chunk_base, uint32_t root_ok) {
+    B_k_b3_chunks<4, true>{}(stream, n_events, NQ, n_chunks, cvs, quads, n_quads, chunk_base, root_ok);
+}
 
 // Same for a bit-per-rep transcript (the preprocessing stream): every bit is hashed as the
 // 0x00/0xFF byte the reference feeds its hasher (gf2/recon.rs:314-321).
 // RPL as in k_b3_chunks: 4 = one lane per quad word, 1 = four lanes share it (short transcripts: more, lighter wavefronts)
-template <int RPL>
+template <int RPL, bool UNI = false>
 struct B_k_b3_chunks_bits {
     __device__ __forceinline__ void operator()(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) const {
     run((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stream, n_events, NQ, n_chunks, cvs, chunk_base, root_ok);
     }
     static __device__ __forceinline__ void run(uint64_t tid, const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) {
     constexpr uint32_t SUBS = 4 / RPL;
-    const uint64_t c = tid / (NQ * SUBS);
-    const uint32_t ql = (uint32_t)(tid % (NQ * SUBS));
+    static_assert(!UNI || RPL == 4, "a chunk per wavefront needs one lane per quad word");
+    const uint32_t lanes_per_chunk = UNI ? 64u : NQ * SUBS;  // (UNI: NQ = 64, see B_k_b3_chunks)
+    uint64_t c = tid / lanes_per_chunk;
+    if (UNI) c = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)c) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32);
+    const uint32_t ql = (uint32_t)(tid % lanes_per_chunk);
     const uint32_t q = ql / SUBS, sub = ql % SUBS;
     if (c >= n_chunks) return;
     const uint64_t ev0 = c * 1024;
@@ -812,8 +830,14 @@ struct B_k_b3_chunks_bits {
         uint32_t m[RPL][16];
         uint32_t nbs[64];
         if (blen == 64) {
+            if (UNI) {
+                const uint8_t* rb = stream + e0 * 32;
 #pragma unroll
-            for (int e = 0; e < 64; e++) nbs[e] = stream[(e0 + e) * h + o];
+                for (int e = 0; e < 64; e++) nbs[e] = *(rb + e * 32 + o);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 64; e++) nbs[e] = stream[(e0 + e) * h + o];
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 64; e++) nbs[e] = (e0 + e < n_events) ? (uint32_t)stream[(e0 + e) * h + o] : 0u;
@@ -843,6 +867,9 @@ struct B_k_b3_chunks_bits {
 };
 __global__ __launch_bounds__(256) void k_b3_chunks_bits(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) {
     B_k_b3_chunks_bits<4>{}(stream, n_events, NQ, n_chunks, cvs, chunk_base, root_ok);
+}
+__global__ __launch_bounds__(256) void k_b3_chunks_bits_uni(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) {
+    B_k_b3_chunks_bits<4, true>{}(stream, n_events, NQ, n_chunks, cvs, chunk_base, root_ok);
 }
 __global__ __launch_bounds__(256) void k_b3_chunks_bits1(const uint8_t* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs, uint64_t chunk_base, uint32_t root_ok) {
     B_k_b3_chunks_bits<1>{}(stream, n_events, NQ, n_chunks, cvs, chunk_base, root_ok);
@@ -1109,6 +1136,8 @@ void launch_b3_stream_chunks(hipStream_t st, const uint32_t* d_stream, uint64_t 
     // one repetition per lane gives four times the wavefronts, each a quarter as long
     if ((d_quads && n_quads * 4 <= NQ) || threads * (g_recorder ? g_recorder->batch : 1u) < b3_rpl1_lanes())
         launch<B_k_b3_chunks<1>, 256>(k_b3_chunks<1>, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv, d_quads, n_quads, chunk_base, root_ok);
+    else if (RV_B3_RPL == 4 && NQ == 64 && !d_quads)
+        launch<B_k_b3_chunks<4, true>, 256>(k_b3_chunks_uni, st, dim3((unsigned)((threads + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv, d_quads, n_quads, chunk_base, root_ok);
     else
         launch<B_k_b3_chunks<RV_B3_RPL>, 256>(k_b3_chunks<RV_B3_RPL>, st, dim3((unsigned)((threads * (4 / RV_B3_RPL) + 255) / 256)), dim3(256), d_stream, n_events, NQ, n, d_cv, d_quads, n_quads, chunk_base, root_ok);
 }
@@ -1130,6 +1159,9 @@ void launch_b3_stream_bits_chunks(hipStream_t st, const uint8_t* d_stream, uint6
     if (threads * (g_recorder ? g_recorder->batch : 1u) < b3_rpl1_lanes())
         launch<B_k_b3_chunks_bits<1>, 256>(k_b3_chunks_bits1, st, dim3((unsigned)((threads * 4 + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
                                            d_cv, chunk_base, root_ok);
+    else if (NQ == 64)
+        launch<B_k_b3_chunks_bits<4, true>, 256>(k_b3_chunks_bits_uni, st, dim3((unsigned)((threads + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
+                                                 d_cv, chunk_base, root_ok);
     else
         launch<B_k_b3_chunks_bits<4>, 256>(k_b3_chunks_bits, st, dim3((unsigned)((threads + 255) / 256)), dim3(256), d_stream, n_events, NQ, n,
                                            d_cv, chunk_base, root_ok);
