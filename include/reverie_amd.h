@@ -114,6 +114,7 @@ enum {
     RV_PH_JOIN = 4,   /* k_join                                                        */
     RV_PH_OPEN = 5,   /* k_fs_challenge + k_open_headers + k_extract_rows / k_extract_from_bits / k_extract64 */
     RV_PH_EARLY = 6,  /* launches only (their time is inside RV_PH_INTERP): k_pack_corr_all + k_publish of rv_prove's early-corrections path */
+    RV_PH_CLEAR = 7,  /* k_clear of the flat prover schedule: runs on a stream of its own beside the mask generator (its time is not part of a proof's critical path unless it outlasts RV_PH_MASKS) */
     RV_PH_COUNT = 8
 };
 typedef struct rv_profile {
@@ -484,6 +485,15 @@ uint64_t rv_hook_early_proofs(void);
  * after a chunk's ready level writes one of its rows and the ready level itself does, [6 + k] = chunk k's ready level (k < 16).
  * Returns the compiler's status. */
 int rv_hook_early_plan(const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, uint64_t out[22]);
+/* The flat prover schedule of a program (host only, no device; csrc/flat.h: the Mul gates of a pure GF(2) circuit in program
+ * order behind its XOR rows, instead of one launch per dependency level -- what rv_prove runs for whole proofs and repetition
+ * shards of eligible circuits; RV_FLAT=0 turns it off, proof bytes are the same either way).  out[0] = eligible (0 / 1),
+ * [1] = Mul records, [2] = XOR gates, [3] = x-levels, [4] = Input / AssertZero gates, [5] = 1 when the plan checks against the
+ * level-sorted gate stream (every gate present once, every XOR gate behind the XOR rows it reads, Mul record i = the gate with
+ * preprocessing row i), [6] = the circuit's dependency levels, [7] = bands (`bands` asked for: equal ranges of the
+ * program's Mul gates, each with the XOR rows no earlier band needed), [8 + k] = x-levels of band k (k < 16).
+ * Returns the compiler's status. */
+int rv_hook_flat_plan(const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, uint32_t bands, uint64_t out[24]);
 
 #ifdef __cplusplus
 }

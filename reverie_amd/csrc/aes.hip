@@ -596,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void k_aes_z64_masks(const uint32_t* __rest
 
 template <int QW>
 static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
-                            uint64_t n_blocks, uint32_t* d_masks) {
+                            uint64_t n_blocks, uint32_t* d_masks, uint32_t reserve_cus) {
     const uint32_t n_qg = NQ / QW;
     constexpr uint32_t JW = 64 / QW;
     // Target workgroup count: a workgroup takes a whole CU (88 KiB LDS, 512 x 256 registers), so ONE workgroup per CU
@@ -612,7 +612,8 @@ static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t
     // recorded for a batch of proofs (rv_prove_batch): the batch supplies the parallelism, so a proof's share of the
     // chip is its 1/batch of the workgroups, at least one per quad group -- each workgroup fills 88 KiB of LDS with
     // round keys before its first block
-    const uint64_t wgs = g_recorder ? std::max<uint64_t>(n_qg, target_wgs / std::max(g_recorder->batch, 1u)) : target_wgs;
+    const uint64_t wgs = g_recorder ? std::max<uint64_t>(n_qg, target_wgs / std::max(g_recorder->batch, 1u))
+                                    : (target_wgs > 2 * (uint64_t)reserve_cus ? target_wgs - reserve_cus : target_wgs);
     uint64_t per = (n_blocks * n_qg + wgs - 1) / wgs;
     per = ((per + 8 * JW - 1) / (8 * JW)) * (8 * JW);
     const uint64_t chunks = (n_blocks + per - 1) / per;
@@ -621,14 +622,14 @@ static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t
 }
 
 void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
-                          uint64_t n_blocks, uint32_t* d_masks) {
+                          uint64_t n_blocks, uint32_t* d_masks, uint32_t reserve_cus) {
     if (!n_blocks) return;
     if (NQ % 16 == 0)
-        launch_masks_qw<16>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
+        launch_masks_qw<16>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks, reserve_cus);
     else if (NQ % 8 == 0)
-        launch_masks_qw<8>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
+        launch_masks_qw<8>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks, reserve_cus);
     else
-        launch_masks_qw<2>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
+        launch_masks_qw<2>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks, reserve_cus);
 }
 template <int QW>
 static void launch_z64_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks,

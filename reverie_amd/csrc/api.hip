@@ -20,6 +20,7 @@
 
 #include "b3.h"
 #include "compile.h"
+#include "flat.h"
 #include "internal.h"
 #include "launch.h"
 #include "repprog.h"
@@ -133,6 +134,10 @@ struct rv_ctx {
     size_t lds_bytes = 0;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     hipStream_t stream = nullptr;   // setup, AES masks, hashing, openings (VALU-heavy work)
     hipStream_t stream2 = nullptr;  // the interpreter (HBM-bound), pipelined against the mask generator
+    hipStream_t stream3 = nullptr;  // the flat schedule's cleartext pass (k_clear), beside the mask generator
+    hipStream_t stream_x = nullptr; // the flat schedule's XOR rows, running ahead of the Mul launches on `stream`
+    hipEvent_t clear_a = nullptr, clear_b = nullptr;  // profiling: around k_clear on stream3 (rv_profile slot RV_PH_CLEAR)
+    bool clear_timed = false;
     std::vector<rv_ctx*> workers;            // rv_prove_batch on large circuits: one worker context per host thread
     bool pipeline = false;          // RV_PIPELINE=1: mask generator and interpreter on two streams, chunk-wise (measured slower: DESIGN.md)
     // Small proofs (AES-128: 99 KB) leave through this page-locked, device-mapped buffer: the opening kernels write into it
@@ -240,6 +245,12 @@ struct rv_ctx {
             if (hipEventElapsedTime(&ms, m.a, m.b) == hipSuccess) prof.ms[m.phase] += ms;
             prof.launches[m.phase] += m.launches;
         }
+        if (clear_timed) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, clear_a, clear_b) == hipSuccess) prof.ms[RV_PH_CLEAR] += ms;
+            prof.launches[RV_PH_CLEAR]++;
+            clear_timed = false;
+        }
         for (auto& kv : ev_refs) ev_pool.push_back(kv.first);  // (an event may be the end of one mark and the start of the next)
         ev_refs.clear();
         marks.clear();
@@ -318,8 +329,17 @@ extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
         set_device_lds_limit(c->lds_bytes);
     }
     if (const char* e = getenv("RV_PIPELINE")) c->pipeline = atoi(e) != 0;
-    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // The runtime multiplexes the streams of one priority over four hardware queues (a fifth stream would share the first one's),
+    // and a queue that issues short kernels back to back keeps the dispatcher from a queue of the same or a lower priority.  The
+    // main stream therefore gets the high priority (RV_MAIN_PRIO=0: all streams alike): its long kernels go out the moment their
+    // dependencies are met, and the flat schedule's short XOR launches (stream_x) fill in beside them.
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0, (void)hipGetLastError();
+    static const bool main_prio = !(getenv("RV_MAIN_PRIO") && atoi(getenv("RV_MAIN_PRIO")) == 0);
+    hipError_t se = main_prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete c;
         return hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
@@ -335,6 +355,8 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipStreamSynchronize(ctx->stream3);
+    (void)hipStreamSynchronize(ctx->stream_x);
     ctx->trim();
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -348,6 +370,10 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     for (rv_ctx* w : ctx->workers) rv_ctx_destroy(w);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
+    (void)hipStreamDestroy(ctx->stream3);
+    (void)hipStreamDestroy(ctx->stream_x);
+    if (ctx->clear_a) (void)hipEventDestroy(ctx->clear_a);
+    if (ctx->clear_b) (void)hipEventDestroy(ctx->clear_b);
     delete ctx;
     pinned_pool_trim();
 }
@@ -526,7 +552,32 @@ struct rv_circuit {
     LdsRec* d_lds_recs = nullptr;
     mutable std::once_flag ec_once;
     mutable EarlyPlan ec_plan;
+    // flat prover schedule (flat.h): present when the circuit is eligible (the big vectors live on the device only)
+    FlatPlan flat;
+    Gate* d_xgates = nullptr;
+    MulRec* d_muls = nullptr;
+    Gate* d_others = nullptr;
+    uint32_t n_others = 0;
+    ClearRec* d_clear_s = nullptr;
+    ClearRecK* d_clear_k = nullptr;
+    ClearLevel* d_clear_levels = nullptr;
 };
+
+// RV_FLAT: 0 = the level-synchronous interpreter everywhere; 1 (default) = the flat schedule for the prover of eligible circuits
+// of at least RV_FLAT_MIN gates (2^20: below, the cleartext pass does not hide behind the mask generator); 2 = for every eligible
+// circuit.  Read at every call (tests switch it).
+static int flat_mode() {
+    const char* e = getenv("RV_FLAT");
+    return e ? atoi(e) : 1;
+}
+// workgroups of the cleartext pass = compute units the mask generator leaves free for them
+static uint32_t clear_wgs() {
+    static const uint32_t v = [] {
+        const char* e = getenv("RV_CLEAR_WGS");
+        return e ? (uint32_t)std::min(std::max(atoi(e), 1), 64) : 8u;
+    }();
+    return v;
+}
 
 // LDS the rep-sliced interpreter may use for wire slots (a workgroup owns the CU: 160 KiB minus a little headroom)
 static uint32_t rep_lds_budget(const rv_ctx* ctx) {
@@ -852,6 +903,30 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         c->vclr_ok = cc.gates64.empty() && narrow_levels <= 16 && !cc.row_prg_base;
     }
     if (cc.n_random_or_recon) c->vclr_ok = false;  // (values that differ between repetitions)
+    if (c->vclr_ok && flat_mode()) {
+        // the flat schedule of the prover: Mul records in program order, XOR rows by x-level, the rest
+        static const uint64_t flat_min = getenv("RV_FLAT_MIN") ? (uint64_t)atoll(getenv("RV_FLAT_MIN")) : (1ull << 20);
+        const uint32_t bands = getenv("RV_FLAT_BANDS") ? (uint32_t)std::max(atoi(getenv("RV_FLAT_BANDS")), 1) : 8u;
+        if ((flat_mode() >= 2 || cc.gates.size() >= flat_min) && build_flat_plan(cc, c->flat, bands)) {
+            c->n_others = (uint32_t)c->flat.others.size();
+            if ((rc = up(c->flat.xgates.data(), c->flat.xgates.size() * sizeof(Gate), (void**)&c->d_xgates)) ||
+                (rc = up(c->flat.muls.data(), c->flat.muls.size() * sizeof(MulRec), (void**)&c->d_muls)) ||
+                (rc = up(c->flat.others.data(), c->flat.others.size() * sizeof(Gate), (void**)&c->d_others)) ||
+                (rc = up(c->flat.clear_s.data(), c->flat.clear_s.size() * sizeof(ClearRec), (void**)&c->d_clear_s)) ||
+                (rc = up(c->flat.clear_k.data(), c->flat.clear_k.size() * sizeof(ClearRecK), (void**)&c->d_clear_k)) ||
+                (rc = up(c->flat.clear_levels.data(), c->flat.clear_levels.size() * sizeof(ClearLevel), (void**)&c->d_clear_levels))) {
+                rv_circuit_destroy(c);
+                return rc;
+            }
+            UPCHK(hipStreamSynchronize(ctx->stream));
+            decltype(c->flat.xgates)().swap(c->flat.xgates);  // the device holds them now
+            decltype(c->flat.muls)().swap(c->flat.muls);
+            std::vector<Gate>().swap(c->flat.others);
+            decltype(c->flat.clear_s)().swap(c->flat.clear_s);
+            decltype(c->flat.clear_k)().swap(c->flat.clear_k);
+            std::vector<ClearLevel>().swap(c->flat.clear_levels);
+        }
+    }
     return RV_OK;
 #undef UPCHK
 }
@@ -870,6 +945,12 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     c->ctx->release(c->d_rep_segs);
     c->ctx->release(c->d_rep_recs);
     c->ctx->release(c->d_lds_recs);
+    c->ctx->release(c->d_xgates);
+    c->ctx->release(c->d_muls);
+    c->ctx->release(c->d_others);
+    c->ctx->release(c->d_clear_s);
+    c->ctx->release(c->d_clear_k);
+    c->ctx->release(c->d_clear_levels);
     delete c;
 }
 
@@ -1017,6 +1098,11 @@ struct rv_shard {
     uint8_t* d_pre = nullptr;     // [n_pre][NQ/2]
     uint8_t* d_wit = nullptr;
     uint8_t* d_vclr = nullptr;  // MODE_PROVE_V: cleartext value per share row
+    // flat schedule (flat.h): operand values per Mul, the cleartext pass's barrier words {arrivals, abort, error word}, its end
+    bool flat = false;
+    uint8_t* d_vb = nullptr;
+    uint32_t* d_sync = nullptr;
+    hipEvent_t ev_clear = nullptr;
     // rep-sliced prover path (rep.hip): rep-major masks / transcripts instead of the row arrays above
     bool rep = false;
     uint8_t *d_masks_rep = nullptr, *d_on_rep = nullptr, *d_pre_rep = nullptr, *d_vbits = nullptr;
@@ -1055,9 +1141,11 @@ struct rv_shard {
         misc_events.clear();
         if (ev_setup) ctx->sync_pool.push_back(ev_setup);
         ev_setup = nullptr;
+        if (ev_clear) ctx->sync_pool.push_back(ev_clear);
+        ev_clear = nullptr;
         void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk,    d_masks,  d_wires,   d_on,     d_pre,    d_wit,  d_cv[0],
                       d_cv[1], d_dig,  d_h,       d_err,   d_omit,   d_offs,    d_out,    d_masks64, d_wmask64,
-                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr};
+                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr, d_vb, d_sync};
         for (void* p : ps) ctx->release(p);
         for (void* p : extra) ctx->release(p);
     }
@@ -1069,6 +1157,10 @@ extern "C" void rv_shard_destroy(rv_shard* s) {
     // work forked onto the second stream (the verifier's side copy of the proof, the two-stream pipeline): its buffers go back to
     // the arena below and the caller's host buffers leave scope -- nothing of it may still be in flight
     if (!s->misc_events.empty() || !s->mask_chunks.empty() || s->ev_setup || s->ec) (void)hipStreamSynchronize(s->ctx->stream2);
+    if (s->ev_clear) {
+        (void)hipStreamSynchronize(s->ctx->stream3);
+        (void)hipStreamSynchronize(s->ctx->stream_x);
+    }
     s->destroy();
     delete s;
 }
@@ -1114,7 +1206,7 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
         const uint64_t target = ctx->pipeline ? std::max<uint64_t>((n_blocks + 11) / 12, 2048) : std::max<uint64_t>(n_blocks, 1);
         for (uint64_t b0 = 0; b0 < n_blocks; b0 += target) {
             const uint64_t nb = std::min(target, n_blocks - b0);
-            launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, b0, nb, s->d_masks + (size_t)b0 * 128 * s->NQ);
+            launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, b0, nb, s->d_masks + (size_t)b0 * 128 * s->NQ, s->flat ? clear_wgs() : 0);
             ctx->count();
             if (ctx->pipeline) {
                 hipEvent_t e = ctx->get_sync_event();
@@ -1386,6 +1478,74 @@ extern "C" int rv_hook_early_plan(const rv_op* ops, size_t n_ops, size_t z64_wir
     }
 }
 
+// Host-only view of the flat prover schedule (tests; csrc/flat.h): built as circuit_upload builds it, then replayed against the
+// level-sorted gate stream it was made from.
+extern "C" int rv_hook_flat_plan(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, uint32_t bands, uint64_t out[24]) {
+    if (!out || (n_ops && !ops) || (flags & ~RV_COMPILE_WHOLE_PROVER)) return RV_E_ARG;
+    try {
+        Compiled cc;
+        int rc = compile_ops(ops, n_ops, z64_wires, gf2_wires, cc, nullptr, ((flags & RV_COMPILE_WHOLE_PROVER) && !getenv("RV_LAZY_K")) ? RV_LIN_K : 0);
+        if (rc) return rc;
+        for (int i = 0; i < 24; i++) out[i] = 0;
+        FlatPlan P;
+        if (!build_flat_plan(cc, P, bands)) return RV_OK;
+        out[0] = 1, out[1] = P.muls.size(), out[2] = P.xgates.size(), out[3] = P.xlevels.size(), out[4] = P.others.size();
+        out[6] = P.n_clear_levels, out[7] = P.bands.size();
+        for (size_t k = 0; k < P.bands.size() && k < 16; k++) out[8 + k] = P.bands[k].x1 - P.bands[k].x0;
+        bool good = P.muls.size() + P.xgates.size() + P.others.size() == cc.gates.size() && !P.bands.empty();
+        // replay: band after band, its x-levels in order, then its Mul range -- every computed row a gate reads must have been
+        // written by an EARLIER launch, and is written exactly once
+        std::vector<uint8_t> written(cc.n_rows - cc.zero_row, 0);  // 1: by an earlier launch, 2: by the launch in progress
+        auto row_ready = [&](uint32_t row) { return row <= cc.zero_row || written[row - cc.zero_row] == 1; };
+        uint32_t x_next = 0, mul_next = 0;
+        for (const auto& B : P.bands) {
+            if (!good) break;
+            good = B.x0 == x_next && B.x1 >= B.x0 && B.x1 <= P.xlevels.size() && B.mul0 == mul_next && B.mul1 >= B.mul0 && B.mul1 <= P.muls.size() &&
+                   B.mul0 % 1024 == 0;
+            if (!good) break;
+            for (uint32_t l = B.x0; l < B.x1 && good; l++) {
+                const LevelRange& r = P.xlevels[l];
+                good = r.lo == r.mul && r.xork == r.hi && (l == 0 ? r.lo == 0 : r.lo == P.xlevels[l - 1].hi) && r.hi > r.lo;
+                for (uint32_t i = r.lo; i < r.hi && good; i++) {
+                    const Gate& g = P.xgates[i];
+                    good = g_op(g) == G_XORK && g.dst > cc.zero_row && !written[g.dst - cc.zero_row] && (g_na(g) == 2 && g_nb(g) == 0) == (i < r.xor2);
+                    for (int k = 0; k < RV_LIN_K && good; k++) good = row_ready(g.a[k]) && row_ready(g.b[k]);
+                    if (good) written[g.dst - cc.zero_row] = 2;
+                }
+                for (uint32_t i = r.lo; i < r.hi && good; i++) written[P.xgates[i].dst - cc.zero_row] = 1;
+            }
+            for (uint32_t i = B.mul0; i < B.mul1 && good; i++)
+                for (int k = 0; k < RV_LIN_K && good; k++) good = row_ready(P.muls[i].a[k]) && row_ready(P.muls[i].b[k]);
+            x_next = B.x1, mul_next = B.mul1;
+        }
+        good = good && x_next == P.xlevels.size() && mul_next == P.muls.size() &&
+               (P.xlevels.empty() || P.xlevels.back().hi == P.xgates.size());
+        for (const Gate& g : P.others)
+            for (int k = 0; k < RV_LIN_K && good; k++) good = row_ready(g.a[k]);  // (AssertZero rows: behind every band)
+        // Mul record i is the Mul gate with preprocessing row i, field by field
+        size_t n_mul = 0, n_oth = 0;
+        for (const Gate& g : cc.gates) {
+            if (!good) break;
+            const uint32_t op = g_op(g);
+            if (op == G_MUL) {
+                const MulRec& r = P.muls[g.ep];
+                good = r.m == g.m && (r.eo_flags & MULREC_EO_MASK) == g.eo && ((r.eo_flags >> 30) & 1u) == g_ca(g) && (r.eo_flags >> 31) == g_cb(g) &&
+                       ((r.eo_flags >> 26) & 3u) == std::max(g_na(g), 1u) - 1 && ((r.eo_flags >> 28) & 3u) == std::max(g_nb(g), 1u) - 1;
+                for (int k = 0; k < RV_LIN_K; k++) good = good && r.a[k] == g.a[k] && r.b[k] == g.b[k];
+                n_mul++;
+            } else if (op != G_XORK) {
+                n_oth++;
+            }
+        }
+        good = good && n_mul == P.muls.size() && n_oth == P.others.size();
+        out[5] = good;
+        return RV_OK;
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
+}
+
 // Early corrections, device side.  early_flush (called by the level loop) puts, behind the level that completes a chunk, the
 // packing kernel and a stamp kernel into the interpreter's own stream; the host -- idle once a proof is queued -- sees the
 // stamp in the mapped mailbox and hands the chunk's copy to the second stream (early_pump), which therefore only ever
@@ -1404,15 +1564,13 @@ extern "C" int rv_hook_early_plan(const rv_op* ops, size_t n_ops, size_t z64_wir
 //    processor between the first queue's level launches, and the 163 launches paid 0.2 ms for it (interpreter phase 2.40 - 2.45 ms
 //    against 2.17 - 2.2 now; tools/copy_beside.py: copy-engine transfers alone beside the levels cost 0.03 ms).  The host waits for
 //    the stream itself after the challenge -- a signal wait on the host side, no packet.
-static int early_flush(rv_shard* s, size_t levels_queued) {
+static int early_flush_chunks(rv_shard* s, size_t last) {
     EarlyRun* e = s->ec;
     rv_ctx* ctx = s->ctx;
     const auto& chunks = e->plan->chunks;
-    if (e->next >= chunks.size() || chunks[e->next].ready_level >= levels_queued) return RV_OK;
+    if (e->next >= chunks.size() || last <= e->next) return RV_OK;
     static const int pack_stream = getenv("RV_EARLY_PACK_STREAM") ? atoi(getenv("RV_EARLY_PACK_STREAM")) : 1;  // 1: every chunk in-stream, 0: the last one, 2: none
     const size_t first = e->next;
-    size_t last = first;
-    while (last < chunks.size() && chunks[last].ready_level < levels_queued) last++;
     for (size_t k = first; k < last; k++) {
         const bool in_stream = pack_stream == 1 || (pack_stream != 2 && k + 1 == chunks.size());
         const auto& ch = chunks[k];
@@ -1431,6 +1589,23 @@ static int early_flush(rv_shard* s, size_t levels_queued) {
     if (ctx->profiling) ctx->prof.launches[RV_PH_EARLY]++;
     e->next = last;
     return RV_OK;
+}
+// level-synchronous schedule: the chunks whose preprocessing rows are final once `levels_queued` levels are in the stream
+static int early_flush(rv_shard* s, size_t levels_queued) {
+    EarlyRun* e = s->ec;
+    const auto& chunks = e->plan->chunks;
+    if (e->next >= chunks.size() || chunks[e->next].ready_level >= levels_queued) return RV_OK;
+    size_t last = e->next;
+    while (last < chunks.size() && chunks[last].ready_level < levels_queued) last++;
+    return early_flush_chunks(s, last);
+}
+// flat schedule: the chunks that lie inside the first `muls_queued` Mul gates of the program (preprocessing row = Mul ordinal)
+static int early_flush_muls(rv_shard* s, uint64_t muls_queued) {
+    EarlyRun* e = s->ec;
+    const auto& chunks = e->plan->chunks;
+    size_t last = e->next;
+    while (last < chunks.size() && std::min<uint64_t>(8 * (chunks[last].byte0 + chunks[last].nbytes), s->c->cc.n_pre) <= muls_queued) last++;
+    return early_flush_chunks(s, last);
 }
 
 // host side: waits for every chunk's stamp in turn and queues its packing kernel (unless done), its copy to the host and the
@@ -1466,7 +1641,70 @@ static int early_pump(rv_shard* s) {
     return RV_OK;
 }
 
+// The flat schedule (flat.h): band after band the XOR rows x-level by x-level, then the band's Mul gates in program order;
+// the Input / AssertZero transcript rows behind the last band.  The cleartext pass (queued on stream3 at commit time) must
+// have ended before the first Mul launch.
+static int shard_run_flat(rv_shard* s, const InterpParams& p) {
+    rv_ctx* ctx = s->ctx;
+    const rv_circuit* c = s->c;
+    const FlatPlan& F = c->flat;
+    hipStream_t st = ctx->stream;
+    // RV_FLAT_XSTREAM (default 1): the XOR rows run on the second stream, band after band, AHEAD of the Mul launches of the main
+    // stream (band b's Mul gates wait for band b's XOR rows only): the ~140 short, latency-bound x-level launches of the
+    // 10^7-gate circuit then sit beside the eight long Mul launches instead of between them
+    static const bool xstream = !(getenv("RV_FLAT_XSTREAM") && atoi(getenv("RV_FLAT_XSTREAM")) == 0);
+    const bool two = xstream && F.bands.size() > 1;
+    hipStream_t sx = two ? ctx->stream_x : st;
+    ctx->phase(RV_PH_INTERP, st);
+    int rc;
+    if (two) {  // the second stream starts behind everything queued so far (masks, the zero row)
+        hipEvent_t e = ctx->get_sync_event();
+        s->misc_events.push_back(e);
+        HIPCHK(hipEventRecord(e, st));
+        HIPCHK(hipStreamWaitEvent(sx, e, 0));
+    }
+    bool joined = false;
+    // (host order: band b's XOR launches and their event, THEN the main stream's wait for it -- the runtime resolves a wait for an
+    // event of another stream to that stream's tail at the time the wait is queued: with every band's XOR launches queued first,
+    // band 0's Mul gates waited for the last band's XOR rows)
+    for (size_t b = 0; b < F.bands.size(); b++) {
+        const auto& B = F.bands[b];
+        for (uint32_t x = B.x0; x < B.x1; x++) {
+            launch_interp(sx, MODE_PROVE_F, c->d_xgates, F.xlevels[x], p, nullptr);
+            ctx->count();
+        }
+        if (two && B.x1 > B.x0) {
+            hipEvent_t e = ctx->get_sync_event();
+            s->misc_events.push_back(e);
+            HIPCHK(hipEventRecord(e, sx));
+            HIPCHK(hipStreamWaitEvent(st, e, 0));
+        }
+        if (!joined) {
+            HIPCHK(hipStreamWaitEvent(st, s->ev_clear, 0));
+            launch_or_word(st, s->d_err, (const int*)(s->d_sync + 2));
+            joined = true;
+        }
+        if (B.mul1 > B.mul0) {
+            launch_mul_flat(st, s->NQ, c->d_muls, B.mul0, B.mul1, p.rows, p.on, p.pre, s->d_vclr);
+            ctx->count();
+        }
+        if (s->ec && (rc = early_flush_muls(s, B.mul1))) return rc;
+    }
+    if (!joined) {
+        HIPCHK(hipStreamWaitEvent(st, s->ev_clear, 0));
+        launch_or_word(st, s->d_err, (const int*)(s->d_sync + 2));
+    }
+    if (c->n_others) {
+        launch_interp(st, MODE_PROVE_F, c->d_others, LevelRange{0, 0, 0, 0, 0, c->n_others}, p, nullptr);
+        ctx->count();
+    }
+    if (s->ec && (rc = early_flush_muls(s, c->cc.n_pre))) return rc;
+    HIPCHK(hipGetLastError());
+    return RV_OK;
+}
+
 static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const Interp64Params& p64) {
+    if (s->flat) return shard_run_flat(s, p);
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     const bool has64 = !cc.gates64.empty();
@@ -1721,10 +1959,41 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         if (hipMemcpyAsync(s->d_wit64, wit_z64, cc.n_in64 * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
             return fail(RV_E_DEVICE);
     }
+    static const bool vclr_on = [] {
+        const char* e = getenv("RV_VCLR");
+        return !e || atoi(e) != 0;
+    }();
+    const bool rep_path = c->rep_ok && (rep_mode() >= 2 || (rep_mode() == 1 && rep_count == RV_TOTAL_REPS));
+    const bool use_vclr = !rep_path && vclr_on && c->vclr_ok && (s->NQ == 64 || s->NQ == 32 || s->NQ == 16 || s->NQ == 8) && !ctx->pipeline;
+    if (use_vclr && c->flat.ok && flat_mode() != 0 && mul_flat_supports(s->NQ) && !g_recorder) {
+        // flat schedule: the cleartext pass starts as soon as the witness is on the device, on a stream of its own, and runs
+        // beside the key schedules and the mask generator (which leaves it clear_wgs() compute units)
+        s->flat = true;
+        if ((rc = dalloc(ctx, (size_t)cc.n_rows, &s->d_vclr)) || (rc = dalloc(ctx, (size_t)4, &s->d_sync))) return fail(rc);
+        hipEvent_t ev_in = ctx->get_sync_event();
+        s->misc_events.push_back(ev_in);
+        s->ev_clear = ctx->get_sync_event();
+        if (hipEventRecord(ev_in, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream3, ev_in, 0) != hipSuccess ||
+            hipMemsetAsync(s->d_sync, 0, 16, ctx->stream3) != hipSuccess || hipMemsetAsync(s->d_vclr + cc.zero_row, 0, 1, ctx->stream3) != hipSuccess)
+            return fail(RV_E_DEVICE);
+        const bool timed = ctx->profiling && !ctx->clear_timed;
+        if (timed) {
+            if (!ctx->clear_a) (void)hipEventCreate(&ctx->clear_a);
+            if (!ctx->clear_b) (void)hipEventCreate(&ctx->clear_b);
+            (void)hipEventRecord(ctx->clear_a, ctx->stream3);
+        }
+        launch_clear(ctx->stream3, clear_wgs(), c->d_clear_s, c->d_clear_k, c->d_clear_levels, (uint32_t)c->flat.n_clear_levels, s->d_wit, s->d_vclr,
+                     (int*)(s->d_sync + 2), s->d_sync);
+        if (timed) {
+            (void)hipEventRecord(ctx->clear_b, ctx->stream3);
+            ctx->clear_timed = true;
+        }
+        if (hipEventRecord(s->ev_clear, ctx->stream3) != hipSuccess) return fail(RV_E_DEVICE);
+    }
     ctx->phase(RV_PH_SETUP);
     ctx->count();
     launch_expand_seeds(ctx->stream, s->d_seeds, s->R, s->d_keys);
-    if (c->rep_ok && (rep_mode() >= 2 || (rep_mode() == 1 && rep_count == RV_TOTAL_REPS))) {
+    if (rep_path) {
         if ((rc = shard_commit_rep(s))) return fail(rc);
     } else {
         if ((rc = shard_setup_prg(s, nullptr))) return fail(rc);
@@ -1734,11 +2003,9 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         Interp64Params p64{};
         p64.wit = s->d_wit64;
         int mode = MODE_PROVE;
-        static const bool vclr_on = [] {
-            const char* e = getenv("RV_VCLR");
-            return !e || atoi(e) != 0;
-        }();
-        if (vclr_on && c->vclr_ok && (s->NQ == 64 || s->NQ == 32 || s->NQ == 16 || s->NQ == 8) && !ctx->pipeline) {
+        if (s->flat) {
+            mode = MODE_PROVE_F;  // (no corr rows, no value bytes: shard_run_flat)
+        } else if (use_vclr) {
             // eligible circuits (whole proofs and the repetition shards with a specialised interpreter): cleartext values
             // instead of corr rows (internal.h: MODE_PROVE_V)
             if ((rc = dalloc(ctx, (size_t)cc.n_rows, &s->d_vclr))) return fail(rc);
@@ -1763,7 +2030,7 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     }
     ctx->collect();
     ctx->prof.calls++;
-    if (err) return fail(RV_E_WITNESS_INVALID);
+    if (err) return fail((err & RV_DEV_CLEAR_ABORT) ? RV_E_DEVICE : RV_E_WITNESS_INVALID);
     *out = s;
     return RV_OK;
 }
@@ -2301,7 +2568,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
             break;
         }
         if ((int)ctx->h_fs[8]) {
-            rc = RV_E_WITNESS_INVALID;
+            rc = ((int)ctx->h_fs[8] & RV_DEV_CLEAR_ABORT) ? RV_E_DEVICE : RV_E_WITNESS_INVALID;
             break;
         }
         size_t off = 32;
@@ -2373,7 +2640,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         }
         ctx->collect();
         if (err) {
-            rc = RV_E_WITNESS_INVALID;
+            rc = (err & RV_DEV_CLEAR_ABORT) ? RV_E_DEVICE : RV_E_WITNESS_INVALID;
             break;
         }
         size_t off = 32;
@@ -2411,7 +2678,7 @@ static int rv_prove_device_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         }
         ctx->collect();
         if (err) {
-            rc = RV_E_WITNESS_INVALID;
+            rc = (err & RV_DEV_CLEAR_ABORT) ? RV_E_DEVICE : RV_E_WITNESS_INVALID;
             break;
         }
         memcpy(omit, back, RV_TOTAL_REPS);

@@ -110,7 +110,10 @@ struct Interp64Params {
 // by the interpreter itself level by level).  The three 32-byte corr-row accesses of a gate become one-byte accesses at
 // wave-uniform addresses.  Not for circuits with Random gates / B2A (values that differ between repetitions) and only
 // in the one-launch-per-level kernels (a level reads what the previous LAUNCH wrote).
-enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1, MODE_PROVE_V = 2 };
+// MODE_PROVE_F: the flat prover schedule (flat.h) -- the level kernels run only what is left of the gate stream once the Mul
+// gates have a kernel of their own and the wire values a pass of their own: XOR rows (shares only) and the Input / AssertZero
+// transcript rows.  No corr rows, no value bytes, no checks.
+enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1, MODE_PROVE_V = 2, MODE_PROVE_F = 3 };
 // bit set in the device error word when an AssertZero of an online-verified repetition does not reconstruct to zero
 // (VerifierTranscriptOnline.okay, online.rs:175-177; only the strict verifier looks at it)
 constexpr int RV_DEV_ZERO_CHECK = 0x100;
@@ -149,8 +152,9 @@ constexpr uint32_t RK_AREAS = 13;
 constexpr uint64_t RV_MAX_CTR_BLOCKS = 1ull << 24;
 void launch_key_schedule(hipStream_t st, const uint8_t* d_keys, uint32_t n_slots, uint8_t* d_rkbytes /*[n][RK_BYTES]*/);
 void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, uint32_t* d_rk /*[RK_AREAS][128][NQ]*/);
+// reserve_cus: compute units to leave free (the flat schedule's cleartext pass runs beside the generator)
 void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
-                          uint64_t n_blocks, uint32_t* d_masks);
+                          uint64_t n_blocks, uint32_t* d_masks, uint32_t reserve_cus = 0);
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
                        uint8_t* d_out);
 // per-level class boundaries: [lo, mul11) G_MUL with one base per operand, [mul11, mul) other G_MUL,

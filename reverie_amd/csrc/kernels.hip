@@ -69,6 +69,7 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
             corr = onm ? (p.sup_in[(size_t)g.x * p.sup_nq + q] & onm) : 0u;  // (rows of quads without an opened repetition are never written)
         }
         if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = corr;
+        if (MODE == MODE_PROVE_F) break;  // (the wire's value is k_clear's business)
         if (MODE == MODE_PROVE_V) {
             if (q == 0) p.vclr[g.dst] = p.wit[g.x] ? 1 : 0;
         } else {
@@ -78,6 +79,7 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     }
     case G_XORK: {
         p.rows[(size_t)g.dst * NQ + q] = gather_rows(p.rows, g.a, NQ, q) ^ gather_rows(p.rows, g.b, NQ, q);
+        if (MODE == MODE_PROVE_F) break;
         if (MODE == MODE_PROVE_V) {
             if (q == 0) p.vclr[g.dst] = (uint8_t)(g_ca(g) ^ gather_vclr(p.vclr, g.a) ^ gather_vclr(p.vclr, g.b));
             break;
@@ -91,10 +93,12 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         break;
     }
     case G_RANDOM: {
+        if (MODE == MODE_PROVE_F) break;
         if (!(q & 1)) p.corr[(size_t)g.dst * (NQ >> 1) + (q >> 1)] = 0;
         break;
     }
     case G_MUL: {
+        if (MODE == MODE_PROVE_F) break;  // (k_mul_flat runs the Mul gates of a flat schedule)
         const uint32_t lx = gather_rows(p.rows, g.a, NQ, q), ly = gather_rows(p.rows, g.b, NQ, q);
         const uint32_t lab = p.rows[(size_t)g.m * NQ + q], lnew = p.rows[(size_t)(g.m + 1) * NQ + q];
         const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
@@ -134,6 +138,7 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         break;
     }
     case G_RECON: {
+        if (MODE == MODE_PROVE_F) break;
         // B2A's recorded reconstruction (combine.rs:181-183): value = reconstruct(mask) + corr
         uint32_t m = gather_rows(p.rows, g.a, NQ, q);
         if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
@@ -149,6 +154,7 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         uint32_t m = gather_rows(p.rows, g.a, NQ, q);
         if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
         if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = m;
+        if (MODE == MODE_PROVE_F) break;  // (k_clear checks the wire's value)
         if (MODE == MODE_PROVE_V) {
             // the wire's value itself must be zero (prover.rs:221-228), the same in every repetition
             if (q == 0 && (gather_vclr(p.vclr, g.a) ^ g_ca(g)) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
@@ -372,8 +378,10 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
             // only the slots the gate uses (N == 2: both by construction)
             if (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) {
                 rr[u][i] = p.rows[(size_t)id * NQ + q];
-                // H corr bytes per row: the first H lanes of the gate's lane group carry them (MODE_PROVE_V: one value byte)
-                if (MODE == MODE_PROVE_V) {
+                // H corr bytes per row: the first H lanes of the gate's lane group carry them (MODE_PROVE_V: one value byte;
+                // MODE_PROVE_F: shares only)
+                if (MODE == MODE_PROVE_F) {
+                } else if (MODE == MODE_PROVE_V) {
                     if (q == 0) cc[u][i] = p.vclr[id];
                 } else if (q < H) {
                     cc[u][i] = p.corr[(size_t)id * H + q];
@@ -395,7 +403,8 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
 #pragma unroll
     for (int u = 0; u < U; u++) {
         p.rows[(size_t)g[u].dst * NQ + q] = x[u];
-        if (MODE == MODE_PROVE_V) {
+        if (MODE == MODE_PROVE_F) {
+        } else if (MODE == MODE_PROVE_V) {
             if (q == 0) p.vclr[g[u].dst] = (uint8_t)((bx[u] ^ g_ca(g[u])) & 1u);
         } else if (q < H) {
             p.corr[(size_t)g[u].dst * H + q] = (uint8_t)(bx[u] ^ (g_ca(g[u]) ? 0xFFu : 0u));
@@ -543,7 +552,12 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
     uint64_t blocks = (waves + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    if (mode == MODE_PROVE_V) {
+    if (mode == MODE_PROVE_F) {
+        if (general)
+            hipLaunchKernelGGL((k_interp_full<MODE_PROVE_F, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
+        else
+            hipLaunchKernelGGL((k_interp_full<MODE_PROVE_F, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
+    } else if (mode == MODE_PROVE_V) {
         if (general)
             hipLaunchKernelGGL((k_interp_full<MODE_PROVE_V, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
         else
@@ -671,7 +685,9 @@ void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRan
     const uint64_t want = (uint64_t)(r.hi - r.lo) * p.NQ;
     uint64_t blocks = (want + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (mode == MODE_PROVE)
+    if (mode == MODE_PROVE_F)
+        hipLaunchKernelGGL(k_interp<MODE_PROVE_F>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);
+    else if (mode == MODE_PROVE)
         hipLaunchKernelGGL(k_interp<MODE_PROVE>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);
     else
         hipLaunchKernelGGL(k_interp<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);

@@ -1,0 +1,122 @@
+"""The flat prover schedule (reverie_amd/csrc/flat.h, flatk.hip): Mul gates in program order behind the XOR rows, cleartext
+values from k_clear -- against the CPU oracle and against the level-synchronous interpreter (RV_FLAT=0), byte for byte.
+Reference: Instance::op_mul / step (src/interpreter/single.rs:25-157), ProverTranscript (src/transcript/prover.rs:181-232)."""
+import os
+
+import numpy as np
+import pytest
+
+import circuits
+from reverie_amd.ops import GF2, program
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rv():
+    import reverie_amd
+
+    return reverie_amd
+
+
+def _prove(rv, prog, wit, wc, seeds, monkeypatch, flat, bands=None, hint=True):
+    monkeypatch.setenv("RV_FLAT", str(flat))
+    if bands is not None:
+        monkeypatch.setenv("RV_FLAT_BANDS", str(bands))
+    c = rv.Circuit(prog, wc, whole_prover=hint)
+    try:
+        p = rv.Proof.new(c, wit, [], seeds=seeds)
+        assert p.verify(c, strict=True)
+        return bytes(p)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_flat_random_programs_vs_oracle(rv, oracle, monkeypatch, seed):
+    """random GF(2) programs (wire reuse, constants, every linear op): forced flat schedule == oracle == level schedule"""
+    rng = np.random.default_rng(9000 + seed)
+    prog, wit, wc = circuits.random_gf2(rng, n_in=int(rng.integers(1, 40)), n_gates=int(rng.integers(50, 4000)), n_wires=int(rng.integers(3, 200)))
+    seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+    want = oracle.prove(prog, wit, [], wc, seeds)
+    for hint in (True, False):
+        for bands in (1, 3):
+            assert _prove(rv, prog, wit, wc, seeds, monkeypatch, 2, bands, hint) == want
+    assert _prove(rv, prog, wit, wc, seeds, monkeypatch, 0) == want
+
+
+@pytest.mark.parametrize("n_in,width,layers,p_and,bands", [
+    (1, 1, 40, 0.5, 1), (127, 63, 9, 0.5, 2), (128, 64, 9, 1.0, 4), (129, 65, 9, 0.5, 8), (5, 255, 12, 0.5, 1), (64, 256, 30, 0.7, 8),
+    (300, 257, 12, 0.5, 3), (2, 513, 5, 0.5, 8), (1000, 1025, 4, 0.3, 2), (16, 4097, 3, 0.5, 1), (4096, 8192, 2, 0.0, 4), (256, 2048, 24, 0.5, 8)])
+def test_flat_layered_shapes_vs_oracle(rv, oracle, monkeypatch, n_in, width, layers, p_and, bands):
+    """layered circuits around the kernels' switch points, one band and several, with and without Mul gates"""
+    prog, wit, wc, st = circuits.layered_gf2(n_in=n_in, width=width, layers=layers, p_and=p_and, seed=n_in * 7919 + width, fold_to=width)
+    seeds = np.random.default_rng(width).integers(0, 256, (256, 16), dtype=np.uint8)
+    want = oracle.prove(prog, wit, [], wc, seeds, threads=8)
+    assert _prove(rv, prog, wit, wc, seeds, monkeypatch, 2, bands) == want
+
+
+def test_flat_invalid_witness_and_reuse(rv, oracle, rule_seeds, monkeypatch):
+    """an AssertZero that fails is reported by the cleartext pass; the same circuit then proves a valid witness"""
+    monkeypatch.setenv("RV_FLAT", "2")
+    prog, wit, wc, st = circuits.layered_gf2(n_in=64, width=512, layers=8)
+    c = rv.Circuit(prog, wc, whole_prover=True)
+    bad = np.array(wit, np.uint8).copy()
+    flipped = False
+    for i in range(len(bad)):  # (a flipped input that reaches an output)
+        bad[i] ^= 1
+        try:
+            rv.Proof.new(c, bad, [], seeds=rule_seeds)
+        except rv.ReverieError as e:
+            assert e.code == 1
+            flipped = True
+            break
+        bad[i] ^= 1
+    assert flipped
+    good = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+    assert bytes(good) == oracle.prove(prog, wit, [], wc, rule_seeds)
+
+
+@pytest.mark.parametrize("reps", [32, 64, 128])
+def test_flat_shards_vs_oracle(rv, oracle, monkeypatch, reps):
+    """repetition shards (rows of 8 / 16 / 32 quad words) through the flat schedule: assembled proof == oracle"""
+    from reverie_amd.dist import HipShardBackend, assemble
+    from reverie_amd.proof import challenge, combine_digests
+
+    monkeypatch.setenv("RV_FLAT", "2")
+    monkeypatch.setenv("RV_FLAT_BANDS", "3")
+    prog, wit, wc, st = circuits.layered_gf2(n_in=200, width=700, layers=10, seed=reps, fold_to=700)
+    seeds = np.random.default_rng(reps).integers(0, 256, (256, 16), dtype=np.uint8)
+    want = oracle.prove(prog, wit, [], wc, seeds, threads=8)
+    c = rv.Circuit(prog, wc)
+    be = HipShardBackend(c)
+    shards = [be.commit(wit, [], seeds[b:b + reps], b, reps) for b in range(0, 256, reps)]
+    try:
+        comm = combine_digests(np.concatenate([be.digests(s) for s in shards]))
+        omit = challenge(comm)
+        parts = [be.open(s, omit)[:2] for s in shards]
+    finally:
+        for s in shards:
+            be.destroy(s)
+    assert assemble(comm, parts) == want
+
+
+def test_flat_early_corrections(rv, oracle, rule_seeds, monkeypatch):
+    """the early-corrections path on top of the flat schedule (chunks flushed by Mul ranges), poisoned staging"""
+    from reverie_amd import _lib
+
+    monkeypatch.setenv("RV_FLAT", "2")
+    monkeypatch.setenv("RV_EARLY", "2")
+    monkeypatch.setenv("RV_EARLY_MIN", "1000")
+    monkeypatch.setenv("RV_EARLY_POISON", "1")
+    prog, wit, wc, st = circuits.layered_gf2(n_in=256, width=4096, layers=20)
+    want = oracle.prove(prog, wit, [], wc, rule_seeds, threads=8)
+    for bands, chunks in ((1, 4), (8, 4), (5, 7)):
+        monkeypatch.setenv("RV_FLAT_BANDS", str(bands))
+        monkeypatch.setenv("RV_EARLY_CHUNKS", str(chunks))
+        c = rv.Circuit(prog, wc, whole_prover=True)
+        n0 = _lib.lib().rv_hook_early_proofs()
+        p = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+        assert bytes(p) == want
+        assert _lib.lib().rv_hook_early_proofs() == n0 + 1
+        c.close()
