@@ -331,11 +331,11 @@ extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
     if (const char* e = getenv("RV_PIPELINE")) c->pipeline = atoi(e) != 0;
     // The runtime multiplexes the streams of one priority over four hardware queues (a fifth stream would share the first one's),
     // and a queue that issues short kernels back to back keeps the dispatcher from a queue of the same or a lower priority.  The
-    // main stream therefore gets the high priority (RV_MAIN_PRIO=0: all streams alike): its long kernels go out the moment their
-    // dependencies are met, and the flat schedule's short XOR launches (stream_x) fill in beside them.
+    // main stream can therefore get the high priority (RV_MAIN_PRIO=1; default: all streams alike): its long kernels go out the moment their
+    // dependencies are met, and the flat schedule's short XOR launches (stream_x) fill in beside them.  (Measured: no gain; off.)
     int prio_lo = 0, prio_hi = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0, (void)hipGetLastError();
-    static const bool main_prio = !(getenv("RV_MAIN_PRIO") && atoi(getenv("RV_MAIN_PRIO")) == 0);
+    static const bool main_prio = getenv("RV_MAIN_PRIO") && atoi(getenv("RV_MAIN_PRIO")) != 0;
     hipError_t se = main_prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
@@ -552,6 +552,15 @@ struct rv_circuit {
     LdsRec* d_lds_recs = nullptr;
     mutable std::once_flag ec_once;
     mutable EarlyPlan ec_plan;
+    // k_interp_persist: per row width the levels' step tables (built and uploaded at first use), and whether any level has enough
+    // multi-base gates for the kernel variant with their loops
+    struct PersistTab {
+        std::vector<PLevel> h;
+        PLevel* d = nullptr;
+    };
+    mutable std::mutex persist_mu;
+    mutable std::map<uint32_t, PersistTab> persist_tab;
+    bool persist_gen = false;
     // flat prover schedule (flat.h): present when the circuit is eligible (the big vectors live on the device only)
     FlatPlan flat;
     Gate* d_xgates = nullptr;
@@ -561,14 +570,17 @@ struct rv_circuit {
     ClearRec* d_clear_s = nullptr;
     ClearRecK* d_clear_k = nullptr;
     ClearLevel* d_clear_levels = nullptr;
+    ClearRec* d_lite_s = nullptr;
+    ClearRecK* d_lite_k = nullptr;
 };
 
-// RV_FLAT: 0 = the level-synchronous interpreter everywhere; 1 (default) = the flat schedule for the prover of eligible circuits
+// RV_FLAT: 0 (default) = the level-synchronous interpreter everywhere; 1 = the flat schedule for the prover of eligible circuits
 // of at least RV_FLAT_MIN gates (2^20: below, the cleartext pass does not hide behind the mask generator); 2 = for every eligible
-// circuit.  Read at every call (tests switch it).
+// circuit.  Read at every call (tests switch it).  Off by default: byte-identical, but on the 10^7-gate circuit the ~140 dependent
+// x-level launches of its XOR rows cost what the level boundaries saved ("Flat schedule").
 static int flat_mode() {
     const char* e = getenv("RV_FLAT");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 0;
 }
 // workgroups of the cleartext pass = compute units the mask generator leaves free for them
 static uint32_t clear_wgs() {
@@ -903,6 +915,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         c->vclr_ok = cc.gates64.empty() && narrow_levels <= 16 && !cc.row_prg_base;
     }
     if (cc.n_random_or_recon) c->vclr_ok = false;  // (values that differ between repetitions)
+    c->persist_gen = persist_general(cc.level_range.data(), cc.level_range.size());
     if (c->vclr_ok && flat_mode()) {
         // the flat schedule of the prover: Mul records in program order, XOR rows by x-level, the rest
         static const uint64_t flat_min = getenv("RV_FLAT_MIN") ? (uint64_t)atoll(getenv("RV_FLAT_MIN")) : (1ull << 20);
@@ -914,7 +927,9 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
                 (rc = up(c->flat.others.data(), c->flat.others.size() * sizeof(Gate), (void**)&c->d_others)) ||
                 (rc = up(c->flat.clear_s.data(), c->flat.clear_s.size() * sizeof(ClearRec), (void**)&c->d_clear_s)) ||
                 (rc = up(c->flat.clear_k.data(), c->flat.clear_k.size() * sizeof(ClearRecK), (void**)&c->d_clear_k)) ||
-                (rc = up(c->flat.clear_levels.data(), c->flat.clear_levels.size() * sizeof(ClearLevel), (void**)&c->d_clear_levels))) {
+                (rc = up(c->flat.clear_levels.data(), c->flat.clear_levels.size() * sizeof(ClearLevel), (void**)&c->d_clear_levels)) ||
+                (rc = up(c->flat.lite_s.data(), c->flat.lite_s.size() * sizeof(ClearRec), (void**)&c->d_lite_s)) ||
+                (rc = up(c->flat.lite_k.data(), c->flat.lite_k.size() * sizeof(ClearRecK), (void**)&c->d_lite_k))) {
                 rv_circuit_destroy(c);
                 return rc;
             }
@@ -925,6 +940,8 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
             decltype(c->flat.clear_s)().swap(c->flat.clear_s);
             decltype(c->flat.clear_k)().swap(c->flat.clear_k);
             std::vector<ClearLevel>().swap(c->flat.clear_levels);
+            decltype(c->flat.lite_s)().swap(c->flat.lite_s);
+            decltype(c->flat.lite_k)().swap(c->flat.lite_k);
         }
     }
     return RV_OK;
@@ -945,12 +962,15 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     c->ctx->release(c->d_rep_segs);
     c->ctx->release(c->d_rep_recs);
     c->ctx->release(c->d_lds_recs);
+    for (auto& kv : c->persist_tab) c->ctx->release(kv.second.d);
     c->ctx->release(c->d_xgates);
     c->ctx->release(c->d_muls);
     c->ctx->release(c->d_others);
     c->ctx->release(c->d_clear_s);
     c->ctx->release(c->d_clear_k);
     c->ctx->release(c->d_clear_levels);
+    c->ctx->release(c->d_lite_s);
+    c->ctx->release(c->d_lite_k);
     delete c;
 }
 
@@ -1099,7 +1119,7 @@ struct rv_shard {
     uint8_t* d_wit = nullptr;
     uint8_t* d_vclr = nullptr;  // MODE_PROVE_V: cleartext value per share row
     // flat schedule (flat.h): operand values per Mul, the cleartext pass's barrier words {arrivals, abort, error word}, its end
-    bool flat = false;
+    bool flat = false, split = false;
     uint8_t* d_vb = nullptr;
     uint32_t* d_sync = nullptr;
     hipEvent_t ev_clear = nullptr;
@@ -1157,7 +1177,7 @@ extern "C" void rv_shard_destroy(rv_shard* s) {
     // work forked onto the second stream (the verifier's side copy of the proof, the two-stream pipeline): its buffers go back to
     // the arena below and the caller's host buffers leave scope -- nothing of it may still be in flight
     if (!s->misc_events.empty() || !s->mask_chunks.empty() || s->ev_setup || s->ec) (void)hipStreamSynchronize(s->ctx->stream2);
-    if (s->ev_clear) {
+    if (s->ev_clear || s->split) {
         (void)hipStreamSynchronize(s->ctx->stream3);
         (void)hipStreamSynchronize(s->ctx->stream_x);
     }
@@ -1641,6 +1661,34 @@ static int early_pump(rv_shard* s) {
     return RV_OK;
 }
 
+// RV_PERSIST: 1 = the levels of a MODE_PROVE_V run go through k_interp_persist (no launch per level), 0 (default) = one launch per level.
+// Off: byte-identical, but the in-launch hand-off between levels (arrival counters + polling) costs more than the launch boundary
+// it replaces ("Persistent level kernel").
+static int persist_mode() {
+    const char* e = getenv("RV_PERSIST");
+    return e ? atoi(e) : 0;
+}
+// the circuit's step table for rows of NQ quad words, on the device (built at first use; the upload is queued on the context's stream
+// ahead of the launch that reads it)
+static const rv_circuit::PersistTab* persist_table(rv_ctx* ctx, const rv_circuit* c, uint32_t NQ) {
+    std::lock_guard<std::mutex> lk(c->persist_mu);
+    auto it = c->persist_tab.find(NQ);
+    if (it != c->persist_tab.end()) return it->second.d ? &it->second : nullptr;
+    rv_circuit::PersistTab& T = c->persist_tab[NQ];
+    const size_t n = c->cc.level_range.size();
+    T.h.resize(n);
+    build_persist_levels(c->cc.level_range.data(), n, NQ, c->persist_gen, T.h.data());
+    void* d = nullptr;
+    if (ctx->alloc(std::max<size_t>(n, 1) * sizeof(PLevel), &d)) return nullptr;
+    if (n && hipMemcpyAsync(d, T.h.data(), n * sizeof(PLevel), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->release(d);
+        return nullptr;
+    }
+    T.d = (PLevel*)d;
+    return &T;
+}
+
 // The flat schedule (flat.h): band after band the XOR rows x-level by x-level, then the band's Mul gates in program order;
 // the Input / AssertZero transcript rows behind the last band.  The cleartext pass (queued on stream3 at commit time) must
 // have ended before the first Mul launch.
@@ -1703,8 +1751,96 @@ static int shard_run_flat(rv_shard* s, const InterpParams& p) {
     return RV_OK;
 }
 
+// MODE_PROVE_V without a launch per level: the levels in as few k_interp_persist launches as the early-corrections chunks allow
+// (a chunk's packing kernel sits behind the level that completes it)
+static int shard_run_persist(rv_shard* s, const InterpParams& p) {
+    rv_ctx* ctx = s->ctx;
+    const rv_circuit* c = s->c;
+    const Compiled& cc = c->cc;
+    const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+    const rv_circuit::PersistTab* T = persist_table(ctx, c, s->NQ);
+    if (!T) return RV_E_NOMEM;
+    // segment ends: after the level that completes a chunk (early corrections), and after the last level
+    std::vector<uint32_t> cuts;
+    if (s->ec)
+        for (const auto& ch : s->ec->plan->chunks)
+            if (ch.ready_level + 1 < n_levels && (cuts.empty() || cuts.back() != ch.ready_level + 1)) cuts.push_back(ch.ready_level + 1);
+    cuts.push_back((uint32_t)n_levels);
+    int rc;
+    if ((rc = dalloc(ctx, cuts.size() * PERSIST_SYNC_WORDS, &s->d_sync))) return rc;
+    HIPCHK(hipMemsetAsync(s->d_sync, 0, cuts.size() * PERSIST_SYNC_WORDS * 4, ctx->stream));
+    ctx->phase(RV_PH_INTERP, ctx->stream);
+    uint32_t l0 = 0;
+    for (size_t k = 0; k < cuts.size(); k++) {
+        const uint32_t l1 = cuts[k];
+        if (s->ec && (rc = early_flush(s, l0))) return rc;
+        if (l1 > l0) {
+            const uint64_t n_steps = (uint64_t)T->h[l1 - 1].step0 + T->h[l1 - 1].n_steps - T->h[l0].step0;
+            launch_interp_persist(ctx->stream, s->NQ, c->persist_gen, c->d_gates, T->d, l0, l1, n_steps, p, s->d_sync + k * PERSIST_SYNC_WORDS);
+            ctx->count();
+        }
+        l0 = l1;
+    }
+    if (s->ec && (rc = early_flush(s, n_levels))) return rc;
+    HIPCHK(hipGetLastError());
+    return RV_OK;
+}
+
+// The split schedule (flat.h): the dependency levels as a CHAIN of light launches on a stream of its own -- per level the XOR
+// gates and the other gates' cleartext values -- and, a band behind it on the main stream, the Mul gates in program order.
+static int shard_run_split(rv_shard* s, const InterpParams& p) {
+    rv_ctx* ctx = s->ctx;
+    const rv_circuit* c = s->c;
+    const Compiled& cc = c->cc;
+    const FlatPlan& F = c->flat;
+    hipStream_t st = ctx->stream;
+    static const bool xstream = !(getenv("RV_FLAT_XSTREAM") && atoi(getenv("RV_FLAT_XSTREAM")) == 0);
+    hipStream_t sx = xstream ? ctx->stream_x : st;
+    const uint32_t n_levels = (uint32_t)F.n_clear_levels;
+    ctx->phase(RV_PH_INTERP, st);
+    int rc;
+    auto fork = [&](hipStream_t from, hipStream_t to) -> int {
+        if (from == to) return RV_OK;
+        hipEvent_t e = ctx->get_sync_event();
+        s->misc_events.push_back(e);
+        HIPCHK(hipEventRecord(e, from));
+        HIPCHK(hipStreamWaitEvent(to, e, 0));
+        return RV_OK;
+    };
+    if ((rc = fork(st, sx))) return rc;  // the chain starts behind everything queued so far (masks, the zero row, the error word)
+    uint32_t l = 0;
+    auto chain_to = [&](uint32_t l1) {
+        for (; l < l1; l++) {
+            if (cc.level_start[l + 1] == cc.level_start[l]) continue;
+            launch_level_split(sx, c->d_gates, cc.level_range[l], F.lite_levels[l], c->d_lite_s, c->d_lite_k, p);
+            ctx->count();
+        }
+    };
+    // (host order matters: a wait for another stream's event resolves to that stream's tail when the wait is queued)
+    for (const auto& B : F.bands) {
+        chain_to(std::min(B.level_end, n_levels));
+        if ((rc = fork(sx, st))) return rc;
+        if (B.mul1 > B.mul0) {
+            launch_mul_flat(st, s->NQ, c->d_muls, B.mul0, B.mul1, p.rows, p.on, p.pre, s->d_vclr);
+            ctx->count();
+        }
+        if (s->ec && (rc = early_flush_muls(s, B.mul1))) return rc;
+    }
+    chain_to(n_levels);
+    if ((rc = fork(sx, st))) return rc;
+    if (c->n_others) {  // the Input / AssertZero transcript rows
+        launch_interp(st, MODE_PROVE_F, c->d_others, LevelRange{0, 0, 0, 0, 0, c->n_others}, p, nullptr);
+        ctx->count();
+    }
+    if (s->ec && (rc = early_flush_muls(s, cc.n_pre))) return rc;
+    HIPCHK(hipGetLastError());
+    return RV_OK;
+}
+
 static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const Interp64Params& p64) {
+    if (s->split) return shard_run_split(s, p);
     if (s->flat) return shard_run_flat(s, p);
+    if (mode == MODE_PROVE_V && persist_mode() && persist_supports(s->NQ) && !g_recorder) return shard_run_persist(s, p);
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     const bool has64 = !cc.gates64.empty();
@@ -1965,7 +2101,12 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     }();
     const bool rep_path = c->rep_ok && (rep_mode() >= 2 || (rep_mode() == 1 && rep_count == RV_TOTAL_REPS));
     const bool use_vclr = !rep_path && vclr_on && c->vclr_ok && (s->NQ == 64 || s->NQ == 32 || s->NQ == 16 || s->NQ == 8) && !ctx->pipeline;
-    if (use_vclr && c->flat.ok && flat_mode() != 0 && mul_flat_supports(s->NQ) && !g_recorder) {
+    if (use_vclr && c->flat.ok && flat_mode() == 1 && mul_flat_supports(s->NQ) && !g_recorder) {
+        // split schedule: the level chain computes the values itself (shard_run_split)
+        s->split = true;
+        if ((rc = dalloc(ctx, (size_t)cc.n_rows, &s->d_vclr))) return fail(rc);
+        if (hipMemsetAsync(s->d_vclr + cc.zero_row, 0, 1, ctx->stream) != hipSuccess) return fail(RV_E_DEVICE);
+    } else if (use_vclr && c->flat.ok && flat_mode() >= 2 && mul_flat_supports(s->NQ) && !g_recorder) {
         // flat schedule: the cleartext pass starts as soon as the witness is on the device, on a stream of its own, and runs
         // beside the key schedules and the mask generator (which leaves it clear_wgs() compute units)
         s->flat = true;
@@ -2003,7 +2144,10 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         Interp64Params p64{};
         p64.wit = s->d_wit64;
         int mode = MODE_PROVE;
-        if (s->flat) {
+        if (s->split) {
+            mode = MODE_PROVE_V;  // (the level chain keeps the value bytes: shard_run_split)
+            p.vclr = s->d_vclr;
+        } else if (s->flat) {
             mode = MODE_PROVE_F;  // (no corr rows, no value bytes: shard_run_flat)
         } else if (use_vclr) {
             // eligible circuits (whole proofs and the repetition shards with a specialised interpreter): cleartext values
@@ -2030,7 +2174,7 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     }
     ctx->collect();
     ctx->prof.calls++;
-    if (err) return fail((err & RV_DEV_CLEAR_ABORT) ? RV_E_DEVICE : RV_E_WITNESS_INVALID);
+    if (err) return fail((err & (RV_DEV_CLEAR_ABORT | RV_DEV_PERSIST_ABORT)) ? RV_E_DEVICE : RV_E_WITNESS_INVALID);
     *out = s;
     return RV_OK;
 }
@@ -2568,7 +2712,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
             break;
         }
         if ((int)ctx->h_fs[8]) {
-            rc = ((int)ctx->h_fs[8] & RV_DEV_CLEAR_ABORT) ? RV_E_DEVICE : RV_E_WITNESS_INVALID;
+            rc = ((int)ctx->h_fs[8] & (RV_DEV_CLEAR_ABORT | RV_DEV_PERSIST_ABORT)) ? RV_E_DEVICE : RV_E_WITNESS_INVALID;
             break;
         }
         size_t off = 32;
@@ -2640,7 +2784,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         }
         ctx->collect();
         if (err) {
-            rc = (err & RV_DEV_CLEAR_ABORT) ? RV_E_DEVICE : RV_E_WITNESS_INVALID;
+            rc = (err & (RV_DEV_CLEAR_ABORT | RV_DEV_PERSIST_ABORT)) ? RV_E_DEVICE : RV_E_WITNESS_INVALID;
             break;
         }
         size_t off = 32;
@@ -2678,7 +2822,7 @@ static int rv_prove_device_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         }
         ctx->collect();
         if (err) {
-            rc = (err & RV_DEV_CLEAR_ABORT) ? RV_E_DEVICE : RV_E_WITNESS_INVALID;
+            rc = (err & (RV_DEV_CLEAR_ABORT | RV_DEV_PERSIST_ABORT)) ? RV_E_DEVICE : RV_E_WITNESS_INVALID;
             break;
         }
         memcpy(omit, back, RV_TOTAL_REPS);

@@ -19,6 +19,9 @@ bool build_flat_plan(const Compiled& cc, FlatPlan& P, uint32_t want_bands) {
     P.clear_s.clear();
     P.clear_k.clear();
     P.clear_levels.clear();
+    P.lite_s.clear();
+    P.lite_k.clear();
+    P.lite_levels.clear();
     if (!cc.gates64.empty() || cc.row_prg_base || cc.n_random_or_recon || cc.gates.empty()) return false;
     if (cc.n_on >= (1ull << MULREC_EO_BITS) || cc.n_rows >= 0xFFFFFFF0ull || cc.level_start.size() < 2) return false;
     const auto t0 = std::chrono::steady_clock::now();
@@ -124,7 +127,9 @@ bool build_flat_plan(const Compiled& cc, FlatPlan& P, uint32_t want_bands) {
                 P.others.push_back(g);
             }
         }
-    // ---- the cleartext pass's records: the level-sorted stream again, 16 or 32 bytes per gate ----
+    // ---- value records: the level-sorted stream again, 16 or 32 bytes per gate (every gate for the cleartext pass of the flat
+    // schedule; everything but the XOR gates for the split schedule's level chain) ----
+    std::vector<uint32_t> mul_level(n_bands, 0);  // per band: 1 + the highest dependency level of its Mul gates
     {
         const size_t n_levels = cc.level_start.size() - 1;
         // XOR / AssertZero: one list of bases (the sum is symmetric): two of them still make a 16-byte record
@@ -132,43 +137,56 @@ bool build_flat_plan(const Compiled& cc, FlatPlan& P, uint32_t want_bands) {
             const uint32_t op = g_op(g);
             return (op == G_XORK || op == G_ASSERT) ? g_na(g) + g_nb(g) <= 2 : (g_na(g) <= 1 && g_nb(g) <= 1);
         };
-        size_t ns = 0, nk = 0;
-        for (size_t i = 0; i < n; i++) (simple(cc.gates[i]) ? ns : nk)++;
-        P.clear_s.resize(ns);
-        P.clear_k.resize(nk);
-        P.clear_levels.resize(n_levels);
-        size_t is = 0, ik = 0;
-        for (size_t l = 0; l < n_levels; l++) {
-            ClearLevel L{(uint32_t)is, 0, (uint32_t)ik, 0};
-            for (uint32_t i = cc.level_start[l]; i < cc.level_start[l + 1]; i++) {
-                const Gate& g = cc.gates[i];
-                const uint32_t op = g_op(g);
-                uint32_t na = g_na(g), nb = g_nb(g);
-                if (simple(g)) {
-                    uint32_t a0 = g.a[0], b0 = g.b[0];
-                    if (op == G_INPUT) {
-                        a0 = g.x, na = nb = 0;
-                    } else if (op == G_XORK || op == G_ASSERT) {
-                        uint32_t rows[2] = {0, 0}, cnt = 0;
-                        for (uint32_t k = 0; k < na; k++) rows[cnt++] = g.a[k];
-                        for (uint32_t k = 0; k < nb; k++) rows[cnt++] = g.b[k];
-                        a0 = rows[0], b0 = rows[1], na = cnt >= 1, nb = cnt >= 2;
+        auto build = [&](bool with_xor, decltype(P.clear_s)& S, decltype(P.clear_k)& K, std::vector<ClearLevel>& LV) {
+            size_t ns = 0, nk = 0;
+            for (size_t i = 0; i < n; i++)
+                if (with_xor || g_op(cc.gates[i]) != G_XORK) (simple(cc.gates[i]) ? ns : nk)++;
+            S.resize(ns);
+            K.resize(nk);
+            LV.resize(n_levels);
+            size_t is = 0, ik = 0;
+            for (size_t l = 0; l < n_levels; l++) {
+                ClearLevel L{(uint32_t)is, 0, (uint32_t)ik, 0};
+                for (uint32_t i = cc.level_start[l]; i < cc.level_start[l + 1]; i++) {
+                    const Gate& g = cc.gates[i];
+                    const uint32_t op = g_op(g);
+                    if (!with_xor && op == G_XORK) continue;
+                    uint32_t na = g_na(g), nb = g_nb(g);
+                    if (simple(g)) {
+                        uint32_t a0 = g.a[0], b0 = g.b[0];
+                        if (op == G_INPUT) {
+                            a0 = g.x, na = nb = 0;
+                        } else if (op == G_XORK || op == G_ASSERT) {
+                            uint32_t rows[2] = {0, 0}, cnt = 0;
+                            for (uint32_t k = 0; k < na; k++) rows[cnt++] = g.a[k];
+                            for (uint32_t k = 0; k < nb; k++) rows[cnt++] = g.b[k];
+                            a0 = rows[0], b0 = rows[1], na = cnt >= 1, nb = cnt >= 2;
+                        }
+                        S[is++] = ClearRec{g.dst, a0, b0, op | (g_ca(g) << 3) | (g_cb(g) << 4) | (na << 8) | (nb << 10)};
+                    } else {
+                        ClearRecK r;
+                        r.dst = g.dst, r.meta = op | (g_ca(g) << 3) | (g_cb(g) << 4) | (na << 8) | (nb << 10);
+                        for (int k = 0; k < RV_LIN_K; k++) r.a[k] = g.a[k], r.b[k] = g.b[k];
+                        K[ik++] = r;
                     }
-                    P.clear_s[is++] = ClearRec{g.dst, a0, b0, op | (g_ca(g) << 3) | (g_cb(g) << 4) | (na << 8) | (nb << 10)};
-                } else {
-                    ClearRecK r;
-                    r.dst = g.dst, r.meta = op | (g_ca(g) << 3) | (g_cb(g) << 4) | (na << 8) | (nb << 10);
-                    for (int k = 0; k < RV_LIN_K; k++) r.a[k] = g.a[k], r.b[k] = g.b[k];
-                    P.clear_k[ik++] = r;
                 }
+                L.s1 = (uint32_t)is, L.g1 = (uint32_t)ik;
+                LV[l] = L;
             }
-            L.s1 = (uint32_t)is, L.g1 = (uint32_t)ik;
-            P.clear_levels[l] = L;
-        }
+        };
+        build(true, P.clear_s, P.clear_k, P.clear_levels);
+        build(false, P.lite_s, P.lite_k, P.lite_levels);
+        for (size_t l = 0; l < n_levels; l++)
+            for (uint32_t i = cc.level_start[l]; i < cc.level_start[l + 1]; i++)
+                if (g_op(cc.gates[i]) == G_MUL) {
+                    const uint32_t b = band_of_mul(cc.gates[i].ep);
+                    mul_level[b] = std::max(mul_level[b], (uint32_t)l + 1);
+                }
+        for (size_t b = 1; b < n_bands; b++) mul_level[b] = std::max(mul_level[b], mul_level[b - 1]);
     }
     P.bands.resize(n_bands);
     for (size_t b = 0; b < n_bands; b++)
-        P.bands[b] = FlatPlan::Band{xbase[b], xbase[b + 1], band_mul0[b], b + 1 < n_bands ? band_mul0[b + 1] : (uint32_t)n_mul};
+        P.bands[b] = FlatPlan::Band{xbase[b], xbase[b + 1], band_mul0[b], b + 1 < n_bands ? band_mul0[b + 1] : (uint32_t)n_mul, mul_level[b]};
     P.ok = true;
     if (getenv("RV_COMPILE_STATS")) {
         fprintf(stderr, "[rv flat] %zu gates -> %llu Mul (program order), %llu XOR rows, %llu others in %zu bands, %zu x-levels; %.1f ms\n", n,

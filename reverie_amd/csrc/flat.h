@@ -56,6 +56,7 @@ struct FlatPlan {
     struct Band {
         uint32_t x0, x1;      // x-levels [x0, x1) of `xlevels`
         uint32_t mul0, mul1;  // Mul records [mul0, mul1); mul0 a multiple of 1024
+        uint32_t level_end;   // split schedule: the band's Mul gates may run once the level chain has passed levels [0, level_end)
     };
     std::vector<Band> bands;
     std::vector<Gate, BigAlloc<Gate>> xgates;   // G_XORK gates sorted by (band, x-level), inside one by class (two bases, others)
@@ -66,6 +67,11 @@ struct FlatPlan {
     std::vector<ClearRec, BigAlloc<ClearRec>> clear_s;
     std::vector<ClearRecK, BigAlloc<ClearRecK>> clear_k;
     std::vector<ClearLevel> clear_levels;
+    // the split schedule's level chain: per dependency level the value records of everything that is NOT an XOR gate (Mul, Input,
+    // AssertZero: a lane each, bytes only) -- the XOR gates of the level run from the level-sorted gate stream itself
+    std::vector<ClearRec, BigAlloc<ClearRec>> lite_s;
+    std::vector<ClearRecK, BigAlloc<ClearRecK>> lite_k;
+    std::vector<ClearLevel> lite_levels;
     uint64_t n_clear_levels = 0;                // dependency levels the cleartext pass walks (= the circuit's)
 };
 
@@ -83,6 +89,10 @@ constexpr int RV_DEV_CLEAR_ABORT = 0x40000000;  // device error word: k_clear ga
 // *d_dst |= *d_src (the cleartext pass's error word joins the proof's behind the event that ends the pass)
 void launch_or_word(hipStream_t st, int* d_dst, const int* d_src);
 bool mul_flat_supports(uint32_t NQ);
+// split schedule, one dependency level of the chain: the level's XOR gates (rows and value bytes, MODE_PROVE_V's arithmetic) and
+// the value bytes of its other gates (kernels.hip)
+void launch_level_split(hipStream_t st, const Gate* d_gates, const LevelRange& r, const ClearLevel& lite, const ClearRec* d_lite_s, const ClearRecK* d_lite_k,
+                        const InterpParams& p);
 // Mul records [i0, i1) (i0 a multiple of 8)
 void launch_mul_flat(hipStream_t st, uint32_t NQ, const MulRec* d_recs, uint32_t i0, uint32_t i1, const uint32_t* d_rows, uint32_t* d_on, uint8_t* d_pre,
                      const uint8_t* d_v);

@@ -162,6 +162,21 @@ void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys
 struct LevelRange {
     uint32_t lo, mul11, mul, xor2, xork, hi;
 };
+// k_interp_persist (kernels.hip): a level's wave-steps as launch_interp would deal them out, and where they sit in the circuit's
+// sequence of steps
+struct PLevel {
+    LevelRange r;
+    uint32_t n_full[4];  // full unrolled steps of classes 0..3
+    uint32_t n_steps;    // wave-steps of the level (full steps + the leftover gates', 64 / NQ gates each)
+    uint32_t step0;      // wave-steps of all the levels before it
+};
+constexpr uint32_t PERSIST_SYNC_WORDS = 64;        // per launch: 32 arrival counters, the abort word, padding to 256 bytes
+constexpr int RV_DEV_PERSIST_ABORT = 0x20000000;   // device error word: a persistent launch gave up waiting (reported as RV_E_DEVICE)
+void build_persist_levels(const LevelRange* lr, size_t n_levels, uint32_t NQ, bool general, PLevel* out);
+bool persist_general(const LevelRange* lr, size_t n_levels);
+bool persist_supports(uint32_t NQ);
+void launch_interp_persist(hipStream_t st, uint32_t NQ, bool general, const Gate* d_gates, const PLevel* d_levels, uint32_t l0, uint32_t l1, uint64_t n_steps,
+                           const InterpParams& p, uint32_t* d_sync);
 // next: the level launched after this one by launch_interp too (nullable) -- the tail of this launch prefetches
 // its first gate records
 void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p,

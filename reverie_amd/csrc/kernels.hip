@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "b3.h"
+#include "flat.h"
 #include "gf2dev.h"
 #include "internal.h"
 #include "launch.h"
@@ -56,7 +57,60 @@ __device__ __forceinline__ uint32_t gather_vclr(const uint8_t* vclr, const uint3
     return v;
 }
 
-template <int MODE>
+// Accesses that must be seen across workgroups INSIDE one launch (k_interp_persist: a level reads what other compute units,
+// on other XCDs, wrote a few microseconds earlier in the same kernel): agent-scope relaxed atomics = `sc1` loads that bypass the
+// reader's L1 and write-through `sc1` stores (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 on both sides needs no fence).
+// COH = false: the plain accesses of the one-launch-per-level kernels.
+// (experiment switches: which of the three kinds of access take the coherent form)
+#ifndef RV_COH_LDROW
+#define RV_COH_LDROW 1
+#endif
+#ifndef RV_COH_STROW
+#define RV_COH_STROW 1
+#endif
+#ifndef RV_COH_V
+#define RV_COH_V 1
+#endif
+template <bool COH>
+__device__ __forceinline__ uint32_t ld_row(const uint32_t* p) {
+    if (COH && RV_COH_LDROW) return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_row(uint32_t* p, uint32_t v) {
+    if (COH && RV_COH_STROW)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ uint32_t ld_v(const uint8_t* p) {
+    if (COH && RV_COH_V) return __hip_atomic_load(const_cast<uint8_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_v(uint8_t* p, uint8_t v) {
+    if (COH && RV_COH_V)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ uint32_t gather_rows_c(const uint32_t* rows, const uint32_t* ids, uint32_t NQ, uint32_t q) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < RV_LIN_K; i++) v ^= ld_row<COH>(&rows[(size_t)ids[i] * NQ + q]);
+    return v;
+}
+template <bool COH>
+__device__ __forceinline__ uint32_t gather_vclr_c(const uint8_t* vclr, const uint32_t* ids) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < RV_LIN_K; i++) v ^= ld_v<COH>(&vclr[ids[i]]);
+    return v;
+}
+
+template <int MODE, bool COH = false>
 __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParams& p, uint32_t NQ, uint32_t q, uint32_t onm) {
     switch (g_op(g)) {
     case G_INPUT: {
@@ -71,17 +125,17 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = corr;
         if (MODE == MODE_PROVE_F) break;  // (the wire's value is k_clear's business)
         if (MODE == MODE_PROVE_V) {
-            if (q == 0) p.vclr[g.dst] = p.wit[g.x] ? 1 : 0;
+            if (q == 0) st_v<COH>(&p.vclr[g.dst], p.wit[g.x] ? 1 : 0);
         } else {
             store_bits(p.corr, g.dst, NQ, q, corr);
         }
         break;
     }
     case G_XORK: {
-        p.rows[(size_t)g.dst * NQ + q] = gather_rows(p.rows, g.a, NQ, q) ^ gather_rows(p.rows, g.b, NQ, q);
+        st_row<COH>(&p.rows[(size_t)g.dst * NQ + q], gather_rows_c<COH>(p.rows, g.a, NQ, q) ^ gather_rows_c<COH>(p.rows, g.b, NQ, q));
         if (MODE == MODE_PROVE_F) break;
         if (MODE == MODE_PROVE_V) {
-            if (q == 0) p.vclr[g.dst] = (uint8_t)(g_ca(g) ^ gather_vclr(p.vclr, g.a) ^ gather_vclr(p.vclr, g.b));
+            if (q == 0) st_v<COH>(&p.vclr[g.dst], (uint8_t)((g_ca(g) ^ gather_vclr_c<COH>(p.vclr, g.a) ^ gather_vclr_c<COH>(p.vclr, g.b)) & 1u));
             break;
         }
         // corr bits: plain byte XOR, no expansion needed
@@ -99,13 +153,13 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     }
     case G_MUL: {
         if (MODE == MODE_PROVE_F) break;  // (k_mul_flat runs the Mul gates of a flat schedule)
-        const uint32_t lx = gather_rows(p.rows, g.a, NQ, q), ly = gather_rows(p.rows, g.b, NQ, q);
+        const uint32_t lx = gather_rows_c<COH>(p.rows, g.a, NQ, q), ly = gather_rows_c<COH>(p.rows, g.b, NQ, q);
         const uint32_t lab = p.rows[(size_t)g.m * NQ + q], lnew = p.rows[(size_t)(g.m + 1) * NQ + q];
         const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
         uint32_t cx, cy, vx = 0, vy = 0;
         if (MODE == MODE_PROVE_V) {
-            vx = gather_vclr(p.vclr, g.a) ^ g_ca(g);
-            vy = gather_vclr(p.vclr, g.b) ^ g_cb(g);
+            vx = (gather_vclr_c<COH>(p.vclr, g.a) ^ g_ca(g)) & 1u;
+            vy = (gather_vclr_c<COH>(p.vclr, g.b) ^ g_cb(g)) & 1u;
             cx = a ^ (vx ? 0xFFFFFFFFu : 0u);  // corr = value - reconstruct(mask)
             cy = b ^ (vy ? 0xFFFFFFFFu : 0u);
         } else {
@@ -131,7 +185,7 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = s;
         store_bits(p.pre, g.ep, NQ, q, delta);
         if (MODE == MODE_PROVE_V) {
-            if (q == 0) p.vclr[g.dst] = (uint8_t)(vx & vy);
+            if (q == 0) st_v<COH>(&p.vclr[g.dst], (uint8_t)(vx & vy));
         } else {
             store_bits(p.corr, g.dst, NQ, q, r ^ delta ^ (cx & cy));
         }
@@ -151,13 +205,13 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         break;
     }
     case G_ASSERT: {
-        uint32_t m = gather_rows(p.rows, g.a, NQ, q);
+        uint32_t m = gather_rows_c<COH>(p.rows, g.a, NQ, q);
         if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
         if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = m;
         if (MODE == MODE_PROVE_F) break;  // (k_clear checks the wire's value)
         if (MODE == MODE_PROVE_V) {
             // the wire's value itself must be zero (prover.rs:221-228), the same in every repetition
-            if (q == 0 && (gather_vclr(p.vclr, g.a) ^ g_ca(g)) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+            if (q == 0 && ((gather_vclr_c<COH>(p.vclr, g.a) ^ g_ca(g)) & 1u) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
         } else {
             const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
             if (MODE == MODE_PROVE) {
@@ -258,7 +312,7 @@ __device__ __forceinline__ void pf_sink(uint32_t v) { asm volatile("" ::"v"(v));
 // wave-uniform and the records come through scalar loads.  KA / KB = operand base rows actually
 // loaded per gate: exact for the common one-base-per-operand class, RV_LIN_K (unused slots point at
 // the L1-hot zero row) for the rest.
-template <int MODE, int NQ, int U, int KA, int KB>
+template <int MODE, int NQ, int U, int KA, int KB, bool COH = false>
 __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
                                      uint32_t onm, const Gate* pf = nullptr) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
@@ -281,8 +335,8 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
             ra[u][i] = 0;
             ca[u][i] = 0;
             if (i == 0 || i < na) {
-                ra[u][i] = p.rows[(size_t)g[u].a[i] * NQ + q];
-                ca[u][i] = MODE == MODE_PROVE_V ? p.vclr[g[u].a[i]] : p.corr[(size_t)g[u].a[i] * H + (q >> 1)];
+                ra[u][i] = ld_row<COH>(&p.rows[(size_t)g[u].a[i] * NQ + q]);
+                ca[u][i] = MODE == MODE_PROVE_V ? ld_v<COH>(&p.vclr[g[u].a[i]]) : p.corr[(size_t)g[u].a[i] * H + (q >> 1)];
             }
         }
 #pragma unroll
@@ -290,8 +344,8 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
             rb[u][i] = 0;
             cb[u][i] = 0;
             if (i == 0 || i < nb) {
-                rb[u][i] = p.rows[(size_t)g[u].b[i] * NQ + q];
-                cb[u][i] = MODE == MODE_PROVE_V ? p.vclr[g[u].b[i]] : p.corr[(size_t)g[u].b[i] * H + (q >> 1)];
+                rb[u][i] = ld_row<COH>(&p.rows[(size_t)g[u].b[i] * NQ + q]);
+                cb[u][i] = MODE == MODE_PROVE_V ? ld_v<COH>(&p.vclr[g[u].b[i]]) : p.corr[(size_t)g[u].b[i] * H + (q >> 1)];
             }
         }
         // lambda_ab is read exactly once and the online row is not read again before the hash phase: nontemporal, so
@@ -350,7 +404,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
         if (MODE != MODE_VERIFY || on_wr) __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
         store_bits(p.pre, g[u].ep, NQ, q, delta);
         if (MODE == MODE_PROVE_V) {
-            if (q == 0) p.vclr[g[u].dst] = (uint8_t)(vx & vy);
+            if (q == 0) st_v<COH>(&p.vclr[g[u].dst], (uint8_t)(vx & vy));
         } else {
             store_bits(p.corr, g[u].dst, NQ, q, r ^ delta ^ (cx & cy));
         }
@@ -359,7 +413,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
 }
 
 // G_XORK: N = base rows loaded per gate (2: a[0], a[1]; 6: a[0..2], b[0..2] with zero-row padding)
-template <int MODE, int NQ, int U, int N>
+template <int MODE, int NQ, int U, int N, bool COH = false>
 __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
                                      const Gate* pf = nullptr) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
@@ -377,12 +431,12 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
             cc[u][i] = 0;
             // only the slots the gate uses (N == 2: both by construction)
             if (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) {
-                rr[u][i] = p.rows[(size_t)id * NQ + q];
+                rr[u][i] = ld_row<COH>(&p.rows[(size_t)id * NQ + q]);
                 // H corr bytes per row: the first H lanes of the gate's lane group carry them (MODE_PROVE_V: one value byte;
                 // MODE_PROVE_F: shares only)
                 if (MODE == MODE_PROVE_F) {
                 } else if (MODE == MODE_PROVE_V) {
-                    if (q == 0) cc[u][i] = p.vclr[id];
+                    if (q == 0) cc[u][i] = ld_v<COH>(&p.vclr[id]);
                 } else if (q < H) {
                     cc[u][i] = p.corr[(size_t)id * H + q];
                 }
@@ -402,10 +456,10 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-        p.rows[(size_t)g[u].dst * NQ + q] = x[u];
+        st_row<COH>(&p.rows[(size_t)g[u].dst * NQ + q], x[u]);
         if (MODE == MODE_PROVE_F) {
         } else if (MODE == MODE_PROVE_V) {
-            if (q == 0) p.vclr[g[u].dst] = (uint8_t)((bx[u] ^ g_ca(g[u])) & 1u);
+            if (q == 0) st_v<COH>(&p.vclr[g[u].dst], (uint8_t)((bx[u] ^ g_ca(g[u])) & 1u));
         } else if (q < H) {
             p.corr[(size_t)g[u].dst * H + q] = (uint8_t)(bx[u] ^ (g_ca(g[u]) ? 0xFFu : 0u));
         }
@@ -572,6 +626,279 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
             hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
         else
             hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_interp_persist: the dependency levels of a circuit WITHOUT a launch each (round 4).
+//
+// One launch per level costs a kernel boundary (~2.5 us behind a streaming kernel) plus the fill and drain of ~1.5
+// generations of short-lived wavefronts: 163 levels x ~12.8 us on the 10^7-gate circuit, and ~7 us per level however narrow
+// the rows of a repetition shard are.  Here the grid is as many workgroups as the chip holds at once and stays for levels
+// [l0, l1): the wave-steps of a level (the same 4-gate class steps run_level deals out) are dealt to the wavefronts round-robin,
+// continuing where the previous level stopped.  A wavefront with a step in level l first makes sure every step of the levels
+// before it has ended -- `done` = 32 counters (one atomic per wavefront and level, spread over 32 words so that no word
+// sees more than a few arrivals per microsecond) whose sum it polls with one 128-byte load -- and adds its own steps when its
+// stores have drained.  Nothing waits for a slower wavefront that has no business with it, no workgroup is launched or retired
+// at a level boundary, and a wavefront whose level-l work is done starts its level-(l + 1) step's gate records at once.
+//
+// What crosses compute units inside the launch (operand rows that are XOR outputs, the cleartext value bytes) goes through
+// write-through stores and L1-bypassing loads (COH = true above).  Fresh PRG masks and transcripts do not: the former were
+// written by the mask generator's launch, the latter are read by later launches.
+// Every wait is bounded (PERSIST_SPIN_TICKS): a wavefront that gives up sets the abort word, everybody leaves, and the proof
+// fails with RV_E_DEVICE instead of hanging the queue (a grid larger than the chip can hold at once would do that).
+// ------------------------------------------------------------------------------------
+constexpr uint32_t PERSIST_SHARDS = 32;
+constexpr long long PERSIST_SPIN_TICKS = 200000000ll;  // wall_clock64: 100 MHz -> 2 s
+
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;  // lanes 0..31 hold the sum of lanes 0..31
+}
+
+// true when the steps [0, need) of the launch have all ended (seen: the last total this wavefront read); false = abort
+__device__ __forceinline__ bool persist_wait(uint32_t* sync, uint32_t need, uint32_t& seen, uint32_t lane) {
+    if (seen >= need) return true;
+    const long long t0 = wall_clock64();
+    for (uint32_t spins = 0;; spins++) {
+        uint32_t v = 0;
+        if (lane < PERSIST_SHARDS) v = __hip_atomic_load(sync + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum32(v));
+        if (total >= need) {
+            seen = total;
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        if ((spins & 255u) == 255u) {
+            uint32_t ab = 0;
+            if (lane == 0) ab = __hip_atomic_load(sync + PERSIST_SHARDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ab = (uint32_t)__builtin_amdgcn_readfirstlane((int)ab);
+            if (ab || wall_clock64() - t0 > PERSIST_SPIN_TICKS) {
+                if (lane == 0) __hip_atomic_store(sync + PERSIST_SHARDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+template <int MODE, int NQ, bool GENERAL>
+__global__ __launch_bounds__(256, GENERAL ? 1 : 8) void k_interp_persist(const Gate* __restrict__ gates, const PLevel* __restrict__ levels, uint32_t l0, uint32_t l1,
+                                                                         InterpParams p, uint32_t* __restrict__ sync) {
+    constexpr uint32_t GPW = 64 / NQ;
+    constexpr int U = interp_unroll(NQ, GENERAL);
+    constexpr uint32_t STEP = (uint32_t)U * GPW;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t q = lane % NQ, sub = lane / NQ;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t W = gridDim.x * (blockDim.x >> 6);
+    const uint32_t base0 = levels[l0].step0;  // steps are counted from the launch's first level
+    uint32_t seen = 0;
+    PLevel Ln = levels[l0];
+    for (uint32_t l = l0; l < l1; l++) {
+        const PLevel L = Ln;
+        Ln = levels[l + 1 < l1 ? l + 1 : l];  // (the next level's table entry travels while this level runs)
+        const uint32_t first_step = L.step0 - base0;
+        // the wavefront's first step in this level: steps are dealt round-robin across the levels
+        const uint32_t rot = first_step % W;
+        uint32_t t = wave >= rot ? wave - rot : wave + W - rot;
+        if (t >= L.n_steps) continue;
+        if (!persist_wait(sync, first_step, seen, lane)) {
+            if (lane == 0) atomicOr(p.err, RV_DEV_PERSIST_ABORT);
+            return;
+        }
+        const uint32_t begin[5] = {L.r.lo, L.r.mul11, L.r.mul, L.r.xor2, L.r.xork}, end[5] = {L.r.mul11, L.r.mul, L.r.xor2, L.r.xork, L.r.hi};
+        uint32_t mine = 0;
+        for (; t < L.n_steps; t += W, mine++) {
+            uint32_t tt = t;
+            if (tt < L.n_full[0]) {
+                mulU<MODE, NQ, U, 1, 1, true>(gates, begin[0] + tt * STEP, p, sub, q, 0u);
+                continue;
+            }
+            tt -= L.n_full[0];
+            if (GENERAL && tt < L.n_full[1]) {
+                mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K, true>(gates, begin[1] + tt * STEP, p, sub, q, 0u);
+                continue;
+            }
+            tt -= L.n_full[1];
+            if (tt < L.n_full[2]) {
+                xorU<MODE, NQ, U, 2, true>(gates, begin[2] + tt * STEP, p, sub, q);
+                continue;
+            }
+            tt -= L.n_full[2];
+            if (GENERAL && tt < L.n_full[3]) {
+                xorU<MODE, NQ, U, 2 * RV_LIN_K, true>(gates, begin[3] + tt * STEP, p, sub, q);
+                continue;
+            }
+            tt -= L.n_full[3];
+            // the gates that do not fill an unrolled step, GPW at a time, class after class
+            uint32_t c0 = 0, e0 = 0, found = 0;
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const uint32_t rest = begin[c] + (c < 4 ? L.n_full[c] * STEP : 0u);
+                const uint32_t n = (end[c] - rest + GPW - 1) / GPW;
+                if (!found) {
+                    if (tt < n) c0 = rest + tt * GPW, e0 = end[c], found = 1;
+                    else tt -= n;
+                }
+            }
+            const uint32_t gi = c0 + sub;
+            if (found && gi < e0) interp_one_impl<MODE, true>(gates[gi], p, NQ, q, 0u);
+        }
+        // this wavefront's share of the level has ended once its write-through stores have left
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(sync + (wave % PERSIST_SHARDS), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// per-level step tables of a compiled circuit (host): the same class steps launch_interp_full would deal out
+void build_persist_levels(const LevelRange* lr, size_t n_levels, uint32_t NQ, bool general, PLevel* out) {
+    const uint32_t GPW = 64 / NQ;
+    const uint32_t STEP = (uint32_t)interp_unroll((int)NQ, general) * GPW;
+    uint64_t step0 = 0;
+    for (size_t l = 0; l < n_levels; l++) {
+        PLevel L{};
+        L.r = lr[l];
+        const uint32_t begin[5] = {L.r.lo, L.r.mul11, L.r.mul, L.r.xor2, L.r.xork}, end[5] = {L.r.mul11, L.r.mul, L.r.xor2, L.r.xork, L.r.hi};
+        uint32_t n = 0;
+        for (int c = 0; c < 5; c++) {
+            const uint32_t full = (c == 4 || (!general && (c == 1 || c == 3))) ? 0u : (end[c] - begin[c]) / STEP;
+            if (c < 4) L.n_full[c] = full;
+            n += full + ((end[c] - (begin[c] + full * STEP)) + GPW - 1) / GPW;
+        }
+        L.n_steps = n;
+        L.step0 = (uint32_t)step0;
+        step0 += n;
+        out[l] = L;
+    }
+}
+bool persist_general(const LevelRange* lr, size_t n_levels) {
+    for (size_t l = 0; l < n_levels; l++)
+        if (level_is_general(lr[l])) return true;
+    return false;
+}
+
+template <int NQ, bool GENERAL>
+static int launch_persist_nq(hipStream_t st, const Gate* d_gates, const PLevel* d_levels, uint32_t l0, uint32_t l1, uint64_t n_steps, const InterpParams& p,
+                             uint32_t* d_sync) {
+    // as many workgroups as are resident at once, one short of the occupancy query's answer per compute unit (it is one too
+    // high for some register counts: MI355X_MICROARCH.md, residency) -- every wavefront of the grid must be running for the
+    // waits to end
+    static const uint32_t max_blocks = [] {
+        int dev = 0, cus = 0, occ = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_interp_persist<MODE_PROVE_V, NQ, GENERAL>, 256, 0) != hipSuccess || occ <= 0) {
+            (void)hipGetLastError();
+            occ = 2;
+        }
+        if (const char* e = getenv("RV_PERSIST_OCC")) occ = std::max(atoi(e), 1);
+        else if (occ > 2) occ -= 1;
+        return (uint32_t)(occ * cus);
+    }();
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((n_steps + 3) / 4, 1), max_blocks);
+    hipLaunchKernelGGL((k_interp_persist<MODE_PROVE_V, NQ, GENERAL>), dim3(blocks), dim3(256), 0, st, d_gates, d_levels, l0, l1, p, d_sync);
+    return 0;
+}
+
+bool persist_supports(uint32_t NQ) { return NQ == 64 || NQ == 32 || NQ == 16 || NQ == 8; }
+
+// levels [l0, l1) in one launch (MODE_PROVE_V); d_sync: PERSIST_SYNC_WORDS zeroed words of this launch's own
+void launch_interp_persist(hipStream_t st, uint32_t NQ, bool general, const Gate* d_gates, const PLevel* d_levels, uint32_t l0, uint32_t l1, uint64_t n_steps,
+                           const InterpParams& p, uint32_t* d_sync) {
+    if (l1 <= l0) return;
+    switch (NQ) {
+    case 64: general ? launch_persist_nq<64, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync) : launch_persist_nq<64, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync); break;
+    case 32: general ? launch_persist_nq<32, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync) : launch_persist_nq<32, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync); break;
+    case 16: general ? launch_persist_nq<16, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync) : launch_persist_nq<16, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync); break;
+    case 8: general ? launch_persist_nq<8, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync) : launch_persist_nq<8, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync); break;
+    default: break;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_level_split: one dependency level of the split prover schedule's CHAIN (flat.h): the level's XOR gates as the level
+// kernels run them (rows and value bytes), and -- a lane per gate, bytes only -- the cleartext values of its Mul / Input /
+// AssertZero gates.  The Mul gates' row work (four rows in, a transcript row out) is not here: k_mul_flat runs it in program
+// order on the main stream, a band behind this chain.  Value byte of a share row: bit 0 = the wire's value; a Mul's output row
+// also carries its operands' values in bits 1 and 2 for k_mul_flat.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void lite_finish(const InterpParams& p, uint32_t meta, uint32_t dst, uint32_t xa, uint32_t xb) {
+    const uint32_t op = meta & 7u, ca = (meta >> 3) & 1u, cb = (meta >> 4) & 1u;
+    if (op == G_MUL) {
+        const uint32_t vx = (xa ^ ca) & 1u, vy = (xb ^ cb) & 1u;
+        p.vclr[dst] = (uint8_t)((vx & vy) | (vx << 1) | (vy << 2));
+    } else if (op == G_INPUT) {
+        p.vclr[dst] = (uint8_t)(xa ? 1 : 0);
+    } else if (op == G_ASSERT) {
+        if (((xa ^ xb ^ ca) & 1u) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+    } else if (op == G_XORK) {
+        p.vclr[dst] = (uint8_t)((xa ^ xb ^ ca) & 1u);
+    }
+}
+template <int NQ, bool GENERAL>
+__global__ __launch_bounds__(256) void k_level_split(const Gate* __restrict__ gates, LevelRange xr, ClearLevel lite, const ClearRec* __restrict__ recs,
+                                                     const ClearRecK* __restrict__ recs_k, uint32_t lite_blocks, InterpParams p) {
+    if (blockIdx.x < lite_blocks) {
+        const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+        const uint32_t ns = lite.s1 - lite.s0, ng = lite.g1 - lite.g0;
+        if (t < ns) {
+            const uint4 r = *(const uint4*)(recs + lite.s0 + t);  // dst a0 b0 meta
+            const uint32_t meta = r.w;
+            uint32_t xa = 0, xb = 0;
+            if ((meta & 7u) == G_INPUT) {
+                xa = p.wit[r.y];
+            } else {
+                if ((meta >> 8) & 3u) xa = p.vclr[r.y];
+                if ((meta >> 10) & 3u) xb = p.vclr[r.z];
+            }
+            lite_finish(p, meta, r.x, xa, xb);
+        } else if (t - ns < ng) {
+            const uint4* qq = (const uint4*)(recs_k + lite.g0 + (t - ns));
+            const uint4 r0 = qq[0], r1 = qq[1];  // dst meta a0 a1 | a2 b0 b1 b2
+            const uint32_t meta = r0.y, na = (meta >> 8) & 3u, nb = (meta >> 10) & 3u;
+            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+            if (na > 0) t0 = p.vclr[r0.z];
+            if (na > 1) t1 = p.vclr[r0.w];
+            if (na > 2) t2 = p.vclr[r1.x];
+            if (nb > 0) t3 = p.vclr[r1.y];
+            if (nb > 1) t4 = p.vclr[r1.z];
+            if (nb > 2) t5 = p.vclr[r1.w];
+            lite_finish(p, meta, r0.x, t0 ^ t1 ^ t2, t3 ^ t4 ^ t5);
+        }
+        return;
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(((blockIdx.x - lite_blocks) * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t n_waves = (gridDim.x - lite_blocks) * (blockDim.x >> 6);
+    run_level<MODE_PROVE_V, NQ, true, GENERAL>(gates, xr, p, wave, n_waves, lane, 0u);
+}
+
+template <int NQ>
+static void launch_level_split_nq(hipStream_t st, const Gate* d_gates, const LevelRange& r, const ClearLevel& lite, const ClearRec* d_lite_s,
+                                  const ClearRecK* d_lite_k, const InterpParams& p) {
+    constexpr uint32_t GPW = 64 / NQ;
+    // the XOR classes of the level only (its Mul gates have a kernel of their own, everything else goes by value records)
+    const LevelRange xr{r.mul, r.mul, r.mul, r.xor2, r.xork, r.xork};
+    const bool general = level_is_general(xr);
+    const uint32_t u = (uint32_t)interp_unroll(NQ, general);
+    const uint64_t n_lite = (uint64_t)(lite.s1 - lite.s0) + (lite.g1 - lite.g0);
+    const uint32_t lite_blocks = (uint32_t)((n_lite + 255) / 256);
+    const uint64_t waves = ((uint64_t)(xr.hi - xr.lo) + u * GPW - 1) / (u * GPW);
+    const uint32_t xblocks = (uint32_t)std::min<uint64_t>((waves + 3) / 4, 4096);
+    if (!lite_blocks && !xblocks) return;
+    if (general)
+        hipLaunchKernelGGL((k_level_split<NQ, true>), dim3(lite_blocks + xblocks), dim3(256), 0, st, d_gates, xr, lite, d_lite_s, d_lite_k, lite_blocks, p);
+    else
+        hipLaunchKernelGGL((k_level_split<NQ, false>), dim3(lite_blocks + xblocks), dim3(256), 0, st, d_gates, xr, lite, d_lite_s, d_lite_k, lite_blocks, p);
+}
+void launch_level_split(hipStream_t st, const Gate* d_gates, const LevelRange& r, const ClearLevel& lite, const ClearRec* d_lite_s, const ClearRecK* d_lite_k,
+                        const InterpParams& p) {
+    switch (p.NQ) {
+    case 64: return launch_level_split_nq<64>(st, d_gates, r, lite, d_lite_s, d_lite_k, p);
+    case 32: return launch_level_split_nq<32>(st, d_gates, r, lite, d_lite_s, d_lite_k, p);
+    case 16: return launch_level_split_nq<16>(st, d_gates, r, lite, d_lite_s, d_lite_k, p);
+    case 8: return launch_level_split_nq<8>(st, d_gates, r, lite, d_lite_s, d_lite_k, p);
+    default: break;
     }
 }
 

@@ -1,5 +1,5 @@
-"""A/B of the flat prover schedule on the 10^7-gate circuit (same box, same process): ms per host-to-host proof and per-phase GPU
-times with RV_FLAT=0 / 1, bytes compared with each other.  python tools/flat_ab.py [reps] [bands,...]   (AB_P_AND=1.0: all-AND)"""
+"""A/B of the persistent level kernel (k_interp_persist) on the 10^7-gate circuit (same box, same process): ms per host-to-host proof and per-phase GPU
+times with RV_PERSIST=0 / 1, bytes compared with each other.  python tools/flat_ab.py [reps] [bands,...]   (AB_P_AND=1.0: all-AND)"""
 import ctypes as C
 import os
 import sys
@@ -12,7 +12,7 @@ from reverie_amd import _lib
 import circuits
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-band_list = sys.argv[2].split(",") if len(sys.argv) > 2 else ["8"]
+band_list = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"]
 p_and = float(os.environ.get("AB_P_AND", "0.5"))
 prog, wit, wc, st = circuits.layered_gf2(p_and=p_and)
 seeds = np.frombuffer(bytes(range(256)) * 16, np.uint8).reshape(256, 16)
@@ -45,11 +45,12 @@ def run(label):
     return b, ok
 
 
-os.environ["RV_FLAT"] = "0"
-ref, ok = run("RV_FLAT=0")
+os.environ["RV_PERSIST"] = "0"
+ref, ok = run("RV_PERSIST=0")
 print("  verifies:", ok, flush=True)
-for b in band_list:
-    os.environ["RV_FLAT"] = os.environ.get("AB_FLAT", "1")
-    os.environ["RV_FLAT_BANDS"] = b
-    got, ok = run(f"RV_FLAT=1 bands={b}")
+for occ in band_list:
+    os.environ["RV_PERSIST"] = "1"
+    if occ != "0":
+        os.environ["RV_PERSIST_OCC"] = occ
+    got, ok = run(f"RV_PERSIST=1 occ={occ}")
     print("  bytes equal:", got == ref, " verifies:", ok, flush=True)
