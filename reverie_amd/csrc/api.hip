@@ -1769,14 +1769,20 @@ static int shard_run_persist(rv_shard* s, const InterpParams& p) {
     int rc;
     if ((rc = dalloc(ctx, cuts.size() * PERSIST_SYNC_WORDS, &s->d_sync))) return rc;
     HIPCHK(hipMemsetAsync(s->d_sync, 0, cuts.size() * PERSIST_SYNC_WORDS * 4, ctx->stream));
+    const bool flow = persist_mode() >= 2;
     ctx->phase(RV_PH_INTERP, ctx->stream);
+    if (flow) {
+        // dataflow form: every value byte starts as "not ready", the zero row's as ready with value 0
+        HIPCHK(hipMemsetAsync(s->d_vclr, 0, (size_t)cc.n_rows, ctx->stream));
+        HIPCHK(hipMemsetAsync(s->d_vclr + cc.zero_row, 0x80, 1, ctx->stream));
+    }
     uint32_t l0 = 0;
     for (size_t k = 0; k < cuts.size(); k++) {
         const uint32_t l1 = cuts[k];
         if (s->ec && (rc = early_flush(s, l0))) return rc;
         if (l1 > l0) {
             const uint64_t n_steps = (uint64_t)T->h[l1 - 1].step0 + T->h[l1 - 1].n_steps - T->h[l0].step0;
-            launch_interp_persist(ctx->stream, s->NQ, c->persist_gen, c->d_gates, T->d, l0, l1, n_steps, p, s->d_sync + k * PERSIST_SYNC_WORDS);
+            launch_interp_persist(ctx->stream, s->NQ, c->persist_gen, c->d_gates, T->d, l0, l1, n_steps, p, s->d_sync + k * PERSIST_SYNC_WORDS, flow);
             ctx->count();
         }
         l0 = l1;

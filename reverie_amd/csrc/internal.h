@@ -175,8 +175,10 @@ constexpr int RV_DEV_PERSIST_ABORT = 0x20000000;   // device error word: a persi
 void build_persist_levels(const LevelRange* lr, size_t n_levels, uint32_t NQ, bool general, PLevel* out);
 bool persist_general(const LevelRange* lr, size_t n_levels);
 bool persist_supports(uint32_t NQ);
+// flow: the dataflow form (k_interp_flow): no counters, a gate waits for the ready bits of its own operands' value bytes -- the
+// whole vclr array must be zero before the first launch of a proof, but for the zero row's byte (0x80: ready, value 0)
 void launch_interp_persist(hipStream_t st, uint32_t NQ, bool general, const Gate* d_gates, const PLevel* d_levels, uint32_t l0, uint32_t l1, uint64_t n_steps,
-                           const InterpParams& p, uint32_t* d_sync);
+                           const InterpParams& p, uint32_t* d_sync, bool flow = false);
 // next: the level launched after this one by launch_interp too (nullable) -- the tail of this launch prefetches
 // its first gate records
 void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p,

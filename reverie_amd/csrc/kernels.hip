@@ -682,6 +682,244 @@ __device__ __forceinline__ bool persist_wait(uint32_t* sync, uint32_t need, uint
     }
 }
 
+// ---- dataflow form (k_interp_flow): no counters at all.  Every share row that the interpreter writes, and every PRG row whose
+// wire VALUE it computes (Mul / Input outputs), has one byte in `vclr`: bit 7 = "the row and its value are final", bit 0 = the
+// cleartext value.  A gate reads its operands' bytes first (write-through stores, L1-bypassing loads: a stale copy can only say
+// "not yet", each byte is written once per proof), waits on exactly those, and only then gathers the rows; an XOR gate stores its
+// row, drains, and sets the byte.  The steps are dealt to the resident wavefronts in (level, class) order as above, so a producer's
+// step is always handed out before its consumers': the waits end whatever the timing, and nothing that is not a real dependency
+// is ever waited for -- the wavefronts run through the level boundaries.
+constexpr uint32_t V_READY = 0x80u;
+
+struct FlowCtl {
+    uint32_t* sync;   // [0] abort word
+    long long t0;
+    uint32_t spins;
+    // false: give up (another wavefront did, or this one has waited PERSIST_SPIN_TICKS)
+    __device__ __forceinline__ bool again(uint32_t lane) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 127u) != 0) return true;
+        uint32_t ab = 0;
+        if (lane == 0) ab = __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ab = (uint32_t)__builtin_amdgcn_readfirstlane((int)ab);
+        if (ab || wall_clock64() - t0 > PERSIST_SPIN_TICKS) {
+            if (lane == 0) __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        return true;
+    }
+};
+
+template <int NQ, int U, int KA, int KB>
+__device__ __forceinline__ bool mulD(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q, FlowCtl& fc, uint32_t lane) {
+    constexpr uint32_t GPW = 64 / NQ;
+    Gate g[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
+    uint32_t lab[U], lnew[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {  // the fresh masks depend on nothing
+        lab[u] = __builtin_nontemporal_load(&p.rows[(size_t)g[u].m * NQ + q]);
+        lnew[u] = p.rows[(size_t)(g[u].m + 1) * NQ + q];
+    }
+    uint32_t bx[U], by[U];
+    for (;;) {
+        uint32_t ca[U][KA], cb[U][KB];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
+#pragma unroll
+            for (int i = 0; i < KA; i++) ca[u][i] = (i == 0 || i < na) ? ld_v<true>(&p.vclr[g[u].a[i]]) : V_READY;
+#pragma unroll
+            for (int i = 0; i < KB; i++) cb[u][i] = (i == 0 || i < nb) ? ld_v<true>(&p.vclr[g[u].b[i]]) : V_READY;
+        }
+        uint32_t all = V_READY;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            bx[u] = 0, by[u] = 0;
+#pragma unroll
+            for (int i = 0; i < KA; i++) all &= ca[u][i], bx[u] ^= ca[u][i];
+#pragma unroll
+            for (int i = 0; i < KB; i++) all &= cb[u][i], by[u] ^= cb[u][i];
+        }
+        if (__all((all & V_READY) != 0)) break;
+        if (!fc.again(lane)) return false;
+    }
+    uint32_t lx[U], ly[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
+        lx[u] = 0, ly[u] = 0;
+#pragma unroll
+        for (int i = 0; i < KA; i++)
+            if (i == 0 || i < na) lx[u] ^= ld_row<true>(&p.rows[(size_t)g[u].a[i] * NQ + q]);
+#pragma unroll
+        for (int i = 0; i < KB; i++)
+            if (i == 0 || i < nb) ly[u] ^= ld_row<true>(&p.rows[(size_t)g[u].b[i] * NQ + q]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t a = recon32(lx[u]), b = recon32(ly[u]), c = recon32(lab[u]);
+        const uint32_t vx = (bx[u] ^ g_ca(g[u])) & 1u, vy = (by[u] ^ g_cb(g[u])) & 1u;
+        const uint32_t cx = a ^ (vx ? 0xFFFFFFFFu : 0u), cy = b ^ (vy ? 0xFFFFFFFFu : 0u);  // corr = value - reconstruct(mask)
+        const uint32_t delta = (a & b) ^ c;
+        const uint32_t s = (ly[u] & cx) ^ (lx[u] & cy) ^ lab[u] ^ lnew[u];
+        __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
+        store_bits(p.pre, g[u].ep, NQ, q, delta);
+        if (q == 0) st_v<true>(&p.vclr[g[u].dst], (uint8_t)(V_READY | (vx & vy)));  // (the output's mask is a PRG row: only its value is new)
+    }
+    return true;
+}
+
+template <int NQ, int U, int N>
+__device__ __forceinline__ bool xorD(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q, FlowCtl& fc, uint32_t lane) {
+    constexpr uint32_t GPW = 64 / NQ;
+    Gate g[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
+    uint32_t bx[U];
+    for (;;) {
+        uint32_t all = V_READY;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
+            bx[u] = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const uint32_t id = (N == 2) ? g[u].a[i] : (i < RV_LIN_K ? g[u].a[i] : g[u].b[i - RV_LIN_K]);
+                const uint32_t c = (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) ? ld_v<true>(&p.vclr[id]) : V_READY;
+                all &= c, bx[u] ^= c;
+            }
+        }
+        if (__all((all & V_READY) != 0)) break;
+        if (!fc.again(lane)) return false;
+    }
+    uint32_t x[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
+        x[u] = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t id = (N == 2) ? g[u].a[i] : (i < RV_LIN_K ? g[u].a[i] : g[u].b[i - RV_LIN_K]);
+            if (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) x[u] ^= ld_row<true>(&p.rows[(size_t)id * NQ + q]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) st_row<true>(&p.rows[(size_t)g[u].dst * NQ + q], x[u]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have left before their bytes say so
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        if (q == 0) st_v<true>(&p.vclr[g[u].dst], (uint8_t)(V_READY | ((bx[u] ^ g_ca(g[u])) & 1u)));
+    return true;
+}
+
+// one gate per lane group (the gates that do not fill an unrolled step)
+__device__ __forceinline__ bool oneD(const Gate& g, bool active, const InterpParams& p, uint32_t NQ, uint32_t q, FlowCtl& fc, uint32_t lane) {
+    const uint32_t op = active ? g_op(g) : 0xFFu;
+    uint32_t va = 0, vb = 0;
+    for (;;) {
+        uint32_t all = V_READY;
+        va = 0, vb = 0;
+        if (op == G_XORK || op == G_MUL || op == G_ASSERT) {
+#pragma unroll
+            for (int i = 0; i < RV_LIN_K; i++) {  // (unused slots hold the zero row: ready, value 0)
+                const uint32_t a = ld_v<true>(&p.vclr[g.a[i]]), b = (op == G_ASSERT) ? V_READY : ld_v<true>(&p.vclr[g.b[i]]);
+                all &= a & b, va ^= a, vb ^= b;
+            }
+        }
+        if (__all((all & V_READY) != 0)) break;
+        if (!fc.again(lane)) return false;
+    }
+    bool wrote_row = false;
+    if (op == G_INPUT) {
+        const uint32_t lam = p.rows[(size_t)g.m * NQ + q];
+        const uint32_t w = p.wit[g.x] ? 0xFFFFFFFFu : 0u;
+        p.on[(size_t)g.eo * NQ + q] = w ^ recon32(lam);
+        if (q == 0) st_v<true>(&p.vclr[g.dst], (uint8_t)(V_READY | (w & 1u)));
+    } else if (op == G_XORK) {
+        st_row<true>(&p.rows[(size_t)g.dst * NQ + q], gather_rows_c<true>(p.rows, g.a, NQ, q) ^ gather_rows_c<true>(p.rows, g.b, NQ, q));
+        wrote_row = true;
+    } else if (op == G_MUL) {
+        const uint32_t lx = gather_rows_c<true>(p.rows, g.a, NQ, q), ly = gather_rows_c<true>(p.rows, g.b, NQ, q);
+        const uint32_t lab = p.rows[(size_t)g.m * NQ + q], lnew = p.rows[(size_t)(g.m + 1) * NQ + q];
+        const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
+        const uint32_t vx = (va ^ g_ca(g)) & 1u, vy = (vb ^ g_cb(g)) & 1u;
+        const uint32_t cx = a ^ (vx ? 0xFFFFFFFFu : 0u), cy = b ^ (vy ? 0xFFFFFFFFu : 0u);
+        p.on[(size_t)g.eo * NQ + q] = (ly & cx) ^ (lx & cy) ^ lab ^ lnew;
+        store_bits(p.pre, g.ep, NQ, q, (a & b) ^ c);
+        if (q == 0) st_v<true>(&p.vclr[g.dst], (uint8_t)(V_READY | (vx & vy)));
+    } else if (op == G_ASSERT) {
+        p.on[(size_t)g.eo * NQ + q] = gather_rows_c<true>(p.rows, g.a, NQ, q);
+        if (q == 0 && ((va ^ g_ca(g)) & 1u) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+    }
+    if (__any(wrote_row)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wrote_row && q == 0) st_v<true>(&p.vclr[g.dst], (uint8_t)(V_READY | ((va ^ vb ^ g_ca(g)) & 1u)));
+    }
+    return true;
+}
+
+template <int NQ, bool GENERAL>
+__global__ __launch_bounds__(256, GENERAL ? 1 : 8) void k_interp_flow(const Gate* __restrict__ gates, const PLevel* __restrict__ levels, uint32_t l0, uint32_t l1,
+                                                                      InterpParams p, uint32_t* __restrict__ sync) {
+    constexpr uint32_t GPW = 64 / NQ;
+    constexpr int U = interp_unroll(NQ, GENERAL);
+    constexpr uint32_t STEP = (uint32_t)U * GPW;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t q = lane % NQ, sub = lane / NQ;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t W = gridDim.x * (blockDim.x >> 6);
+    const uint32_t base0 = levels[l0].step0;
+    FlowCtl fc{sync + PERSIST_SHARDS, wall_clock64(), 0u};
+    bool ok = true;
+    PLevel Ln = levels[l0];
+    for (uint32_t l = l0; l < l1 && ok; l++) {
+        const PLevel L = Ln;
+        Ln = levels[l + 1 < l1 ? l + 1 : l];
+        const uint32_t rot = (L.step0 - base0) % W;
+        uint32_t t = wave >= rot ? wave - rot : wave + W - rot;
+        const uint32_t begin[5] = {L.r.lo, L.r.mul11, L.r.mul, L.r.xor2, L.r.xork}, end[5] = {L.r.mul11, L.r.mul, L.r.xor2, L.r.xork, L.r.hi};
+        for (; t < L.n_steps && ok; t += W) {
+            uint32_t tt = t;
+            if (tt < L.n_full[0]) {
+                ok = mulD<NQ, U, 1, 1>(gates, begin[0] + tt * STEP, p, sub, q, fc, lane);
+                continue;
+            }
+            tt -= L.n_full[0];
+            if (GENERAL && tt < L.n_full[1]) {
+                ok = mulD<NQ, U, RV_LIN_K, RV_LIN_K>(gates, begin[1] + tt * STEP, p, sub, q, fc, lane);
+                continue;
+            }
+            tt -= L.n_full[1];
+            if (tt < L.n_full[2]) {
+                ok = xorD<NQ, U, 2>(gates, begin[2] + tt * STEP, p, sub, q, fc, lane);
+                continue;
+            }
+            tt -= L.n_full[2];
+            if (GENERAL && tt < L.n_full[3]) {
+                ok = xorD<NQ, U, 2 * RV_LIN_K>(gates, begin[3] + tt * STEP, p, sub, q, fc, lane);
+                continue;
+            }
+            tt -= L.n_full[3];
+            uint32_t c0 = 0, e0 = 0, found = 0;
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const uint32_t rest = begin[c] + (c < 4 ? L.n_full[c] * STEP : 0u);
+                const uint32_t n = (end[c] - rest + GPW - 1) / GPW;
+                if (!found) {
+                    if (tt < n) c0 = rest + tt * GPW, e0 = end[c], found = 1;
+                    else tt -= n;
+                }
+            }
+            const uint32_t gi = c0 + sub;
+            const bool active = found && gi < e0;
+            ok = oneD(gates[active ? gi : L.r.lo], active, p, NQ, q, fc, lane);
+        }
+    }
+    if (!ok && lane == 0) atomicOr(p.err, RV_DEV_PERSIST_ABORT);
+}
+
 template <int MODE, int NQ, bool GENERAL>
 __global__ __launch_bounds__(256, GENERAL ? 1 : 8) void k_interp_persist(const Gate* __restrict__ gates, const PLevel* __restrict__ levels, uint32_t l0, uint32_t l1,
                                                                          InterpParams p, uint32_t* __restrict__ sync) {
@@ -780,7 +1018,7 @@ bool persist_general(const LevelRange* lr, size_t n_levels) {
 
 template <int NQ, bool GENERAL>
 static int launch_persist_nq(hipStream_t st, const Gate* d_gates, const PLevel* d_levels, uint32_t l0, uint32_t l1, uint64_t n_steps, const InterpParams& p,
-                             uint32_t* d_sync) {
+                             uint32_t* d_sync, bool flow) {
     // as many workgroups as are resident at once, one short of the occupancy query's answer per compute unit (it is one too
     // high for some register counts: MI355X_MICROARCH.md, residency) -- every wavefront of the grid must be running for the
     // waits to end
@@ -795,8 +1033,22 @@ static int launch_persist_nq(hipStream_t st, const Gate* d_gates, const PLevel* 
         else if (occ > 2) occ -= 1;
         return (uint32_t)(occ * cus);
     }();
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((n_steps + 3) / 4, 1), max_blocks);
-    hipLaunchKernelGGL((k_interp_persist<MODE_PROVE_V, NQ, GENERAL>), dim3(blocks), dim3(256), 0, st, d_gates, d_levels, l0, l1, p, d_sync);
+    static const uint32_t max_blocks_flow = [] {
+        int dev = 0, cus = 0, occ = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_interp_flow<NQ, GENERAL>, 256, 0) != hipSuccess || occ <= 0) {
+            (void)hipGetLastError();
+            occ = 2;
+        }
+        if (const char* e = getenv("RV_PERSIST_OCC")) occ = std::max(atoi(e), 1);
+        else if (occ > 2) occ -= 1;
+        return (uint32_t)(occ * cus);
+    }();
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((n_steps + 3) / 4, 1), flow ? max_blocks_flow : max_blocks);
+    if (flow)
+        hipLaunchKernelGGL((k_interp_flow<NQ, GENERAL>), dim3(blocks), dim3(256), 0, st, d_gates, d_levels, l0, l1, p, d_sync);
+    else
+        hipLaunchKernelGGL((k_interp_persist<MODE_PROVE_V, NQ, GENERAL>), dim3(blocks), dim3(256), 0, st, d_gates, d_levels, l0, l1, p, d_sync);
     return 0;
 }
 
@@ -804,13 +1056,13 @@ bool persist_supports(uint32_t NQ) { return NQ == 64 || NQ == 32 || NQ == 16 || 
 
 // levels [l0, l1) in one launch (MODE_PROVE_V); d_sync: PERSIST_SYNC_WORDS zeroed words of this launch's own
 void launch_interp_persist(hipStream_t st, uint32_t NQ, bool general, const Gate* d_gates, const PLevel* d_levels, uint32_t l0, uint32_t l1, uint64_t n_steps,
-                           const InterpParams& p, uint32_t* d_sync) {
+                           const InterpParams& p, uint32_t* d_sync, bool flow) {
     if (l1 <= l0) return;
     switch (NQ) {
-    case 64: general ? launch_persist_nq<64, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync) : launch_persist_nq<64, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync); break;
-    case 32: general ? launch_persist_nq<32, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync) : launch_persist_nq<32, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync); break;
-    case 16: general ? launch_persist_nq<16, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync) : launch_persist_nq<16, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync); break;
-    case 8: general ? launch_persist_nq<8, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync) : launch_persist_nq<8, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync); break;
+    case 64: general ? launch_persist_nq<64, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow) : launch_persist_nq<64, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow); break;
+    case 32: general ? launch_persist_nq<32, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow) : launch_persist_nq<32, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow); break;
+    case 16: general ? launch_persist_nq<16, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow) : launch_persist_nq<16, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow); break;
+    case 8: general ? launch_persist_nq<8, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow) : launch_persist_nq<8, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow); break;
     default: break;
     }
 }

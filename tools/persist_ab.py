@@ -49,7 +49,7 @@ os.environ["RV_PERSIST"] = "0"
 ref, ok = run("RV_PERSIST=0")
 print("  verifies:", ok, flush=True)
 for occ in band_list:
-    os.environ["RV_PERSIST"] = "1"
+    os.environ["RV_PERSIST"] = os.environ.get("AB_PERSIST", "1")
     if occ != "0":
         os.environ["RV_PERSIST_OCC"] = occ
     got, ok = run(f"RV_PERSIST=1 occ={occ}")
