@@ -572,6 +572,9 @@ struct rv_circuit {
     ClearLevel* d_clear_levels = nullptr;
     ClearRec* d_lite_s = nullptr;
     ClearRecK* d_lite_k = nullptr;
+    ClearLevel* d_lite_levels = nullptr;
+    PLevel* d_chain_levels = nullptr;  // k_chain: step tables of the levels' XOR classes (rows of 64 quad words)
+    bool chain_gen = false;
 };
 
 // RV_FLAT: 0 (default) = the level-synchronous interpreter everywhere; 1 = the flat schedule for the prover of eligible circuits
@@ -929,7 +932,15 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
                 (rc = up(c->flat.clear_k.data(), c->flat.clear_k.size() * sizeof(ClearRecK), (void**)&c->d_clear_k)) ||
                 (rc = up(c->flat.clear_levels.data(), c->flat.clear_levels.size() * sizeof(ClearLevel), (void**)&c->d_clear_levels)) ||
                 (rc = up(c->flat.lite_s.data(), c->flat.lite_s.size() * sizeof(ClearRec), (void**)&c->d_lite_s)) ||
-                (rc = up(c->flat.lite_k.data(), c->flat.lite_k.size() * sizeof(ClearRecK), (void**)&c->d_lite_k))) {
+                (rc = up(c->flat.lite_k.data(), c->flat.lite_k.size() * sizeof(ClearRecK), (void**)&c->d_lite_k)) ||
+                (rc = up(c->flat.lite_levels.data(), c->flat.lite_levels.size() * sizeof(ClearLevel), (void**)&c->d_lite_levels))) {
+                rv_circuit_destroy(c);
+                return rc;
+            }
+            c->chain_gen = chain_general(cc.level_range.data(), cc.level_range.size());
+            std::vector<PLevel> xl(cc.level_range.size());
+            build_chain_levels(cc.level_range.data(), cc.level_range.size(), 64, c->chain_gen, xl.data());
+            if ((rc = up(xl.data(), xl.size() * sizeof(PLevel), (void**)&c->d_chain_levels))) {
                 rv_circuit_destroy(c);
                 return rc;
             }
@@ -971,6 +982,8 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     c->ctx->release(c->d_clear_levels);
     c->ctx->release(c->d_lite_s);
     c->ctx->release(c->d_lite_k);
+    c->ctx->release(c->d_lite_levels);
+    c->ctx->release(c->d_chain_levels);
     delete c;
 }
 
@@ -1815,7 +1828,27 @@ static int shard_run_split(rv_shard* s, const InterpParams& p) {
     };
     if ((rc = fork(st, sx))) return rc;  // the chain starts behind everything queued so far (masks, the zero row, the error word)
     uint32_t l = 0;
+    // RV_FLAT=3: a band's levels in ONE launch on one XCD (k_chain) instead of a launch per level
+    const bool one_xcd = flat_mode() == 3 && chain_supports(s->NQ);
+    uint32_t* d_chain = nullptr;  // [0] the proof's chain XCD, [64] abort word, from [128] on two counters per level
+    if (one_xcd) {
+        if ((rc = dalloc(ctx, (size_t)128 + 2 * (size_t)n_levels, &s->d_sync))) return rc;
+        d_chain = s->d_sync;
+        HIPCHK(hipMemsetAsync(d_chain, 0, ((size_t)128 + 2 * (size_t)n_levels) * 4, st));
+        HIPCHK(hipMemsetAsync(d_chain, 0xFF, 4, st));
+        if ((rc = fork(st, sx))) return rc;
+    }
+    static const uint32_t chain_wgs = getenv("RV_CHAIN_WGS") ? (uint32_t)std::max(atoi(getenv("RV_CHAIN_WGS")), 1) : 512u;
     auto chain_to = [&](uint32_t l1) {
+        if (one_xcd) {
+            if (l1 > l) {
+                launch_chain(sx, chain_wgs, c->chain_gen, c->d_gates, c->d_chain_levels, c->d_lite_levels, c->d_lite_s, c->d_lite_k, l, l1, d_chain, d_chain + 128 + 2 * l,
+                             d_chain + 64, p);
+                ctx->count();
+            }
+            l = std::max(l, l1);
+            return;
+        }
         for (; l < l1; l++) {
             if (cc.level_start[l + 1] == cc.level_start[l]) continue;
             launch_level_split(sx, c->d_gates, cc.level_range[l], F.lite_levels[l], c->d_lite_s, c->d_lite_k, p);
@@ -1834,6 +1867,12 @@ static int shard_run_split(rv_shard* s, const InterpParams& p) {
     }
     chain_to(n_levels);
     if ((rc = fork(sx, st))) return rc;
+    if (one_xcd && getenv("RV_CHAIN_DEBUG")) {
+        uint32_t w[3] = {0, 0, 0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(w, d_chain, sizeof w, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[rv chain] XCD %u, workgroup launches that took part / left: %u / %u\n", w[0], w[1], w[2]);
+    }
     if (c->n_others) {  // the Input / AssertZero transcript rows
         launch_interp(st, MODE_PROVE_F, c->d_others, LevelRange{0, 0, 0, 0, 0, c->n_others}, p, nullptr);
         ctx->count();
@@ -2107,7 +2146,7 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     }();
     const bool rep_path = c->rep_ok && (rep_mode() >= 2 || (rep_mode() == 1 && rep_count == RV_TOTAL_REPS));
     const bool use_vclr = !rep_path && vclr_on && c->vclr_ok && (s->NQ == 64 || s->NQ == 32 || s->NQ == 16 || s->NQ == 8) && !ctx->pipeline;
-    if (use_vclr && c->flat.ok && flat_mode() == 1 && mul_flat_supports(s->NQ) && !g_recorder) {
+    if (use_vclr && c->flat.ok && (flat_mode() == 1 || (flat_mode() == 3 && chain_supports(s->NQ))) && mul_flat_supports(s->NQ) && !g_recorder) {
         // split schedule: the level chain computes the values itself (shard_run_split)
         s->split = true;
         if ((rc = dalloc(ctx, (size_t)cc.n_rows, &s->d_vclr))) return fail(rc);

@@ -89,6 +89,13 @@ constexpr int RV_DEV_CLEAR_ABORT = 0x40000000;  // device error word: k_clear ga
 // *d_dst |= *d_src (the cleartext pass's error word joins the proof's behind the event that ends the pass)
 void launch_or_word(hipStream_t st, int* d_dst, const int* d_src);
 bool mul_flat_supports(uint32_t NQ);
+// the chain on one XCD (kernels.hip: k_chain)
+struct PLevel;
+void build_chain_levels(const LevelRange* lr, size_t n_levels, uint32_t NQ, bool general, PLevel* out);
+bool chain_general(const LevelRange* lr, size_t n_levels);
+bool chain_supports(uint32_t NQ);
+void launch_chain(hipStream_t st, uint32_t n_wgs, bool general, const Gate* d_gates, const PLevel* d_xlevels, const ClearLevel* d_lite, const ClearRec* d_lite_s,
+                  const ClearRecK* d_lite_k, uint32_t l0, uint32_t l1, uint32_t* d_chosen, uint32_t* d_ctr, uint32_t* d_abort, const InterpParams& p);
 // split schedule, one dependency level of the chain: the level's XOR gates (rows and value bytes, MODE_PROVE_V's arithmetic) and
 // the value bytes of its other gates (kernels.hip)
 void launch_level_split(hipStream_t st, const Gate* d_gates, const LevelRange& r, const ClearLevel& lite, const ClearRec* d_lite_s, const ClearRecK* d_lite_k,

@@ -60,7 +60,9 @@ __device__ __forceinline__ uint32_t gather_vclr(const uint8_t* vclr, const uint3
 // Accesses that must be seen across workgroups INSIDE one launch (k_interp_persist: a level reads what other compute units,
 // on other XCDs, wrote a few microseconds earlier in the same kernel): agent-scope relaxed atomics = `sc1` loads that bypass the
 // reader's L1 and write-through `sc1` stores (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 on both sides needs no fence).
-// COH = false: the plain accesses of the one-launch-per-level kernels.
+// COH = 0: the plain accesses of the one-launch-per-level kernels.  COH = 2 (k_chain: every workgroup of the launch sits on ONE
+// XCD, i.e. behind one L2): loads bypass the L1 the same way, stores are plain -- they stay in the shared L2, where the other
+// compute units of the XCD find them at L2 latency instead of memory latency.
 // (experiment switches: which of the three kinds of access take the coherent form)
 #ifndef RV_COH_LDROW
 #define RV_COH_LDROW 1
@@ -71,38 +73,38 @@ __device__ __forceinline__ uint32_t gather_vclr(const uint8_t* vclr, const uint3
 #ifndef RV_COH_V
 #define RV_COH_V 1
 #endif
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ uint32_t ld_row(const uint32_t* p) {
     if (COH && RV_COH_LDROW) return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ void st_row(uint32_t* p, uint32_t v) {
-    if (COH && RV_COH_STROW)
+    if (COH == 1 && RV_COH_STROW)
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
         *p = v;
 }
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ uint32_t ld_v(const uint8_t* p) {
     if (COH && RV_COH_V) return __hip_atomic_load(const_cast<uint8_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ void st_v(uint8_t* p, uint8_t v) {
-    if (COH && RV_COH_V)
+    if (COH == 1 && RV_COH_V)
         __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
         *p = v;
 }
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ uint32_t gather_rows_c(const uint32_t* rows, const uint32_t* ids, uint32_t NQ, uint32_t q) {
     uint32_t v = 0;
 #pragma unroll
     for (int i = 0; i < RV_LIN_K; i++) v ^= ld_row<COH>(&rows[(size_t)ids[i] * NQ + q]);
     return v;
 }
-template <bool COH>
+template <int COH>
 __device__ __forceinline__ uint32_t gather_vclr_c(const uint8_t* vclr, const uint32_t* ids) {
     uint32_t v = 0;
 #pragma unroll
@@ -110,7 +112,7 @@ __device__ __forceinline__ uint32_t gather_vclr_c(const uint8_t* vclr, const uin
     return v;
 }
 
-template <int MODE, bool COH = false>
+template <int MODE, int COH = 0>
 __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParams& p, uint32_t NQ, uint32_t q, uint32_t onm) {
     switch (g_op(g)) {
     case G_INPUT: {
@@ -312,7 +314,7 @@ __device__ __forceinline__ void pf_sink(uint32_t v) { asm volatile("" ::"v"(v));
 // wave-uniform and the records come through scalar loads.  KA / KB = operand base rows actually
 // loaded per gate: exact for the common one-base-per-operand class, RV_LIN_K (unused slots point at
 // the L1-hot zero row) for the rest.
-template <int MODE, int NQ, int U, int KA, int KB, bool COH = false>
+template <int MODE, int NQ, int U, int KA, int KB, int COH = 0>
 __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
                                      uint32_t onm, const Gate* pf = nullptr) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
@@ -413,7 +415,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
 }
 
 // G_XORK: N = base rows loaded per gate (2: a[0], a[1]; 6: a[0..2], b[0..2] with zero-row padding)
-template <int MODE, int NQ, int U, int N, bool COH = false>
+template <int MODE, int NQ, int U, int N, int COH = 0>
 __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q,
                                      const Gate* pf = nullptr) {
     constexpr uint32_t GPW = 64 / NQ, H = NQ / 2;
@@ -484,7 +486,7 @@ __device__ __forceinline__ void interp_one(const Gate& g, const InterpParams& p,
 // take the common per-gate loop.
 // UXOR: unroll depth of the Xor classes when it differs from the Mul classes' (0 = the same) -- the single-workgroup
 // kernel runs 8-gate Xor steps on circuits without multi-base gates
-template <int MODE, int NQ, bool ROTATE, bool GENERAL = true, bool PF = false, int UXOR = 0>
+template <int MODE, int NQ, bool ROTATE, bool GENERAL = true, bool PF = false, int UXOR = 0, int COH = 0>
 __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const LevelRange& r, const InterpParams& p, uint32_t wave,
                                           uint32_t n_waves, uint32_t lane, uint32_t onm, const Gate* pf_gates = nullptr,
                                           const PfPlan* pf = nullptr) {
@@ -506,10 +508,10 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
         for (uint32_t g0 = begin[c] + my(slot) * STEP; g0 < rest[c]; g0 += n_waves * STEP) {
             const Gate* t = nullptr;
             if (PF && pf->dist) t = pf_target<U * GPW>(pf_gates, *pf, slot + (g0 - begin[c]) / STEP);
-            if (c == 0) mulU<MODE, NQ, U, 1, 1>(gates, g0, p, sub, q, onm, t);               // G_MUL, one base per operand
-            if (c == 1 && GENERAL) mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K>(gates, g0, p, sub, q, onm, t); // other G_MUL
-            if (c == 2) xorU<MODE, NQ, UX, 2>(gates, g0, p, sub, q, t);                            // G_XORK of two bases
-            if (c == 3 && GENERAL) xorU<MODE, NQ, UX, 2 * RV_LIN_K>(gates, g0, p, sub, q, t);                 // other G_XORK
+            if (c == 0) mulU<MODE, NQ, U, 1, 1, COH>(gates, g0, p, sub, q, onm, t);               // G_MUL, one base per operand
+            if (c == 1 && GENERAL) mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K, COH>(gates, g0, p, sub, q, onm, t); // other G_MUL
+            if (c == 2) xorU<MODE, NQ, UX, 2, COH>(gates, g0, p, sub, q, t);                            // G_XORK of two bases
+            if (c == 3 && GENERAL) xorU<MODE, NQ, UX, 2 * RV_LIN_K, COH>(gates, g0, p, sub, q, t);                 // other G_XORK
         }
         slot += n_full;
     }
@@ -524,7 +526,7 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
         for (int c = 1; c < 5; c++)
             if (t >= cum[c]) c0 = rest[c], e0 = end[c], base = cum[c];
         const uint32_t gi = c0 + (t - base) * GPW + sub;
-        if (gi < e0) interp_one<MODE>(gates[gi], p, NQ, q, onm);
+        if (gi < e0) interp_one_impl<MODE, COH>(gates[gi], p, NQ, q, onm);
     }
 }
 
@@ -729,9 +731,9 @@ __device__ __forceinline__ bool mulD(const Gate* __restrict__ gates, uint32_t g0
         for (int u = 0; u < U; u++) {
             const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
 #pragma unroll
-            for (int i = 0; i < KA; i++) ca[u][i] = (i == 0 || i < na) ? ld_v<true>(&p.vclr[g[u].a[i]]) : V_READY;
+            for (int i = 0; i < KA; i++) ca[u][i] = (i == 0 || i < na) ? ld_v<1>(&p.vclr[g[u].a[i]]) : V_READY;
 #pragma unroll
-            for (int i = 0; i < KB; i++) cb[u][i] = (i == 0 || i < nb) ? ld_v<true>(&p.vclr[g[u].b[i]]) : V_READY;
+            for (int i = 0; i < KB; i++) cb[u][i] = (i == 0 || i < nb) ? ld_v<1>(&p.vclr[g[u].b[i]]) : V_READY;
         }
         uint32_t all = V_READY;
 #pragma unroll
@@ -752,10 +754,10 @@ __device__ __forceinline__ bool mulD(const Gate* __restrict__ gates, uint32_t g0
         lx[u] = 0, ly[u] = 0;
 #pragma unroll
         for (int i = 0; i < KA; i++)
-            if (i == 0 || i < na) lx[u] ^= ld_row<true>(&p.rows[(size_t)g[u].a[i] * NQ + q]);
+            if (i == 0 || i < na) lx[u] ^= ld_row<1>(&p.rows[(size_t)g[u].a[i] * NQ + q]);
 #pragma unroll
         for (int i = 0; i < KB; i++)
-            if (i == 0 || i < nb) ly[u] ^= ld_row<true>(&p.rows[(size_t)g[u].b[i] * NQ + q]);
+            if (i == 0 || i < nb) ly[u] ^= ld_row<1>(&p.rows[(size_t)g[u].b[i] * NQ + q]);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -766,7 +768,7 @@ __device__ __forceinline__ bool mulD(const Gate* __restrict__ gates, uint32_t g0
         const uint32_t s = (ly[u] & cx) ^ (lx[u] & cy) ^ lab[u] ^ lnew[u];
         __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
         store_bits(p.pre, g[u].ep, NQ, q, delta);
-        if (q == 0) st_v<true>(&p.vclr[g[u].dst], (uint8_t)(V_READY | (vx & vy)));  // (the output's mask is a PRG row: only its value is new)
+        if (q == 0) st_v<1>(&p.vclr[g[u].dst], (uint8_t)(V_READY | (vx & vy)));  // (the output's mask is a PRG row: only its value is new)
     }
     return true;
 }
@@ -787,7 +789,7 @@ __device__ __forceinline__ bool xorD(const Gate* __restrict__ gates, uint32_t g0
 #pragma unroll
             for (int i = 0; i < N; i++) {
                 const uint32_t id = (N == 2) ? g[u].a[i] : (i < RV_LIN_K ? g[u].a[i] : g[u].b[i - RV_LIN_K]);
-                const uint32_t c = (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) ? ld_v<true>(&p.vclr[id]) : V_READY;
+                const uint32_t c = (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) ? ld_v<1>(&p.vclr[id]) : V_READY;
                 all &= c, bx[u] ^= c;
             }
         }
@@ -802,15 +804,15 @@ __device__ __forceinline__ bool xorD(const Gate* __restrict__ gates, uint32_t g0
 #pragma unroll
         for (int i = 0; i < N; i++) {
             const uint32_t id = (N == 2) ? g[u].a[i] : (i < RV_LIN_K ? g[u].a[i] : g[u].b[i - RV_LIN_K]);
-            if (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) x[u] ^= ld_row<true>(&p.rows[(size_t)id * NQ + q]);
+            if (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) x[u] ^= ld_row<1>(&p.rows[(size_t)id * NQ + q]);
         }
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) st_row<true>(&p.rows[(size_t)g[u].dst * NQ + q], x[u]);
+    for (int u = 0; u < U; u++) st_row<1>(&p.rows[(size_t)g[u].dst * NQ + q], x[u]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have left before their bytes say so
 #pragma unroll
     for (int u = 0; u < U; u++)
-        if (q == 0) st_v<true>(&p.vclr[g[u].dst], (uint8_t)(V_READY | ((bx[u] ^ g_ca(g[u])) & 1u)));
+        if (q == 0) st_v<1>(&p.vclr[g[u].dst], (uint8_t)(V_READY | ((bx[u] ^ g_ca(g[u])) & 1u)));
     return true;
 }
 
@@ -824,7 +826,7 @@ __device__ __forceinline__ bool oneD(const Gate& g, bool active, const InterpPar
         if (op == G_XORK || op == G_MUL || op == G_ASSERT) {
 #pragma unroll
             for (int i = 0; i < RV_LIN_K; i++) {  // (unused slots hold the zero row: ready, value 0)
-                const uint32_t a = ld_v<true>(&p.vclr[g.a[i]]), b = (op == G_ASSERT) ? V_READY : ld_v<true>(&p.vclr[g.b[i]]);
+                const uint32_t a = ld_v<1>(&p.vclr[g.a[i]]), b = (op == G_ASSERT) ? V_READY : ld_v<1>(&p.vclr[g.b[i]]);
                 all &= a & b, va ^= a, vb ^= b;
             }
         }
@@ -836,26 +838,26 @@ __device__ __forceinline__ bool oneD(const Gate& g, bool active, const InterpPar
         const uint32_t lam = p.rows[(size_t)g.m * NQ + q];
         const uint32_t w = p.wit[g.x] ? 0xFFFFFFFFu : 0u;
         p.on[(size_t)g.eo * NQ + q] = w ^ recon32(lam);
-        if (q == 0) st_v<true>(&p.vclr[g.dst], (uint8_t)(V_READY | (w & 1u)));
+        if (q == 0) st_v<1>(&p.vclr[g.dst], (uint8_t)(V_READY | (w & 1u)));
     } else if (op == G_XORK) {
-        st_row<true>(&p.rows[(size_t)g.dst * NQ + q], gather_rows_c<true>(p.rows, g.a, NQ, q) ^ gather_rows_c<true>(p.rows, g.b, NQ, q));
+        st_row<1>(&p.rows[(size_t)g.dst * NQ + q], gather_rows_c<1>(p.rows, g.a, NQ, q) ^ gather_rows_c<1>(p.rows, g.b, NQ, q));
         wrote_row = true;
     } else if (op == G_MUL) {
-        const uint32_t lx = gather_rows_c<true>(p.rows, g.a, NQ, q), ly = gather_rows_c<true>(p.rows, g.b, NQ, q);
+        const uint32_t lx = gather_rows_c<1>(p.rows, g.a, NQ, q), ly = gather_rows_c<1>(p.rows, g.b, NQ, q);
         const uint32_t lab = p.rows[(size_t)g.m * NQ + q], lnew = p.rows[(size_t)(g.m + 1) * NQ + q];
         const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
         const uint32_t vx = (va ^ g_ca(g)) & 1u, vy = (vb ^ g_cb(g)) & 1u;
         const uint32_t cx = a ^ (vx ? 0xFFFFFFFFu : 0u), cy = b ^ (vy ? 0xFFFFFFFFu : 0u);
         p.on[(size_t)g.eo * NQ + q] = (ly & cx) ^ (lx & cy) ^ lab ^ lnew;
         store_bits(p.pre, g.ep, NQ, q, (a & b) ^ c);
-        if (q == 0) st_v<true>(&p.vclr[g.dst], (uint8_t)(V_READY | (vx & vy)));
+        if (q == 0) st_v<1>(&p.vclr[g.dst], (uint8_t)(V_READY | (vx & vy)));
     } else if (op == G_ASSERT) {
-        p.on[(size_t)g.eo * NQ + q] = gather_rows_c<true>(p.rows, g.a, NQ, q);
+        p.on[(size_t)g.eo * NQ + q] = gather_rows_c<1>(p.rows, g.a, NQ, q);
         if (q == 0 && ((va ^ g_ca(g)) & 1u) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
     }
     if (__any(wrote_row)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (wrote_row && q == 0) st_v<true>(&p.vclr[g.dst], (uint8_t)(V_READY | ((va ^ vb ^ g_ca(g)) & 1u)));
+        if (wrote_row && q == 0) st_v<1>(&p.vclr[g.dst], (uint8_t)(V_READY | ((va ^ vb ^ g_ca(g)) & 1u)));
     }
     return true;
 }
@@ -950,22 +952,22 @@ __global__ __launch_bounds__(256, GENERAL ? 1 : 8) void k_interp_persist(const G
         for (; t < L.n_steps; t += W, mine++) {
             uint32_t tt = t;
             if (tt < L.n_full[0]) {
-                mulU<MODE, NQ, U, 1, 1, true>(gates, begin[0] + tt * STEP, p, sub, q, 0u);
+                mulU<MODE, NQ, U, 1, 1, 1>(gates, begin[0] + tt * STEP, p, sub, q, 0u);
                 continue;
             }
             tt -= L.n_full[0];
             if (GENERAL && tt < L.n_full[1]) {
-                mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K, true>(gates, begin[1] + tt * STEP, p, sub, q, 0u);
+                mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K, 1>(gates, begin[1] + tt * STEP, p, sub, q, 0u);
                 continue;
             }
             tt -= L.n_full[1];
             if (tt < L.n_full[2]) {
-                xorU<MODE, NQ, U, 2, true>(gates, begin[2] + tt * STEP, p, sub, q);
+                xorU<MODE, NQ, U, 2, 1>(gates, begin[2] + tt * STEP, p, sub, q);
                 continue;
             }
             tt -= L.n_full[2];
             if (GENERAL && tt < L.n_full[3]) {
-                xorU<MODE, NQ, U, 2 * RV_LIN_K, true>(gates, begin[3] + tt * STEP, p, sub, q);
+                xorU<MODE, NQ, U, 2 * RV_LIN_K, 1>(gates, begin[3] + tt * STEP, p, sub, q);
                 continue;
             }
             tt -= L.n_full[3];
@@ -981,7 +983,7 @@ __global__ __launch_bounds__(256, GENERAL ? 1 : 8) void k_interp_persist(const G
                 }
             }
             const uint32_t gi = c0 + sub;
-            if (found && gi < e0) interp_one_impl<MODE, true>(gates[gi], p, NQ, q, 0u);
+            if (found && gi < e0) interp_one_impl<MODE, 1>(gates[gi], p, NQ, q, 0u);
         }
         // this wavefront's share of the level has ended once its write-through stores have left
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1152,6 +1154,184 @@ void launch_level_split(hipStream_t st, const Gate* d_gates, const LevelRange& r
     case 8: return launch_level_split_nq<8>(st, d_gates, r, lite, d_lite_s, d_lite_k, p);
     default: break;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// k_chain: the split schedule's level chain as ONE launch per band, on ONE XCD (round 4).
+//
+// A dependency level of the chain is small (the 10^7-gate circuit: ~9 400 XOR gates and ~30 000 value bytes), and what makes
+// it expensive as a launch of its own is latency: a kernel boundary, then two dependent trips to memory.  The workgroups of one
+// XCD share an L2: what one compute unit stores (plain, write-through to L2) another finds there a few hundred nanoseconds
+// later if it bypasses its own L1 (sc1 loads), and an atomic without the sc1 bit executes in that L2.  So the chain runs on the
+// workgroups that land on ONE XCD -- the first workgroup of a proof's first chain launch claims its own XCD for the proof
+// (`chosen`), every workgroup on another XCD leaves at once -- with the levels separated by an L2-local hand-off instead of a
+// launch: per level a ticket counter (a ticket = 16 wave-steps of XOR gates or 1 024 value records, taken by a whole workgroup)
+// and a count of finished tickets.  Nobody needs to know how many workgroups take part, or when they start: correct for any
+// placement (one workgroup suffices), fast when the hardware deals workgroups to the XCDs round-robin as it is observed to.
+// Meanwhile the other seven XCDs run the previous band's Mul gates (k_mul_flat leaves the chosen XCD alone).
+// Every wait is bounded (PERSIST_SPIN_TICKS): abort word, RV_DEV_PERSIST_ABORT, the proof fails with RV_E_DEVICE.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t CHAIN_NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xFu;
+}
+
+struct ChainParams {
+    const Gate* gates;
+    const PLevel* xlevels;      // per dependency level: the step table of its XOR classes (build_persist_levels over XOR-only ranges)
+    const ClearLevel* lite;     // per dependency level: its value records
+    const ClearRec* lite_s;
+    const ClearRecK* lite_k;
+    uint32_t l0, l1;
+    uint32_t* chosen;           // one word per proof: the chain's XCD (CHAIN_NONE until the first workgroup claims one)
+    uint32_t* ctr;              // [2 * (l1 - l0)] zeroed: per level the next ticket, the finished tickets (L2-local)
+    uint32_t* abort_word;
+};
+
+template <int NQ, bool GENERAL>
+__global__ __launch_bounds__(1024) void k_chain(ChainParams cp, InterpParams p) {
+    __shared__ uint32_t s_tk, s_go;
+    constexpr uint32_t GPW = 64 / NQ;
+    constexpr int U = interp_unroll(NQ, GENERAL);
+    constexpr uint32_t STEP = (uint32_t)U * GPW;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wiw = tid >> 6;
+    const uint32_t q = lane % NQ, sub = lane / NQ;
+    if (tid == 0) {
+        const uint32_t mine = xcc_id();
+        uint32_t c = __hip_atomic_load(cp.chosen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c == CHAIN_NONE) {
+            uint32_t expect = CHAIN_NONE;
+            __hip_atomic_compare_exchange_strong(cp.chosen, &expect, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c = expect == CHAIN_NONE ? mine : expect;
+        }
+        s_go = c == mine;
+        // (statistics: workgroups of this launch that take part / that left, per proof)
+        __hip_atomic_fetch_add(cp.chosen + (c == mine ? 1 : 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_go) return;
+    const long long t0 = wall_clock64();
+    for (uint32_t l = cp.l0; l < cp.l1; l++) {
+        const PLevel L = cp.xlevels[l];
+        const ClearLevel C = cp.lite[l];
+        uint32_t* tk = cp.ctr + 2 * (l - cp.l0);
+        const uint32_t n_lite = (C.s1 - C.s0) + (C.g1 - C.g0), ns = C.s1 - C.s0;
+        const uint32_t tx = (L.n_steps + 15) / 16, tl = (n_lite + 1023) / 1024, n_tickets = tx + tl;
+        const uint32_t begin[5] = {L.r.lo, L.r.mul11, L.r.mul, L.r.xor2, L.r.xork}, end[5] = {L.r.mul11, L.r.mul, L.r.xor2, L.r.xork, L.r.hi};
+        for (;;) {
+            __syncthreads();
+            if (tid == 0) s_tk = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (no sc1: executes in this XCD's L2)
+            __syncthreads();
+            const uint32_t k = s_tk;
+            if (k >= n_tickets) break;
+            if (k < tx) {
+                // 16 wave-steps of the level's XOR gates, one per wavefront
+                const uint32_t t = k * 16 + wiw;
+                if (t < L.n_steps) {
+                    uint32_t tt = t;
+                    if (tt < L.n_full[2]) {
+                        xorU<MODE_PROVE_V, NQ, U, 2, 2>(cp.gates, begin[2] + tt * STEP, p, sub, q);
+                    } else if (GENERAL && (tt -= L.n_full[2]) < L.n_full[3]) {
+                        xorU<MODE_PROVE_V, NQ, U, 2 * RV_LIN_K, 2>(cp.gates, begin[3] + tt * STEP, p, sub, q);
+                    } else {
+                        if (!GENERAL) tt -= L.n_full[2];
+                        else tt -= L.n_full[3];
+                        uint32_t c0 = 0, e0 = 0, found = 0;
+#pragma unroll
+                        for (int c = 2; c < 4; c++) {  // (the table holds XOR classes only)
+                            const uint32_t rest = begin[c] + L.n_full[c] * STEP;
+                            const uint32_t n = (end[c] - rest + GPW - 1) / GPW;
+                            if (!found) {
+                                if (tt < n) c0 = rest + tt * GPW, e0 = end[c], found = 1;
+                                else tt -= n;
+                            }
+                        }
+                        const uint32_t gi = c0 + sub;
+                        if (found && gi < e0) interp_one_impl<MODE_PROVE_V, 2>(cp.gates[gi], p, NQ, q, 0u);
+                    }
+                }
+            } else {
+                // 1 024 value records of the level's other gates, a lane each
+                const uint32_t t = (k - tx) * 1024 + tid;
+                if (t < ns) {
+                    const uint4 r = *(const uint4*)(cp.lite_s + C.s0 + t);  // dst a0 b0 meta
+                    const uint32_t meta = r.w;
+                    uint32_t xa = 0, xb = 0;
+                    if ((meta & 7u) == G_INPUT) {
+                        xa = p.wit[r.y];
+                    } else {
+                        if ((meta >> 8) & 3u) xa = ld_v<2>(&p.vclr[r.y]);
+                        if ((meta >> 10) & 3u) xb = ld_v<2>(&p.vclr[r.z]);
+                    }
+                    lite_finish(p, meta, r.x, xa, xb);
+                } else if (t < n_lite) {
+                    const uint4* qq = (const uint4*)(cp.lite_k + C.g0 + (t - ns));
+                    const uint4 r0 = qq[0], r1 = qq[1];  // dst meta a0 a1 | a2 b0 b1 b2
+                    const uint32_t meta = r0.y, na = (meta >> 8) & 3u, nb = (meta >> 10) & 3u;
+                    uint32_t t0v = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+                    if (na > 0) t0v = ld_v<2>(&p.vclr[r0.z]);
+                    if (na > 1) t1 = ld_v<2>(&p.vclr[r0.w]);
+                    if (na > 2) t2 = ld_v<2>(&p.vclr[r1.x]);
+                    if (nb > 0) t3 = ld_v<2>(&p.vclr[r1.y]);
+                    if (nb > 1) t4 = ld_v<2>(&p.vclr[r1.z]);
+                    if (nb > 2) t5 = ld_v<2>(&p.vclr[r1.w]);
+                    lite_finish(p, meta, r0.x, t0v ^ t1 ^ t2, t3 ^ t4 ^ t5);
+                }
+            }
+            // the ticket has ended once every wavefront's stores have reached the L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(tk + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (l + 1 == cp.l1) break;
+        // the next level starts when every ticket of this one has ended (one poller per workgroup)
+        if (tid == 0) {
+            uint32_t ok = 1;
+            for (uint32_t spins = 0; __hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_tickets; spins++) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 255u) == 255u) {
+                    if (__hip_atomic_load(cp.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > PERSIST_SPIN_TICKS) {
+                        __hip_atomic_store(cp.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        atomicOr(p.err, RV_DEV_PERSIST_ABORT);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            s_go = ok;
+        }
+        __syncthreads();
+        if (!s_go) return;
+    }
+}
+
+// step tables of the levels' XOR classes (host)
+void build_chain_levels(const LevelRange* lr, size_t n_levels, uint32_t NQ, bool general, PLevel* out) {
+    std::vector<LevelRange> xr(n_levels);
+    for (size_t l = 0; l < n_levels; l++) xr[l] = LevelRange{lr[l].mul, lr[l].mul, lr[l].mul, lr[l].xor2, lr[l].xork, lr[l].xork};
+    build_persist_levels(xr.data(), n_levels, NQ, general, out);
+}
+bool chain_general(const LevelRange* lr, size_t n_levels) {
+    for (size_t l = 0; l < n_levels; l++)
+        if (lr[l].xork - lr[l].xor2 >= 64) return true;
+    return false;
+}
+
+bool chain_supports(uint32_t NQ) { return NQ == 64; }
+
+// levels [l0, l1) of the chain; d_ctr: 2 * (l1 - l0) zeroed words; n_wgs workgroups of 1 024 threads are launched (those that land
+// on the proof's chain XCD do the work)
+void launch_chain(hipStream_t st, uint32_t n_wgs, bool general, const Gate* d_gates, const PLevel* d_xlevels, const ClearLevel* d_lite, const ClearRec* d_lite_s,
+                  const ClearRecK* d_lite_k, uint32_t l0, uint32_t l1, uint32_t* d_chosen, uint32_t* d_ctr, uint32_t* d_abort, const InterpParams& p) {
+    if (l1 <= l0) return;
+    const ChainParams cp{d_gates, d_xlevels, d_lite, d_lite_s, d_lite_k, l0, l1, d_chosen, d_ctr, d_abort};
+    if (general)
+        hipLaunchKernelGGL((k_chain<64, true>), dim3(n_wgs), dim3(1024), 0, st, cp, p);
+    else
+        hipLaunchKernelGGL((k_chain<64, false>), dim3(n_wgs), dim3(1024), 0, st, cp, p);
 }
 
 // Narrow levels (deep circuits: ripple-carry adders, AES/SHA rounds) would be launch-bound at one

@@ -19,7 +19,7 @@ def rv():
     return reverie_amd
 
 
-SCHEDULES = (1, 2)  # RV_FLAT: 1 = split (level chain + program-order Mul kernel), 2 = flat (cleartext pass + x-levels)
+SCHEDULES = (1, 2, 3)  # RV_FLAT: 1 = split (level chain + program-order Mul kernel), 2 = flat (cleartext pass + x-levels)
 
 
 def _prove(rv, prog, wit, wc, seeds, monkeypatch, flat, bands=None, hint=True):
