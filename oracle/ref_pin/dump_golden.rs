@@ -84,16 +84,21 @@ fn dump_golden() {
                 w2.clear();
                 w64.clear();
             }
-            "op" => {
-                let v: Vec<u64> = f[1..].iter().map(|x| x.parse().unwrap()).collect();
+            // "op d o dst a b imm" = one op; "opx n d o dst a b imm" = the same op n times in a row
+            "op" | "opx" => {
+                let skip = if f[0] == "opx" { 2 } else { 1 };
+                let count: usize = if f[0] == "opx" { f[1].parse().unwrap() } else { 1 };
+                let v: Vec<u64> = f[skip..].iter().map(|x| x.parse().unwrap()).collect();
                 let (dom, opc, dst, a, b, imm) = (v[0], v[1], v[2] as usize, v[3] as usize, v[4] as usize, v[5]);
-                ops.push(match dom {
-                    0 => CombineOperation::GF2(gf2_op(opc, dst, a, b, imm)),
-                    1 => CombineOperation::Z64(z64_op(opc, dst, a, b, imm)),
-                    2 => CombineOperation::B2A(dst, a),
-                    3 => CombineOperation::SizeHint(a, b),
-                    _ => panic!("bad domain {}", dom),
-                });
+                for _ in 0..count {
+                    ops.push(match dom {
+                        0 => CombineOperation::GF2(gf2_op(opc, dst, a, b, imm)),
+                        1 => CombineOperation::Z64(z64_op(opc, dst, a, b, imm)),
+                        2 => CombineOperation::B2A(dst, a),
+                        3 => CombineOperation::SizeHint(a, b),
+                        _ => panic!("bad domain {}", dom),
+                    });
+                }
             }
             "w2" => w2.extend(f[1..].iter().map(|x| *x == "1")),
             "w64" => w64.extend(f[1..].iter().map(|x| x.parse::<u64>().unwrap())),
@@ -110,6 +115,8 @@ fn dump_golden() {
                 let bytes = bincode::serialize(&proof).unwrap();
                 let path = format!("{}/proof_{}.bin", out_dir, name);
                 fs::write(&path, &bytes).unwrap();
+                // ... and its BLAKE3 digest next to it (compare.py sets the large cases against the committed digest)
+                fs::write(format!("{}/proof_{}.b3", out_dir, name), blake3::hash(&bytes).to_hex().as_str()).unwrap();
                 println!("{}: {} ops -> {} bytes -> {}", name, ops.len(), bytes.len(), path);
             }
             other => panic!("cases.txt: unknown record {}", other),

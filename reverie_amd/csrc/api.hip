@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/random.h>
+#include <time.h>
 
 #include <algorithm>
 #include <array>
@@ -113,7 +114,10 @@ struct HelperPool {
             std::lock_guard<std::mutex> lk(mu);
             job = nullptr;
         }
-        while (running.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+        for (uint32_t spins = 0; running.load(std::memory_order_acquire) > 0; spins++) {
+            __builtin_ia32_pause();
+            if (spins > 4000) std::this_thread::yield();  // (a helper descheduled in the middle of its last piece)
+        }
     }
     ~HelperPool() {
         {
@@ -166,6 +170,7 @@ struct rv_ctx {
     uint32_t* h_fs = nullptr;
     uint32_t fs_seq = 0;
     HelperPool* ec_pool = nullptr;
+    double ec_wait_us[17] = {0};  // running averages of the early-corrections waits (per chunk stamp, [16] the challenge): mailbox_wait
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
         if (!sync_pool.empty()) {
@@ -1329,7 +1334,13 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
         const Compiled& cc = c->cc;
         // (read per circuit, not once per process: the tests lower them)
         const uint64_t min_events = getenv("RV_EARLY_MIN") ? (uint64_t)atoll(getenv("RV_EARLY_MIN")) : (1ull << 21);
-        const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? atoi(getenv("RV_EARLY_CHUNKS")) : 4;
+        // (the progress stamp carries the chunk count in eight bits; a bad knob gives no plan, i.e. the plain path, not a failed proof)
+        const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? std::min(atoi(getenv("RV_EARLY_CHUNKS")), 255) : 4;
+        auto reps_env = [](uint32_t dflt) -> uint32_t {
+            const char* e = getenv("RV_EARLY_REPS");
+            if (!e) return dflt;
+            return (uint32_t)std::min(std::max(atoi(e), 0), (int)RV_TOTAL_REPS);
+        };
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
         if (!cc.gates64.empty()) {
             // ---- Z64 ----
@@ -1354,7 +1365,7 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
             const uint64_t vec_bytes = 8 * cc.n_corr64;
             uint32_t r_spec;
             if (getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2) {
-                r_spec = getenv("RV_EARLY_REPS") ? (uint32_t)atoi(getenv("RV_EARLY_REPS")) : 128;
+                r_spec = reps_env(128);
             } else {
                 const double t_window = (double)cc.gates64.size() * 10e-9 + (double)cc.n_corr64 * 6e-9;
                 // (0.65 of what the window could carry: 112 .. 176 staged repetitions of the benchmark circuit give the same proof time,
@@ -1393,7 +1404,7 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
         // repetitions beyond them are extracted and copied the plain way.  RV_EARLY=2: all of them (RV_EARLY_REPS overrides).
         uint32_t r_spec = RV_TOTAL_REPS;
         if (getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2) {
-            if (getenv("RV_EARLY_REPS")) r_spec = (uint32_t)atoi(getenv("RV_EARLY_REPS"));
+            r_spec = reps_env(RV_TOTAL_REPS);
         } else {
             const double t_window = std::max((double)n_levels * 13e-6, (double)cc.gates.size() * 0.25e-9) + (double)cc.n_pre * 0.21e-9 + 0.3e-3;
             r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.9 * t_window * 55e9 / ((double)cc.n_pre / 8.0));
@@ -1641,6 +1652,47 @@ static int early_flush_muls(rv_shard* s, uint64_t muls_queued) {
     return early_flush_chunks(s, last);
 }
 
+// The host's waits of the early-corrections path (a chunk's stamp, the challenge): the mailbox is written by the GPU, so there is
+// nothing to block on -- but the caller need not burn a core for the milliseconds a proof takes either.  The wait SLEEPS through
+// most of what the same wait took last time on this context (`ema_us`, a running average per kind of wait: proofs of one circuit
+// repeat their timing to a few percent), then spins for the rest, so the word is seen as promptly as before; RV_EARLY_SPIN=1 spins
+// all the way.  Bounded: RV_EARLY_TIMEOUT_MS (default 20 000) without the awaited word is RV_E_DEVICE with a message, not a hang.
+template <class Pred>
+static int mailbox_wait(rv_ctx* ctx, Pred arrived, double* ema_us, const char* what) {
+    static const bool spin_only = getenv("RV_EARLY_SPIN") && atoi(getenv("RV_EARLY_SPIN")) != 0;
+    static const long timeout_ms = getenv("RV_EARLY_TIMEOUT_MS") ? std::max(atol(getenv("RV_EARLY_TIMEOUT_MS")), 1l) : 20000;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+    if (!spin_only && ema_us && *ema_us > 200.0) {
+        // sleep until ~80 % of the expected wait (minus the scheduler's slack) is over, in naps short enough to notice an early word
+        const double until = 0.8 * *ema_us - 80.0;
+        while (!arrived()) {
+            const double left = until - elapsed_us();
+            if (left < 30.0) break;
+            timespec ts{0, (long)(std::min(left, 250.0) * 1000.0)};
+            nanosleep(&ts, nullptr);
+        }
+    }
+    int rc = RV_OK;
+    for (uint64_t spins = 0; !arrived(); spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFF) == 0xFFFF) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q != hipErrorNotReady && !arrived()) {
+                rc = q == hipSuccess ? RV_E_DEVICE : hip_fail(q, what, __FILE__, __LINE__);
+                break;
+            }
+            if (elapsed_us() > 1e3 * (double)timeout_ms) {
+                g_last_error = std::string(what) + ": no word from the device within RV_EARLY_TIMEOUT_MS";
+                rc = RV_E_DEVICE;
+                break;
+            }
+        }
+    }
+    if (rc == RV_OK && ema_us) *ema_us = *ema_us > 0 ? 0.7 * *ema_us + 0.3 * elapsed_us() : elapsed_us();
+    return rc;
+}
+
 // host side: waits for every chunk's stamp in turn and queues its packing kernel (unless done), its copy to the host and the
 // stamp that says it has arrived
 static int early_pump(rv_shard* s) {
@@ -1650,13 +1702,7 @@ static int early_pump(rv_shard* s) {
     for (; e->pumped < chunks.size(); e->pumped++) {
         const size_t k = e->pumped;
         if (k >= e->packed.size()) return RV_E_DEVICE;
-        for (uint64_t spins = 0; !e->ready(k); spins++) {
-            __builtin_ia32_pause();
-            if ((spins & 0xFFFF) == 0xFFFF) {
-                const hipError_t q = hipStreamQuery(ctx->stream);
-                if (q != hipErrorNotReady && !e->ready(k)) return q == hipSuccess ? RV_E_DEVICE : hip_fail(q, "early corrections (pump)", __FILE__, __LINE__);
-            }
-        }
+        if (int rcw = mailbox_wait(ctx, [&] { return e->ready(k); }, k < 16 ? &ctx->ec_wait_us[k] : nullptr, "early corrections (pump)")) return rcw;
         const auto& ch = chunks[k];
         if (e->plan->z64) {
             // word range [byte0, byte0 + nbytes) of the first r_spec repetitions' preprocessing rows (16-byte multiples on both
@@ -2692,17 +2738,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         if ((rc = early_pump(s))) break;
         // the challenge: poll the mailbox (now and then make sure the stream is still alive)
         volatile uint32_t* box = ctx->h_fs;
-        for (uint64_t spins = 0; __atomic_load_n(&box[0], __ATOMIC_ACQUIRE) != seq; spins++) {
-            __builtin_ia32_pause();
-            if ((spins & 0xFFFF) == 0xFFFF) {
-                const hipError_t q = hipStreamQuery(ctx->stream);
-                if (q != hipErrorNotReady && __atomic_load_n(&box[0], __ATOMIC_ACQUIRE) != seq) {
-                    rc = q == hipSuccess ? RV_E_DEVICE : hip_fail(q, "early corrections", __FILE__, __LINE__);
-                    break;
-                }
-            }
-        }
-        if (rc) break;
+        if ((rc = mailbox_wait(ctx, [&] { return __atomic_load_n(&box[0], __ATOMIC_ACQUIRE) == seq; }, &ctx->ec_wait_us[16], "early corrections (challenge)"))) break;
         t_chal = since();
         const uint8_t* omit_all = (const uint8_t*)(ctx->h_fs + 16) + 32;
         uint32_t opened[RV_ONLINE_REPS], n_open = 0;

@@ -32,6 +32,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <chrono>
+#include <exception>
 #include <functional>
 #include <limits>
 #include <memory>
@@ -139,6 +140,17 @@ class Pool {
     std::atomic<int> pending_{0};
     std::atomic<bool> stop_{false};
     const std::function<void(int)>* fn_ = nullptr;
+    // the first exception a pass throws on any thread (a bad_alloc while a pass grows its vectors is the realistic one): kept until
+    // every thread has left the pass, then rethrown on the calling thread -- never out of a worker (std::terminate), and never
+    // while workers still run over the caller's locals
+    std::mutex err_mu_;
+    std::exception_ptr err_;
+    int pass_ = 0;
+    const int throw_at_ = getenv("RV_TEST_POOL_THROW") ? atoi(getenv("RV_TEST_POOL_THROW")) : 0;
+    void note_exception() {
+        std::lock_guard<std::mutex> g(err_mu_);
+        if (!err_) err_ = std::current_exception();
+    }
     void worker(int t) {
         uint64_t seen = 0;
         for (;;) {
@@ -152,7 +164,13 @@ class Pool {
             }
             seen = gen_.load(std::memory_order_acquire);
             if (stop_.load(std::memory_order_acquire)) return;
-            (*fn_)(t);
+            try {
+                // (test knob RV_TEST_POOL_THROW=k: the last worker fails with bad_alloc in the k-th pass of every compile)
+                if (throw_at_ && t == n_ - 1 && pass_ == throw_at_) throw std::bad_alloc();
+                (*fn_)(t);
+            } catch (...) {
+                note_exception();
+            }
             pending_.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
@@ -169,14 +187,26 @@ class Pool {
     int size() const { return n_; }
     void run(const std::function<void(int)>& f) {
         fn_ = &f;
+        pass_++;
         pending_.store(n_ - 1, std::memory_order_release);
         gen_.fetch_add(1, std::memory_order_acq_rel);
-        f(0);
+        try {
+            f(0);
+        } catch (...) {
+            note_exception();
+        }
         uint32_t spins = 0;
         while (pending_.load(std::memory_order_acquire)) {
             RV_PAUSE();
             if (++spins > 2000) std::this_thread::yield();
         }
+        std::exception_ptr e;
+        {
+            std::lock_guard<std::mutex> g(err_mu_);
+            e = err_;
+            err_ = nullptr;
+        }
+        if (e) std::rethrow_exception(e);  // (every thread has left f: the caller may unwind)
     }
     // [lo, hi) of thread t's share of n items
     static void slice(size_t n, int t, int nt, size_t& lo, size_t& hi) {
@@ -251,7 +281,7 @@ void* big_alloc(size_t bytes) {
 // against the previous round's unmapping (20 - 30 ms per compile on the 10^7-gate circuit).  Above a cap it frees at once.
 namespace {
 struct Reaper {
-    static constexpr size_t CAP_BYTES = (size_t)6 << 30;
+    static constexpr size_t CAP_BYTES = (size_t)2 << 30;  // (more than this queued: free at once, in the one burst it then takes)
     static constexpr int QUIET_MS = 250;
     std::mutex mu;
     std::condition_variable cv;

@@ -262,6 +262,12 @@ __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, 
 #ifndef RV_INTERP_UNROLL_FAST
 #define RV_INTERP_UNROLL_FAST 4
 #endif
+// two-row Xor steps of the full-width variant without the multi-base loops when they differ from its Mul steps (0 = the same).
+// The point of unequal steps: a level's wave-steps against the wavefronts the chip holds at once -- a level that needs 1.4
+// generations of wavefronts takes two rounds of memory latency, one that fits takes one
+#ifndef RV_INTERP_UXOR_FAST
+#define RV_INTERP_UXOR_FAST 0
+#endif
 // `general` = the kernel variant that also carries the multi-base Mul / Xor loops (more registers)
 __host__ __device__ constexpr int interp_unroll(int NQ, bool general = true) {
     return NQ >= 64 ? (general ? RV_INTERP_UNROLL : RV_INTERP_UNROLL_FAST) : NQ >= 32 ? RV_INTERP_UNROLL_MID : RV_INTERP_UNROLL_SMALL;
@@ -541,7 +547,9 @@ __global__ __launch_bounds__(256, (GENERAL || NQ != 64) ? 1 : 8) void k_interp_f
     // ROTATE here too: a wavefront then runs ONE step of one class instead of a Mul step followed by an Xor step
     // (two generations of short-lived wavefronts beat one generation of twice-as-long ones: 2.52 -> 2.40 ms;
     // interleaving the two classes wave by wave instead of class after class is worse again, 2.56)
-    run_level<MODE, NQ, true, GENERAL, true>(gates, r, p, wave, n_waves, lane, onm, gates, &pf);
+    constexpr int UXL = (!GENERAL && NQ == 64) ? RV_INTERP_UXOR_FAST : 0;
+    constexpr bool PFL = UXL == 0 || UXL == interp_unroll(NQ, GENERAL);  // (the prefetch plan assumes one step size)
+    run_level<MODE, NQ, true, GENERAL, PFL, UXL>(gates, r, p, wave, n_waves, lane, onm, gates, &pf);
 }
 
 // Batched proofs of one circuit (rv_prove_batch): blockIdx.y selects the proof; its buffers come from a device array
@@ -1530,8 +1538,13 @@ struct B_k_b3_chunks {
             if (UNI) {
                 const char* rb = (const char*)(stream + e0 * 64);
                 const uint32_t qoff = q * 4u;
+#ifdef RV_B3_NOLOAD  // (experiment: the kernel without its message loads)
+#pragma unroll
+                for (int e = 0; e < 64; e++) w[e] = (uint32_t)(uintptr_t)rb * (e + 1) + qoff;
+#else
 #pragma unroll
                 for (int e = 0; e < 64; e++) w[e] = *(const uint32_t*)(rb + e * 256 + qoff);
+#endif
             } else {
 #pragma unroll
                 for (int e = 0; e < 64; e++) w[e] = stream[(e0 + e) * NQ + q];
@@ -1553,7 +1566,14 @@ struct B_k_b3_chunks {
                 m[i][k] = lo | (hi << 16);
             }
         }
+#ifdef RV_B3_NOCOMP  // (experiment: the kernel without its compressions)
+#pragma unroll
+        for (int i = 0; i < RPL; i++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) cv[i][k & 7] ^= m[i][k] + flags;
+#else
         b3::compress_n<RPL>(cv, m, c + chunk_base, blen, flags);  // the lane's repetitions in lockstep
+#endif
     }
     const uint32_t R = NQ * 4;
 #pragma unroll

@@ -38,3 +38,24 @@ def rule_seeds(oracle):
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_ops(m):
+    """op tuples of a case of tests/golden/proofs.json (plain list, or run-length encoded for the large digest-only cases)"""
+    if "ops" in m:
+        return [tuple(o) for o in m["ops"]]
+    out = []
+    for count, op in m["ops_rle"]:
+        out += [tuple(op)] * count
+    return out
+
+
+def golden_matches(oracle_mod, name, m, proof: bytes) -> bool:
+    """proof == the committed golden proof (byte for byte), or -- digest-only cases -- has its length and BLAKE3 digest"""
+    import ctypes as C
+
+    if not m.get("digest_only"):
+        return proof == open(os.path.join(GOLDEN, f"proof_{name}.bin"), "rb").read()
+    buf = C.create_string_buffer(32)
+    oracle_mod.lib().rvo_blake3_hash(proof, C.c_size_t(len(proof)), buf)
+    return len(proof) == m["proof_len"] and buf.raw.hex() == m["proof_blake3"]

@@ -82,7 +82,9 @@ class Rep:
         self.pre2 = bytearray()
         self.on64 = bytearray()
         self.pre64 = bytearray()
-        self.recs2, self.corrs2, self.inputs2 = [], [], []
+        # (recs2: the broadcast byte of every reconstruction, player p at bit 7 - p; corrs2: one 0 / 1 byte each -- bytearrays, so
+        # that the 70 000-gate case fits in memory: 256 repetitions x 70 000 events)
+        self.recs2, self.corrs2, self.inputs2 = bytearray(), bytearray(), []
         self.recs64, self.corrs64, self.inputs64 = [], [], []
 
     # A.2 masks
@@ -103,7 +105,7 @@ class Rep:
 
     def reconstruct2(self, bits):  # prover.rs:209-213
         self.on2.append(self.share_byte(bits))
-        self.recs2.append(list(bits))
+        self.recs2.append(self.share_byte(bits))
         return sum(bits) & 1
 
     def correction2(self, d):  # prover.rs:215-219
@@ -298,8 +300,8 @@ def prove(ops, wit2, wit64, wire_counts, seeds):
                 keys = list(rep.keys)
                 keys[o] = bytes(16)
                 if dom == 2:
-                    recs = pack_bits([s[o] for s in rep.recs2])
-                    corrs = pack_bits(rep.corrs2)
+                    recs = pack_bits([(s >> (7 - o)) & 1 for s in rep.recs2])
+                    corrs = pack_bits(list(rep.corrs2))
                     inputs = pack_bits(rep.inputs2)
                 else:
                     recs = b"".join(struct.pack("<Q", s[o]) for s in rep.recs64)
@@ -372,6 +374,14 @@ def circ_empty():
     return [], [], [], (0, 0)
 
 
+def circ_bench70k():
+    """the reference's own bench circuit (proof/mod.rs:318-354: two inputs, N x Mul(2, 0, 1) on reused wires) at N = 70 000:
+    every repetition's transcripts are 70 kB -- 69 BLAKE3 chunks, a seven-level tree, and past BufferedHasher's 64 KiB flush
+    (crypto/hash.rs:5-6,36-51), none of which the six small cases reach at whole-proof level"""
+    ops = [GF2.Input(0), GF2.Input(1)] + [GF2.Mul(2, 0, 1)] * 70000
+    return ops, [1, 1], [0], (128, 128)
+
+
 def circ_adder64():
     """config 1: 64-bit ripple-carry adder, outputs asserted against the clear sum."""
     A, Bv = 0x0123456789ABCDEF, 0xFEDCBA9876543210
@@ -409,7 +419,10 @@ CIRCUITS = {
     "sizehint_mixed": circ_sizehint_mixed,
     "empty": circ_empty,
     "adder64": circ_adder64,
+    "bench70k": circ_bench70k,
 }
+# cases whose proof is too large to commit: proofs.json keeps its length and BLAKE3 digest, and the ops run-length encoded
+DIGEST_ONLY = {"bench70k"}
 
 
 def main():
@@ -452,15 +465,26 @@ def main():
         sg["cases"].append({"omit": omit, "gf2": gf2, "z64_first4": z64[:4], "z64_last": z64[-1], "z64_sha256_json": h})
     json.dump(sg, open(os.path.join(HERE, "sharegen.json"), "w"))
 
-    # ---- whole proofs
-    meta = {}
+    # ---- whole proofs (python gen_golden.py name ... : only those cases, merged into the existing proofs.json)
+    only = set(sys.argv[1:])
+    meta = json.load(open(os.path.join(HERE, "proofs.json"))) if only else {}
     for name, fn in CIRCUITS.items():
+        if only and name not in only:
+            continue
         ops, w2, w64, wc = fn()
         proof, hs, digests, comm, omit = prove(ops, w2, w64, wc, seeds)
-        with open(os.path.join(HERE, f"proof_{name}.bin"), "wb") as f:
-            f.write(proof)
+        if name not in DIGEST_ONLY:
+            with open(os.path.join(HERE, f"proof_{name}.bin"), "wb") as f:
+                f.write(proof)
+        rle = []  # [count, op] runs
+        for o in ops:
+            if rle and rle[-1][1] == list(o):
+                rle[-1][0] += 1
+            else:
+                rle.append([1, list(o)])
         meta[name] = {
-            "ops": [list(o) for o in ops], "wit_gf2": w2, "wit_z64": [str(x) for x in w64], "wire_counts": list(wc),
+            **({"ops_rle": rle, "digest_only": True} if name in DIGEST_ONLY else {"ops": [list(o) for o in ops]}),
+            "wit_gf2": w2, "wit_z64": [str(x) for x in w64], "wire_counts": list(wc),
             "proof_len": len(proof), "proof_blake3": blake3(proof).hex(), "comm": comm.hex(),
             "omit": [omit.get(r, 8) for r in range(256)],
             "h": [h.hex() for h in hs[:8]] + [hs[255].hex()],

@@ -314,3 +314,27 @@ def test_early_plan_pcie_window(L, monkeypatch):
     assert p["ok"] and p["check"] and p["reps"] == 256, p
     monkeypatch.setenv("RV_EARLY_REPS", "96")
     assert early_plan(L, prog, wc)["reps"] == 96
+
+
+def test_parallel_compiler_survives_a_failing_worker(monkeypatch):
+    """a bad_alloc on a worker thread of the parallel compiler must come back as RV_E_NOMEM from the calling thread
+    (after every worker has left the pass), not as std::terminate; the next compile works (compile_par.cpp: Pool)"""
+    import ctypes as C
+
+    from reverie_amd import _lib
+
+    L = _lib.lib()
+    prog, wit, wc, st = circuits.layered_gf2(n_in=256, width=4096, layers=60)
+    assert len(prog) >= 200_000
+    ci = _lib.CircuitInfo()
+
+    def compile_once():
+        return L.rv_hook_compile_info(prog.ctypes.data_as(C.c_void_p), C.c_size_t(len(prog)), C.c_size_t(int(wc[0])), C.c_size_t(int(wc[1])),
+                                      C.c_uint32(1), C.c_size_t(0), C.byref(ci))
+
+    monkeypatch.setenv("RV_COMPILE_THREADS", "4")
+    for k in (1, 3, 6):
+        monkeypatch.setenv("RV_TEST_POOL_THROW", str(k))
+        assert compile_once() == 6  # RV_E_NOMEM
+    monkeypatch.delenv("RV_TEST_POOL_THROW")
+    assert compile_once() == 0 and ci.gf2_muls == st["and"]

@@ -54,7 +54,10 @@ def _stream(rv, prog, w2, w64, wc, seeds, cuts1, cuts2=None):
     return proof, info
 
 
-@pytest.mark.parametrize("name", sorted(META))
+SMALL_GOLDEN = sorted(n for n in META if not META[n].get("digest_only"))  # (the 70 000-gate case: test_stream_bench70k)
+
+
+@pytest.mark.parametrize("name", SMALL_GOLDEN)
 def test_stream_golden(rv, rule_seeds, name):
     m = META[name]
     prog = program([tuple(o) for o in m["ops"]]) if m["ops"] else np.zeros(0, OP_DTYPE)
@@ -67,6 +70,20 @@ def test_stream_golden(rv, rule_seeds, name):
     for cuts in ([], [n // 2], list(range(1, n, 3)), list(range(7, n, 50))):
         proof, _ = _stream(rv, prog, w2, w64, wc, seeds, cuts)
         assert bytes(proof) == gold, (name, cuts[:4])
+
+
+def test_stream_bench70k(rv, oracle, rule_seeds):
+    """the 70 000-gate golden case (the reference's bench circuit: 69 BLAKE3 chunks per transcript, the tree, the 64 KiB flush of
+    BufferedHasher) through the streaming prover, cut in halves and every 4 099 ops: length and BLAKE3 digest of the golden proof"""
+    from conftest import golden_matches, golden_ops
+
+    m = META["bench70k"]
+    prog = program(golden_ops(m))
+    w2, w64, wc = m["wit_gf2"], [int(x) for x in m["wit_z64"]], tuple(m["wire_counts"])
+    n = len(prog)
+    for cuts in ([n // 2], list(range(4099, n, 4099))):
+        proof, _ = _stream(rv, prog, w2, w64, wc, rule_seeds, cuts)
+        assert golden_matches(oracle, "bench70k", m, bytes(proof)), cuts[:3]
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -246,7 +263,7 @@ def _verify_stream(proof, prog, wc, cuts, strict=True):
         sv.close()
 
 
-@pytest.mark.parametrize("name", sorted(META))
+@pytest.mark.parametrize("name", SMALL_GOLDEN)
 def test_stream_verify_golden(rv, name):
     m = META[name]
     prog = program([tuple(o) for o in m["ops"]]) if m["ops"] else np.zeros(0, OP_DTYPE)
