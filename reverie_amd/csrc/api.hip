@@ -344,7 +344,10 @@ extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
     hipError_t se = main_prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
-    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking);
+    // (RV_X_PRIO=1: the chain stream at the high priority instead -- its short dependent launches then win the dispatcher whenever
+    // wavefront slots are free)
+    static const bool x_prio = getenv("RV_X_PRIO") && atoi(getenv("RV_X_PRIO")) != 0;
+    if (se == hipSuccess) se = x_prio ? hipStreamCreateWithPriority(&c->stream_x, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete c;
         return hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
@@ -571,7 +574,7 @@ struct rv_circuit {
     Gate* d_xgates = nullptr;
     MulRec* d_muls = nullptr;
     Gate* d_others = nullptr;
-    uint32_t n_others = 0;
+    uint32_t n_others = 0, n_other_inputs = 0;  // (the Input gates first)
     ClearRec* d_clear_s = nullptr;
     ClearRecK* d_clear_k = nullptr;
     ClearLevel* d_clear_levels = nullptr;
@@ -930,6 +933,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         const uint32_t bands = getenv("RV_FLAT_BANDS") ? (uint32_t)std::max(atoi(getenv("RV_FLAT_BANDS")), 1) : 8u;
         if ((flat_mode() >= 2 || cc.gates.size() >= flat_min) && build_flat_plan(cc, c->flat, bands)) {
             c->n_others = (uint32_t)c->flat.others.size();
+            c->n_other_inputs = c->flat.n_other_inputs;
             if ((rc = up(c->flat.xgates.data(), c->flat.xgates.size() * sizeof(Gate), (void**)&c->d_xgates)) ||
                 (rc = up(c->flat.muls.data(), c->flat.muls.size() * sizeof(MulRec), (void**)&c->d_muls)) ||
                 (rc = up(c->flat.others.data(), c->flat.others.size() * sizeof(Gate), (void**)&c->d_others)) ||
@@ -1138,6 +1142,11 @@ struct rv_shard {
     uint8_t* d_vclr = nullptr;  // MODE_PROVE_V: cleartext value per share row
     // flat schedule (flat.h): operand values per Mul, the cleartext pass's barrier words {arrivals, abort, error word}, its end
     bool flat = false, split = false;
+    // split schedule with the transcript hashes band by band (RV_SPLIT_HASH, default on): chunks [0, *_chunks_done) of the two
+    // transcripts have their chaining values in d_cv[0] (preprocessing) / d_cv[1] (online); d_cvx = the tree reductions' scratch
+    bool split_hash = false;
+    uint64_t pre_chunks_done = 0, on_chunks_done = 0;
+    uint32_t* d_cvx = nullptr;
     uint8_t* d_vb = nullptr;
     uint32_t* d_sync = nullptr;
     hipEvent_t ev_clear = nullptr;
@@ -1183,7 +1192,7 @@ struct rv_shard {
         ev_clear = nullptr;
         void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk,    d_masks,  d_wires,   d_on,     d_pre,    d_wit,  d_cv[0],
                       d_cv[1], d_dig,  d_h,       d_err,   d_omit,   d_offs,    d_out,    d_masks64, d_wmask64,
-                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr, d_vb, d_sync};
+                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr, d_vb, d_sync, d_cvx};
         for (void* p : ps) ctx->release(p);
         for (void* p : extra) ctx->release(p);
     }
@@ -1901,6 +1910,33 @@ static int shard_run_split(rv_shard* s, const InterpParams& p) {
             ctx->count();
         }
     };
+    // the Input gates' transcript rows depend on nothing: first, so that the online transcript completes from its head on
+    if (c->n_other_inputs) {
+        launch_interp(st, MODE_PROVE_F, c->d_others, LevelRange{0, 0, 0, 0, 0, c->n_other_inputs}, p, nullptr);
+        ctx->count();
+    }
+    // RV_SPLIT_HASH (default 1): the BLAKE3 chunks of both transcripts that a band completes are hashed right behind the band's
+    // Mul gates, on the main stream -- VALU-bound work in what is otherwise the shadow of the (latency-bound) level chain
+    static const bool split_hash = !(getenv("RV_SPLIT_HASH") && atoi(getenv("RV_SPLIT_HASH")) == 0);
+    const uint64_t pre_chunks = cc.n_pre == 0 ? 1 : (cc.n_pre + 1023) / 1024, on_chunks = cc.n_on == 0 ? 1 : (cc.n_on + 1023) / 1024;
+    s->split_hash = split_hash && !s->d_on_quads && pre_chunks > 1 && on_chunks > 1;
+    if (s->split_hash && (rc = dalloc(ctx, b3_stream_scratch_words(std::max(cc.n_on, cc.n_pre), s->R), &s->d_cvx))) return rc;
+    auto hash_upto = [&](uint64_t pre_rows, uint64_t on_rows) {
+        if (!s->split_hash) return;
+        const uint64_t pc = std::min(pre_rows / 1024, pre_chunks - 1), oc = std::min(on_rows / 1024, on_chunks - 1);  // (the last chunk: shard_run_hash)
+        if (pc > s->pre_chunks_done) {
+            launch_b3_stream_bits_chunks(st, s->d_pre + s->pre_chunks_done * 1024 * (s->NQ / 2), (pc - s->pre_chunks_done) * 1024, s->NQ,
+                                         s->d_cv[0] + s->pre_chunks_done * s->R * 8, s->pre_chunks_done, 0);
+            s->pre_chunks_done = pc;
+            ctx->count();
+        }
+        if (oc > s->on_chunks_done) {
+            launch_b3_stream_chunks(st, s->d_on + s->on_chunks_done * 1024 * s->NQ, (oc - s->on_chunks_done) * 1024, s->NQ, s->d_cv[1] + s->on_chunks_done * s->R * 8,
+                                    nullptr, 0, s->on_chunks_done, 0);
+            s->on_chunks_done = oc;
+            ctx->count();
+        }
+    };
     // (host order matters: a wait for another stream's event resolves to that stream's tail when the wait is queued)
     for (const auto& B : F.bands) {
         chain_to(std::min(B.level_end, n_levels));
@@ -1910,6 +1946,7 @@ static int shard_run_split(rv_shard* s, const InterpParams& p) {
             ctx->count();
         }
         if (s->ec && (rc = early_flush_muls(s, B.mul1))) return rc;
+        hash_upto(B.mul1, B.on_end);
     }
     chain_to(n_levels);
     if ((rc = fork(sx, st))) return rc;
@@ -1919,8 +1956,8 @@ static int shard_run_split(rv_shard* s, const InterpParams& p) {
         (void)hipMemcpy(w, d_chain, sizeof w, hipMemcpyDeviceToHost);
         fprintf(stderr, "[rv chain] XCD %u, workgroup launches that took part / left: %u / %u\n", w[0], w[1], w[2]);
     }
-    if (c->n_others) {  // the Input / AssertZero transcript rows
-        launch_interp(st, MODE_PROVE_F, c->d_others, LevelRange{0, 0, 0, 0, 0, c->n_others}, p, nullptr);
+    if (c->n_others > c->n_other_inputs) {  // the AssertZero transcript rows
+        launch_interp(st, MODE_PROVE_F, c->d_others + c->n_other_inputs, LevelRange{0, 0, 0, 0, 0, c->n_others - c->n_other_inputs}, p, nullptr);
         ctx->count();
     }
     if (s->ec && (rc = early_flush_muls(s, cc.n_pre))) return rc;
@@ -2008,7 +2045,16 @@ static int shard_run_hash(rv_shard* s) {
     const size_t DW = (size_t)s->R * 8;
     uint32_t n_launch;
     static const bool pair_on = !(getenv("RV_B3_PAIR") && atoi(getenv("RV_B3_PAIR")) == 0);
-    if (pair_on && launch_b3_pair_small(ctx->stream, s->d_pre, cc.n_pre, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW, dig + 1 * DW,
+    if (s->split_hash) {
+        // the bands hashed their chunks behind their Mul gates (shard_run_split): what is left of the two streams, then the trees
+        const uint64_t pre_chunks = (cc.n_pre + 1023) / 1024, on_chunks = (cc.n_on + 1023) / 1024;
+        launch_b3_stream_bits_chunks(ctx->stream, s->d_pre + s->pre_chunks_done * 1024 * (s->NQ / 2), cc.n_pre - s->pre_chunks_done * 1024, s->NQ,
+                                     s->d_cv[0] + s->pre_chunks_done * s->R * 8, s->pre_chunks_done, 0);
+        launch_b3_stream_chunks(ctx->stream, s->d_on + s->on_chunks_done * 1024 * s->NQ, cc.n_on - s->on_chunks_done * 1024, s->NQ,
+                                s->d_cv[1] + s->on_chunks_done * s->R * 8, nullptr, 0, s->on_chunks_done, 0);
+        n_launch = 2 + b3_reduce_tree(ctx->stream, s->d_cv[0], s->d_cvx, pre_chunks, s->R, dig + 0 * DW);
+        n_launch += b3_reduce_tree(ctx->stream, s->d_cv[1], s->d_cvx, on_chunks, s->R, dig + 1 * DW);
+    } else if (pair_on && launch_b3_pair_small(ctx->stream, s->d_pre, cc.n_pre, s->d_on, cc.n_on, s->NQ, s->d_cv[0], s->d_cv[1], dig + 0 * DW, dig + 1 * DW,
                                         s->d_on_quads, s->n_on_quads)) {
         n_launch = 2;  // short transcripts (small circuits): both streams in the same two launches
     } else {

@@ -123,10 +123,13 @@ bool build_flat_plan(const Compiled& cc, FlatPlan& P, uint32_t want_bands) {
                 const uint32_t na = std::max(g_na(g), 1u) - 1, nb = std::max(g_nb(g), 1u) - 1;
                 r.eo_flags = g.eo | (na << 26) | (nb << 28) | (g_ca(g) << 30) | (g_cb(g) << 31);
                 P.muls[g.ep] = r;
-            } else {
+            } else if (op == G_INPUT) {
                 P.others.push_back(g);
             }
         }
+    P.n_other_inputs = (uint32_t)P.others.size();
+    for (size_t i = 0; i < n; i++)
+        if (g_op(cc.gates[i]) == G_ASSERT) P.others.push_back(cc.gates[i]);
     // ---- value records: the level-sorted stream again, 16 or 32 bytes per gate (every gate for the cleartext pass of the flat
     // schedule; everything but the XOR gates for the split schedule's level chain) ----
     std::vector<uint32_t> mul_level(n_bands, 0);  // per band: 1 + the highest dependency level of its Mul gates
@@ -184,9 +187,29 @@ bool build_flat_plan(const Compiled& cc, FlatPlan& P, uint32_t want_bands) {
                 }
         for (size_t b = 1; b < n_bands; b++) mul_level[b] = std::max(mul_level[b], mul_level[b - 1]);
     }
+    // leading online rows final after band b: everything before the first row that is still to come -- the first Mul of the
+    // next band, or the first AssertZero (their rows are written behind the last band)
+    std::vector<uint32_t> on_end(n_bands, (uint32_t)cc.n_on);
+    {
+        uint64_t first_assert = cc.n_on;
+        std::vector<uint64_t> first_mul_eo(n_bands + 1, cc.n_on);  // smallest eo among the Mul gates of band b
+        for (size_t i = 0; i < n; i++) {
+            const Gate& g = cc.gates[i];
+            if (g_op(g) == G_ASSERT) first_assert = std::min<uint64_t>(first_assert, g.eo);
+            if (g_op(g) == G_MUL) {
+                const uint32_t b = band_of_mul(g.ep);
+                first_mul_eo[b] = std::min<uint64_t>(first_mul_eo[b], g.eo);
+            }
+        }
+        uint64_t later = cc.n_on;  // smallest eo among the Mul gates of the bands behind b
+        for (size_t b = n_bands; b-- > 0;) {
+            on_end[b] = (uint32_t)std::min(later, first_assert);
+            later = std::min(later, first_mul_eo[b]);
+        }
+    }
     P.bands.resize(n_bands);
     for (size_t b = 0; b < n_bands; b++)
-        P.bands[b] = FlatPlan::Band{xbase[b], xbase[b + 1], band_mul0[b], b + 1 < n_bands ? band_mul0[b + 1] : (uint32_t)n_mul, mul_level[b]};
+        P.bands[b] = FlatPlan::Band{xbase[b], xbase[b + 1], band_mul0[b], b + 1 < n_bands ? band_mul0[b + 1] : (uint32_t)n_mul, mul_level[b], on_end[b]};
     P.ok = true;
     if (getenv("RV_COMPILE_STATS")) {
         fprintf(stderr, "[rv flat] %zu gates -> %llu Mul (program order), %llu XOR rows, %llu others in %zu bands, %zu x-levels; %.1f ms\n", n,

@@ -57,12 +57,14 @@ struct FlatPlan {
         uint32_t x0, x1;      // x-levels [x0, x1) of `xlevels`
         uint32_t mul0, mul1;  // Mul records [mul0, mul1); mul0 a multiple of 1024
         uint32_t level_end;   // split schedule: the band's Mul gates may run once the level chain has passed levels [0, level_end)
+        uint32_t on_end;      // leading online-transcript rows that are final once the Input rows and this band's Mul gates have run
     };
     std::vector<Band> bands;
     std::vector<Gate, BigAlloc<Gate>> xgates;   // G_XORK gates sorted by (band, x-level), inside one by class (two bases, others)
     std::vector<LevelRange> xlevels;            // per x-level: lo = mul11 = mul, [mul, xor2) two bases, [xor2, xork) others, hi = xork
     std::vector<MulRec, BigAlloc<MulRec>> muls; // program order: muls[ep]
-    std::vector<Gate> others;                   // G_INPUT / G_ASSERT (their transcript rows)
+    std::vector<Gate> others;                   // G_INPUT / G_ASSERT (their transcript rows): the n_other_inputs Input gates first
+    uint32_t n_other_inputs = 0;
     // the cleartext pass: every gate of the circuit, level by level
     std::vector<ClearRec, BigAlloc<ClearRec>> clear_s;
     std::vector<ClearRecK, BigAlloc<ClearRecK>> clear_k;
