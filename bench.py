@@ -36,7 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PROFILE_TAG = "r03"    # profiles/<tag>_pmc_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r04"    # profiles/<tag>_pmc_traffic.json feeds roofline.traffic
 
 
 def rule_seeds():
@@ -88,6 +88,44 @@ def cpu_baseline(prog, w2, w64, wc, seeds, units, unit, what, runs=5):
         "cpu_model": hi["cpu_model"], "physical_cores": hi["physical_cores"], "logical_cpus": hi["logical_cpus"],
         "simd": "AES-NI, AVX2 (movemask bit transpose, 8-way BLAKE3)", "proof_bytes": len(proof),
     }, proof
+
+
+def shard_times(ctx, prog, wc, wit, seeds, n_and):
+    """Per-rank time of a sharded proof on ONE GPU (tools/shard_time.py): what each of N GPUs would spend on its 256 / N
+    repetitions of the workload -- commit -> digests to the host -> challenge -> openings left in HBM -- without the collective.
+    The strong-scaling ceiling of --gpus N follows from it: t(256) / (N * t(256 / N)).  Neutral gate stream (no prover hint), as
+    the multi-GPU path compiles it."""
+    import torch
+
+    import reverie_amd
+    from reverie_amd.dist import HipShardBackend
+    from reverie_amd.proof import challenge, combine_digests
+
+    c = reverie_amd.Circuit(prog, wc, ctx)
+    be = HipShardBackend(c)
+    out = {}
+    for count in (256, 128, 64, 32):
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            shard = be.commit(wit, [], seeds[:count], 0, count)
+            h = be.digests(shard)
+            allh = np.zeros((256, 32), np.uint8)  # (the other ranks' digests: the challenge only has to be a valid map)
+            allh[:count] = h
+            omit = challenge(combine_digests(allh))
+            lens = be.open_sizes(shard, omit)
+            buf = torch.empty(max(sum(lens), 1), dtype=torch.uint8, device="cuda")
+            be.open_into(shard, omit, buf)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+            be.destroy(shard)
+        out[str(count)] = min(ts[1:]) * 1e3
+    c.close()
+    base = out["256"]
+    return {"ms": out, "strong_scaling_ceiling": {str(256 // int(k)): base / (v * (256 // int(k))) for k, v in out.items() if k != "256"},
+            "note": "one rank's share of a sharded proof (commit, digests to the host, host challenge, openings left in HBM), min of 4 after a "
+                    "warm-up, no collective; ceiling[N] = t(256) / (N * t(256 / N)) = the best strong-scaling efficiency N GPUs can reach"}
 
 
 class HostProver:
@@ -570,6 +608,11 @@ def main():
                                           "circuit compiled by rv_circuit_compile (the prover's has the RV_COMPILE_WHOLE_PROVER hint)"}
             parity["rv_prove_is_deterministic"] = bytes(host_proof) == bytes(last)
             del host_proof
+            # what a rank of a sharded proof costs (the strong-scaling ceiling from a driver record)
+            try:
+                result["shard_ms"] = shard_times(ctx, prog, wc, wit, seeds, n_and)
+            except Exception as e:  # noqa: BLE001
+                result["shard_ms"] = {"error": repr(e)}
             # the same proof left in HBM (round 1's headline) -- or, with --device-resident, the host-to-host one
             n2 = max(args.steps // 2, 5)
             if args.device_resident:

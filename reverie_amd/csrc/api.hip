@@ -169,6 +169,11 @@ struct rv_ctx {
     size_t d_ec_cap = 0;
     uint32_t* h_fs = nullptr;
     uint32_t fs_seq = 0;
+    // ... and the staging of the opened repetitions' broadcast-bit vectors on their way out (RecStage below): [40][pitch] on the
+    // device and page-locked on the host
+    uint8_t* d_rs = nullptr;
+    uint8_t* h_rs = nullptr;
+    size_t rs_cap = 0;
     HelperPool* ec_pool = nullptr;
     double ec_wait_us[17] = {0};  // running averages of the early-corrections waits (per chunk stamp, [16] the challenge): mailbox_wait
     std::vector<hipEvent_t> sync_pool;
@@ -374,6 +379,8 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     if (ctx->h_ec) (void)hipHostFree(ctx->h_ec);
     if (ctx->d_ec) (void)hipFree(ctx->d_ec);
     if (ctx->h_fs) (void)hipHostFree(ctx->h_fs);
+    if (ctx->h_rs) (void)hipHostFree(ctx->h_rs);
+    if (ctx->d_rs) (void)hipFree(ctx->d_rs);
     delete ctx->ec_pool;
     for (rv_ctx* w : ctx->workers) rv_ctx_destroy(w);
     (void)hipStreamDestroy(ctx->stream);
@@ -2402,11 +2409,30 @@ extern "C" int rv_shard_open_size(const rv_shard* s, const uint8_t omit[RV_TOTAL
 // fs_mailbox (host-mapped, nullable; device Fiat-Shamir only): the challenge is also published there -- sequence number fs_seq
 // in word 0 once comm[32], the opening map [256] and {n_on, n_pre} stand from word 16 on --, and the corrections vectors are
 // NOT extracted (early corrections: the host has them already, rv_prove_impl)
+// rv_prove's early path, second half (round 4): the opened repetitions' broadcast-bit vectors -- the other 25 MB of a 50 MB proof --
+// do not go into the proof image and out through one kernel copy behind the extraction (0.24 + 0.47 ms on the 10^7-gate circuit);
+// they are extracted in slices into a dense staging block [40][pitch], every finished slice leaves through the copy engine (a 2-D
+// transfer with 16-byte pitches: the fast path) while the next one is extracted, and the helper threads scatter the slices into
+// the proof as they arrive.  cut[k] .. cut[k + 1] = byte range of slice k; ev[k] = its copy has arrived.
+struct RecStage {
+    uint8_t* d = nullptr;
+    uint8_t* h = nullptr;
+    uint64_t pitch = 0;
+    std::vector<uint64_t> cut;
+    std::vector<hipEvent_t> ev;
+    // a slice's extraction is announced by a stamp in the mailbox (word 2: seq << 8 | slices extracted), and the HOST then hands
+    // its copy to the second stream: a wait queued there ahead of time would sit at the head of that queue through the whole proof
+    // (polled by the command processor between the main stream's launches) and hold the corrections' copies back behind it
+    uint32_t* box_dev = nullptr;
+    uint32_t seq = 0;
+};
+
 static int shard_open_impl(rv_shard* s, const uint8_t* omit /* NULL: device Fiat-Shamir */, void* dst, void** dptr, size_t lens[4],
                            bool framed = false, uint8_t* comm_out = nullptr, uint8_t* omit_out = nullptr, bool no_sync = false,
                            const uint8_t* d_all_h = nullptr /* device: all 256 digests (sharded proofs after the all-gather) */,
                            uint32_t* fs_mailbox = nullptr, uint32_t fs_seq = 0, uint32_t corr2_rep_min = 0, uint32_t corr64_rep_min = 0 /* early
-                           corrections: the GF(2) / Z64 corrections vectors of the repetitions below these are not extracted */);
+                           corrections: the GF(2) / Z64 corrections vectors of the repetitions below these are not extracted */,
+                           RecStage* rec_stage = nullptr /* the GF(2) broadcast-bit vectors leave in slices through this staging */);
 
 extern "C" int rv_shard_open_device(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS], void** dptr, size_t lens[4]) {
     if (!omit) return RV_E_ARG;
@@ -2423,7 +2449,7 @@ extern "C" int rv_shard_open_into(rv_shard* s, const uint8_t omit[RV_TOTAL_REPS]
 // holds all 256 repetitions.  comm_out / omit_out (nullable) then receive comm and the opening map.
 static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** dptr, size_t lens[4], bool framed, uint8_t* comm_out,
                            uint8_t* omit_out, bool no_sync, const uint8_t* d_all_h, uint32_t* fs_mailbox, uint32_t fs_seq, uint32_t corr2_rep_min,
-                           uint32_t corr64_rep_min) {
+                           uint32_t corr64_rep_min, RecStage* rec_stage) {
     if (!s || !dptr || !lens) return RV_E_ARG;
     if (fs_mailbox && (omit || s->rep)) return RV_E_ARG;
     rv_ctx* ctx = s->ctx;
@@ -2517,7 +2543,18 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
         launch_rep_open(ctx->stream, s->d_pre_rep, s->pre_stride, nullptr, cc.n_pre, 1, d_ol, s->d_omit, s->d_offs + 3 * s->R, d_out);
         launch_rep_open(ctx->stream, s->d_on_rep, s->on_stride, s->c->d_in_rows, cc.n_in, 1, d_ol, s->d_omit, s->d_offs + 4 * s->R, d_out);
     } else if (any_on) {
-        launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
+        if (rec_stage) {
+            // slice by slice: extract into the staging block, then (second stream, behind an event) the slice's 2-D copy to the host
+            // (host order: the event, then the other stream's wait for it -- a wait resolves to the stream's tail at queueing time)
+            for (size_t k = 0; k + 1 < rec_stage->cut.size(); k++) {
+                const uint64_t b0 = rec_stage->cut[k], b1 = rec_stage->cut[k + 1];
+                launch_extract_bits_stage(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, s->d_omit, rec_stage->d, rec_stage->pitch, b0, b1 - b0);
+                launch_publish(ctx->stream, nullptr, 0, nullptr, rec_stage->box_dev + 2, (rec_stage->seq << 8) | (uint32_t)(k + 1));
+                ctx->count(2);
+            }
+        } else {
+            launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
+        }
         if (corr2_rep_min < s->R) launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out, corr2_rep_min);
         launch_extract_bits(ctx->stream, s->d_on, s->c->d_in_rows, cc.n_in, s->NQ, 1, s->d_omit, s->d_offs + 4 * s->R, d_out);
         launch_extract64(ctx->stream, s->d_on64, cc.on_words64, s->c->d_rec_offs64, cc.n_rec64, 1, s->R, s->d_omit,
@@ -2744,8 +2781,48 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
             }
         }
     }
+    // ... and the broadcast-bit vectors in slices through the copy engine (RecStage; RV_EARLY_REC=1, off by default: through the
+    // proof image and one kernel copy, as in round 3; RV_EARLY_REC_SLICES, default 4).  Measured on the 10^7-gate circuit: 5.74 -
+    // 5.9 ms against 5.63 -- the link is still busy with the corrections' last chunk when the challenge arrives, the kernel copy
+    // of the image already runs at link rate, and the host scatters 25 MB more
+    RecStage rs;
+    bool rec_staged = false;
+    const uint64_t rec_min = getenv("RV_EARLY_REC_MIN") ? (uint64_t)atoll(getenv("RV_EARLY_REC_MIN")) : (1ull << 20);  // (read per call: the tests lower it)
+    if (early && !er.plan->z64 && getenv("RV_EARLY_REC") && atoi(getenv("RV_EARLY_REC")) != 0 && c->cc.n_rec >= rec_min) {
+        const uint64_t n_bytes = c->cc.n_rec / 8 + 1, g = extract_stage_granule(c->cc.n_rec);
+        rs.pitch = (n_bytes + 255) & ~255ull;
+        const size_t need = (size_t)RV_ONLINE_REPS * rs.pitch;
+        bool ok = g % 16 == 0;
+        if (ok && ctx->rs_cap < need) {
+            if (ctx->h_rs) (void)hipHostFree(ctx->h_rs);
+            if (ctx->d_rs) (void)hipFree(ctx->d_rs);
+            ctx->h_rs = ctx->d_rs = nullptr;
+            ctx->rs_cap = 0;
+            if (hipHostMalloc((void**)&ctx->h_rs, need, hipHostMallocDefault) == hipSuccess && hipMalloc((void**)&ctx->d_rs, need) == hipSuccess)
+                ctx->rs_cap = need;
+            else
+                ok = false, (void)hipGetLastError();
+        }
+        if (ok) {
+            const int S = std::min(std::max(getenv("RV_EARLY_REC_SLICES") ? atoi(getenv("RV_EARLY_REC_SLICES")) : 4, 1), 32);
+            // the first slice half the size of the others: the link starts sooner
+            const uint64_t units = 2 * (uint64_t)S - 1;
+            rs.cut.push_back(0);
+            for (int k = 0; k < S; k++) {
+                const uint64_t at = k + 1 == S ? rs.pitch : std::min<uint64_t>(((n_bytes * (2 * (uint64_t)k + 1) / units + g - 1) / g) * g, rs.pitch);
+                if (at > rs.cut.back()) rs.cut.push_back(at);
+            }
+            for (size_t k = 0; k + 1 < rs.cut.size(); k++) rs.ev.push_back(ctx->get_sync_event());
+            rs.d = ctx->d_rs, rs.h = ctx->h_rs;
+            rs.box_dev = fs_dev, rs.seq = er.seq;
+            rec_staged = true;
+        }
+    }
     int rc = rv_shard_commit_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, 0, RV_TOTAL_REPS, &s, /*defer_sync=*/true, early ? &er : nullptr);
-    if (rc) return rc;
+    if (rc) {
+        for (hipEvent_t e : rs.ev) ctx->sync_pool.push_back(e);
+        return rc;
+    }
     if (early) {
         // the proof's buffer, now that the GPU is busy (a fresh page-locked buffer of a 640 MB proof takes 45 ms to map).  Without it
         // the plain path below still works: the stamps in the stream are harmless, nothing was handed to the second stream yet
@@ -2763,7 +2840,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         const uint32_t seq = er.seq;
         const bool z64 = er.plan->z64;
         if ((rc = shard_open_impl(s, nullptr, nullptr, &d, lens, true, nullptr, nullptr, /*no_sync=*/true, nullptr, fs_dev, seq, z64 ? 0 : er.plan->r_spec,
-                                  z64 ? er.plan->r_spec : 0)))
+                                  z64 ? er.plan->r_spec : 0, rec_staged ? &rs : nullptr)))
             break;
         const size_t total = 32 + 4 * 8 + lens[0] + lens[1] + lens[2] + lens[3];
         if (total != EL.total || er.packed.size() != er.plan->chunks.size() || er.plan->chunks.size() > 255) {
@@ -2774,7 +2851,10 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         // (Z64: only the records of the opened repetitions below r_spec -- the kernel counts them -- go without their vectors)
         const uint64_t corr_at = 145 + (z64 ? EL.l64r : EL.l2r);
         const uint64_t rec_first = z64 ? EL.base[2] : EL.base[0], rec_size = z64 ? EL.sz64 : EL.sz2, corr_len = z64 ? EL.l64c : EL.l2c;
-        launch_copy_gaps(ctx->stream, (const uint8_t*)d, out_dev, total, rec_first, rec_size, corr_at, corr_len, RV_ONLINE_REPS, s->d_omit, er.plan->r_spec);
+        if (rec_staged)
+            launch_copy_gaps2(ctx->stream, (const uint8_t*)d, out_dev, total, rec_first, rec_size, 137, EL.l2r, corr_at, corr_len, RV_ONLINE_REPS, s->d_omit, er.plan->r_spec);
+        else
+            launch_copy_gaps(ctx->stream, (const uint8_t*)d, out_dev, total, rec_first, rec_size, corr_at, corr_len, RV_ONLINE_REPS, s->d_omit, er.plan->r_spec);
         launch_store_word(ctx->stream, s->d_err, (int*)(fs_dev + 8));
         if (hipGetLastError() != hipSuccess) {
             rc = RV_E_DEVICE;
@@ -2807,7 +2887,27 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
             for (uint32_t j = 0; j < n_open; j++)
                 if (opened[j] < er.plan->r_spec) n_staged = j + 1;
             const size_t n_pieces = chunks.size() * n_staged;
-            const std::function<void(int)> job = [&](int) {
+            const std::function<void(int)> job = [&](int t) {
+                if (t == 0 && rec_staged) {
+                    // the caller's thread first hands the slices of the broadcast-bit vectors to the copy engine, each as soon as its
+                    // extraction is announced (the helpers scatter the corrections meanwhile)
+                    for (size_t k = 0; k + 1 < rs.cut.size(); k++) {
+                        auto extracted = [&] {  // (stamps overwrite each other: "at least k + 1 slices of THIS proof")
+                            const uint32_t v = __atomic_load_n(&box[2], __ATOMIC_ACQUIRE);
+                            return (v >> 8) == (rs.seq & 0xFFFFFFu) && (v & 0xFFu) > k;
+                        };
+                        if (mailbox_wait(ctx, extracted, nullptr, "early corrections (slice)")) {
+                            bad.store(1);
+                            return;
+                        }
+                        const uint64_t b0 = rs.cut[k], b1 = rs.cut[k + 1];
+                        if (hipMemcpy2DAsync(rs.h + b0, rs.pitch, rs.d + b0, rs.pitch, b1 - b0, RV_ONLINE_REPS, hipMemcpyDeviceToHost, ctx->stream2) != hipSuccess ||
+                            hipEventRecord(rs.ev[k], ctx->stream2) != hipSuccess) {
+                            bad.store(1);
+                            return;
+                        }
+                    }
+                }
                 for (;;) {
                     const size_t t = next_piece.fetch_add(1, std::memory_order_relaxed);
                     if (t >= n_pieces) return;
@@ -2822,6 +2922,28 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
                 rc = hip_fail(hipGetLastError(), "early corrections (copy)", __FILE__, __LINE__);
                 break;
             }
+        }
+        if (rec_staged) {
+            // the broadcast-bit vectors, slice by slice as their copies arrive: record j's bytes [cut[k], cut[k + 1]) from staging row j
+            const uint64_t l2r = EL.l2r;
+            for (size_t k = 0; k + 1 < rs.cut.size() && !rc; k++) {
+                if (hipEventSynchronize(rs.ev[k]) != hipSuccess) {
+                    rc = hip_fail(hipGetLastError(), "early corrections (broadcast bits)", __FILE__, __LINE__);
+                    break;
+                }
+                const uint64_t b0 = rs.cut[k], b1 = std::min(rs.cut[k + 1], l2r);
+                if (b1 <= b0) continue;
+                std::atomic<uint32_t> next_rec{0};
+                const std::function<void(int)> job = [&](int) {
+                    for (;;) {
+                        const uint32_t j = next_rec.fetch_add(1, std::memory_order_relaxed);
+                        if (j >= n_open) return;
+                        memcpy(out + rec_first + (size_t)j * rec_size + 137 + b0, rs.h + (size_t)j * rs.pitch + b0, b1 - b0);
+                    }
+                };
+                ctx->ec_pool->run(job);
+            }
+            if (rc) break;
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
             rc = hip_fail(hipGetLastError(), "proof (early corrections)", __FILE__, __LINE__);
@@ -2925,6 +3047,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
         out = nullptr;
     } while (0);
     rv_shard_destroy(s);  // (waits for both streams: nothing writes into `out` any more)
+    for (hipEvent_t e : rs.ev) ctx->sync_pool.push_back(e);
     if (!dst) rv_free(out);
     return rc;
 }

@@ -198,6 +198,11 @@ void launch_store_word(hipStream_t st, const int* d_src, int* dst_mapped);
 void launch_pack_corr_all(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint64_t byte0, uint64_t n_bytes, uint64_t pitch, uint8_t* d_out);
 void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
                       uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit /*[256]*/, uint32_t rep_limit);
+void launch_copy_gaps2(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t h1_at, uint64_t h1_len,
+                       uint64_t h2_at, uint64_t h2_len, uint32_t n_rec, const uint8_t* d_omit /*[256]*/, uint32_t rep_limit);
+uint32_t extract_stage_granule(uint64_t n_items);
+void launch_extract_bits_stage(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ, const uint8_t* d_omit,
+                               uint8_t* d_stage, uint64_t pitch, uint64_t byte0, uint64_t n_bytes_slice);
 void launch_publish(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, uint32_t* flag_mapped, uint32_t seq);
 void launch_store_words(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, const int* d_err, int* dst_err_mapped);
 // a narrow stretch with its live wires in LDS (ldsrun.h); d_pp != null: `batch` proofs, parameters from the device array

@@ -2139,8 +2139,9 @@ void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, 
 constexpr uint32_t EX_TB = 128;
 
 // slot of every opened repetition (rank among the opened ones) and its output offset, into LDS
+// stage_pitch != 0: the output is a dense staging block, slot k's bytes at k * stage_pitch (dst_off is not read)
 __device__ __forceinline__ uint32_t ex_slots(const uint8_t* __restrict__ omit, const uint64_t* __restrict__ dst_off, uint32_t R,
-                                             uint8_t* s_slot /*[256]*/, uint64_t* s_dst /*[RV_ONLINE_REPS]*/, uint32_t* s_cnt /*[5]*/) {
+                                             uint8_t* s_slot /*[256]*/, uint64_t* s_dst /*[RV_ONLINE_REPS]*/, uint32_t* s_cnt /*[5]*/, uint64_t stage_pitch = 0) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool on = tid < R && omit[tid] < 8;
     const unsigned long long bal = __ballot(on);
@@ -2150,7 +2151,7 @@ __device__ __forceinline__ uint32_t ex_slots(const uint8_t* __restrict__ omit, c
     for (uint32_t w = 0; w < wave; w++) base += s_cnt[w];
     const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
     s_slot[tid] = (on && slot < RV_ONLINE_REPS) ? (uint8_t)slot : (uint8_t)0xFF;
-    if (on && slot < RV_ONLINE_REPS) s_dst[slot] = dst_off[tid];
+    if (on && slot < RV_ONLINE_REPS) s_dst[slot] = stage_pitch ? (uint64_t)slot * stage_pitch : dst_off[tid];
     uint32_t n = 0;
     for (uint32_t w = 0; w < 4; w++) n += s_cnt[w];
     __syncthreads();
@@ -2168,7 +2169,10 @@ __device__ __forceinline__ void ex_flush(const uint8_t* s_buf, const uint64_t* s
 
 template <int KIND>
 struct B_k_extract_rows {
-    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out) const {
+    // stage_pitch / block0: a SLICE of the vectors (workgroups block0 .. block0 + gridDim.x of the whole launch) into a dense staging
+    // block [slot][stage_pitch] instead of the proof image (rv_prove's early path: the slices leave through the copy engine while
+    // the next ones are extracted)
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out, uint64_t stage_pitch, uint32_t block0) const {
     __shared__ uint8_t s_buf[RV_ONLINE_REPS * EX_TB];
     __shared__ uint32_t s_rows[8 * EX_TB];
     __shared__ uint8_t s_slot[256];
@@ -2177,7 +2181,7 @@ struct B_k_extract_rows {
     __shared__ uint8_t s_aq[64];
     __shared__ uint32_t s_naq;
     const uint64_t n_bytes = n_items / 8 + 1;
-    const uint64_t t0 = (uint64_t)blockIdx.x * tb;
+    const uint64_t t0 = (uint64_t)(blockIdx.x + block0) * tb;
     const uint32_t nb = (uint32_t)((n_bytes - t0 < tb) ? n_bytes - t0 : tb);
     // this workgroup's row ids, one coalesced pass (ordinals past the end repeat the last item; masked below)
     for (uint32_t i = threadIdx.x; i < 8 * nb; i += 256) {
@@ -2185,7 +2189,7 @@ struct B_k_extract_rows {
         if (it >= n_items) it = n_items ? n_items - 1 : 0;
         s_rows[i] = rows ? rows[it] : (uint32_t)it;
     }
-    const uint32_t n_slots = ex_slots(omit, dst_off, 4 * NQ, s_slot, s_dst, s_cnt);  // contains the barrier for s_rows
+    const uint32_t n_slots = ex_slots(omit, dst_off, 4 * NQ, s_slot, s_dst, s_cnt, stage_pitch);  // contains the barrier for s_rows
     if (!n_slots) return;
     // the quad words that hold an opened repetition (about 30 of 64 for a whole proof), compacted: thread = (output byte,
     // such a quad), so no lane idles on a quad nobody opened (k_extract_rows<0> 263 -> 240 us on the 10^7-gate circuit)
@@ -2245,8 +2249,8 @@ struct B_k_extract_rows {
 }
 };
 template <int KIND>
-__global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out) {
-    B_k_extract_rows<KIND>{}(stream, rows, n_items, NQ, tb, omit, dst_off, out);
+__global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out, uint64_t stage_pitch, uint32_t block0) {
+    B_k_extract_rows<KIND>{}(stream, rows, n_items, NQ, tb, omit, dst_off, out, stage_pitch, block0);
 }
 
 // Bit-per-rep source (the preprocessing stream, [n][NQ/2] bytes; nibble bit k of quad q <-> repetition 4q+3-k):
@@ -2497,10 +2501,24 @@ void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d
     const dim3 grid((unsigned)((n_bytes + tb - 1) / tb));
     if (kind == 0)
         launch<B_k_extract_rows<0>, 256>(k_extract_rows<0>, st, grid, dim3(256), (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
-                           d_dst_off, d_out);
+                           d_dst_off, d_out, 0, 0);
     else
         launch<B_k_extract_rows<1>, 256>(k_extract_rows<1>, st, grid, dim3(256), (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
-                           d_dst_off, d_out);
+                           d_dst_off, d_out, 0, 0);
+}
+// the same vectors (kind 0: the omitted players' broadcast bits) as a slice into a dense staging block: output bytes
+// [byte0, byte0 + n_bytes_slice) of every opened repetition's vector go to d_stage + slot * pitch + byte; byte0 a multiple of
+// extract_stage_granule(n_items)
+uint32_t extract_stage_granule(uint64_t n_items) { return std::max(ex_tb_for(n_items / 8 + 1), 16u); }  // (16: the copy engine's fast 2-D path)
+void launch_extract_bits_stage(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ, const uint8_t* d_omit,
+                               uint8_t* d_stage, uint64_t pitch, uint64_t byte0, uint64_t n_bytes_slice) {
+    const uint64_t n_bytes = n_items / 8 + 1;
+    const uint32_t tb = extract_stage_granule(n_items);
+    const uint64_t end = std::min(byte0 + n_bytes_slice, n_bytes);
+    if (end <= byte0) return;
+    const dim3 grid((unsigned)((end - byte0 + tb - 1) / tb));
+    hipLaunchKernelGGL(k_extract_rows<0>, grid, dim3(256), 0, st, (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit, (const uint64_t*)nullptr, d_stage, pitch,
+                       (uint32_t)(byte0 / tb));
 }
 
 // Inverse for the verifier (Pack::unpack / PackSelected::unpack_selected): builds dense
@@ -2820,6 +2838,52 @@ __global__ __launch_bounds__(256) void k_copy_gaps(const uint8_t* __restrict__ i
     for (uint64_t i = a16 + 16 * tid; i < b16; i += 16 * nth) *(uint4*)(dst_mapped + i) = *(const uint4*)(img + i);
     for (uint64_t i = b16 + tid; i < b; i += nth) dst_mapped[i] = img[i];
 }
+// The same with TWO holes per online record: [h1_at, h1_at + h1_len) in every one of the n_rec records (the broadcast-bit vectors:
+// they reach the host through the copy engine, slice by slice) and [h2_at, h2_at + h2_len) in the first m (the corrections vectors,
+// m as above).  What is left -- headers, keys, length words, input vectors, the preprocessing sections -- is a few dozen KB.
+// Piece p (blockIdx.y): 0 = the image's head up to the first record; 1 + 3 j + {0, 1, 2} = record j before hole 1 / between the
+// holes / behind hole 2; the last = everything behind the records.
+__global__ __launch_bounds__(256) void k_copy_gaps2(const uint8_t* __restrict__ img, uint8_t* __restrict__ dst_mapped, uint64_t total, uint64_t first,
+                                                    uint64_t rec, uint64_t h1_at, uint64_t h1_len, uint64_t h2_at, uint64_t h2_len, uint32_t n_rec,
+                                                    const uint8_t* __restrict__ omit, uint32_t rep_limit) {
+    __shared__ uint32_t s_m;
+    if (threadIdx.x < 64) {
+        uint32_t cnt = 0;
+        for (uint32_t r = threadIdx.x; r < rep_limit && r < RV_TOTAL_REPS; r += 64) cnt += omit[r] < 8 ? 1u : 0u;
+        for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (threadIdx.x == 0) s_m = cnt < n_rec ? cnt : n_rec;
+    }
+    __syncthreads();
+    const uint32_t m = s_m, p = blockIdx.y;
+    uint64_t a, b;
+    if (p == 0) {
+        a = 0, b = first;
+    } else if (p == 1 + 3 * n_rec) {
+        a = first + (uint64_t)n_rec * rec, b = total;
+    } else {
+        const uint32_t j = (p - 1) / 3, k = (p - 1) % 3;
+        const uint64_t r0 = first + (uint64_t)j * rec;
+        if (k == 0) a = r0, b = r0 + h1_at;
+        else if (k == 1) a = r0 + h1_at + h1_len, b = j < m ? r0 + h2_at : r0 + rec;
+        else a = j < m ? r0 + h2_at + h2_len : r0 + rec, b = r0 + rec;
+    }
+    if (b <= a) return;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    if (b - a < 4096) {  // (nearly all pieces: a few hundred bytes)
+        for (uint64_t i = a + tid; i < b; i += nth) dst_mapped[i] = img[i];
+        return;
+    }
+    uint64_t a16 = (a + 15) & ~15ull, b16 = b & ~15ull;
+    for (uint64_t i = a + tid; i < a16; i += nth) dst_mapped[i] = img[i];
+    for (uint64_t i = a16 + 16 * tid; i < b16; i += 16 * nth) *(uint4*)(dst_mapped + i) = *(const uint4*)(img + i);
+    for (uint64_t i = b16 + tid; i < b; i += nth) dst_mapped[i] = img[i];
+}
+void launch_copy_gaps2(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t h1_at, uint64_t h1_len,
+                       uint64_t h2_at, uint64_t h2_len, uint32_t n_rec, const uint8_t* d_omit, uint32_t rep_limit) {
+    hipLaunchKernelGGL(k_copy_gaps2, dim3(rep_limit < RV_TOTAL_REPS ? 16 : 1, 3 * n_rec + 2), dim3(256), 0, st, d_img, dst_mapped, total, first, rec, h1_at, h1_len, h2_at,
+                       h2_len, n_rec, d_omit, rep_limit);
+}
+
 void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
                       uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit, uint32_t rep_limit) {
     // (the last piece may be most of the image -- Z64 with few staged repetitions --: enough workgroups per piece to fill PCIe alone)

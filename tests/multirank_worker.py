@@ -39,10 +39,16 @@ def main():
     cases.append(("mixed", prog, w2, w64, wc))
     prog, wit, wc, st = circuits.layered_gf2(n_in=300, width=4096, layers=6)
     cases.append(("layered", prog, wit, [], wc))
+    full = bool(os.environ.get("MULTI_FULL"))
+    if full:
+        # BASELINE config 4 at full size (10 027 008 gates): every rank holds the replicated gate stream and a shard of the
+        # repetitions; the sharded proof against the oracle's and rv_prove's bytes
+        prog, wit, wc, st = circuits.layered_gf2()
+        cases = [("config4", prog, wit, [], wc)]
     worlds = [int(x) for x in (sys.argv[1:] or ["2", "4", "8"])]
     res = {}
     for name, prog, w2, w64, wc in cases:
-        want = oracle_lib.prove(prog, w2, w64, wc, seeds)
+        want = oracle_lib.prove(prog, w2, w64, wc, seeds, threads=32)
         single = bytes(reverie_amd.Proof.new(prog, w2, w64, wc, seeds=seeds))
         assert single == want, name
         g = np.ascontiguousarray(np.asarray(w2, np.uint8))
@@ -54,13 +60,21 @@ def main():
             cm = (C.c_void_p * n)()
             _lib.check(L.rv_comm_create_all(hc, C.c_int(n), cm))
             hcirc = (C.c_void_p * n)(*[c.handle for c in circs])
-            for it in range(2):
+            for it in range(1 if full else 2):
                 out, ln = C.c_void_p(), C.c_size_t()
                 _lib.check(L.rv_prove_multi(cm, hcirc, C.c_int(n), p(g), C.c_size_t(len(g)), p(z), C.c_size_t(len(z)), p(seeds), C.byref(out),
                                             C.byref(ln)))
                 got = C.string_at(out, ln.value)
                 L.rv_free(out)
                 res["%s/%d/%d" % (name, n, it)] = got == want
+            if full:
+                for i in range(n):
+                    L.rv_comm_destroy(C.c_void_p(cm[i]))
+                for c in circs:
+                    c.close()
+                for cx in ctxs:
+                    cx.close()
+                continue
             # seeds = NULL: drawn once for all ranks; the proof must verify
             out, ln = C.c_void_p(), C.c_size_t()
             _lib.check(L.rv_prove_multi(cm, hcirc, C.c_int(n), p(g), C.c_size_t(len(g)), p(z), C.c_size_t(len(z)), None, C.byref(out), C.byref(ln)))

@@ -34,3 +34,14 @@ def test_rv_prove_multi_with_several_ranks_on_one_gpu(worlds):
     assert res and all(res.values()), res
     for n in worlds:
         assert res["mixed/%s/0" % n] and res["layered/%s/1" % n] and res["mixed/%s/invalid-witness" % n]
+
+
+def test_rv_prove_multi_full_size_config4():
+    """BASELINE config 4 at full size (10^7 gates, 5 014 185 AND) through the multi-rank C path with 2 and 8 ranks sharing the GPU:
+    every rank holds the replicated gate stream (0.3 GB) and a 128- / 32-repetition shard; rank 0's framed 50 MB proof must be
+    the oracle's and rv_prove's, byte for byte (reference: proof/mod.rs:127-172)"""
+    env = dict(os.environ, RV_RCCL_PATH=build_shim(), MULTI_FULL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), "2", "8"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res == {"config4/2/0": True, "config4/8/0": True}, res

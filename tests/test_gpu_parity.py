@@ -1226,11 +1226,16 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
 
     L = _lib.lib()
     monkeypatch.setenv("RV_EARLY_MIN", "1000")
+    # round 4: the opened repetitions' broadcast-bit vectors leave in slices through the copy engine (RecStage, api.hip) -- on for
+    # every case here (threshold lowered), with 1 .. 7 slices; the RV_EARLY_REC=0 bytes (one kernel copy, round 3) at the end
+    monkeypatch.setenv("RV_EARLY_REC_MIN", "1000")
+    monkeypatch.setenv("RV_EARLY_REC", "1")
     # (the last case is mostly XOR: its outputs still depend on the inputs after 80 layers, so a flipped witness bit is caught)
     cases = [(64, 8192, 40, 0.5, "10", 16), (37, 4736, 70, 0.6, "3", 37), (64, 8192, 36, 1.0, "1", 16), (128, 16384, 24, 0.5, "16", 16),
              (64, 16384, 80, 0.1, "4", 16)]
     for case_no, (n_in, width, layers, p_and, chunks, fold_to) in enumerate(cases):
         monkeypatch.setenv("RV_EARLY_CHUNKS", chunks)
+        monkeypatch.setenv("RV_EARLY_REC_SLICES", str((4, 1, 7, 3, 2)[case_no]))
         # (cases 1 and 3: only the first 96 / 200 repetitions are staged, the opened ones beyond them take the plain way)
         if case_no in (1, 3):
             monkeypatch.setenv("RV_EARLY_REPS", "96" if case_no == 1 else "200")
@@ -1248,9 +1253,12 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
         again = rv.Proof.new(c, wit, [], seeds=rule_seeds)  # the staging buffers and the mailbox are reused
         assert bytes(again) == want
         assert got.verify(c)
+        monkeypatch.setenv("RV_EARLY_REC", "0")
+        assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == want
+        monkeypatch.setenv("RV_EARLY_REC", "1")
         monkeypatch.setenv("RV_EARLY", "0")
         plain = rv.Proof.new(c, wit, [], seeds=rule_seeds)
-        assert L.rv_hook_early_proofs() == n0 + 2
+        assert L.rv_hook_early_proofs() == n0 + 3
         assert bytes(plain) == want
         monkeypatch.setenv("RV_EARLY", "2")
         if p_and < 0.2:
@@ -1259,7 +1267,7 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
             with pytest.raises(rv.ReverieError) as e:
                 rv.Proof.new(c, bad, [], seeds=rule_seeds)
             assert e.value.code == 1
-            assert L.rv_hook_early_proofs() == n0 + 2
+            assert L.rv_hook_early_proofs() == n0 + 3
             assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == want  # ... and the context is fine afterwards
         c.close()
 
