@@ -654,6 +654,317 @@ void launch_aes_z64_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* 
         launch_z64_qw<2>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks64);
 }
 
+// ------------------------------------------------------------------------------------
+// The Z64 prover's level with the cipher inside (internal.h: Z64FParams).  Replaces, for one dependency level,
+// generator/share.rs:54-65 + z64/domain.rs:64-83 (the two fresh masks of every Mul) AND interpreter/single.rs:25-157
+// instantiated at Z64 (op_mul, the linear ops, Input, AssertZero) with transcript/prover.rs:181-232's records.
+//
+// Lane = (gate sub-index jsub, quad word ql of the workgroup's 16): after the cipher and four 32x32 bit transposes it holds
+// lambda_ab and lambda_new of ITS Mul gate for the 4 repetitions x 8 players of quad q -- 32 slots that are 256 contiguous
+// bytes of every share row, so operand rows are read and result rows written in 16-byte pieces, and the sum over a
+// repetition's players is eight lane-local adds.  Linear gates and the few Input / AssertZero / Const gates of the level use
+// the same mapping (memory only) and are dealt to the wavefronts between their cipher batches.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void z_ld16(const uint64_t* p, uint64_t& a, uint64_t& b) {
+    const ulonglong2 v = *(const ulonglong2*)p;
+    a = v.x;
+    b = v.y;
+}
+__device__ __forceinline__ void z_st16(uint64_t* p, uint64_t a, uint64_t b) { *(ulonglong2*)p = make_ulonglong2(a, b); }
+__device__ __forceinline__ const uint64_t* z_row(const Z64FParams& p, uint32_t ref, uint64_t S) {
+    return (ref & G64_MASK_ROW) ? p.masks + (size_t)(ref & ~G64_MASK_ROW) * S : p.wmask + (size_t)ref * S;
+}
+// one repetition's eight transcript words (64 bytes; the stream is only 8-byte aligned)
+__device__ __forceinline__ void z_store_on(uint64_t* op, const uint64_t* w) {
+    if (((uintptr_t)op & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) z_st16(op + 2 * i, w[2 * i], w[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) op[i] = w[i];
+    }
+}
+
+// Row layout of this path ("swizzled"): inside a workgroup's block of 16 quad words (512 u64), the 16-byte piece i (slots 2i,
+// 2i + 1 of a quad word's 32) of quad ql sits at u64 offset i * 32 + ql * 2 -- piece-major, so that the 16 lanes of a gate
+// read 256 contiguous bytes per load instruction while each lane still collects the 32 slots of ITS quad word (the bitsliced
+// cipher fixes which lane holds which slot).  With a lane's pieces in the natural order (256 contiguous bytes per lane, 256
+// bytes apart between lanes) every load instruction touched 64 lines and the eight wavefronts of a compute unit evicted each
+// other's lines from L1 between the instructions that shared them: 72 ms per proof instead of the 52 of the two-kernel path.
+// Every row this path reads it also wrote (wmask rows, the Mul gates' lambda_new rows) -- except the Input gates' mask rows,
+// which come from k_aes_z64_masks in the natural order and are rewritten in place by the Input gate itself (z64f_oth).
+__device__ __forceinline__ uint32_t z_piece(uint32_t i) { return i * 32; }
+
+template <int QW>
+__device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint32_t gi, bool valid, const Z64FParams& p, const uint32_t* rkl, uint32_t q,
+                                         uint32_t zo, bool writer) {
+    const uint64_t S = (uint64_t)p.NQ * 32;
+    const uint32_t m = valid ? gates[gi].m : 0u;
+    uint32_t lo0[32], hi0[32], lo1[32], hi1[32];
+    {
+        uint32_t s[128], t[128];
+#ifdef RV_ZF_NOAES
+#pragma unroll
+        for (int i = 0; i < 128; i++) t[i] = m * (2 * i + 1);
+#else
+        rounds_0_to_9<QW>(p.first_block + (m >> 1), s, t, rkl);
+        sub_shift(s, t);
+#endif
+        const uint32_t* rk10 = rkl + 10 * 128 * QW;
+        // plane 8*i + k = bit k of keystream byte i; u64 h, bit b  <->  plane 64*h + b (k_aes_z64_masks)
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            lo0[k] = t[31 - k] ^ rk10[(31 - k) * QW];
+            hi0[k] = t[32 + 31 - k] ^ rk10[(32 + 31 - k) * QW];
+            lo1[k] = t[64 + 31 - k] ^ rk10[(64 + 31 - k) * QW];
+            hi1[k] = t[96 + 31 - k] ^ rk10[(96 + 31 - k) * QW];
+        }
+    }
+    transpose32(lo0);
+    transpose32(hi0);
+    transpose32(lo1);
+    transpose32(hi1);
+    // the cipher and the transposes end HERE: without these pins the compiler sinks the last round and the transposes into the
+    // `valid` branch below and schedules them among the row loads (160 registers spilled, the spill reloads then wait for
+    // every outstanding store)
+#pragma unroll
+    for (int k = 0; k < 32; k++) asm volatile("" : "+v"(lo0[k]), "+v"(hi0[k]), "+v"(lo1[k]), "+v"(hi1[k])::"memory");
+    if (!valid) return;
+#ifdef RV_ZF_NOMEM
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) acc += lo0[i] ^ hi0[i] ^ lo1[i] ^ hi1[i];
+        if (acc == 0x12345u) p.pre[gi] = acc;
+        return;
+    }
+#endif
+    const Gate64 g = gates[gi];
+    const uint64_t* ap = z_row(p, g.am, S) + zo;
+    const uint64_t* bp = z_row(p, g.bm, S) + zo;
+    uint64_t* lnp = p.masks + (size_t)(g.m + 1) * S + zo;
+    const uint64_t va = p.v[g.a], vb = p.v[g.b];
+    // Software-pipelined over the lane's four repetitions: the operand pieces of repetition k + 2 are requested BEFORE the
+    // stores of repetition k are issued.  CDNA has one in-order counter for vector loads and stores, so waiting for a load
+    // also waits for every store issued before it -- with load / compute / store / load ... in program order each repetition
+    // paid a load round trip AND a store round trip, and the eight wavefronts of a compute unit kept it at a third of the
+    // row traffic the two-kernel path reaches (measured without the cipher: 80 ms per proof against 25).
+    uint64_t lx[2][8], ly[2][8];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            z_ld16(ap + z_piece(4 * k + i), lx[k][2 * i], lx[k][2 * i + 1]);
+            z_ld16(bp + z_piece(4 * k + i), ly[k][2 * i], ly[k][2 * i + 1]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // lambda_new goes out at once (it is only stored), what stays is lambda_ab - lambda_new per slot and the four sums of lambda_ab:
+    // 72 registers instead of 128 beside the operand pieces
+    uint64_t d[32], cs[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint64_t lab = ((uint64_t)hi0[8 * k + i] << 32) | lo0[8 * k + i];
+            const uint64_t lnw = ((uint64_t)hi1[8 * k + i] << 32) | lo1[8 * k + i];
+            c += lab;
+            d[8 * k + i] = lab - lnw;
+        }
+        cs[k] = c;
+    }
+#ifndef RV_ZF_NOLNEW
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        z_st16(lnp + z_piece(i), ((uint64_t)hi1[2 * i] << 32) | lo1[2 * i], ((uint64_t)hi1[2 * i + 1] << 32) | lo1[2 * i + 1]);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int bf = k & 1;
+        uint64_t w[8];
+        uint64_t a = 0, b = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            a += lx[bf][i];
+            b += ly[bf][i];
+        }
+        // corr = value - reconstruct(mask) (prover.rs:181-199 with the cleartext value known)
+        const uint64_t cx = va - a, cy = vb - b;
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = ly[bf][i] * cx + lx[bf][i] * cy + d[8 * k + i];
+        const uint64_t delta = a * b - cs[k];
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 2 < 4) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                z_ld16(ap + z_piece(4 * (k + 2) + i), lx[bf][2 * i], lx[bf][2 * i + 1]);
+                z_ld16(bp + z_piece(4 * (k + 2) + i), ly[bf][2 * i], ly[bf][2 * i + 1]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t rep = 4 * q + k;
+#ifndef RV_ZF_NOON
+        z_store_on(p.on + (size_t)rep * p.on_words + g.eo, w);
+#else
+        if (w[0] + w[1] + w[2] + w[3] + w[4] + w[5] + w[6] + w[7] == 0x1234567u) z_store_on(p.on + (size_t)rep * p.on_words + g.eo, w);
+#endif
+#ifndef RV_ZF_NOPRE
+        p.pre[(size_t)rep * p.pre_words + g.ep] = delta;
+#else
+        if (delta == 0x1234567u) p.pre[(size_t)rep * p.pre_words + g.ep] = delta;
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (writer) p.v[g.dst] = va * vb;
+}
+
+// Add / Sub / AddConst / SubConst / MulConst: the mask row (z64/share.rs:110-136 player by player; elementwise, so the
+// row layout does not matter) and the value
+__device__ __forceinline__ void z64f_lin(const Gate64& g, const Z64FParams& p, uint32_t zo, bool writer) {
+    const uint64_t S = (uint64_t)p.NQ * 32;
+    const uint64_t* ap = z_row(p, g.am, S) + zo;
+    uint64_t* dp = p.wmask + (size_t)g.dst * S + zo;
+    const uint64_t va = p.v[g.a];
+    if (g.op == G64_ADD || g.op == G64_SUB) {
+        const uint64_t* bp = z_row(p, g.bm, S) + zo;
+        const uint64_t vb = p.v[g.b];
+        const bool sub = g.op == G64_SUB;
+        uint64_t x[32], y[32];  // (every load before the first store: see z64f_mul)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            z_ld16(ap + z_piece(i), x[2 * i], x[2 * i + 1]);
+            z_ld16(bp + z_piece(i), y[2 * i], y[2 * i + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            z_st16(dp + z_piece(i), sub ? x[2 * i] - y[2 * i] : x[2 * i] + y[2 * i], sub ? x[2 * i + 1] - y[2 * i + 1] : x[2 * i + 1] + y[2 * i + 1]);
+        if (writer) p.v[g.dst] = sub ? va - vb : va + vb;
+    } else {
+        const uint64_t f = g.op == G64_MULC ? g.imm : 1;
+        uint64_t x[32];
+#pragma unroll
+        for (int i = 0; i < 16; i++) z_ld16(ap + z_piece(i), x[2 * i], x[2 * i + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; i++) z_st16(dp + z_piece(i), x[2 * i] * f, x[2 * i + 1] * f);
+        if (writer) p.v[g.dst] = g.op == G64_MULC ? va * g.imm : (g.op == G64_ADDC ? va + g.imm : va - g.imm);
+    }
+}
+
+// Input (masked input = witness - reconstruct(fresh mask) into the online transcript; its mask row, written by
+// k_aes_z64_masks in the natural order, is rewritten in this path's layout), AssertZero (the wire's mask shares into the
+// online transcript; the VALUE must be zero, prover.rs:221-228), Const
+__device__ __forceinline__ void z64f_oth(const Gate64& g, const Z64FParams& p, uint32_t q, uint32_t zo, bool writer) {
+    const uint64_t S = (uint64_t)p.NQ * 32;
+    if (g.op == G64_INPUT) {
+        uint64_t* row = p.masks + (size_t)g.m * S;
+        const uint64_t* lp = row + (size_t)q * 32;
+        const uint64_t wv = p.wit[g.x];
+        uint64_t l[32];
+#pragma unroll
+        for (int i = 0; i < 16; i++) z_ld16(lp + 2 * i, l[2 * i], l[2 * i + 1]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint64_t a = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) a += l[8 * k + i];
+            p.on[(size_t)(4 * q + k) * p.on_words + g.eo] = wv - a;
+        }
+        // every lane of the wavefront has its 256 bytes before any lane overwrites them (the 16 lanes of a gate exchange places
+        // inside one 4 KiB block, and they sit in one wavefront)
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; i++) z_st16(row + zo + z_piece(i), l[2 * i], l[2 * i + 1]);
+        if (writer) p.v[g.dst] = wv;
+    } else if (g.op == G64_ASSERT) {
+        const uint64_t* ap = z_row(p, g.am, S) + zo;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint64_t l[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) z_ld16(ap + z_piece(4 * k + i), l[2 * i], l[2 * i + 1]);
+            z_store_on(p.on + (size_t)(4 * q + k) * p.on_words + g.eo, l);
+        }
+        if (writer && p.v[g.a] != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
+    } else if (g.op == G64_CONST) {
+        uint64_t* dp = p.wmask + (size_t)g.dst * S + zo;
+#pragma unroll
+        for (int i = 0; i < 16; i++) z_st16(dp + z_piece(i), 0, 0);
+        if (writer) p.v[g.dst] = g.imm;
+    }
+}
+
+template <int QW>
+__global__ __launch_bounds__(512, 2) void k_z64_fused(const Gate64* __restrict__ gates, Z64FLevel lv, uint32_t mul_per, uint32_t lin_per,
+                                                    uint32_t oth_per, Z64FParams p) {
+    __shared__ uint32_t lds_rk[11 * 128 * QW];
+    constexpr uint32_t JW = 64 / QW, STEP = 8 * JW;  // gates per wavefront and per workgroup iteration
+    const uint32_t n_qg = p.NQ / QW;
+    const uint32_t qg = blockIdx.x % n_qg, chunk = blockIdx.x / n_qg;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ql = lane % QW, jsub = lane / QW;
+    const uint32_t q = qg * QW + ql;
+    const uint32_t zo = qg * (QW * 32) + ql * 2;  // this lane's piece 0 inside a row (u64 units)
+    const bool writer = q == 0;
+    const uint32_t m_lo = min(lv.mul0 + chunk * mul_per, lv.mul1), m_hi = min(m_lo + mul_per, lv.mul1);
+    const uint32_t l_lo = min(lv.mul1 + chunk * lin_per, lv.lin1), l_hi = min(l_lo + lin_per, lv.lin1);
+    const uint32_t o_lo = min(lv.lin1 + chunk * oth_per, lv.oth1), o_hi = min(o_lo + oth_per, lv.oth1);
+    if (m_hi > m_lo) stage_round_keys<QW>(p.rk, p.NQ, qg, lds_rk);  // (uniform over the workgroup)
+    const uint32_t* rkl = lds_rk + ql;
+    const uint32_t mw = m_lo + wave * JW, lw = l_lo + wave * JW;
+    const uint32_t MI = m_hi > mw ? (m_hi - mw + STEP - 1) / STEP : 0u;
+    const uint32_t LI = l_hi > lw ? (l_hi - lw + STEP - 1) / STEP : 0u;
+    uint32_t ld = 0;
+    for (uint32_t it = 0; it < MI; it++) {
+        const uint32_t gi = mw + it * STEP + jsub;
+        z64f_mul<QW>(gates, gi, gi < m_hi, p, rkl, q, zo, writer);
+        const uint32_t lend = (uint32_t)(((uint64_t)(it + 1) * LI) / MI);
+        for (; ld < lend; ld++) {
+            const uint32_t gl = lw + ld * STEP + jsub;
+#ifndef RV_ZF_NOLIN
+            if (gl < l_hi) z64f_lin(gates[gl], p, zo, writer);
+#endif
+        }
+    }
+    for (; ld < LI; ld++) {
+        const uint32_t gl = lw + ld * STEP + jsub;
+        if (gl < l_hi) z64f_lin(gates[gl], p, zo, writer);
+    }
+    for (uint32_t go = o_lo + wave * JW + jsub; go < o_hi; go += STEP) z64f_oth(gates[go], p, q, zo, writer);
+}
+
+bool z64_fused_supports(uint32_t NQ) { return NQ >= 16 && NQ % 16 == 0; }
+
+void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p) {
+    constexpr uint32_t QW = 16, STEP = 8 * (64 / QW);
+    static const uint32_t cus = [] {
+        if (const char* e = getenv("RV_Z64F_WGS")) return (uint32_t)std::max(atoi(e), 1);
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return (uint32_t)n;
+    }();
+    const uint32_t n_qg = p.NQ / QW;
+    const uint32_t n_mul = lv.mul1 - lv.mul0, n_lin = lv.lin1 - lv.mul1, n_oth = lv.oth1 - lv.lin1;
+    if (!(n_mul + n_lin + n_oth)) return;
+    auto up = [](uint64_t x, uint64_t m) { return (x + m - 1) / m * m; };
+    // one generation of workgroups for the cipher work (a workgroup owns its compute unit: 88 KiB of round keys, all registers);
+    // levels with little of it still get enough workgroups for their row traffic
+    uint64_t chunks = 1;
+    if (n_mul) {
+        const uint64_t per = std::max<uint64_t>(up(((uint64_t)n_mul * n_qg + cus - 1) / cus, STEP), STEP);
+        chunks = (n_mul + per - 1) / per;
+    }
+    const uint64_t mem_chunks = std::min<uint64_t>(((uint64_t)n_lin + n_oth + 2 * STEP - 1) / (2 * STEP), std::max<uint32_t>(cus / n_qg, 1) * (n_mul ? 1u : 4u));
+    chunks = std::max<uint64_t>(std::max(chunks, mem_chunks), 1);
+    const uint32_t mul_per = (uint32_t)up((n_mul + chunks - 1) / chunks, STEP), lin_per = (uint32_t)up((n_lin + chunks - 1) / chunks, STEP),
+                   oth_per = (uint32_t)up((n_oth + chunks - 1) / chunks, STEP);
+    hipLaunchKernelGGL(k_z64_fused<QW>, dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_gates, lv, mul_per, lin_per, oth_per, p);
+}
+
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
                        uint8_t* d_out) {
     uint64_t n = (uint64_t)n_keys * n_blocks;

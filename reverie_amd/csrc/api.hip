@@ -536,6 +536,12 @@ struct rv_circuit {
     uint32_t* d_rec_rows = nullptr;
     uint32_t* d_in_rows = nullptr;
     Gate64* d_gates64 = nullptr;
+    // the fused Z64 prover (internal.h: Z64FParams): the gates of every level grouped Mul | linear | other, and the cipher
+    // block runs [first, first + n) whose mask rows belong to Input gates (generated the plain way)
+    bool z64f_ok = false;
+    Gate64* d_gates64f = nullptr;
+    std::vector<Z64FLevel> z64f_levels;
+    std::vector<std::pair<uint64_t, uint64_t>> z64f_runs;
     uint64_t* d_rec_offs64 = nullptr;
     uint64_t* d_in_offs64 = nullptr;
     uint32_t* d_level_start = nullptr;
@@ -607,6 +613,55 @@ static uint32_t clear_wgs() {
         return e ? (uint32_t)std::min(std::max(atoi(e), 1), 64) : 8u;
     }();
     return v;
+}
+
+// RV_Z64_FUSED: 1 (default) = the prover of eligible Z64 circuits runs its mask generator inside the interpreter's level launches
+// (internal.h: Z64FParams); 0 = masks to HBM first, k_interp64 behind.  Read at every call (tests switch it).
+static bool z64_fused_on() {
+    const char* e = getenv("RV_Z64_FUSED");
+    return !e || atoi(e) != 0;
+}
+// the circuit's Z64 gates grouped Mul | linear | other inside every level, the level table, and the cipher block runs whose rows
+// are Input masks.  false: not eligible (a Random or B2A gate, a Mul whose two masks straddle cipher blocks, too many runs)
+static bool build_z64_fused(const Compiled& cc, std::vector<Gate64>& sorted, std::vector<Z64FLevel>& levels, std::vector<std::pair<uint64_t, uint64_t>>& runs) {
+    const size_t n_levels = cc.level_start64.empty() ? 0 : cc.level_start64.size() - 1;
+    if (!n_levels || cc.gates64.size() >= (1ull << 32)) return false;
+    auto cls = [](uint32_t op) -> int {
+        switch (op) {
+        case G64_MUL: return 0;
+        case G64_ADD: case G64_SUB: case G64_ADDC: case G64_SUBC: case G64_MULC: return 1;
+        case G64_INPUT: case G64_ASSERT: case G64_CONST: return 2;
+        default: return -1;
+        }
+    };
+    std::vector<uint64_t> in_blocks;
+    for (const Gate64& g : cc.gates64) {
+        const int k = cls(g.op);
+        if (k < 0) return false;
+        if (g.op == G64_MUL && (g.m & 1)) return false;
+        if (g.op == G64_INPUT) in_blocks.push_back(g.m >> 1);
+    }
+    std::sort(in_blocks.begin(), in_blocks.end());
+    runs.clear();
+    for (uint64_t b : in_blocks) {
+        if (!runs.empty() && b < runs.back().first + runs.back().second) continue;
+        if (!runs.empty() && b == runs.back().first + runs.back().second)
+            runs.back().second++;
+        else
+            runs.emplace_back(b, 1);
+    }
+    if (runs.size() > 64) return false;
+    sorted.resize(cc.gates64.size());
+    levels.assign(n_levels, Z64FLevel{});
+    for (size_t l = 0; l < n_levels; l++) {
+        const uint64_t lo = cc.level_start64[l], hi = cc.level_start64[l + 1];
+        uint64_t n[3] = {0, 0, 0};
+        for (uint64_t i = lo; i < hi; i++) n[cls(cc.gates64[i].op)]++;
+        uint64_t at[3] = {lo, lo + n[0], lo + n[0] + n[1]};
+        levels[l] = Z64FLevel{(uint32_t)lo, (uint32_t)at[1], (uint32_t)at[2], (uint32_t)hi};
+        for (uint64_t i = lo; i < hi; i++) sorted[at[cls(cc.gates64[i].op)]++] = cc.gates64[i];
+    }
+    return true;
 }
 
 // LDS the rep-sliced interpreter may use for wire slots (a workgroup owns the CU: 160 KiB minus a little headroom)
@@ -933,6 +988,18 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         c->vclr_ok = cc.gates64.empty() && narrow_levels <= 16 && !cc.row_prg_base;
     }
     if (cc.n_random_or_recon) c->vclr_ok = false;  // (values that differ between repetitions)
+    if (!cc.gates64.empty() && z64_fused_on() && !cc.row_prg_base) {
+        std::vector<Gate64> sorted;
+        if (build_z64_fused(cc, sorted, c->z64f_levels, c->z64f_runs)) {
+            if ((rc = up(sorted.data(), sorted.size() * sizeof(Gate64), (void**)&c->d_gates64f))) {
+                rv_circuit_destroy(c);
+                return rc;
+            }
+            UPCHK(hipStreamSynchronize(ctx->stream));
+            c->z64f_ok = true;
+            c->cc.info.device_bytes += sorted.size() * sizeof(Gate64);
+        }
+    }
     c->persist_gen = persist_general(cc.level_range.data(), cc.level_range.size());
     if (c->vclr_ok && flat_mode()) {
         // the flat schedule of the prover: Mul records in program order, XOR rows by x-level, the rest
@@ -978,6 +1045,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
 extern "C" void rv_circuit_destroy(rv_circuit* c) {
     if (!c) return;
     c->ctx->release(c->d_gates);
+    c->ctx->release(c->d_gates64f);
     c->ctx->release(c->d_rec_rows);
     c->ctx->release(c->d_in_rows);
     c->ctx->release(c->d_gates64);
@@ -1166,6 +1234,8 @@ struct rv_shard {
     uint64_t* d_masks64 = nullptr;
     uint64_t* d_wmask64 = nullptr;
     uint64_t* d_wcorr64 = nullptr;
+    bool z64f = false;            // the fused Z64 prover (internal.h: Z64FParams)
+    uint64_t* d_v64 = nullptr;    // ... its cleartext values, one per Z64 SSA id
     uint64_t* d_on64 = nullptr;
     uint64_t* d_pre64 = nullptr;
     uint64_t* d_wit64 = nullptr;
@@ -1199,7 +1269,7 @@ struct rv_shard {
         ev_clear = nullptr;
         void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk,    d_masks,  d_wires,   d_on,     d_pre,    d_wit,  d_cv[0],
                       d_cv[1], d_dig,  d_h,       d_err,   d_omit,   d_offs,    d_out,    d_masks64, d_wmask64,
-                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr, d_vb, d_sync, d_cvx};
+                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr, d_vb, d_sync, d_cvx, d_v64};
         for (void* p : ps) ctx->release(p);
         for (void* p : extra) ctx->release(p);
     }
@@ -1246,8 +1316,16 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
             launch_bitslice_rk(ctx->stream, s->d_rkbytes, s->NQ, s->d_rk64);
             rk64 = s->d_rk64;
         }
-        launch_aes_z64_masks(ctx->stream, rk64, s->d_keys64 ? d_keep64 : d_keep, s->NQ, n_blocks64, s->d_masks64);
-        ctx->count(1);
+        if (s->z64f) {
+            // only the Input gates' rows: a Mul's two masks come out of the interpreter's own launches
+            for (const auto& run : s->c->z64f_runs) {
+                launch_aes_z64_masks(ctx->stream, rk64, nullptr, s->NQ, run.second, s->d_masks64 + (size_t)run.first * 2 * s->R * 8, run.first);
+                ctx->count(1);
+            }
+        } else {
+            launch_aes_z64_masks(ctx->stream, rk64, s->d_keys64 ? d_keep64 : d_keep, s->NQ, n_blocks64, s->d_masks64);
+            ctx->count(1);
+        }
     }
     // everything the interpreter reads besides gf2 masks is queued on `stream` before this point
     // (events only when two streams are in play: on one stream the order is the queue order)
@@ -1290,11 +1368,16 @@ static int shard_run_alloc(rv_shard* s, InterpParams& p, Interp64Params& p64) {
     const bool has64 = !cc.gates64.empty();
     if (has64) {
         if ((rc = dalloc(ctx, (size_t)cc.n_ssa64 * s->R * 8, &s->d_wmask64))) return rc;
-        if ((rc = dalloc(ctx, (size_t)cc.n_ssa64 * s->R, &s->d_wcorr64))) return rc;
+        if (s->z64f) {
+            if ((rc = dalloc(ctx, (size_t)cc.n_ssa64, &s->d_v64))) return rc;
+            HIPCHK(hipMemsetAsync(s->d_v64, 0, 8, ctx->stream));  // (SSA id 0 = the zero wire)
+        } else {
+            if ((rc = dalloc(ctx, (size_t)cc.n_ssa64 * s->R, &s->d_wcorr64))) return rc;
+            HIPCHK(hipMemsetAsync(s->d_wcorr64, 0, (size_t)s->R * 8, ctx->pipeline ? ctx->stream2 : ctx->stream));
+        }
         if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.on_words64, 1) * s->R, &s->d_on64))) return rc;
         if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.pre_words64, 1) * s->R, &s->d_pre64))) return rc;
         HIPCHK(hipMemsetAsync(s->d_wmask64, 0, (size_t)s->R * 64, ctx->pipeline ? ctx->stream2 : ctx->stream));
-        HIPCHK(hipMemsetAsync(s->d_wcorr64, 0, (size_t)s->R * 8, ctx->pipeline ? ctx->stream2 : ctx->stream));
     }
     hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
     if (s->ev_setup && ctx->pipeline) HIPCHK(hipStreamWaitEvent(sb, s->ev_setup, 0));
@@ -2029,7 +2112,24 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
             ctx->count();
         }
         if (has64 && cc.level_start64[l + 1] > cc.level_start64[l]) {
-            launch_interp64(sb, mode, s->c->d_gates64, cc.level_start64[l], cc.level_start64[l + 1], p64);
+            if (s->z64f) {
+                Z64FParams zp{};
+                zp.rk = s->d_rk;
+                zp.NQ = s->NQ;
+                zp.wmask = p64.wmask;
+                zp.masks = s->d_masks64;
+                zp.on = p64.on;
+                zp.pre = p64.pre;
+                zp.on_words = p64.on_words;
+                zp.pre_words = p64.pre_words;
+                zp.wit = p64.wit;
+                zp.v = s->d_v64;
+                zp.err = p64.err;
+                zp.first_block = 0;
+                launch_z64_fused(sb, s->c->d_gates64f, s->c->z64f_levels[l], zp);
+            } else {
+                launch_interp64(sb, mode, s->c->d_gates64, cc.level_start64[l], cc.level_start64[l + 1], p64);
+            }
             ctx->count();
         }
     }
@@ -2275,6 +2375,7 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         }
         if (hipEventRecord(s->ev_clear, ctx->stream3) != hipSuccess) return fail(RV_E_DEVICE);
     }
+    s->z64f = !rep_path && c->z64f_ok && z64_fused_on() && z64_fused_supports(s->NQ) && !ctx->pipeline && !g_recorder;
     ctx->phase(RV_PH_SETUP);
     ctx->count();
     launch_expand_seeds(ctx->stream, s->d_seeds, s->R, s->d_keys);
@@ -3763,6 +3864,13 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     s->n_on_quads = (uint32_t)on_quads.size();
     ctx->phase(RV_PH_SETUP);
     ctx->count(2);
+    // (the side stream's unpack kernels read d_omit: uploaded by now)
+    hipEvent_t ev_inputs = nullptr;
+    if (ev_arena) {
+        ev_inputs = ctx->get_sync_event();
+        s->misc_events.push_back(ev_inputs);
+        HC(hipEventRecord(ev_inputs, ctx->stream));
+    }
     launch_expand_seeds(ctx->stream, s->d_seeds, R, s->d_keys);
     launch_overlay_rows(ctx->stream, (uint32_t*)s->d_keys, (const uint32_t*)d_hkeys, s->d_omit, R, 32, 1);
     if (has64) {
@@ -3779,25 +3887,40 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     // ---- the interpreter's stream: the proof itself (tens of MB from pageable memory: the host blocks in this
     //      copy while the mask kernels above already run) and the supplied-value rows unpacked from it
     hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
+    hipStream_t su = sb;  // the stream of the GF(2) unpack kernels
     if (!blob) {
         // on ONE stream the copy would queue up behind the mask kernels; from the second stream it runs beside them
         // (copy engine next to compute) and the unpack kernels wait for its event
         static const bool side = !(getenv("RV_VERIFY_SIDE_COPY") && atoi(getenv("RV_VERIFY_SIDE_COPY")) == 0);
+        // ... and so do the GF(2) supplied-value rows (round 4): three memory-bound transposes that find room beside the
+        // VALU-bound mask generator instead of standing between it and the interpreter (RV_VERIFY_SIDE_UNPACK=0: behind it)
+        static const bool side_unpack = !(getenv("RV_VERIFY_SIDE_UNPACK") && atoi(getenv("RV_VERIFY_SIDE_UNPACK")) == 0);
         hipStream_t sc = (side && ev_arena) ? ctx->stream2 : sb;
         if (sc != sb) HC(hipStreamWaitEvent(sc, ev_arena, 0));
         HC(hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, sc));
         HC(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, sc));
         if (sc != sb) {
-            hipEvent_t e = ctx->get_sync_event();
-            s->misc_events.push_back(e);
-            HC(hipEventRecord(e, sc));
-            HC(hipStreamWaitEvent(sb, e, 0));
+            if (side_unpack && ev_inputs) {
+                HC(hipStreamWaitEvent(sc, ev_inputs, 0));
+                su = sc;
+            } else {
+                hipEvent_t e = ctx->get_sync_event();
+                s->misc_events.push_back(e);
+                HC(hipEventRecord(e, sc));
+                HC(hipStreamWaitEvent(sb, e, 0));
+            }
         }
     }
     if (s->ev_setup && ctx->pipeline) HC(hipStreamWaitEvent(sb, s->ev_setup, 0));  // d_omit / d_omit64 come from stream 1
-    launch_unpack_bits(sb, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in, sup_nq);
-    launch_unpack_bits(sb, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr, sup_nq);
-    launch_unpack_bits(sb, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec, sup_nq);
+    launch_unpack_bits(su, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in, sup_nq);
+    launch_unpack_bits(su, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr, sup_nq);
+    launch_unpack_bits(su, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec, sup_nq);
+    if (su != sb) {
+        hipEvent_t e = ctx->get_sync_event();
+        s->misc_events.push_back(e);
+        HC(hipEventRecord(e, su));
+        HC(hipStreamWaitEvent(sb, e, 0));
+    }
     Interp64Params p64{};
     if (has64) {
         HC(hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, sb));

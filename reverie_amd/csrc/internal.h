@@ -215,6 +215,33 @@ void launch_interp64(hipStream_t st, int mode, const Gate64* d_gates, uint32_t l
 // Z64 masks: masks64[m][slot] = LE64(keystream[slot][8m..8m+8)), blocks [first, first+n_blocks) -> masks 2*first..
 void launch_aes_z64_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t n_blocks,
                           uint64_t* d_masks64, uint64_t first_block = 0);
+// The Z64 prover with the mask generator INSIDE the interpreter (round 4; aes.hip: k_z64_fused).  A Mul's two fresh masks
+// (lambda_ab = row m, lambda_new = row m + 1, m even) are exactly one cipher block per (repetition, player) stream, so the
+// lane that runs the bitsliced cipher for counter m / 2 and the 32 slots of a quad word holds both rows of its 4 repetitions
+// x 8 players in registers: lambda_ab never reaches HBM, lambda_new is stored once (later gates read it as an operand), and
+// the gate's row traffic is issued by a wavefront whose neighbour on the SIMD is busy with its own cipher rounds.  Public
+// corrections are not kept at all: the prover knows the wires' cleartext values (v: one u64 per Z64 SSA id, the same in every
+// repetition; corr = value - reconstruct(mask), the sum over a repetition's 8 players being lane-local in this mapping).
+// Eligible: Input / Add / Sub / AddConst / SubConst / MulConst / Mul / AssertZero / Const gates only (Random and B2A values
+// differ between repetitions), every Mul's m even, NQ a multiple of 16.
+struct Z64FLevel {
+    uint32_t mul0, mul1, lin1, oth1;  // gates [mul0, mul1) Mul, [mul1, lin1) Add .. MulConst, [lin1, oth1) Input / AssertZero / Const
+};
+struct Z64FParams {
+    const uint32_t* rk;  // bitsliced round keys (k_bitslice_rk)
+    uint32_t NQ;
+    uint64_t* wmask;     // [ssa][R * 8]
+    uint64_t* masks;     // [mask row][R * 8]
+    uint64_t* on;        // [R][on_words]
+    uint64_t* pre;       // [R][pre_words]
+    uint64_t on_words, pre_words;
+    const uint64_t* wit;
+    uint64_t* v;         // [ssa] cleartext values
+    int* err;
+    uint64_t first_block;  // counter of mask rows 0, 1
+};
+bool z64_fused_supports(uint32_t NQ);
+void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p);
 // BLAKE3 of R contiguous streams of n_words u64 each -> digests[R][8]
 uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
                       uint32_t* d_digest);
