@@ -348,17 +348,30 @@ extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
     static const bool main_prio = getenv("RV_MAIN_PRIO") && atoi(getenv("RV_MAIN_PRIO")) != 0;
     hipError_t se = main_prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
-    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
-    // (RV_X_PRIO=1: the chain stream at the high priority instead -- its short dependent launches then win the dispatcher whenever
-    // wavefront slots are free)
-    static const bool x_prio = getenv("RV_X_PRIO") && atoi(getenv("RV_X_PRIO")) != 0;
-    if (se == hipSuccess) se = x_prio ? hipStreamCreateWithPriority(&c->stream_x, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking);
+    // (stream3 / stream_x -- the flat and split schedules' side streams -- are made by ctx_side_streams() when such a schedule first
+    // runs: streams are dealt to the four hardware queues in creation order, so two idle ones per context put the main streams of
+    // rv_prove_batch's worker contexts all on ONE queue and its proofs in flight ran one after the other: 4.9 -> 6.2 ms per proof)
     if (se != hipSuccess) {
         delete c;
         return hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
     }
     *out = c;
     return RV_OK;
+}
+
+// the side streams of the flat / split prover schedules (RV_FLAT != 0), on first use
+static int ctx_side_streams(rv_ctx* c) {
+    if (c->stream3 && c->stream_x) return RV_OK;
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0, (void)hipGetLastError();
+    hipError_t se = hipSuccess;
+    if (!c->stream3) se = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
+    // (RV_X_PRIO=1: the chain stream at the high priority -- its short dependent launches then win the dispatcher whenever
+    // wavefront slots are free)
+    static const bool x_prio = getenv("RV_X_PRIO") && atoi(getenv("RV_X_PRIO")) != 0;
+    if (se == hipSuccess && !c->stream_x)
+        se = x_prio ? hipStreamCreateWithPriority(&c->stream_x, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking);
+    return se == hipSuccess ? RV_OK : hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
 }
 
 static void pinned_pool_trim();  // idle page-locked output buffers (defined with the pool below)
@@ -368,8 +381,8 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
-    (void)hipStreamSynchronize(ctx->stream3);
-    (void)hipStreamSynchronize(ctx->stream_x);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+    if (ctx->stream_x) (void)hipStreamSynchronize(ctx->stream_x);
     ctx->trim();
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -385,8 +398,8 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     for (rv_ctx* w : ctx->workers) rv_ctx_destroy(w);
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
-    (void)hipStreamDestroy(ctx->stream3);
-    (void)hipStreamDestroy(ctx->stream_x);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    if (ctx->stream_x) (void)hipStreamDestroy(ctx->stream_x);
     if (ctx->clear_a) (void)hipEventDestroy(ctx->clear_a);
     if (ctx->clear_b) (void)hipEventDestroy(ctx->clear_b);
     delete ctx;
@@ -1282,8 +1295,8 @@ extern "C" void rv_shard_destroy(rv_shard* s) {
     // the arena below and the caller's host buffers leave scope -- nothing of it may still be in flight
     if (!s->misc_events.empty() || !s->mask_chunks.empty() || s->ev_setup || s->ec) (void)hipStreamSynchronize(s->ctx->stream2);
     if (s->ev_clear || s->split) {
-        (void)hipStreamSynchronize(s->ctx->stream3);
-        (void)hipStreamSynchronize(s->ctx->stream_x);
+        if (s->ctx->stream3) (void)hipStreamSynchronize(s->ctx->stream3);
+        if (s->ctx->stream_x) (void)hipStreamSynchronize(s->ctx->stream_x);
     }
     s->destroy();
     delete s;
@@ -2347,12 +2360,14 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     const bool use_vclr = !rep_path && vclr_on && c->vclr_ok && (s->NQ == 64 || s->NQ == 32 || s->NQ == 16 || s->NQ == 8) && !ctx->pipeline;
     if (use_vclr && c->flat.ok && (flat_mode() == 1 || (flat_mode() == 3 && chain_supports(s->NQ))) && mul_flat_supports(s->NQ) && !g_recorder) {
         // split schedule: the level chain computes the values itself (shard_run_split)
+        if ((rc = ctx_side_streams(ctx))) return fail(rc);
         s->split = true;
         if ((rc = dalloc(ctx, (size_t)cc.n_rows, &s->d_vclr))) return fail(rc);
         if (hipMemsetAsync(s->d_vclr + cc.zero_row, 0, 1, ctx->stream) != hipSuccess) return fail(RV_E_DEVICE);
     } else if (use_vclr && c->flat.ok && flat_mode() >= 2 && mul_flat_supports(s->NQ) && !g_recorder) {
         // flat schedule: the cleartext pass starts as soon as the witness is on the device, on a stream of its own, and runs
         // beside the key schedules and the mask generator (which leaves it clear_wgs() compute units)
+        if ((rc = ctx_side_streams(ctx))) return fail(rc);
         s->flat = true;
         if ((rc = dalloc(ctx, (size_t)cc.n_rows, &s->d_vclr)) || (rc = dalloc(ctx, (size_t)4, &s->d_sync))) return fail(rc);
         hipEvent_t ev_in = ctx->get_sync_event();
