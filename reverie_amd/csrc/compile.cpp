@@ -874,6 +874,25 @@ int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
         }
         fprintf(stderr, "[rv compile] level widths: <=16:%u <=32:%u <=64:%u <=128:%u <=256:%u <=1024:%u more:%u\n", hist[0], hist[1], hist[2],
                 hist[3], hist[4], hist[5], hist[6]);
+        {
+            // cipher blocks (128 GF(2) mask rows = 64 Mul gates in program order) a level's Mul gates touch, summed over the levels,
+            // against the blocks there are: what a mask generator inside the level launches would have to run
+            uint64_t touched = 0, odd = 0;
+            std::vector<uint64_t> blk;
+            for (uint32_t l = 0; l < n_levels; l++) {
+                blk.clear();
+                for (uint64_t i = out.level_start[l]; i < out.level_start[l + 1]; i++)
+                    if (g_op(out.gates[i]) == G_MUL) {
+                        const uint64_t m = out.gates[i].m - out.row_prg_base;
+                        blk.push_back(m >> 7);
+                        odd += m & 1;
+                    }
+                std::sort(blk.begin(), blk.end());
+                touched += (uint64_t)(std::unique(blk.begin(), blk.end()) - blk.begin());
+            }
+            fprintf(stderr, "[rv compile] Mul cipher blocks: %llu touched level by level, %llu dense (mul / 64), %llu Mul gates with an odd mask index\n",
+                    (unsigned long long)touched, (unsigned long long)((n_mul + 63) / 64), (unsigned long long)odd);
+        }
         fprintf(stderr, "[rv compile] lazy_k=%d levels=%u mul=%llu (one-base %llu) xork=%llu row_reads=%llu row_writes=%llu corr_reads=%llu\n",
                 b.lazy_k, n_levels, (unsigned long long)n_mul, (unsigned long long)n_mul11, (unsigned long long)n_xor,
                 (unsigned long long)rd, (unsigned long long)wr, (unsigned long long)crd);
