@@ -270,9 +270,10 @@ def secondary_records(ctx, seeds, quick):
            "mul_per_s": st["mul"] * steps / dt, "verifies_strict": ok, "verify_ms": tv * 1e3,
            "phase_ms": phase_ms(ctx, lambda: hp.run(2), 2),
            "note": "host to host; the 640 MB proof alone is ~11 ms of PCIe, of which the early-corrections path (the corrections vectors of the first "
-                   "128 repetitions cross PCIe while the kernels run: csrc/api.hip) hides ~2.5; profiles/r02_z64_* hold the kernel trace and the "
-                   "PMC traffic (k_interp64 moves ~150 GB per proof at ~5.5 TB/s, k_aes_z64_masks is VALU-bound: 2.05e9 "
-                   "cipher blocks + the bit transposes)"}
+                   "128 repetitions cross PCIe while the kernels run: csrc/api.hip) hides ~2; the prover runs the mask generator inside the "
+                   "interpreter's level launches (k_z64_fused, csrc/aes.hip; RV_Z64_FUSED=0 = k_aes_z64_masks then k_interp64: 26.9 + 26.4 ms); "
+                   f"profiles/{PROFILE_TAG}_z64_* hold the kernel trace and the PMC traffic of both (fused: 122.6 GB and 40.6 ms per proof, "
+                   "two kernels: 182 GB), DESIGN.md the analysis (2.05e9 cipher blocks at the VALU rate = 27 ms)"}
     circ.close()
     del p
     # the FULL circuit through the CPU oracle once (a 640 MB proof, ~20 GB of host memory, ~10 s on 32 threads): the byte-for-byte

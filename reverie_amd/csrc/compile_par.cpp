@@ -21,6 +21,7 @@
 // compiler (which also produces the canonical error code).
 #include "compile.h"
 
+#include <unistd.h>
 #include <sched.h>
 #include <sys/mman.h>
 #include <stdio.h>
@@ -281,7 +282,14 @@ void* big_alloc(size_t bytes) {
 // against the previous round's unmapping (20 - 30 ms per compile on the 10^7-gate circuit).  Above a cap it frees at once.
 namespace {
 struct Reaper {
-    static constexpr size_t CAP_BYTES = (size_t)2 << 30;  // (more than this queued: free at once, in the one burst it then takes)
+    // more than this queued: free at once, in the one burst it then takes.  An eighth of the machine's memory, 4 .. 32 GiB: the
+    // streaming prover queues ~6 GB per proof of the 10^7-gate circuit while its compile workers run, and with a 2 GiB cap the
+    // unmapping ran against their page faults (0.125 -> 0.155 s per streamed proof)
+    const size_t CAP_BYTES = [] {
+        const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+        const size_t phys = pages > 0 && psz > 0 ? (size_t)pages * (size_t)psz : (size_t)32 << 30;
+        return std::min<size_t>(std::max<size_t>(phys / 8, (size_t)4 << 30), (size_t)32 << 30);
+    }();
     static constexpr int QUIET_MS = 250;
     std::mutex mu;
     std::condition_variable cv;
