@@ -478,6 +478,11 @@ int rv_hook_shard_stream_digests(rv_shard *s, uint8_t *out);
  * ProverTranscript::extract returns, prover.rs:57-175 -- cross PCIe before the challenge exists).  The bytes are the same
  * either way; the tests use the counter to know which path they compared.  RV_EARLY=0 turns the path off. */
 uint64_t rv_hook_early_proofs(void);
+/* Verifications this process has run with one u64 of public corrections per share row instead of corr rows (csrc/kernels.hip:
+ * MODE_VERIFY_C -- the verify-mode interpreter of whole proofs of pure GF(2) one-base gate streams; replaces nothing of the
+ * reference's: verifier/online.rs:122-183 computes the same values).  The answer is the same either way; the tests use the
+ * counter to know which path they compared.  RV_VERIFY_VC=0 turns the path off. */
+uint64_t rv_hook_verify_vc_count(void);
 /* The early-corrections plan of a program (host only, no device): the ops are compiled as rv_circuit_compile_ex(flags) would and
  * the plan rv_prove would use is built and checked against the compiled gate records.  out[0] = a plan exists (0 / 1: the circuit
  * is pure GF(2) with >= 2^21 Mul gates -- RV_EARLY_MIN -- or pure Z64, its preprocessing rows complete in step with the levels

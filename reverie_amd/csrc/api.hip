@@ -1439,6 +1439,8 @@ static bool lds_run_for_batch(const rv_circuit* c, size_t level, size_t batch) {
 // circuit whose first rows are written by its last level gains nothing and keeps the plain path).
 static std::atomic<uint64_t> g_early_proofs{0};
 extern "C" uint64_t rv_hook_early_proofs(void) { return g_early_proofs.load(std::memory_order_relaxed); }
+static std::atomic<uint64_t> g_verify_vc{0};
+extern "C" uint64_t rv_hook_verify_vc_count(void) { return g_verify_vc.load(std::memory_order_relaxed); }
 
 static const EarlyPlan* early_plan(const rv_circuit* c) {
     std::call_once(c->ec_once, [c] {
@@ -2087,7 +2089,8 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
             HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
             waited++;
         }
-        if (mode != MODE_PROVE_V && s->c->lds_run_of_level[l] >= 0 && lds_run_fits_rows(s->c->lds_runs[(size_t)s->c->lds_run_of_level[l]].qs, p.NQ)) {
+        const bool own_launch = mode == MODE_PROVE_V || mode == MODE_VERIFY_C;  // (these modes exist in the one-launch-per-level kernel only)
+        if (!own_launch && s->c->lds_run_of_level[l] >= 0 && lds_run_fits_rows(s->c->lds_runs[(size_t)s->c->lds_run_of_level[l]].qs, p.NQ)) {
             // a narrow stretch with its live wires in LDS: one launch, NQ / qs workgroups
             const auto& pl = s->c->lds_runs[(size_t)s->c->lds_run_of_level[l]];
             if (l == pl.run.l0) {
@@ -2101,7 +2104,7 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
             }
             continue;
         }
-        if (s->c->run_of_level[l] >= 0 && mode != MODE_PROVE_V) {
+        if (s->c->run_of_level[l] >= 0 && !own_launch) {
             // a run of narrow levels: one launch for the whole run (its mask needs were waited for above
             // level by level as the loop advances, so wait for the run's last level first)
             const auto& run = s->c->narrow_runs[(size_t)s->c->run_of_level[l]];
@@ -2118,7 +2121,7 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
         }
         if (cc.level_start[l + 1] > cc.level_start[l]) {
             // the level that follows as a launch of its own (not a narrow run) gets its first gate records prefetched
-            const LevelRange* next = (l + 1 < n_levels && (s->c->run_of_level[l + 1] < 0 || mode == MODE_PROVE_V) && cc.level_start[l + 2] > cc.level_start[l + 1])
+            const LevelRange* next = (l + 1 < n_levels && (s->c->run_of_level[l + 1] < 0 || own_launch) && cc.level_start[l + 2] > cc.level_start[l + 1])
                                          ? &cc.level_range[l + 1]
                                          : nullptr;
             launch_interp(sb, mode, s->c->d_gates, cc.level_range[l], p, next);
@@ -3954,7 +3957,23 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     p.sup_corr = d_sup_corr;
     p.sup_rec = d_sup_rec;
     p.sup_nq = sup_nq;
-    if ((rc = shard_run(s, MODE_VERIFY, p, p64))) return fail(rc);
+    // whole proofs of eligible circuits (the conditions of the prover's MODE_PROVE_V, and every opened repetition in the first
+    // sixteen quad words -- the verifier's slot order puts them into the first ten): one u64 of corrections per row instead of
+    // corr rows (internal.h: MODE_VERIFY_C; RV_VERIFY_VC=0: corr rows)
+    const bool vc_on = !(getenv("RV_VERIFY_VC") && atoi(getenv("RV_VERIFY_VC")) == 0);  // (read at every call: tests switch it)
+    int vmode = MODE_VERIFY;
+    // (not for gate streams with multi-base levels -- the prover's lazy linear forms: their kernel variant runs at 4 - 5 wavefronts
+    // per SIMD either way and measured 0.07 ms SLOWER with the compact corrections; one-base streams: -0.03 ... -0.08 ms)
+    if (vc_on && c->vclr_ok && !c->persist_gen && NQ == 64 && sup_nq == 16 && !on_quads.empty() && !ctx->pipeline && !g_recorder) {
+        uint64_t* d_vc = nullptr;
+        if ((rc = dalloc(ctx, (size_t)cc.n_rows, &d_vc))) return fail(rc);
+        track(d_vc);
+        HC(hipMemsetAsync(d_vc + cc.zero_row, 0, 8, ctx->stream));
+        p.vc = d_vc;
+        vmode = MODE_VERIFY_C;
+        g_verify_vc.fetch_add(1, std::memory_order_relaxed);
+    }
+    if ((rc = shard_run(s, vmode, p, p64))) return fail(rc);
     // preprocessing slots: the online commitment is the one carried by the proof (preprocess.rs:55-57)
     launch_overlay_rows(ctx->stream, s->d_dig + 1 * DW, (const uint32_t*)d_hco, s->d_omit, R, 8, 0);
     launch_overlay_rows(ctx->stream, s->d_dig + 3 * DW, (const uint32_t*)d_hco64, s->d_omit, R, 8, 0);

@@ -113,7 +113,9 @@ struct Interp64Params {
 // MODE_PROVE_F: the flat prover schedule (flat.h) -- the level kernels run only what is left of the gate stream once the Mul
 // gates have a kernel of their own and the wire values a pass of their own: XOR rows (shares only) and the Input / AssertZero
 // transcript rows.  No corr rows, no value bytes, no checks.
-enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1, MODE_PROVE_V = 2, MODE_PROVE_F = 3 };
+// MODE_VERIFY_C: the verifier of a whole proof with one u64 of public corrections per share row (the opened repetitions' quad
+// words, InterpParams::vc) instead of corr rows; full-width rows, every level launched on its own, no Random / B2A gates.
+enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1, MODE_PROVE_V = 2, MODE_PROVE_F = 3, MODE_VERIFY_C = 4 };
 // bit set in the device error word when an AssertZero of an online-verified repetition does not reconstruct to zero
 // (VerifierTranscriptOnline.okay, online.rs:175-177; only the strict verifier looks at it)
 constexpr int RV_DEV_ZERO_CHECK = 0x100;
@@ -125,6 +127,7 @@ struct InterpParams {
     uint32_t* on;
     uint8_t* pre;             // [n_pre][NQ/2]
     uint8_t* vclr;            // MODE_PROVE_V: [n_rows] cleartext value of every share row's wire (0 / 1)
+    uint64_t* vc;             // MODE_VERIFY_C: [n_rows] nibble q = the corr bits of quad word q (q < 16: the opened repetitions' quad words)
     const uint8_t* wit;       // prover: witness bits, one byte each
     const uint32_t* on_mask;  // verify: [NQ] 0xFF byte per online-verified rep
     const uint32_t* sup_in;   // verify: [n_inputs][NQ] supplied masked inputs (smeared)

@@ -57,6 +57,32 @@ __device__ __forceinline__ uint32_t gather_vclr(const uint8_t* vclr, const uint3
     return v;
 }
 
+// MODE_VERIFY_C (round 4): the verifier of a whole proof without corr rows.  Only the opened repetitions need public
+// corrections, and in the verifier's slot order they sit in the first sixteen quad words of a row: ONE u64 per row (nibble q =
+// the four corr bits of quad word q, the 32-byte row's own bit order) instead of a 32-byte row that every lane gathers a byte
+// of.  An operand's corrections are then one 8-byte access at a wave-uniform address per base row, an XOR gate's are a u64 XOR
+// by one lane, and lazy linear forms stop costing the verifier a row access per base.
+__device__ __forceinline__ uint32_t vc_nib(uint64_t c, uint32_t q) {
+    const uint32_t w = (q & 8) ? (uint32_t)(c >> 32) : (uint32_t)c;
+    return q < 16 ? (w >> (4 * (q & 7))) & 0xFu : 0u;
+}
+__device__ __forceinline__ uint64_t gather_vc(const uint64_t* vc, const uint32_t* ids) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < RV_LIN_K; i++) v ^= vc[ids[i]];
+    return v;
+}
+// the lanes q = 0 .. 15 of a full-width row (one DPP row) put their nibbles together: lanes 7 and 15 end up with the low and
+// the high word (OR over the eight lanes before them) and store it
+__device__ __forceinline__ void vc_store(uint64_t* vc, size_t row, uint32_t q, uint32_t smeared) {
+    uint32_t v = q < 16 ? compress4(smeared) << (4 * (q & 7)) : 0u;
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    if (q == 7 || q == 15) ((uint32_t*)(vc + row))[q >> 3] = v;
+}
+constexpr bool is_verify(int mode) { return mode == MODE_VERIFY || mode == MODE_VERIFY_C; }
+
 // Accesses that must be seen across workgroups INSIDE one launch (k_interp_persist: a level reads what other compute units,
 // on other XCDs, wrote a few microseconds earlier in the same kernel): agent-scope relaxed atomics = `sc1` loads that bypass the
 // reader's L1 and write-through `sc1` stores (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 on both sides needs no fence).
@@ -118,16 +144,18 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     case G_INPUT: {
         const uint32_t lam = p.rows[(size_t)g.m * NQ + q];
         uint32_t corr;
-        if (MODE != MODE_VERIFY) {
+        if (!is_verify(MODE)) {
             const uint32_t w = p.wit[g.x] ? 0xFFFFFFFFu : 0u;
             corr = w ^ recon32(lam);
         } else {
             corr = onm ? (p.sup_in[(size_t)g.x * p.sup_nq + q] & onm) : 0u;  // (rows of quads without an opened repetition are never written)
         }
-        if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = corr;
+        if (!is_verify(MODE) || onm) p.on[(size_t)g.eo * NQ + q] = corr;
         if (MODE == MODE_PROVE_F) break;  // (the wire's value is k_clear's business)
         if (MODE == MODE_PROVE_V) {
             if (q == 0) st_v<COH>(&p.vclr[g.dst], p.wit[g.x] ? 1 : 0);
+        } else if (MODE == MODE_VERIFY_C) {
+            vc_store(p.vc, g.dst, q, corr);
         } else {
             store_bits(p.corr, g.dst, NQ, q, corr);
         }
@@ -140,6 +168,10 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
             if (q == 0) st_v<COH>(&p.vclr[g.dst], (uint8_t)((g_ca(g) ^ gather_vclr_c<COH>(p.vclr, g.a) ^ gather_vclr_c<COH>(p.vclr, g.b)) & 1u));
             break;
         }
+        if (MODE == MODE_VERIFY_C) {
+            if (q == 0) p.vc[g.dst] = gather_vc(p.vc, g.a) ^ gather_vc(p.vc, g.b) ^ (g_ca(g) ? ~0ull : 0ull);
+            break;
+        }
         // corr bits: plain byte XOR, no expansion needed
         if (!(q & 1)) {
             const size_t h = NQ >> 1, o = q >> 1;
@@ -150,6 +182,10 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     }
     case G_RANDOM: {
         if (MODE == MODE_PROVE_F) break;
+        if (MODE == MODE_VERIFY_C) {
+            if (q == 0) p.vc[g.dst] = 0;
+            break;
+        }
         if (!(q & 1)) p.corr[(size_t)g.dst * (NQ >> 1) + (q >> 1)] = 0;
         break;
     }
@@ -164,6 +200,9 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
             vy = (gather_vclr_c<COH>(p.vclr, g.b) ^ g_cb(g)) & 1u;
             cx = a ^ (vx ? 0xFFFFFFFFu : 0u);  // corr = value - reconstruct(mask)
             cy = b ^ (vy ? 0xFFFFFFFFu : 0u);
+        } else if (MODE == MODE_VERIFY_C) {
+            cx = expand4(vc_nib(gather_vc(p.vc, g.a), q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
+            cy = expand4(vc_nib(gather_vc(p.vc, g.b), q)) ^ (g_cb(g) ? 0xFFFFFFFFu : 0u);
         } else {
             cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
             cy = expand4(gather_corr(p.corr, g.b, NQ, q)) ^ (g_cb(g) ? 0xFFFFFFFFu : 0u);
@@ -171,7 +210,7 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         uint32_t delta = (a & b) ^ c;
         uint32_t s = (ly & cx) ^ (lx & cy) ^ lab ^ lnew;
         uint32_t r;
-        if (MODE != MODE_VERIFY) {
+        if (!is_verify(MODE)) {
             r = recon32(s);
         } else {
             // online-verified reps: supplied correction, add the unopened player's broadcast
@@ -184,10 +223,12 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         // verifier: the online transcript is only hashed for quads that hold an opened repetition (the other
         // repetitions' online digests come from the proof), so only those lanes store -- in the verifier's slot order
         // they are the first ten quads of a row, two 32-byte sectors instead of eight
-        if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = s;
+        if (!is_verify(MODE) || onm) p.on[(size_t)g.eo * NQ + q] = s;
         store_bits(p.pre, g.ep, NQ, q, delta);
         if (MODE == MODE_PROVE_V) {
             if (q == 0) st_v<COH>(&p.vclr[g.dst], (uint8_t)(vx & vy));
+        } else if (MODE == MODE_VERIFY_C) {
+            vc_store(p.vc, g.dst, q, r ^ delta ^ (cx & cy));
         } else {
             store_bits(p.corr, g.dst, NQ, q, r ^ delta ^ (cx & cy));
         }
@@ -197,10 +238,10 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         if (MODE == MODE_PROVE_F) break;
         // B2A's recorded reconstruction (combine.rs:181-183): value = reconstruct(mask) + corr
         uint32_t m = gather_rows(p.rows, g.a, NQ, q);
-        if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
+        if (is_verify(MODE) && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
         if (MODE == MODE_PROVE || onm) p.on[(size_t)g.eo * NQ + q] = m;
         uint32_t r = recon32(m);
-        if (MODE == MODE_VERIFY) r &= onm;
+        if (is_verify(MODE)) r &= onm;
         const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
         p.rows[(size_t)g.dst * NQ + q] = 0;
         store_bits(p.corr, g.dst, NQ, q, r ^ cx);
@@ -208,14 +249,14 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     }
     case G_ASSERT: {
         uint32_t m = gather_rows_c<COH>(p.rows, g.a, NQ, q);
-        if (MODE == MODE_VERIFY && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
-        if (MODE != MODE_VERIFY || onm) p.on[(size_t)g.eo * NQ + q] = m;
+        if (is_verify(MODE) && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
+        if (!is_verify(MODE) || onm) p.on[(size_t)g.eo * NQ + q] = m;
         if (MODE == MODE_PROVE_F) break;  // (k_clear checks the wire's value)
         if (MODE == MODE_PROVE_V) {
             // the wire's value itself must be zero (prover.rs:221-228), the same in every repetition
             if (q == 0 && ((gather_vclr_c<COH>(p.vclr, g.a) ^ g_ca(g)) & 1u) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
         } else {
-            const uint32_t cx = expand4(gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
+            const uint32_t cx = expand4(MODE == MODE_VERIFY_C ? vc_nib(gather_vc(p.vc, g.a), q) : gather_corr(p.corr, g.a, NQ, q)) ^ (g_ca(g) ? 0xFFFFFFFFu : 0u);
             if (MODE == MODE_PROVE) {
                 if ((recon32(m) ^ cx) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
             } else {
@@ -237,7 +278,7 @@ __global__ __launch_bounds__(256) void k_interp(const Gate* __restrict__ gates, 
     const uint32_t q = tid % NQ;
     const uint32_t worker = tid / NQ;
     const uint32_t n_workers = (gridDim.x * blockDim.x) / NQ;
-    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[q] : 0u;
+    const uint32_t onm = (is_verify(MODE)) ? p.on_mask[q] : 0u;
     for (uint32_t gi = lo + worker; gi < hi; gi += n_workers) {
         const Gate g = gates[gi];
         interp_one_impl<MODE>(g, p, NQ, q, onm);
@@ -327,7 +368,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
     // verifier: the online rows are stored in whole 32-byte sectors (the quads of the opened repetitions are a sector and a
     // quarter in its slot order, and a partially written sector is a read-modify-write at the memory side; the digests read
     // the opened quads only, so what the others hold does not matter)
-    const bool on_wr = MODE != MODE_VERIFY || ((__ballot(onm != 0) >> ((sub * NQ + q) & ~7u)) & 0xFFull) != 0;
+    const bool on_wr = !is_verify(MODE) || ((__ballot(onm != 0) >> ((sub * NQ + q) & ~7u)) & 0xFFull) != 0;
     Gate g[U];
 #pragma unroll
     for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
@@ -335,6 +376,9 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
     // slots >= 1 are loaded only when the operand really has that many bases (a wave-uniform branch at
     // NQ = 64); every load is issued before any value is used
     uint32_t ra[U][KA], ca[U][KA], rb[U][KB], cb[U][KB];
+    // MODE_VERIFY_C: a lane reads the 32-bit half of a row's corrections word that holds its quad word's nibble (lanes 8 .. 15 the
+    // high one; lanes >= 16 read the low one and use nothing of it)
+    const uint32_t* const vc32 = (const uint32_t*)p.vc + ((q >> 3) & 1u);
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
@@ -344,7 +388,8 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
             ca[u][i] = 0;
             if (i == 0 || i < na) {
                 ra[u][i] = ld_row<COH>(&p.rows[(size_t)g[u].a[i] * NQ + q]);
-                ca[u][i] = MODE == MODE_PROVE_V ? ld_v<COH>(&p.vclr[g[u].a[i]]) : p.corr[(size_t)g[u].a[i] * H + (q >> 1)];
+                ca[u][i] = MODE == MODE_VERIFY_C ? vc32[2 * (size_t)g[u].a[i]]
+                                                 : MODE == MODE_PROVE_V ? ld_v<COH>(&p.vclr[g[u].a[i]]) : p.corr[(size_t)g[u].a[i] * H + (q >> 1)];
             }
         }
 #pragma unroll
@@ -353,7 +398,8 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
             cb[u][i] = 0;
             if (i == 0 || i < nb) {
                 rb[u][i] = ld_row<COH>(&p.rows[(size_t)g[u].b[i] * NQ + q]);
-                cb[u][i] = MODE == MODE_PROVE_V ? ld_v<COH>(&p.vclr[g[u].b[i]]) : p.corr[(size_t)g[u].b[i] * H + (q >> 1)];
+                cb[u][i] = MODE == MODE_VERIFY_C ? vc32[2 * (size_t)g[u].b[i]]
+                                                 : MODE == MODE_PROVE_V ? ld_v<COH>(&p.vclr[g[u].b[i]]) : p.corr[(size_t)g[u].b[i] * H + (q >> 1)];
             }
         }
         // lambda_ab is read exactly once and the online row is not read again before the hash phase: nontemporal, so
@@ -361,7 +407,7 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
         // an operand of the next level -- and the XOR outputs are better left as plain accesses: 2.35 / 2.38)
         lab[u] = __builtin_nontemporal_load(&p.rows[(size_t)g[u].m * NQ + q]);
         lnew[u] = p.rows[(size_t)(g[u].m + 1) * NQ + q];
-        if (MODE == MODE_VERIFY) {
+        if (is_verify(MODE)) {
             sc[u] = sr[u] = 0;
             if (onm) {  // supplied values exist (and are stored) only for quads with an opened repetition
                 sc[u] = p.sup_corr[(size_t)g[u].ep * p.sup_nq + q];
@@ -395,6 +441,9 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
         if (MODE == MODE_PROVE_V) {
             cx = a ^ (vx ? 0xFFFFFFFFu : 0u);  // corr = value - reconstruct(mask)
             cy = b ^ (vy ? 0xFFFFFFFFu : 0u);
+        } else if (MODE == MODE_VERIFY_C) {
+            cx = expand4(q < 16 ? (bx[u] >> (4 * (q & 7))) & 0xFu : 0u) ^ (g_ca(g[u]) ? 0xFFFFFFFFu : 0u);
+            cy = expand4(q < 16 ? (by[u] >> (4 * (q & 7))) & 0xFu : 0u) ^ (g_cb(g[u]) ? 0xFFFFFFFFu : 0u);
         } else {
             cx = expand4((bx[u] >> (4 * (q & 1))) & 0xFu) ^ (g_ca(g[u]) ? 0xFFFFFFFFu : 0u);
             cy = expand4((by[u] >> (4 * (q & 1))) & 0xFu) ^ (g_cb(g[u]) ? 0xFFFFFFFFu : 0u);
@@ -404,15 +453,17 @@ __device__ __forceinline__ void mulU(const Gate* __restrict__ gates, uint32_t g0
         uint32_t r = 0;
         if (MODE == MODE_PROVE) {
             r = recon32(s);
-        } else if (MODE == MODE_VERIFY) {
+        } else if (is_verify(MODE)) {
             delta = (sc[u] & onm) | (delta & ~onm);
             s ^= sr[u];
             r = recon32(s) & onm;
         }
-        if (MODE != MODE_VERIFY || on_wr) __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
+        if (!is_verify(MODE) || on_wr) __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
         store_bits(p.pre, g[u].ep, NQ, q, delta);
         if (MODE == MODE_PROVE_V) {
             if (q == 0) st_v<COH>(&p.vclr[g[u].dst], (uint8_t)(vx & vy));
+        } else if (MODE == MODE_VERIFY_C) {
+            vc_store(p.vc, g[u].dst, q, r ^ delta ^ (cx & cy));
         } else {
             store_bits(p.corr, g[u].dst, NQ, q, r ^ delta ^ (cx & cy));
         }
@@ -445,6 +496,8 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
                 if (MODE == MODE_PROVE_F) {
                 } else if (MODE == MODE_PROVE_V) {
                     if (q == 0) cc[u][i] = ld_v<COH>(&p.vclr[id]);
+                } else if (MODE == MODE_VERIFY_C) {
+                    if (q < 2) cc[u][i] = ((const uint32_t*)p.vc)[2 * (size_t)id + q];  // (lanes 0, 1: the word's two halves)
                 } else if (q < H) {
                     cc[u][i] = p.corr[(size_t)id * H + q];
                 }
@@ -468,6 +521,8 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
         if (MODE == MODE_PROVE_F) {
         } else if (MODE == MODE_PROVE_V) {
             if (q == 0) st_v<COH>(&p.vclr[g[u].dst], (uint8_t)((bx[u] ^ g_ca(g[u])) & 1u));
+        } else if (MODE == MODE_VERIFY_C) {
+            if (q < 2) ((uint32_t*)p.vc)[2 * (size_t)g[u].dst + q] = bx[u] ^ (g_ca(g[u]) ? 0xFFFFFFFFu : 0u);
         } else if (q < H) {
             p.corr[(size_t)g[u].dst * H + q] = (uint8_t)(bx[u] ^ (g_ca(g[u]) ? 0xFFu : 0u));
         }
@@ -539,11 +594,11 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
 // (the full-width variant without the multi-base loops must fit eight wavefronts per SIMD: its verify-mode instance
 // took 70 registers = seven; with the bound it is 61, without scratch.  Narrower rows keep the default: they would spill)
 template <int MODE, int NQ, bool GENERAL>
-__global__ __launch_bounds__(256, (GENERAL || NQ != 64) ? 1 : 8) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p, PfPlan pf) {
+__global__ __launch_bounds__(256, MODE == MODE_VERIFY_C ? (GENERAL ? 4 : 7) : (GENERAL || NQ != 64) ? 1 : 8) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p, PfPlan pf) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[lane % NQ] : 0u;
+    const uint32_t onm = (is_verify(MODE)) ? p.on_mask[lane % NQ] : 0u;
     // ROTATE here too: a wavefront then runs ONE step of one class instead of a Mul step followed by an Xor step
     // (two generations of short-lived wavefronts beat one generation of twice-as-long ones: 2.52 -> 2.40 ms;
     // interleaving the two classes wave by wave instead of class after class is worse again, 2.56)
@@ -560,7 +615,7 @@ __global__ __launch_bounds__(256) void k_interp_full_b(const Gate* __restrict__ 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[lane % NQ] : 0u;
+    const uint32_t onm = (is_verify(MODE)) ? p.on_mask[lane % NQ] : 0u;
     run_level<MODE, NQ, true>(gates, r, p, wave, n_waves, lane, onm);
 }
 
@@ -631,6 +686,11 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
             hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
         else
             hipLaunchKernelGGL((k_interp_full<MODE_PROVE, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
+    } else if (mode == MODE_VERIFY_C && NQ == 64) {
+        if (general)
+            hipLaunchKernelGGL((k_interp_full<NQ == 64 ? MODE_VERIFY_C : MODE_VERIFY, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
+        else
+            hipLaunchKernelGGL((k_interp_full<NQ == 64 ? MODE_VERIFY_C : MODE_VERIFY, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
     } else {
         if (general)
             hipLaunchKernelGGL((k_interp_full<MODE_VERIFY, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
@@ -1364,7 +1424,7 @@ __device__ __forceinline__ void interp_narrow_body(const Gate* __restrict__ gate
     __shared__ __attribute__((aligned(16))) Gate s_g[NARROW_WIN];
     const uint32_t NQ = NQT ? (uint32_t)NQT : p.NQ;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t onm = (MODE == MODE_VERIFY) ? p.on_mask[NQT ? lane % NQ : threadIdx.x % NQ] : 0u;
+    const uint32_t onm = (is_verify(MODE)) ? p.on_mask[NQT ? lane % NQ : threadIdx.x % NQ] : 0u;
     const uint32_t n_lv = l1 - l0;
     {
         const uint32_t* src = (const uint32_t*)(level_range + l0);

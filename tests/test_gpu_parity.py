@@ -1371,3 +1371,62 @@ def test_early_corrections_two_contexts_two_threads(rv, oracle, rule_seeds, monk
         c.close()
     for ctx in ctxs:
         ctx.close()
+
+
+@pytest.mark.parametrize("vc", [1, 0])
+def test_verifier_compact_corrections_vs_oracle(rv, oracle, rule_seeds, monkeypatch, vc):
+    """MODE_VERIFY_C (one u64 of public corrections per share row instead of corr rows; csrc/kernels.hip, internal.h) on circuits
+    that take it -- pure GF(2), wide levels, one base per wire -- against the oracle's verifier (verifier/online.rs:122-183,
+    verifier/preprocess.rs:46-79): valid proofs, bit flips all over the proof, a program whose AssertZero fails (strict and
+    reference-compatible answers), random programs with constants, Random gates and wire reuse."""
+    monkeypatch.setenv("RV_VERIFY_VC", str(vc))
+    rng = np.random.default_rng(4242)
+    prog, wit, wc, st = circuits.layered_gf2(n_in=300, width=1500, layers=9, fold_to=1500)
+    good = oracle.prove(prog, wit, [], wc, rule_seeds, threads=8)
+    c = rv.Circuit(prog, wc)
+    assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == good
+    from reverie_amd import _lib
+
+    n0 = _lib.lib().rv_hook_verify_vc_count()
+    assert rv.Proof(good).verify(c) and rv.Proof(good).verify(c, strict=False)
+    assert _lib.lib().rv_hook_verify_vc_count() == n0 + (2 if vc else 0)  # (the path this test is about was taken / was not)
+    for pos in rng.integers(0, len(good), 24):
+        bad = bytearray(good)
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        res = []
+        for strict in (False, True):
+            try:
+                want = (oracle.verify(prog, wc, bytes(bad), strict=strict), None)
+            except oracle.OracleError as e:
+                want = (None, e.code)
+            try:
+                got = (rv.Proof(bytes(bad)).verify(c, strict=strict), None)
+            except rv.ReverieError as e:
+                got = (None, e.code)
+            assert got == want, (pos, strict)
+            res.append(got)
+    c.close()
+    # a failing assertion: the last AddConst before an AssertZero flipped
+    idx = np.flatnonzero(prog["opcode"] == 3)
+    if len(idx):
+        bad_prog = prog.copy()
+        bad_prog[idx[-1]]["imm"] ^= 1
+        want = (oracle.verify(bad_prog, wc, good), oracle.verify(bad_prog, wc, good, strict=True))
+        assert (rv.Proof(good).verify(bad_prog, wc, strict=False), rv.Proof(good).verify(bad_prog, wc, strict=True)) == want
+    for seed in range(4):
+        r2 = np.random.default_rng(900 + seed)
+        p2, w2, wc2 = circuits.random_gf2(r2, n_in=int(r2.integers(1, 60)), n_gates=int(r2.integers(200, 5000)), n_wires=int(r2.integers(8, 300)))
+        seeds = r2.integers(0, 256, (256, 16), dtype=np.uint8)
+        pf = oracle.prove(p2, w2, [], wc2, seeds, threads=8)
+        assert rv.Proof(pf).verify(p2, wc2) and oracle.verify(p2, wc2, pf, strict=True)
+        bad = bytearray(pf)
+        bad[len(bad) // 2] ^= 4
+        try:
+            want = (oracle.verify(p2, wc2, bytes(bad), strict=True), None)
+        except oracle.OracleError as e:
+            want = (None, e.code)
+        try:
+            got = (rv.Proof(bytes(bad)).verify(p2, wc2), None)
+        except rv.ReverieError as e:
+            got = (None, e.code)
+        assert got == want
