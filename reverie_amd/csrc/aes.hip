@@ -729,6 +729,9 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
     // every outstanding store)
 #pragma unroll
     for (int k = 0; k < 32; k++) asm volatile("" : "+v"(lo0[k]), "+v"(hi0[k]), "+v"(lo1[k]), "+v"(hi1[k])::"memory");
+    // ... and every address below is computed from here on: hoisted above the cipher as loop invariants (the transcript bases of
+    // the lane's four repetitions) they were spilled, and each reload sat between two repetitions' stores, waiting for them
+    asm volatile("" : "+v"(q), "+v"(zo), "+v"(gi));
     if (!valid) return;
 #ifdef RV_ZF_NOMEM
     {
