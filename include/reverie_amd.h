@@ -161,6 +161,10 @@ typedef struct rv_circuit_info {
     /* ABI 4: share rows the GF(2) interpreter reads as gate operands (a Mul's two fresh mask rows not counted) and
      * computed rows it writes (materialised linear gates), per proof -- they depend on how linear gates were compiled */
     uint64_t gf2_operand_rows, gf2_rows_written;
+    /* ABI 6: page-locked host memory rv_prove's early-corrections path stages this circuit's corrections vectors in (0: the path
+     * does not apply to the circuit).  Allocated once per context, on the first proof that takes the path (its first mapping costs
+     * 0.15 - 1.5 s), and kept; RV_EARLY=0 proves without it. */
+    uint64_t early_staging_bytes;
 } rv_circuit_info;
 int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
 

@@ -39,7 +39,7 @@ class CircuitInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_ops", "gf2_inputs", "gf2_muls", "gf2_asserts", "gf2_linear", "gf2_masks", "z64_inputs", "z64_muls",
         "z64_asserts", "z64_linear", "z64_masks", "b2a", "levels", "device_bytes", "scratch_bytes", "compile_us", "upload_us",
-        "gf2_operand_rows", "gf2_rows_written")]
+        "gf2_operand_rows", "gf2_rows_written", "early_staging_bytes")]
 
 
 class BristolInfo(C.Structure):

@@ -45,10 +45,11 @@ static int hip_fail(hipError_t e, const char* what, const char* file, int line) 
     } while (0)
 
 extern "C" const char* rv_last_error(void) { return g_last_error.c_str(); }
-extern "C" uint32_t rv_abi_version(void) { return 5; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
+extern "C" uint32_t rv_abi_version(void) { return 6; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
                                                         //    streaming prover, rv_prove_multi, reconstruct hooks
                                                         // 4: rv_circuit_compile_ex (a pure addition)
                                                         // 5: rv_prove_ops / rv_verify_ops, rv_hook_compile_compare (pure additions)
+                                                        // 6: rv_circuit_info grew by early_staging_bytes (callers must pass the larger struct)
 
 extern "C" const char* rv_strerror(int code) {
     switch (code) {
@@ -1149,9 +1150,11 @@ extern "C" int rv_hook_compile_compare(const rv_op* ops, size_t n_ops, size_t z6
     }
 }
 
+static uint64_t early_staging_bytes_of(const rv_circuit* c);  // (with the early-corrections plan below)
 extern "C" int rv_circuit_get_info(const rv_circuit* c, rv_circuit_info* info) {
     if (!c || !info) return RV_E_ARG;
     *info = c->cc.info;
+    info->early_staging_bytes = early_staging_bytes_of(c);
     return RV_OK;
 }
 
@@ -1581,6 +1584,12 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
         P.ok = true;
     });
     return &c->ec_plan;
+}
+static uint64_t early_staging_bytes_of(const rv_circuit* c) {
+    if (const char* e = getenv("RV_EARLY"))
+        if (atoi(e) == 0) return 0;
+    const EarlyPlan* P = early_plan(c);
+    return P->ok ? (uint64_t)P->bytes : 0;
 }
 
 // Host-only view of the plan (tests): compiles the ops as rv_circuit_compile_ex would, builds the early-corrections plan and checks

@@ -1250,6 +1250,8 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
         got = rv.Proof.new(c, wit, [], seeds=rule_seeds)
         assert L.rv_hook_early_proofs() == n0 + 1, "the early-corrections path was not taken"
         assert bytes(got) == want, (width, layers, chunks, st["and"] % 8)
+        # (rv_circuit_info reports the page-locked staging the path holds per context: every repetition's corrections vector)
+        assert c.info["early_staging_bytes"] >= 256 * ((st["and"] + 7) // 8)
         again = rv.Proof.new(c, wit, [], seeds=rule_seeds)  # the staging buffers and the mailbox are reused
         assert bytes(again) == want
         assert got.verify(c)
@@ -1258,6 +1260,7 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
         monkeypatch.setenv("RV_EARLY_REC", "1")
         monkeypatch.setenv("RV_EARLY", "0")
         plain = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+        assert c.info["early_staging_bytes"] == 0  # (RV_EARLY=0)
         assert L.rv_hook_early_proofs() == n0 + 3
         assert bytes(plain) == want
         monkeypatch.setenv("RV_EARLY", "2")
