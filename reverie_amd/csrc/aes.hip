@@ -903,7 +903,7 @@ __device__ __forceinline__ void z64f_oth(const Gate64& g, const Z64FParams& p, u
 
 template <int QW>
 __global__ __launch_bounds__(512, 2) void k_z64_fused(const Gate64* __restrict__ gates, Z64FLevel lv, uint32_t mul_per, uint32_t lin_per,
-                                                    uint32_t oth_per, Z64FParams p) {
+                                                    uint32_t oth_per, uint32_t lin_bias, Z64FParams p) {
     __shared__ uint32_t lds_rk[11 * 128 * QW];
     constexpr uint32_t JW = 64 / QW, STEP = 8 * JW;  // gates per wavefront and per workgroup iteration
     const uint32_t n_qg = p.NQ / QW;
@@ -918,23 +918,34 @@ __global__ __launch_bounds__(512, 2) void k_z64_fused(const Gate64* __restrict__
     const uint32_t o_lo = min(lv.lin1 + chunk * oth_per, lv.oth1), o_hi = min(o_lo + oth_per, lv.oth1);
     if (m_hi > m_lo) stage_round_keys<QW>(p.rk, p.NQ, qg, lds_rk);  // (uniform over the workgroup)
     const uint32_t* rkl = lds_rk + ql;
-    const uint32_t mw = m_lo + wave * JW, lw = l_lo + wave * JW;
-    const uint32_t MI = m_hi > mw ? (m_hi - mw + STEP - 1) / STEP : 0u;
-    const uint32_t LI = l_hi > lw ? (l_hi - lw + STEP - 1) / STEP : 0u;
+    // Work of the workgroup's eight wavefronts in wavefront steps of JW gates.  Mul steps are dealt round-robin, so TM % 8 wavefronts
+    // run one step more than the others -- and a level of the benchmark circuit has 8 192 +- 64 Mul gates, i.e. on half the levels
+    // a few wavefronts of the chip ran a FIFTH cipher batch while every other one idled for it (5 x 65 us instead of 4).  The
+    // linear steps (memory only, ~1/5 of a Mul step: lin_bias) make up for it: the wavefronts with the extra Mul step take that many
+    // fewer of them.
+    const uint32_t n_m = m_hi - m_lo, n_l = l_hi - l_lo;
+    const uint32_t TM = (n_m + JW - 1) / JW, TL = (n_l + JW - 1) / JW;
+    const uint32_t x = TM % 8;  // wavefronts 0 .. x - 1 run TM / 8 + 1 Mul steps
+    const uint32_t MI = TM / 8 + (wave < x ? 1u : 0u);
+    uint32_t ql_ = (TL + lin_bias * x + 7) / 8;                    // light wavefronts' linear steps; heavy ones: lin_bias fewer
+    if (ql_ < lin_bias) ql_ = (TL + (8 - x) - 1) / (8 - x);        // (not enough linear work to even it out: the light ones take all)
+    const uint32_t qh_ = ql_ > lin_bias ? ql_ - lin_bias : 0u;
+    const uint32_t LI = wave < x ? qh_ : ql_;
+    const uint32_t l0s = wave < x ? wave * qh_ : x * qh_ + (wave - x) * ql_;  // this wavefront's first linear step
     uint32_t ld = 0;
     for (uint32_t it = 0; it < MI; it++) {
-        const uint32_t gi = mw + it * STEP + jsub;
+        const uint32_t gi = m_lo + (wave + 8 * it) * JW + jsub;
         z64f_mul<QW>(gates, gi, gi < m_hi, p, rkl, q, zo, writer);
         const uint32_t lend = (uint32_t)(((uint64_t)(it + 1) * LI) / MI);
         for (; ld < lend; ld++) {
-            const uint32_t gl = lw + ld * STEP + jsub;
+            const uint32_t gl = l_lo + (l0s + ld) * JW + jsub;
 #ifndef RV_ZF_NOLIN
             if (gl < l_hi) z64f_lin(gates[gl], p, zo, writer);
 #endif
         }
     }
     for (; ld < LI; ld++) {
-        const uint32_t gl = lw + ld * STEP + jsub;
+        const uint32_t gl = l_lo + (l0s + ld) * JW + jsub;
         if (gl < l_hi) z64f_lin(gates[gl], p, zo, writer);
     }
     for (uint32_t go = o_lo + wave * JW + jsub; go < o_hi; go += STEP) z64f_oth(gates[go], p, q, zo, writer);
@@ -943,29 +954,29 @@ __global__ __launch_bounds__(512, 2) void k_z64_fused(const Gate64* __restrict__
 bool z64_fused_supports(uint32_t NQ) { return NQ >= 16 && NQ % 16 == 0; }
 
 void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p) {
-    constexpr uint32_t QW = 16, STEP = 8 * (64 / QW);
+    constexpr uint32_t QW = 16, JW = 64 / QW, STEP = 8 * JW;
     static const uint32_t cus = [] {
         if (const char* e = getenv("RV_Z64F_WGS")) return (uint32_t)std::max(atoi(e), 1);
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return (uint32_t)n;
     }();
+    // a Mul step (cipher batch + rows) in linear steps (rows only): what the wavefronts with one Mul step more get fewer of
+    static const uint32_t lin_bias = getenv("RV_Z64F_LIN_BIAS") ? (uint32_t)std::min(std::max(atoi(getenv("RV_Z64F_LIN_BIAS")), 0), 64) : 3u;  // (measured 0 / 3 / 5 / 8: 38.6 / 38.3 / 38.9 / 38.8 ms)
     const uint32_t n_qg = p.NQ / QW;
     const uint32_t n_mul = lv.mul1 - lv.mul0, n_lin = lv.lin1 - lv.mul1, n_oth = lv.oth1 - lv.lin1;
     if (!(n_mul + n_lin + n_oth)) return;
     auto up = [](uint64_t x, uint64_t m) { return (x + m - 1) / m * m; };
-    // one generation of workgroups for the cipher work (a workgroup owns its compute unit: 88 KiB of round keys, all registers);
-    // levels with little of it still get enough workgroups for their row traffic
-    uint64_t chunks = 1;
-    if (n_mul) {
-        const uint64_t per = std::max<uint64_t>(up(((uint64_t)n_mul * n_qg + cus - 1) / cus, STEP), STEP);
-        chunks = (n_mul + per - 1) / per;
-    }
-    const uint64_t mem_chunks = std::min<uint64_t>(((uint64_t)n_lin + n_oth + 2 * STEP - 1) / (2 * STEP), std::max<uint32_t>(cus / n_qg, 1) * (n_mul ? 1u : 4u));
+    // one generation of workgroups, one per compute unit (a workgroup owns it: 88 KiB of round keys, all registers), each with
+    // an equal share of the level in whole wavefront steps; a level with little cipher work still gets enough workgroups for its
+    // row traffic, one with very little of anything only as many as have a workgroup step to do
+    const uint64_t per_qg = std::max<uint32_t>(cus / n_qg, 1);
+    uint64_t chunks = n_mul ? std::min<uint64_t>(per_qg, ((uint64_t)n_mul + STEP - 1) / STEP) : 1;
+    const uint64_t mem_chunks = std::min<uint64_t>(((uint64_t)n_lin + n_oth + 2 * STEP - 1) / (2 * STEP), per_qg * (n_mul ? 1u : 4u));
     chunks = std::max<uint64_t>(std::max(chunks, mem_chunks), 1);
-    const uint32_t mul_per = (uint32_t)up((n_mul + chunks - 1) / chunks, STEP), lin_per = (uint32_t)up((n_lin + chunks - 1) / chunks, STEP),
+    const uint32_t mul_per = (uint32_t)up((n_mul + chunks - 1) / chunks, JW), lin_per = (uint32_t)up((n_lin + chunks - 1) / chunks, JW),
                    oth_per = (uint32_t)up((n_oth + chunks - 1) / chunks, STEP);
-    hipLaunchKernelGGL(k_z64_fused<QW>, dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_gates, lv, mul_per, lin_per, oth_per, p);
+    hipLaunchKernelGGL(k_z64_fused<QW>, dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_gates, lv, mul_per, lin_per, oth_per, lin_bias, p);
 }
 
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
