@@ -272,7 +272,7 @@ def secondary_records(ctx, seeds, quick):
            "note": "host to host; the 640 MB proof alone is ~11 ms of PCIe, of which the early-corrections path (the corrections vectors of the first "
                    "128 repetitions cross PCIe while the kernels run: csrc/api.hip) hides ~2; the prover runs the mask generator inside the "
                    "interpreter's level launches (k_z64_fused, csrc/aes.hip; RV_Z64_FUSED=0 = k_aes_z64_masks then k_interp64: 26.9 + 26.4 ms); "
-                   f"profiles/{PROFILE_TAG}_z64_* hold the kernel trace and the PMC traffic of both (fused: 122.6 GB and 40.6 ms per proof, "
+                   f"profiles/{PROFILE_TAG}_z64_* hold the kernel trace and the PMC traffic of both (fused: 119.2 GB and 38.5 ms per proof, "
                    "two kernels: 182 GB), DESIGN.md the analysis (2.05e9 cipher blocks at the VALU rate = 27 ms)"}
     circ.close()
     del p
