@@ -695,9 +695,9 @@ __device__ __forceinline__ void z_store_on(uint64_t* op, const uint64_t* w) {
 // which come from k_aes_z64_masks in the natural order and are rewritten in place by the Input gate itself (z64f_oth).
 __device__ __forceinline__ uint32_t z_piece(uint32_t i) { return i * 32; }
 
-template <int QW>
+template <int QW, bool VERIFY>
 __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint32_t gi, bool valid, const Z64FParams& p, const uint32_t* rkl, uint32_t q,
-                                         uint32_t zo, bool writer) {
+                                         uint32_t zo, bool writer, uint32_t kp) {
     const uint64_t S = (uint64_t)p.NQ * 32;
     const uint32_t m = valid ? gates[gi].m : 0u;
     uint32_t lo0[32], hi0[32], lo1[32], hi1[32];
@@ -724,6 +724,16 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
     transpose32(hi0);
     transpose32(lo1);
     transpose32(hi1);
+    if (VERIFY) {  // the omitted player's stream of an opened repetition stays zero (k_aes_z64_masks: keep)
+#pragma unroll
+        for (int sl = 0; sl < 32; sl++) {
+            const uint32_t on = (uint32_t)0 - ((kp >> (31 - sl)) & 1u);
+            lo0[sl] &= on;
+            hi0[sl] &= on;
+            lo1[sl] &= on;
+            hi1[sl] &= on;
+        }
+    }
     // the cipher and the transposes end HERE: without these pins the compiler sinks the last round and the transposes into the
     // `valid` branch below and schedules them among the row loads (160 registers spilled, the spill reloads then wait for
     // every outstanding store)
@@ -746,7 +756,13 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
     const uint64_t* ap = z_row(p, g.am, S) + zo;
     const uint64_t* bp = z_row(p, g.bm, S) + zo;
     uint64_t* lnp = p.masks + (size_t)(g.m + 1) * S + zo;
-    const uint64_t va = p.v[g.a], vb = p.v[g.b];
+    const uint32_t R = p.NQ * 4;
+    const uint64_t va = VERIFY ? 0 : p.v[g.a], vb = VERIFY ? 0 : p.v[g.b];
+    // the verifier (verifier/online.rs:122-183, verifier/preprocess.rs:46-79 at Z64): public corrections per repetition, which
+    // repetitions are opened and which player they hide
+    uint64_t cxs[4] = {0, 0, 0, 0}, cys[4] = {0, 0, 0, 0};
+    uint32_t om4 = 0x08080808u;
+    uint64_t dcs[4];
     // Software-pipelined over the lane's four repetitions: the operand pieces of repetition k + 2 are requested BEFORE the
     // stores of repetition k are issued.  CDNA has one in-order counter for vector loads and stores, so waiting for a load
     // also waits for every store issued before it -- with load / compute / store / load ... in program order each repetition
@@ -782,6 +798,13 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
     for (int i = 0; i < 16; i++)
         z_st16(lnp + z_piece(i), ((uint64_t)hi1[2 * i] << 32) | lo1[2 * i], ((uint64_t)hi1[2 * i + 1] << 32) | lo1[2 * i + 1]);
 #endif
+    if (VERIFY) {  // (requested here, once lambda_new has left and freed its registers)
+        z_ld16(p.wcorr + (size_t)g.a * R + 4 * q, cxs[0], cxs[1]);
+        z_ld16(p.wcorr + (size_t)g.a * R + 4 * q + 2, cxs[2], cxs[3]);
+        z_ld16(p.wcorr + (size_t)g.b * R + 4 * q, cys[0], cys[1]);
+        z_ld16(p.wcorr + (size_t)g.b * R + 4 * q + 2, cys[2], cys[3]);
+        om4 = *(const uint32_t*)(p.omit + 4 * q);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -794,10 +817,25 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
             b += ly[bf][i];
         }
         // corr = value - reconstruct(mask) (prover.rs:181-199 with the cleartext value known)
-        const uint64_t cx = va - a, cy = vb - b;
+        const uint64_t cx = VERIFY ? cxs[k] : va - a, cy = VERIFY ? cys[k] : vb - b;
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = ly[bf][i] * cx + lx[bf][i] * cy + d[8 * k + i];
-        const uint64_t delta = a * b - cs[k];
+        uint64_t delta = a * b - cs[k];
+        if (VERIFY) {
+            const uint32_t om = (om4 >> (8 * k)) & 0xFFu;
+            uint64_t rec = 0;
+            if (om < 8) {  // opened: the supplied correction, and the hidden player's broadcast share from the proof
+                const uint32_t rep_ = 4 * q + k;
+                delta = p.sup_corr[(size_t)g.xc * p.sup_r + rep_];
+                const uint64_t sup = p.sup_rec[(size_t)g.x * p.sup_r + rep_];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if ((uint32_t)i == om) w[i] += sup;
+                    rec += w[i];
+                }
+            }
+            dcs[k] = rec + delta + cx * cy;
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (k + 2 < 4) {
 #pragma unroll
@@ -820,19 +858,42 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
 #endif
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (writer) p.v[g.dst] = va * vb;
+    if (VERIFY) {
+        z_st16(p.wcorr + (size_t)g.dst * R + 4 * q, dcs[0], dcs[1]);
+        z_st16(p.wcorr + (size_t)g.dst * R + 4 * q + 2, dcs[2], dcs[3]);
+    } else if (writer) {
+        p.v[g.dst] = va * vb;
+    }
 }
 
 // Add / Sub / AddConst / SubConst / MulConst: the mask row (z64/share.rs:110-136 player by player; elementwise, so the
 // row layout does not matter) and the value
-__device__ __forceinline__ void z64f_lin(const Gate64& g, const Z64FParams& p, uint32_t zo, bool writer) {
+template <bool VERIFY>
+__device__ __forceinline__ void z64f_lin(const Gate64& g, const Z64FParams& p, uint32_t q, uint32_t zo, bool writer) {
     const uint64_t S = (uint64_t)p.NQ * 32;
     const uint64_t* ap = z_row(p, g.am, S) + zo;
     uint64_t* dp = p.wmask + (size_t)g.dst * S + zo;
-    const uint64_t va = p.v[g.a];
+    if (VERIFY) {  // the public corrections of the lane's four repetitions (z64/recon.rs arithmetic)
+        const uint32_t R = p.NQ * 4;
+        uint64_t a4[4], b4[4] = {0, 0, 0, 0};
+        z_ld16(p.wcorr + (size_t)g.a * R + 4 * q, a4[0], a4[1]);
+        z_ld16(p.wcorr + (size_t)g.a * R + 4 * q + 2, a4[2], a4[3]);
+        if (g.op == G64_ADD || g.op == G64_SUB) {
+            z_ld16(p.wcorr + (size_t)g.b * R + 4 * q, b4[0], b4[1]);
+            z_ld16(p.wcorr + (size_t)g.b * R + 4 * q + 2, b4[2], b4[3]);
+        }
+        uint64_t r4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            r4[k] = g.op == G64_ADD ? a4[k] + b4[k] : g.op == G64_SUB ? a4[k] - b4[k] : g.op == G64_ADDC ? a4[k] + g.imm : g.op == G64_SUBC ? a4[k] - g.imm : a4[k] * g.imm;
+        z_st16(p.wcorr + (size_t)g.dst * R + 4 * q, r4[0], r4[1]);
+        z_st16(p.wcorr + (size_t)g.dst * R + 4 * q + 2, r4[2], r4[3]);
+        writer = false;
+    }
+    const uint64_t va = VERIFY ? 0 : p.v[g.a];
     if (g.op == G64_ADD || g.op == G64_SUB) {
         const uint64_t* bp = z_row(p, g.bm, S) + zo;
-        const uint64_t vb = p.v[g.b];
+        const uint64_t vb = VERIFY ? 0 : p.v[g.b];
         const bool sub = g.op == G64_SUB;
         uint64_t x[32], y[32];  // (every load before the first store: see z64f_mul)
 #pragma unroll
@@ -860,12 +921,16 @@ __device__ __forceinline__ void z64f_lin(const Gate64& g, const Z64FParams& p, u
 // Input (masked input = witness - reconstruct(fresh mask) into the online transcript; its mask row, written by
 // k_aes_z64_masks in the natural order, is rewritten in this path's layout), AssertZero (the wire's mask shares into the
 // online transcript; the VALUE must be zero, prover.rs:221-228), Const
+template <bool VERIFY>
 __device__ __forceinline__ void z64f_oth(const Gate64& g, const Z64FParams& p, uint32_t q, uint32_t zo, bool writer) {
     const uint64_t S = (uint64_t)p.NQ * 32;
+    const uint32_t R = p.NQ * 4;
+    const uint32_t om4 = VERIFY ? *(const uint32_t*)(p.omit + 4 * q) : 0x08080808u;
+    if (VERIFY) writer = false;
     if (g.op == G64_INPUT) {
         uint64_t* row = p.masks + (size_t)g.m * S;
         const uint64_t* lp = row + (size_t)q * 32;
-        const uint64_t wv = p.wit[g.x];
+        const uint64_t wv = VERIFY ? 0 : p.wit[g.x];
         uint64_t l[32];
 #pragma unroll
         for (int i = 0; i < 16; i++) z_ld16(lp + 2 * i, l[2 * i], l[2 * i + 1]);
@@ -874,7 +939,14 @@ __device__ __forceinline__ void z64f_oth(const Gate64& g, const Z64FParams& p, u
             uint64_t a = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) a += l[8 * k + i];
-            p.on[(size_t)(4 * q + k) * p.on_words + g.eo] = wv - a;
+            if (VERIFY) {  // the masked input comes with the proof (opened repetitions; the others: junk zero, preprocess.rs:46-79)
+                const uint32_t om = (om4 >> (8 * k)) & 0xFFu;
+                const uint64_t corr = om < 8 ? p.sup_in[(size_t)g.x * p.sup_r + 4 * q + k] : 0;
+                p.wcorr[(size_t)g.dst * R + 4 * q + k] = corr;
+                p.on[(size_t)(4 * q + k) * p.on_words + g.eo] = corr;
+            } else {
+                p.on[(size_t)(4 * q + k) * p.on_words + g.eo] = wv - a;
+            }
         }
         // every lane of the wavefront has its 256 bytes before any lane overwrites them (the 16 lanes of a gate exchange places
         // inside one 4 KiB block, and they sit in one wavefront)
@@ -890,6 +962,20 @@ __device__ __forceinline__ void z64f_oth(const Gate64& g, const Z64FParams& p, u
             uint64_t l[8];
 #pragma unroll
             for (int i = 0; i < 4; i++) z_ld16(ap + z_piece(4 * k + i), l[2 * i], l[2 * i + 1]);
+            if (VERIFY) {
+                const uint32_t om = (om4 >> (8 * k)) & 0xFFu;
+                if (om < 8) {
+                    const uint64_t sup = p.sup_rec[(size_t)g.x * p.sup_r + 4 * q + k];
+                    uint64_t v = p.wcorr[(size_t)g.a * R + 4 * q + k];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        if ((uint32_t)i == om) l[i] += sup;
+                        v += l[i];
+                    }
+                    // online.rs:175-177: okay &= recon.is_zero() -- the reference never reads it; RV_VERIFY_STRICT does
+                    if (v != 0) atomicOr(p.err, RV_DEV_ZERO_CHECK);
+                }
+            }
             z_store_on(p.on + (size_t)(4 * q + k) * p.on_words + g.eo, l);
         }
         if (writer && p.v[g.a] != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
@@ -897,11 +983,15 @@ __device__ __forceinline__ void z64f_oth(const Gate64& g, const Z64FParams& p, u
         uint64_t* dp = p.wmask + (size_t)g.dst * S + zo;
 #pragma unroll
         for (int i = 0; i < 16; i++) z_st16(dp + z_piece(i), 0, 0);
+        if (VERIFY) {
+            z_st16(p.wcorr + (size_t)g.dst * R + 4 * q, g.imm, g.imm);
+            z_st16(p.wcorr + (size_t)g.dst * R + 4 * q + 2, g.imm, g.imm);
+        }
         if (writer) p.v[g.dst] = g.imm;
     }
 }
 
-template <int QW>
+template <int QW, bool VERIFY>
 __global__ __launch_bounds__(512, 2) void k_z64_fused(const Gate64* __restrict__ gates, Z64FLevel lv, uint32_t mul_per, uint32_t lin_per,
                                                     uint32_t oth_per, uint32_t lin_bias, Z64FParams p) {
     __shared__ uint32_t lds_rk[11 * 128 * QW];
@@ -913,6 +1003,7 @@ __global__ __launch_bounds__(512, 2) void k_z64_fused(const Gate64* __restrict__
     const uint32_t q = qg * QW + ql;
     const uint32_t zo = qg * (QW * 32) + ql * 2;  // this lane's piece 0 inside a row (u64 units)
     const bool writer = q == 0;
+    const uint32_t kp = (VERIFY && p.keep) ? p.keep[q] : 0xFFFFFFFFu;
     const uint32_t m_lo = min(lv.mul0 + chunk * mul_per, lv.mul1), m_hi = min(m_lo + mul_per, lv.mul1);
     const uint32_t l_lo = min(lv.mul1 + chunk * lin_per, lv.lin1), l_hi = min(l_lo + lin_per, lv.lin1);
     const uint32_t o_lo = min(lv.lin1 + chunk * oth_per, lv.oth1), o_hi = min(o_lo + oth_per, lv.oth1);
@@ -935,20 +1026,20 @@ __global__ __launch_bounds__(512, 2) void k_z64_fused(const Gate64* __restrict__
     uint32_t ld = 0;
     for (uint32_t it = 0; it < MI; it++) {
         const uint32_t gi = m_lo + (wave + 8 * it) * JW + jsub;
-        z64f_mul<QW>(gates, gi, gi < m_hi, p, rkl, q, zo, writer);
+        z64f_mul<QW, VERIFY>(gates, gi, gi < m_hi, p, rkl, q, zo, writer, kp);
         const uint32_t lend = (uint32_t)(((uint64_t)(it + 1) * LI) / MI);
         for (; ld < lend; ld++) {
             const uint32_t gl = l_lo + (l0s + ld) * JW + jsub;
 #ifndef RV_ZF_NOLIN
-            if (gl < l_hi) z64f_lin(gates[gl], p, zo, writer);
+            if (gl < l_hi) z64f_lin<VERIFY>(gates[gl], p, q, zo, writer);
 #endif
         }
     }
     for (; ld < LI; ld++) {
         const uint32_t gl = l_lo + (l0s + ld) * JW + jsub;
-        if (gl < l_hi) z64f_lin(gates[gl], p, zo, writer);
+        if (gl < l_hi) z64f_lin<VERIFY>(gates[gl], p, q, zo, writer);
     }
-    for (uint32_t go = o_lo + wave * JW + jsub; go < o_hi; go += STEP) z64f_oth(gates[go], p, q, zo, writer);
+    for (uint32_t go = o_lo + wave * JW + jsub; go < o_hi; go += STEP) z64f_oth<VERIFY>(gates[go], p, q, zo, writer);
 }
 
 bool z64_fused_supports(uint32_t NQ) { return NQ >= 16 && NQ % 16 == 0; }
@@ -976,7 +1067,10 @@ void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv
     chunks = std::max<uint64_t>(std::max(chunks, mem_chunks), 1);
     const uint32_t mul_per = (uint32_t)up((n_mul + chunks - 1) / chunks, JW), lin_per = (uint32_t)up((n_lin + chunks - 1) / chunks, JW),
                    oth_per = (uint32_t)up((n_oth + chunks - 1) / chunks, STEP);
-    hipLaunchKernelGGL(k_z64_fused<QW>, dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_gates, lv, mul_per, lin_per, oth_per, lin_bias, p);
+    if (p.omit)
+        hipLaunchKernelGGL((k_z64_fused<QW, true>), dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_gates, lv, mul_per, lin_per, oth_per, lin_bias, p);
+    else
+        hipLaunchKernelGGL((k_z64_fused<QW, false>), dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_gates, lv, mul_per, lin_per, oth_per, lin_bias, p);
 }
 
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,

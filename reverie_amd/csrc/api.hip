@@ -1250,7 +1250,8 @@ struct rv_shard {
     uint64_t* d_masks64 = nullptr;
     uint64_t* d_wmask64 = nullptr;
     uint64_t* d_wcorr64 = nullptr;
-    bool z64f = false;            // the fused Z64 prover (internal.h: Z64FParams)
+    bool z64f = false;            // the fused Z64 prover / verifier (internal.h: Z64FParams)
+    const uint32_t* d_keep64z = nullptr;  // ... the verifier's kept streams per quad word (inside a block the caller tracks)
     uint64_t* d_v64 = nullptr;    // ... its cleartext values, one per Z64 SSA id
     uint64_t* d_on64 = nullptr;
     uint64_t* d_pre64 = nullptr;
@@ -1334,8 +1335,9 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
         }
         if (s->z64f) {
             // only the Input gates' rows: a Mul's two masks come out of the interpreter's own launches
+            s->d_keep64z = s->d_keys64 ? d_keep64 : d_keep;
             for (const auto& run : s->c->z64f_runs) {
-                launch_aes_z64_masks(ctx->stream, rk64, nullptr, s->NQ, run.second, s->d_masks64 + (size_t)run.first * 2 * s->R * 8, run.first);
+                launch_aes_z64_masks(ctx->stream, rk64, s->d_keep64z, s->NQ, run.second, s->d_masks64 + (size_t)run.first * 2 * s->R * 8, run.first);
                 ctx->count(1);
             }
         } else {
@@ -1384,7 +1386,7 @@ static int shard_run_alloc(rv_shard* s, InterpParams& p, Interp64Params& p64) {
     const bool has64 = !cc.gates64.empty();
     if (has64) {
         if ((rc = dalloc(ctx, (size_t)cc.n_ssa64 * s->R * 8, &s->d_wmask64))) return rc;
-        if (s->z64f) {
+        if (s->z64f && !s->d_keys64) {  // (the fused PROVER: cleartext values; the verifier keeps per-repetition corrections)
             if ((rc = dalloc(ctx, (size_t)cc.n_ssa64, &s->d_v64))) return rc;
             HIPCHK(hipMemsetAsync(s->d_v64, 0, 8, ctx->stream));  // (SSA id 0 = the zero wire)
         } else {
@@ -2139,8 +2141,17 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
         if (has64 && cc.level_start64[l + 1] > cc.level_start64[l]) {
             if (s->z64f) {
                 Z64FParams zp{};
-                zp.rk = s->d_rk;
+                zp.rk = s->d_keys64 ? s->d_rk64 : s->d_rk;
                 zp.NQ = s->NQ;
+                if (mode == MODE_VERIFY) {
+                    zp.omit = p64.omit;
+                    zp.keep = s->d_keep64z;
+                    zp.wcorr = p64.wcorr;
+                    zp.sup_in = p64.sup_in;
+                    zp.sup_corr = p64.sup_corr;
+                    zp.sup_rec = p64.sup_rec;
+                    zp.sup_r = p64.sup_r;
+                }
                 zp.wmask = p64.wmask;
                 zp.masks = s->d_masks64;
                 zp.on = p64.on;
@@ -3910,6 +3921,12 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         ctx->count(2);
     }
     ctx->phase(-1);
+    // RV_Z64_FUSED_VERIFY=1: the verifier's Z64 half through k_z64_fused<VERIFY> as well (default: k_aes_z64_masks, then
+    // k_interp64 per level).  Off by default: its kernels take 40 ms instead of 53, and rv_verify takes the same 60 ms -- the
+    // 640 MB proof's 12 ms of PCIe and the unpack kernels used to hide beside the mask generator and now stand in front of the
+    // first level, which needs the opened repetitions' supplied values.
+    s->z64f = has64 && c->z64f_ok && z64_fused_on() && z64_fused_supports(NQ) && !ctx->pipeline && !g_recorder &&
+              getenv("RV_Z64_FUSED_VERIFY") && atoi(getenv("RV_Z64_FUSED_VERIFY")) != 0;
     if ((rc = shard_setup_prg(s, d_keep, d_keep64))) return fail(rc);
     // ---- the interpreter's stream: the proof itself (tens of MB from pageable memory: the host blocks in this
     //      copy while the mask kernels above already run) and the supplied-value rows unpacked from it

@@ -242,6 +242,15 @@ struct Z64FParams {
     uint64_t* v;         // [ssa] cleartext values
     int* err;
     uint64_t first_block;  // counter of mask rows 0, 1
+    // the verifier (omit != null): which player each repetition hides (8: none, a preprocessing-only repetition), the kept streams
+    // per quad word (k_aes_z64_masks' keep), per-repetition public corrections [ssa][R] instead of `v`, and the proof's values
+    const uint8_t* omit;
+    const uint32_t* keep;
+    uint64_t* wcorr;
+    const uint64_t* sup_in;
+    const uint64_t* sup_corr;
+    const uint64_t* sup_rec;
+    uint32_t sup_r;
 };
 bool z64_fused_supports(uint32_t NQ);
 void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p);

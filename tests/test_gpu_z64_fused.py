@@ -159,3 +159,40 @@ def test_fused_shards_vs_oracle(rv, oracle, monkeypatch, reps):
         for s in shards:
             be.destroy(s)
     assert assemble(comm, parts) == want
+
+
+@pytest.mark.parametrize("fused_verify", [1, 0])
+def test_fused_verifier_vs_oracle(rv, oracle, rule_seeds, monkeypatch, fused_verify):
+    """the verifier's Z64 half through k_z64_fused<VERIFY> (RV_Z64_FUSED_VERIFY=1; verifier/online.rs:122-183 and
+    verifier/preprocess.rs:46-79 at Z64): valid proofs, bit flips all over the proof, a program whose AssertZero fails -- strict
+    and reference-compatible answers equal the oracle's"""
+    monkeypatch.setenv("RV_Z64_FUSED_VERIFY", str(fused_verify))
+    rng = np.random.default_rng(5150)
+    for case in range(3):
+        if case == 0:
+            prog, w64, wc, _ = circuits.layered_z64(n_in=64, width=300, n_mul=2500)
+        else:
+            prog, w64, wc = random_z64(rng, n_in=2 * int(rng.integers(1, 10)), n_gates=int(rng.integers(100, 1500)), n_wires=int(rng.integers(8, 100)))
+        good = oracle.prove(prog, [], w64, wc, rule_seeds, threads=8)
+        c = rv.Circuit(prog, wc)
+        assert rv.Proof(good).verify(c) and rv.Proof(good).verify(c, strict=False)
+        for pos in rng.integers(0, len(good), 16):
+            bad = bytearray(good)
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+            for strict in (False, True):
+                try:
+                    want = (oracle.verify(prog, wc, bytes(bad), strict=strict), None)
+                except oracle.OracleError as e:
+                    want = (None, e.code)
+                try:
+                    got = (rv.Proof(bytes(bad)).verify(c, strict=strict), None)
+                except rv.ReverieError as e:
+                    got = (None, e.code)
+                assert got == want, (case, pos, strict)
+        c.close()
+        idx = np.flatnonzero((prog["domain"] == 1) & (prog["opcode"] == 5))  # SubConst feeding an AssertZero
+        if len(idx):
+            bad_prog = prog.copy()
+            bad_prog[idx[-1]]["imm"] ^= 1
+            want = (oracle.verify(bad_prog, wc, good), oracle.verify(bad_prog, wc, good, strict=True))
+            assert (rv.Proof(good).verify(bad_prog, wc, strict=False), rv.Proof(good).verify(bad_prog, wc, strict=True)) == want
