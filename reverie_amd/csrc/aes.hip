@@ -996,8 +996,8 @@ __global__ __launch_bounds__(512, 2) void k_z64_fused(const Gate64* __restrict__
                                                     uint32_t oth_per, uint32_t lin_bias, Z64FParams p) {
     __shared__ uint32_t lds_rk[11 * 128 * QW];
     constexpr uint32_t JW = 64 / QW, STEP = 8 * JW;  // gates per wavefront and per workgroup iteration
-    const uint32_t n_qg = p.NQ / QW;
-    const uint32_t qg = blockIdx.x % n_qg, chunk = blockIdx.x / n_qg;
+    const uint32_t n_qg = p.qgn;
+    const uint32_t qg = p.qg0 + blockIdx.x % n_qg, chunk = blockIdx.x / n_qg;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ql = lane % QW, jsub = lane / QW;
     const uint32_t q = qg * QW + ql;
@@ -1054,9 +1054,9 @@ void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv
     }();
     // a Mul step (cipher batch + rows) in linear steps (rows only): what the wavefronts with one Mul step more get fewer of
     static const uint32_t lin_bias = getenv("RV_Z64F_LIN_BIAS") ? (uint32_t)std::min(std::max(atoi(getenv("RV_Z64F_LIN_BIAS")), 0), 64) : 3u;  // (measured 0 / 3 / 5 / 8: 38.6 / 38.3 / 38.9 / 38.8 ms)
-    const uint32_t n_qg = p.NQ / QW;
+    const uint32_t n_qg = p.qgn;  // (quad groups of this launch)
     const uint32_t n_mul = lv.mul1 - lv.mul0, n_lin = lv.lin1 - lv.mul1, n_oth = lv.oth1 - lv.lin1;
-    if (!(n_mul + n_lin + n_oth)) return;
+    if (!(n_mul + n_lin + n_oth) || !n_qg) return;
     auto up = [](uint64_t x, uint64_t m) { return (x + m - 1) / m * m; };
     // one generation of workgroups, one per compute unit (a workgroup owns it: 88 KiB of round keys, all registers), each with
     // an equal share of the level in whole wavefront steps; a level with little cipher work still gets enough workgroups for its

@@ -1251,6 +1251,7 @@ struct rv_shard {
     uint64_t* d_wmask64 = nullptr;
     uint64_t* d_wcorr64 = nullptr;
     bool z64f = false;            // the fused Z64 prover / verifier (internal.h: Z64FParams)
+    hipEvent_t ev_sup64 = nullptr;        // ... set: the Z64 supplied values arrive on the side stream -- quad groups without an opened repetition run first
     const uint32_t* d_keep64z = nullptr;  // ... the verifier's kept streams per quad word (inside a block the caller tracks)
     uint64_t* d_v64 = nullptr;    // ... its cleartext values, one per Z64 SSA id
     uint64_t* d_on64 = nullptr;
@@ -2093,6 +2094,48 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
     ctx->phase(RV_PH_INTERP, sb);
     size_t waited = 0;  // mask chunks already waited for
     int rc_ec;
+    const uint32_t n_qg64 = s->NQ / 16;
+    auto fused_params = [&](uint32_t qg0, uint32_t qgn) {
+        Z64FParams zp{};
+        zp.rk = s->d_keys64 ? s->d_rk64 : s->d_rk;
+        zp.NQ = s->NQ;
+        zp.wmask = p64.wmask;
+        zp.masks = s->d_masks64;
+        zp.on = p64.on;
+        zp.pre = p64.pre;
+        zp.on_words = p64.on_words;
+        zp.pre_words = p64.pre_words;
+        zp.wit = p64.wit;
+        zp.v = s->d_v64;
+        zp.err = p64.err;
+        zp.first_block = 0;
+        zp.qg0 = qg0;
+        zp.qgn = qgn;
+        if (mode == MODE_VERIFY) {
+            zp.omit = p64.omit;
+            zp.keep = s->d_keep64z;
+            zp.wcorr = p64.wcorr;
+            zp.sup_in = p64.sup_in;
+            zp.sup_corr = p64.sup_corr;
+            zp.sup_rec = p64.sup_rec;
+            zp.sup_r = p64.sup_r;
+        }
+        return zp;
+    };
+    if (s->z64f && s->ev_sup64 && mode == MODE_VERIFY) {
+        // (api: rv_verify_shard_impl, split64) the quad groups without an opened repetition first, every level; then, once the
+        // supplied values are there, the first one
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) HIPCHK(hipStreamWaitEvent(sb, s->ev_sup64, 0));
+            const Z64FParams zp = pass == 0 ? fused_params(1, n_qg64 - 1) : fused_params(0, 1);
+            for (size_t l = 0; l < n_levels; l++)
+                if (cc.level_start64[l + 1] > cc.level_start64[l]) {
+                    launch_z64_fused(sb, s->c->d_gates64f, s->c->z64f_levels[l], zp);
+                    ctx->count();
+                }
+        }
+        return RV_OK;
+    }
     for (size_t l = 0; l < n_levels; l++) {
         if (s->ec && (rc_ec = early_flush(s, l))) return rc_ec;
         while (waited < s->mask_chunks.size() &&
@@ -2140,28 +2183,7 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
         }
         if (has64 && cc.level_start64[l + 1] > cc.level_start64[l]) {
             if (s->z64f) {
-                Z64FParams zp{};
-                zp.rk = s->d_keys64 ? s->d_rk64 : s->d_rk;
-                zp.NQ = s->NQ;
-                if (mode == MODE_VERIFY) {
-                    zp.omit = p64.omit;
-                    zp.keep = s->d_keep64z;
-                    zp.wcorr = p64.wcorr;
-                    zp.sup_in = p64.sup_in;
-                    zp.sup_corr = p64.sup_corr;
-                    zp.sup_rec = p64.sup_rec;
-                    zp.sup_r = p64.sup_r;
-                }
-                zp.wmask = p64.wmask;
-                zp.masks = s->d_masks64;
-                zp.on = p64.on;
-                zp.pre = p64.pre;
-                zp.on_words = p64.on_words;
-                zp.pre_words = p64.pre_words;
-                zp.wit = p64.wit;
-                zp.v = s->d_v64;
-                zp.err = p64.err;
-                zp.first_block = 0;
+                const Z64FParams zp = fused_params(0, n_qg64);
                 launch_z64_fused(sb, s->c->d_gates64f, s->c->z64f_levels[l], zp);
             } else {
                 launch_interp64(sb, mode, s->c->d_gates64, cc.level_start64[l], cc.level_start64[l + 1], p64);
@@ -3903,7 +3925,7 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     ctx->phase(RV_PH_SETUP);
     ctx->count(2);
     // (the side stream's unpack kernels read d_omit: uploaded by now)
-    hipEvent_t ev_inputs = nullptr;
+    hipEvent_t ev_inputs = nullptr, ev_inputs64 = nullptr;
     if (ev_arena) {
         ev_inputs = ctx->get_sync_event();
         s->misc_events.push_back(ev_inputs);
@@ -3919,14 +3941,19 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         launch_expand_seeds(ctx->stream, d_seeds64, R, s->d_keys64);
         launch_overlay_rows(ctx->stream, (uint32_t*)s->d_keys64, (const uint32_t*)d_hkeys64, s->d_omit64, R, 32, 1);
         ctx->count(2);
+        if (ev_arena) {
+            ev_inputs64 = ctx->get_sync_event();
+            s->misc_events.push_back(ev_inputs64);
+            HC(hipEventRecord(ev_inputs64, ctx->stream));
+        }
     }
     ctx->phase(-1);
-    // RV_Z64_FUSED_VERIFY=1: the verifier's Z64 half through k_z64_fused<VERIFY> as well (default: k_aes_z64_masks, then
-    // k_interp64 per level).  Off by default: its kernels take 40 ms instead of 53, and rv_verify takes the same 60 ms -- the
-    // 640 MB proof's 12 ms of PCIe and the unpack kernels used to hide beside the mask generator and now stand in front of the
-    // first level, which needs the opened repetitions' supplied values.
+    // The verifier's Z64 half through k_z64_fused<VERIFY> as well (RV_Z64_FUSED_VERIFY=0: k_aes_z64_masks, then k_interp64 per
+    // level).  Its kernels take 40 ms instead of 53 on the 10^6-MUL circuit; the 640 MB proof's 12 ms of PCIe and the unpack
+    // kernels, which used to hide beside the mask generator, hide beside the quad groups that hold no opened repetition (split64
+    // below): rv_verify 59.5 -> 52.5 ms.
     s->z64f = has64 && c->z64f_ok && z64_fused_on() && z64_fused_supports(NQ) && !ctx->pipeline && !g_recorder &&
-              getenv("RV_Z64_FUSED_VERIFY") && atoi(getenv("RV_Z64_FUSED_VERIFY")) != 0;
+              !(getenv("RV_Z64_FUSED_VERIFY") && atoi(getenv("RV_Z64_FUSED_VERIFY")) == 0);
     if ((rc = shard_setup_prg(s, d_keep, d_keep64))) return fail(rc);
     // ---- the interpreter's stream: the proof itself (tens of MB from pageable memory: the host blocks in this
     //      copy while the mask kernels above already run) and the supplied-value rows unpacked from it
@@ -3959,7 +3986,8 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     launch_unpack_bits(su, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in, sup_nq);
     launch_unpack_bits(su, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr, sup_nq);
     launch_unpack_bits(su, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec, sup_nq);
-    if (su != sb) {
+    const bool split64 = has64 && s->z64f && cc.gates.empty() && su != sb && ev_inputs64 && sup_r == 64 && NQ >= 32;
+    if (su != sb && !split64) {  // (split64: no GF(2) gates, nothing on the main stream reads the proof before ev_sup64)
         hipEvent_t e = ctx->get_sync_event();
         s->misc_events.push_back(e);
         HC(hipEventRecord(e, su));
@@ -3967,10 +3995,23 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     }
     Interp64Params p64{};
     if (has64) {
-        HC(hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, sb));
-        launch_unpack64(sb, d_proof, d_src64 + 4 * R, d_src64 + 5 * R, s->d_omit64, cc.n_in64, R, d_sup_in64, sup_r);
-        launch_unpack64(sb, d_proof, d_src64 + 2 * R, d_src64 + 3 * R, s->d_omit64, cc.n_corr64, R, d_sup_corr64, sup_r);
-        launch_unpack64(sb, d_proof, d_src64 + 0 * R, d_src64 + 1 * R, s->d_omit64, cc.n_rec64, R, d_sup_rec64, sup_r);
+        // The fused Z64 verifier of a pure Z64 circuit whose opened repetitions all sit in the first quad group (sup_r == 64): only
+        // that quad group's workgroups read supplied values, so the other groups' levels run at once and the proof's copy and
+        // the unpack kernels (side stream) hide beside them (shard_run_levels waits for ev_sup64 before the first group's levels)
+        hipStream_t s64 = sb;
+        if (split64) {
+            s64 = su;
+            HC(hipStreamWaitEvent(s64, ev_inputs64, 0));
+        }
+        HC(hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, s64));
+        launch_unpack64(s64, d_proof, d_src64 + 4 * R, d_src64 + 5 * R, s->d_omit64, cc.n_in64, R, d_sup_in64, sup_r);
+        launch_unpack64(s64, d_proof, d_src64 + 2 * R, d_src64 + 3 * R, s->d_omit64, cc.n_corr64, R, d_sup_corr64, sup_r);
+        launch_unpack64(s64, d_proof, d_src64 + 0 * R, d_src64 + 1 * R, s->d_omit64, cc.n_rec64, R, d_sup_rec64, sup_r);
+        if (s64 != sb) {
+            s->ev_sup64 = ctx->get_sync_event();
+            s->misc_events.push_back(s->ev_sup64);
+            HC(hipEventRecord(s->ev_sup64, s64));
+        }
         p64.omit = s->d_omit64;
         p64.sup_in = d_sup_in64;
         p64.sup_corr = d_sup_corr64;

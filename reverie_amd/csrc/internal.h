@@ -242,6 +242,7 @@ struct Z64FParams {
     uint64_t* v;         // [ssa] cleartext values
     int* err;
     uint64_t first_block;  // counter of mask rows 0, 1
+    uint32_t qg0, qgn;     // the launch covers quad groups [qg0, qg0 + qgn) of the NQ / 16 (rows of different groups never meet)
     // the verifier (omit != null): which player each repetition hides (8: none, a preprocessing-only repetition), the kept streams
     // per quad word (k_aes_z64_masks' keep), per-repetition public corrections [ssa][R] instead of `v`, and the proof's values
     const uint8_t* omit;
