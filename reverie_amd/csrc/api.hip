@@ -314,6 +314,12 @@ static int dalloc(rv_ctx* ctx, size_t count, T** out) {
     return rc;
 }
 
+// rv_prove_batch's worker contexts: worker k's main stream gets stream priority level k mod (levels of the device).  HIP deals the
+// streams of ONE priority to four hardware queues in creation order, so which of a process's streams share a queue depends on how
+// many it happened to create before -- and when the workers' main streams fell on one queue, their proofs in flight ran one after the
+// other (a bench run with 10.2 ms per proof instead of 4.9 - 5.1).  Streams of different priorities never share a queue.
+static thread_local int g_ctx_main_prio_level = -1;  // -1: default priority
+
 extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
     if (!out) return RV_E_ARG;
     *out = nullptr;
@@ -347,7 +353,13 @@ extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
     int prio_lo = 0, prio_hi = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0, (void)hipGetLastError();
     static const bool main_prio = getenv("RV_MAIN_PRIO") && atoi(getenv("RV_MAIN_PRIO")) != 0;
-    hipError_t se = main_prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t se;
+    if (g_ctx_main_prio_level >= 0 && prio_lo > prio_hi) {
+        const int levels = prio_lo - prio_hi + 1;  // (numerically lower = higher priority)
+        se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi + g_ctx_main_prio_level % levels);
+    } else {
+        se = main_prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    }
     if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     // (stream3 / stream_x -- the flat and split schedules' side streams -- are made by ctx_side_streams() when such a schedule first
     // runs: streams are dealt to the four hardware queues in creation order, so two idle ones per context put the main streams of
@@ -3359,9 +3371,12 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
             const char* e = getenv("RV_BATCH_THREADS");
             return (size_t)std::min(std::max(e ? atoi(e) : 3, 1), (int)T_MAX);
         }();
+        static const bool worker_prio = !(getenv("RV_BATCH_PRIO") && atoi(getenv("RV_BATCH_PRIO")) == 0);
         while (ctx->workers.size() < T) {
             rv_ctx* w = nullptr;
+            g_ctx_main_prio_level = worker_prio ? (int)ctx->workers.size() : -1;
             int rcw = rv_ctx_create(ctx->device, &w);
+            g_ctx_main_prio_level = -1;
             if (rcw) return rcw;
             ctx->workers.push_back(w);
         }
