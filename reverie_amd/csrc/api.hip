@@ -1264,6 +1264,7 @@ struct rv_shard {
     uint64_t* d_wcorr64 = nullptr;
     bool z64f = false;            // the fused Z64 prover / verifier (internal.h: Z64FParams)
     hipEvent_t ev_sup64 = nullptr;        // ... set: the Z64 supplied values arrive on the side stream -- quad groups without an opened repetition run first
+    std::function<int()> mid64;           // ... what brings them (the proof's copy, the unpack kernels), called once those groups' levels are queued
     const uint32_t* d_keep64z = nullptr;  // ... the verifier's kept streams per quad word (inside a block the caller tracks)
     uint64_t* d_v64 = nullptr;    // ... its cleartext values, one per Z64 SSA id
     uint64_t* d_on64 = nullptr;
@@ -2138,7 +2139,12 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
         // (api: rv_verify_shard_impl, split64) the quad groups without an opened repetition first, every level; then, once the
         // supplied values are there, the first one
         for (int pass = 0; pass < 2; pass++) {
-            if (pass == 1) HIPCHK(hipStreamWaitEvent(sb, s->ev_sup64, 0));
+            if (pass == 1) {
+                int rcm = s->mid64 ? s->mid64() : RV_OK;  // (the proof's copy and the unpack kernels, side stream)
+                s->mid64 = nullptr;
+                if (rcm) return rcm;
+                HIPCHK(hipStreamWaitEvent(sb, s->ev_sup64, 0));
+            }
             const Z64FParams zp = pass == 0 ? fused_params(1, n_qg64 - 1) : fused_params(0, 1);
             for (size_t l = 0; l < n_levels; l++)
                 if (cc.level_start64[l + 1] > cc.level_start64[l]) {
@@ -3974,13 +3980,19 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     //      copy while the mask kernels above already run) and the supplied-value rows unpacked from it
     hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
     hipStream_t su = sb;  // the stream of the GF(2) unpack kernels
-    if (!blob) {
-        // on ONE stream the copy would queue up behind the mask kernels; from the second stream it runs beside them
-        // (copy engine next to compute) and the unpack kernels wait for its event
-        static const bool side = !(getenv("RV_VERIFY_SIDE_COPY") && atoi(getenv("RV_VERIFY_SIDE_COPY")) == 0);
-        // ... and so do the GF(2) supplied-value rows (round 4): three memory-bound transposes that find room beside the
-        // VALU-bound mask generator instead of standing between it and the interpreter (RV_VERIFY_SIDE_UNPACK=0: behind it)
-        static const bool side_unpack = !(getenv("RV_VERIFY_SIDE_UNPACK") && atoi(getenv("RV_VERIFY_SIDE_UNPACK")) == 0);
+    // on ONE stream the proof's copy would queue up behind the mask kernels; from the second stream it runs beside them
+    // (copy engine next to compute) and the unpack kernels wait for its event
+    static const bool side = !(getenv("RV_VERIFY_SIDE_COPY") && atoi(getenv("RV_VERIFY_SIDE_COPY")) == 0);
+    // ... and so do the GF(2) supplied-value rows (round 4): three memory-bound transposes that find room beside the
+    // VALU-bound mask generator instead of standing between it and the interpreter (RV_VERIFY_SIDE_UNPACK=0: behind it)
+    static const bool side_unpack = !(getenv("RV_VERIFY_SIDE_UNPACK") && atoi(getenv("RV_VERIFY_SIDE_UNPACK")) == 0);
+    // The fused Z64 verifier of a pure Z64 circuit whose opened repetitions all sit in the first quad group (sup_r == 64): only
+    // that quad group's workgroups read supplied values, so the other groups' levels are queued FIRST (shard_run_levels), then the
+    // proof's copy and the unpack kernels go to the side stream and hide beside them (a copy from pageable memory blocks the host
+    // until the bytes are staged: issued up front it kept the level launches from being queued), and the first group's levels
+    // wait for ev_sup64.
+    const bool split64 = has64 && s->z64f && cc.gates.empty() && !blob && side && ev_arena && side_unpack && ev_inputs && ev_inputs64 && sup_r == 64 && NQ >= 32;
+    if (!blob && !split64) {
         hipStream_t sc = (side && ev_arena) ? ctx->stream2 : sb;
         if (sc != sb) HC(hipStreamWaitEvent(sc, ev_arena, 0));
         HC(hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, sc));
@@ -3998,34 +4010,39 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         }
     }
     if (s->ev_setup && ctx->pipeline) HC(hipStreamWaitEvent(sb, s->ev_setup, 0));  // d_omit / d_omit64 come from stream 1
-    launch_unpack_bits(su, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in, sup_nq);
-    launch_unpack_bits(su, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr, sup_nq);
-    launch_unpack_bits(su, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec, sup_nq);
-    const bool split64 = has64 && s->z64f && cc.gates.empty() && su != sb && ev_inputs64 && sup_r == 64 && NQ >= 32;
-    if (su != sb && !split64) {  // (split64: no GF(2) gates, nothing on the main stream reads the proof before ev_sup64)
-        hipEvent_t e = ctx->get_sync_event();
-        s->misc_events.push_back(e);
-        HC(hipEventRecord(e, su));
-        HC(hipStreamWaitEvent(sb, e, 0));
+    if (!split64) {  // (split64: a circuit without GF(2) gates has none of these)
+        launch_unpack_bits(su, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in, sup_nq);
+        launch_unpack_bits(su, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr, sup_nq);
+        launch_unpack_bits(su, d_proof, d_src + 0 * R, d_src + 1 * R, s->d_omit, cc.n_rec, NQ, 0, d_sup_rec, sup_nq);
+        if (su != sb) {
+            hipEvent_t e = ctx->get_sync_event();
+            s->misc_events.push_back(e);
+            HC(hipEventRecord(e, su));
+            HC(hipStreamWaitEvent(sb, e, 0));
+        }
     }
     Interp64Params p64{};
     if (has64) {
-        // The fused Z64 verifier of a pure Z64 circuit whose opened repetitions all sit in the first quad group (sup_r == 64): only
-        // that quad group's workgroups read supplied values, so the other groups' levels run at once and the proof's copy and
-        // the unpack kernels (side stream) hide beside them (shard_run_levels waits for ev_sup64 before the first group's levels)
-        hipStream_t s64 = sb;
         if (split64) {
-            s64 = su;
-            HC(hipStreamWaitEvent(s64, ev_inputs64, 0));
-        }
-        HC(hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, s64));
-        launch_unpack64(s64, d_proof, d_src64 + 4 * R, d_src64 + 5 * R, s->d_omit64, cc.n_in64, R, d_sup_in64, sup_r);
-        launch_unpack64(s64, d_proof, d_src64 + 2 * R, d_src64 + 3 * R, s->d_omit64, cc.n_corr64, R, d_sup_corr64, sup_r);
-        launch_unpack64(s64, d_proof, d_src64 + 0 * R, d_src64 + 1 * R, s->d_omit64, cc.n_rec64, R, d_sup_rec64, sup_r);
-        if (s64 != sb) {
             s->ev_sup64 = ctx->get_sync_event();
             s->misc_events.push_back(s->ev_sup64);
-            HC(hipEventRecord(s->ev_sup64, s64));
+            s->mid64 = [&, s, ctx]() -> int {
+                hipStream_t sc = ctx->stream2;
+                if (hipStreamWaitEvent(sc, ev_arena, 0) != hipSuccess || hipMemcpyAsync(d_proof, proof, proof_len, hipMemcpyHostToDevice, sc) != hipSuccess ||
+                    hipStreamWaitEvent(sc, ev_inputs64, 0) != hipSuccess ||
+                    hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, sc) != hipSuccess)
+                    return hip_fail(hipGetLastError(), "rv_verify: the proof's copy", __FILE__, __LINE__);
+                launch_unpack64(sc, d_proof, d_src64 + 4 * R, d_src64 + 5 * R, s->d_omit64, cc.n_in64, R, d_sup_in64, sup_r);
+                launch_unpack64(sc, d_proof, d_src64 + 2 * R, d_src64 + 3 * R, s->d_omit64, cc.n_corr64, R, d_sup_corr64, sup_r);
+                launch_unpack64(sc, d_proof, d_src64 + 0 * R, d_src64 + 1 * R, s->d_omit64, cc.n_rec64, R, d_sup_rec64, sup_r);
+                if (hipEventRecord(s->ev_sup64, sc) != hipSuccess) return hip_fail(hipGetLastError(), "hipEventRecord", __FILE__, __LINE__);
+                return RV_OK;
+            };
+        } else {
+            HC(hipMemcpyAsync(d_src64, src64.data(), src64.size() * 8, hipMemcpyHostToDevice, sb));
+            launch_unpack64(sb, d_proof, d_src64 + 4 * R, d_src64 + 5 * R, s->d_omit64, cc.n_in64, R, d_sup_in64, sup_r);
+            launch_unpack64(sb, d_proof, d_src64 + 2 * R, d_src64 + 3 * R, s->d_omit64, cc.n_corr64, R, d_sup_corr64, sup_r);
+            launch_unpack64(sb, d_proof, d_src64 + 0 * R, d_src64 + 1 * R, s->d_omit64, cc.n_rec64, R, d_sup_rec64, sup_r);
         }
         p64.omit = s->d_omit64;
         p64.sup_in = d_sup_in64;

@@ -12,3 +12,8 @@ ts = []
 for _ in range(4):
     t0 = time.perf_counter(); ok = proof.verify(c); ts.append(time.perf_counter() - t0)
 print("z64 verify", ok, " ".join("%.2f" % (1e3 * t) for t in ts), "ms", file=sys.stderr)
+copy = reverie_amd.Proof(bytes(proof))  # ordinary pageable memory, as a proof read from disk would be
+ts = []
+for _ in range(4):
+    t0 = time.perf_counter(); ok = copy.verify(c); ts.append(time.perf_counter() - t0)
+print("z64 verify (pageable proof)", ok, " ".join("%.2f" % (1e3 * t) for t in ts), "ms", file=sys.stderr)
