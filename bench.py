@@ -269,8 +269,8 @@ def secondary_records(ctx, seeds, quick):
     rec = {"mul_gates": st["mul"], "levels": circ.info["levels"], "proof_bytes": len(data), "ms_per_proof": dt / steps * 1e3,
            "mul_per_s": st["mul"] * steps / dt, "verifies_strict": ok, "verify_ms": tv * 1e3,
            "phase_ms": phase_ms(ctx, lambda: hp.run(2), 2),
-           "note": "host to host; the 640 MB proof alone is ~11 ms of PCIe, of which the early-corrections path (the corrections vectors of the first "
-                   "128 repetitions cross PCIe while the kernels run: csrc/api.hip) hides ~2; the prover runs the mask generator inside the "
+           "note": "host to host; the 640 MB proof alone is ~11 ms of PCIe, of which the early-corrections path (the corrections vectors of all "
+                   "256 repetitions cross PCIe in twelve chunks while the kernels run: csrc/api.hip, 2 GB of page-locked staging) hides ~5; the prover runs the mask generator inside the "
                    "interpreter's level launches (k_z64_fused, csrc/aes.hip; RV_Z64_FUSED=0 = k_aes_z64_masks then k_interp64: 26.9 + 26.4 ms); "
                    f"profiles/{PROFILE_TAG}_z64_* hold the kernel trace and the PMC traffic of both (fused: 119.2 GB and 38.5 ms per proof, "
                    "two kernels: 182 GB), DESIGN.md the analysis (2.05e9 cipher blocks at the VALU rate = 27 ms)"}

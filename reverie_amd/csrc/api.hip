@@ -1500,15 +1500,18 @@ static const EarlyPlan* early_plan(const rv_circuit* c) {
             if (getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2) {
                 r_spec = reps_env(128);
             } else {
-                const double t_window = (double)cc.gates64.size() * 10e-9 + (double)cc.n_corr64 * 6e-9;
-                // (0.65 of what the window could carry: 112 .. 176 staged repetitions of the benchmark circuit give the same proof time,
-                // 67.3 - 69.3 ms against 70.8 plain, 192 make it slower, 73.6 -- so the smaller buffer: 128 repetitions, 1.0 GB)
-                r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.65 * t_window * 55e9 / (double)vec_bytes);
+                // (~19 ns per gate of interpreter + mask generator -- fused or not --, ~6 ns per Mul of hashing)
+                const double t_window = (double)cc.gates64.size() * 19e-9 + (double)cc.n_corr64 * 6e-9;
+                // 0.9 of what the window could carry.  Round 3 staged 128 repetitions of the benchmark circuit in FOUR chunks (more
+                // made the proof slower: the last chunk, a quarter of everything, was still crossing PCIe at the challenge); in twelve
+                // chunks the last one fits the hash phase and all 256 repetitions pay: 54.4 -> 52.7 (192) -> 51.8 ms (256), proofs of
+                // both plans interleaved in one process (tools/z64_early_ab.py).  2 GB of page-locked staging instead of 1 GB.
+                r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.9 * t_window * 55e9 / (double)vec_bytes);
             }
             r_spec = std::min<uint32_t>(r_spec, RV_TOTAL_REPS) & ~7u;
             if (r_spec < 64) return;
             const uint64_t pitch = (vec_bytes + 127) & ~127ull;
-            const uint64_t K = (uint64_t)n_chunks_env;
+            const uint64_t K = getenv("RV_EARLY_CHUNKS") ? (uint64_t)n_chunks_env : 12;  // (Z64: twelve chunks unless told otherwise)
             const uint64_t per = ((vec_bytes + K - 1) / K + 127) & ~127ull;
             for (uint64_t b0 = 0; b0 < vec_bytes; b0 += per) {
                 EarlyPlan::Chunk ch{};
