@@ -175,7 +175,12 @@ int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
  *          proof/mod.rs:131-134).  NULL => drawn from the OS (getrandom).
  * *proof:  bincode(Proof), allocated by the library, released with rv_free.  Proofs of a megabyte and more come in
  *          page-locked memory from a small process-wide pool (the device-to-host copy runs at PCIe rate and
- *          rv_free recycles the buffer for the next proof); the pointer is ordinary readable/writable host memory. */
+ *          rv_free recycles the buffer for the next proof); the pointer is ordinary readable/writable host memory.
+ * Memory the call leaves on the context (kept for the next proof, released by rv_ctx_destroy): the device arena's cached blocks
+ *          (rv_circuit_info::scratch_bytes), and -- for circuits that take the early-corrections path, pure GF(2) with >= 2^21
+ *          Mul gates or pure Z64 with >= 2^17 -- page-locked staging of rv_circuit_info::early_staging_bytes (160 MB for the
+ *          10^7-gate GF(2) benchmark circuit, 2 GB for the 10^6-MUL Z64 one; its first mapping costs 0.15 - 1.5 s inside the first
+ *          such proof) plus as much device memory for GF(2); RV_EARLY=0 in the environment proves without it. */
 int rv_prove(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64,
              size_t n_z64, const uint8_t *seeds, uint8_t **proof, size_t *proof_len);
 
