@@ -318,9 +318,10 @@ static int dalloc(rv_ctx* ctx, size_t count, T** out) {
 // streams of ONE priority to four hardware queues in creation order, so which of a process's streams share a queue depends on how
 // many it happened to create before -- and when the workers' main streams fell on one queue, their proofs in flight ran one after the
 // other (a bench run with 10.2 ms per proof instead of 4.9 - 5.1).  Streams of different priorities never share a queue.
-static thread_local int g_ctx_main_prio_level = -1;  // -1: default priority
+static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level /* -1: default priority */);
+extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) { return ctx_create_impl(device_ordinal, out, -1); }
 
-extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
+static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level) {
     if (!out) return RV_E_ARG;
     *out = nullptr;
     int n = 0;
@@ -354,9 +355,9 @@ extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) {
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0, (void)hipGetLastError();
     static const bool main_prio = getenv("RV_MAIN_PRIO") && atoi(getenv("RV_MAIN_PRIO")) != 0;
     hipError_t se;
-    if (g_ctx_main_prio_level >= 0 && prio_lo > prio_hi) {
+    if (main_prio_level >= 0 && prio_lo > prio_hi) {
         const int levels = prio_lo - prio_hi + 1;  // (numerically lower = higher priority)
-        se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi + g_ctx_main_prio_level % levels);
+        se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi + main_prio_level % levels);
     } else {
         se = main_prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     }
@@ -3383,9 +3384,7 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
         static const bool worker_prio = !(getenv("RV_BATCH_PRIO") && atoi(getenv("RV_BATCH_PRIO")) == 0);
         while (ctx->workers.size() < T) {
             rv_ctx* w = nullptr;
-            g_ctx_main_prio_level = worker_prio ? (int)ctx->workers.size() : -1;
-            int rcw = rv_ctx_create(ctx->device, &w);
-            g_ctx_main_prio_level = -1;
+            int rcw = ctx_create_impl(ctx->device, &w, worker_prio ? (int)ctx->workers.size() : -1);
             if (rcw) return rcw;
             ctx->workers.push_back(w);
         }
