@@ -1,0 +1,400 @@
+// AES-128-CTR share expansion, lane-distributed form ("col4") for gfx950.
+//
+// Replaces the same reference code as k_aes_gf2_masks (aes.hip): crypto/prg.rs:16-37 (PRG::gen), generator/batch.rs:13-40,
+// generator/share.rs:54-65 (the ShareGen refill) and algebra/gf2/domain.rs:66-378 (batches_to_shares), all under
+// /root/reference/src/ -- and writes the identical masks[(j*128 + b)*NQ + q] rows.
+//
+// k_aes_gf2_masks keeps a whole bitsliced state in ONE lane: 128 planes + a column of temporaries = 256 VGPRs, two wavefronts per
+// SIMD, a compute unit per workgroup -- nothing else fits beside it, which is why every attempt to run the VALU-bound cipher
+// next to the latency-bound interpreter failed (rounds 2 - 4).  Here a QUAD of lanes holds one state:
+//   lane c of the quad = state column c = 4 bytes x 8 bit planes = 32 VGPRs (32 slots per word, as before)
+//   SubBytes    lane-local: the 74-op cover of aes_sbox.inc, four times
+//   MixColumns  lane-local: a column is a lane; plane by plane over the four rows, in place
+//   ShiftRows   folded into AddRoundKey: the state is kept SHIFTED (y_i = ShiftRows(x_i); SubBytes commutes with it), so a round
+//               ends with y[row r] = quad_perm_r(t[row r]) ^ srk[row r] -- ONE v_xor_b32_dpp per word, round keys stored pre-shifted
+// 417 VALU instructions per lane and round = 104 per byte (the 128-plane form: 101), 80 VGPRs instead of 256.
+// Output: the wavefront's lanes are (quad ql, column c) = 4*ql + c; a ds_bpermute per word regroups them as 16*c + ql so that
+// sixteen consecutive lanes store 64 contiguous bytes of one mask row, like k_aes_gf2_masks (without it the stores cost 20 %).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "internal.h"
+#include "launch.h"
+
+namespace rv {
+
+#define XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+
+__device__ __forceinline__ void c4_sbox8(uint32_t& b7, uint32_t& b6, uint32_t& b5, uint32_t& b4, uint32_t& b3, uint32_t& b2, uint32_t& b1,
+                                         uint32_t& b0) {
+    const uint32_t U0 = b7, U1 = b6, U2 = b5, U3 = b4, U4 = b3, U5 = b2, U6 = b1, U7 = b0;
+#include "aes_sbox.inc"
+    b7 = S0;
+    b6 = S1;
+    b5 = S2;
+    b4 = S3;
+    b3 = S4;
+    b2 = S5;
+    b1 = S6;
+    b0 = S7;
+}
+
+// quad_perm_R(t) ^ k: lane c of every quad reads lane (c + R) & 3.  The builtin folds into one v_xor_b32_dpp and the compiler
+// keeps the VALU-write -> DPP-read distance (inline assembly would hide the hazard from it).
+template <int R>
+__device__ __forceinline__ uint32_t c4_shift_xor(uint32_t t, uint32_t k) {
+    if (R == 0) return t ^ k;
+    constexpr int ctrl = R == 1 ? 0x39 : (R == 2 ? 0x4E : 0x93);  // quad_perm:[R, R+1, R+2, R+3] mod 4
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, ctrl, 0xf, 0xf, true) ^ k;
+}
+
+constexpr uint32_t C4_AREAS = 11;                      // srk0 .. srk9 (pre-shifted), rk10
+constexpr uint32_t C4_IMG_U4 = C4_AREAS * 8 * 64;      // uint4 per group of 16 quad words: [area][plane][lane] -> rows 0..3
+constexpr uint32_t C4_LDS_BYTES = C4_IMG_U4 * 16;      // 88 KiB
+
+// the key image of one group of 16 quad words, from the plane-major round keys of k_bitslice_rk (areas 0..10 = rk0..rk10,
+// 11 / 12 = the first-round constants: internal.h RK_BYTES):
+// img[((qg*11 + area)*8 + k)*64 + lane].row = plane k of a key byte of quad 16*qg + ql, lane = 4*ql + c:
+//   areas 2..9  round key byte (row, (c + row) & 3): pre-shifted, the state is kept shifted
+//   area 10     round key byte (row, c): the last AddRoundKey meets the state unshifted
+//   area 1      K1 byte (row, (c + row) & 3): round-1 output with S(state bytes 13..15) taken as zero, shifted
+//   area 0      .x only: rk0 byte 15 - c, the ONE byte of the lane's column that meets the counter (c < 3)
+__global__ void k_rk_col4(const uint32_t* __restrict__ rk, uint32_t NQ, uint32_t* __restrict__ img) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = (NQ / 16) * C4_IMG_U4 * 4;
+    if (t >= n) return;
+    const uint32_t row = t & 3, lane = (t >> 2) & 63, k = (t >> 8) & 7, area = (t >> 11) % C4_AREAS, qg = (t >> 11) / C4_AREAS;
+    const uint32_t ql = lane >> 2, c = lane & 3;
+    uint32_t ga = area, byte = 4 * ((c + row) & 3) + row;
+    if (area == 10) byte = 4 * c + row;
+    if (area == 1) ga = 12;
+    if (area == 0) {
+        ga = 11;
+        byte = 15 - c;
+        if (row != 0 || c == 3) {
+            img[t] = 0;
+            return;
+        }
+    }
+    img[t] = rk[(size_t)(ga * 128 + 8 * byte + k) * NQ + 16 * qg + ql];
+}
+
+// one middle round on the shifted state: s = ShiftRows(MixColumns(SubBytes(s))) ^ srk.  MixColumns plane by plane:
+// out_r[k] = d_r[k-1] ^ all[k] ^ a_r[k] (^ d_r[7] for k = 1, 3, 4; d_r[-1] = d_r[7]) with d_r = a_r ^ a_(r+1), all = a_0^a_1^a_2^a_3:
+// beside the state only d[7], d[k-1], d[k] and the plane's four key words are live
+__device__ __forceinline__ void c4_round(uint32_t* s, const uint4* rk4 /* lds + area*8*64 + lane */) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        c4_sbox8(s[8 * r + 7], s[8 * r + 6], s[8 * r + 5], s[8 * r + 4], s[8 * r + 3], s[8 * r + 2], s[8 * r + 1], s[8 * r + 0]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    uint32_t d7[4], prev[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) prev[r] = d7[r] = s[8 * r + 7] ^ s[8 * ((r + 1) & 3) + 7];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint4 kv = rk4[k * 64];
+        uint32_t cur[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) cur[r] = k == 7 ? d7[r] : (s[8 * r + k] ^ s[8 * ((r + 1) & 3) + k]);
+        const uint32_t all = cur[0] ^ cur[2];
+        uint32_t t[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            t[r] = XOR3(prev[r], all, s[8 * r + k]);
+            if (k == 1 || k == 3 || k == 4) t[r] ^= d7[r];
+        }
+        s[k] = t[0] ^ kv.x;
+        s[8 + k] = c4_shift_xor<1>(t[1], kv.y);
+        s[16 + k] = c4_shift_xor<2>(t[2], kv.z);
+        s[24 + k] = c4_shift_xor<3>(t[3], kv.w);
+#pragma unroll
+        for (int r = 0; r < 4; r++) prev[r] = cur[r];
+    }
+}
+
+// Rounds 0 and 1 of CTR block j (< 2^24) into the shifted state s.  Only state bytes 13..15 meet the counter; in the shifted state
+// lane c (< 3) holds exactly one of them, byte 15 - c, in row r0 = 3 - c.  Everything else of round 1 is a constant of the key
+// (K1, image area 1), and MixColumns is linear: the lane runs ONE S-box, v = S(rk0[15 - c] ^ counter byte c), and adds its
+// column's share 2v / 3v / v / v (rows r0, r0 - 1, the other two) -- 197 instructions instead of a full round's 417.
+__device__ __forceinline__ void c4_rounds_0_1(uint32_t j, uint32_t c, const uint4* rkl, uint32_t* s) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = rkl[k * 64].x ^ (uint32_t)__builtin_amdgcn_sbfe((int)j, 8 * c + k, 1);
+    c4_sbox8(v[7], v[6], v[5], v[4], v[3], v[2], v[1], v[0]);
+    // e[r] = all ones in the lanes whose counter byte sits in row r (r0 = 3 - c); made here, per block, from an opaque copy of c:
+    // hoisted out of the block loop the four masks would sit in registers the rounds need (selects on c itself compile to branches)
+    uint32_t co = c;
+    asm volatile("" : "+v"(co));
+    uint32_t e[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) e[r] = co == (uint32_t)(3 - r) ? ~0u : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] &= ~e[0];  // column 3 holds no counter byte: v = 0 there (e[0] marks c == 3)
+    const uint32_t x[8] = {v[7], v[0] ^ v[7], v[1], v[2] ^ v[7], v[3] ^ v[7], v[4], v[5], v[6]};  // xtime(v)
+    const uint4* k1 = rkl + 8 * 64;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint4 kv = k1[k * 64];
+        // row r of the lane's column gets 2v = x where e[r], 3v = x ^ v where e[r + 1], v elsewhere: two 3-input LUTs per word
+        uint32_t t[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t sel = __builtin_amdgcn_bitop3_b32(e[r], x[k], v[k], 0xca);        // e ? x : v
+            t[r] = __builtin_amdgcn_bitop3_b32(sel, x[k], e[(r + 1) & 3], 0x78);             // sel ^ (x & e')
+        }
+        s[k] = t[0] ^ kv.x;
+        s[8 + k] = c4_shift_xor<1>(t[1], kv.y);
+        s[16 + k] = c4_shift_xor<2>(t[2], kv.z);
+        s[24 + k] = c4_shift_xor<3>(t[3], kv.w);
+    }
+}
+
+// Which (quad group, block range) a workgroup takes.  The n_qg workgroups of one block range write the n_qg 64-byte pieces of the
+// SAME mask rows; with xcd_map they sit on the same XCD (workgroups go round-robin over the eight XCDs: blockIdx % 8), so the pieces
+// meet in ONE L2 and leave it as whole lines instead of as four partial writes from four L2s (the grid is a multiple of 8 * n_qg)
+__device__ __forceinline__ void c4_place(uint32_t n_qg, int xcd_map, uint32_t& qg, uint64_t& chunk) {
+    if (xcd_map) {
+        const uint32_t in = blockIdx.x % (8 * n_qg);
+        qg = in / 8;
+        chunk = (uint64_t)(blockIdx.x / (8 * n_qg)) * 8 + in % 8;
+    } else {
+        qg = blockIdx.x % n_qg;
+        chunk = blockIdx.x / n_qg;
+    }
+}
+
+// A workgroup = 16 quad words (their key image in LDS for its lifetime) x a range of CTR blocks; a wavefront = one CTR block of
+// the 16 quads per trip.  WAVES wavefronts of 80 registers: with 8 the workgroup leaves three quarters of every SIMD's register
+// file and all of its other wavefront slots to whatever else is resident (the interpreter's level launches: api.hip, RV_OVERLAP).
+template <int WAVES, int WPE, int NT /* 1: nontemporal stores, 2: timing probe without stores */>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_aes_gf2_masks_col4(
+    const uint4* __restrict__ img, const uint32_t* __restrict__ keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks, uint32_t blocks_per_wg,
+    uint32_t* __restrict__ masks, int xcd_map) {
+    extern __shared__ uint4 c4_lds[];  // C4_IMG_U4 (dynamic: a static 88 KiB would make the compiler size the register budget for 2 waves)
+    const uint32_t n_qg = NQ / 16;
+    uint32_t qg;
+    uint64_t chunk;
+    c4_place(n_qg, xcd_map, qg, chunk);
+    {
+        const uint4* src = img + (size_t)qg * C4_IMG_U4;
+        constexpr uint32_t T = WAVES * 64, FULL = C4_IMG_U4 / T, REST = C4_IMG_U4 % T;
+        uint4 v[FULL];
+#pragma unroll
+        for (uint32_t i = 0; i < FULL; i++) v[i] = src[threadIdx.x + i * T];
+#pragma unroll
+        for (uint32_t i = 0; i < FULL; i++) c4_lds[threadIdx.x + i * T] = v[i];
+        if (REST != 0 && threadIdx.x < REST) c4_lds[threadIdx.x + FULL * T] = src[threadIdx.x + FULL * T];
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t c = lane & 3;
+    const uint4* rkl = c4_lds + lane;
+    // after the regrouping a lane stores for (column cs, quad qs)
+    const uint32_t cs = lane >> 4, qs = qg * 16 + (lane & 15);
+    const uint32_t from = 4 * (4 * (lane & 15) + cs);  // ds_bpermute address of source lane 4*ql + c
+    const uint32_t kp = keep ? keep[qs] : 0xFFFFFFFFu;
+    const uint64_t j_lo = chunk * blocks_per_wg;
+    const uint64_t j_hi = (j_lo + blocks_per_wg < n_blocks) ? j_lo + blocks_per_wg : n_blocks;
+    for (uint64_t jl = j_lo + wave; jl < j_hi; jl += WAVES) {
+        const uint32_t j = (uint32_t)(first_block + jl);
+        uint32_t s[32];
+        c4_rounds_0_1(j, c, rkl, s);
+#pragma unroll 1
+        for (int r = 2; r < 10; r++) c4_round(s, rkl + r * 8 * 64);
+        // last round: SubBytes (the state is shifted already), AddRoundKey
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            c4_sbox8(s[8 * r + 7], s[8 * r + 6], s[8 * r + 5], s[8 * r + 4], s[8 * r + 3], s[8 * r + 2], s[8 * r + 1], s[8 * r + 0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // keystream bit order is MSB-first inside each byte (gf2/domain.rs: share 8i+j <- bit 7-j of byte i): byte 4*cs + r, plane k
+        // -> mask index 8*(4*cs + r) + 7 - k
+        // (NT == 3, timing probe: every block lands in the same 8 MiB, which never leaves the caches)
+        uint32_t* out = masks + ((size_t)(NT == 3 ? (jl & 255) : jl) * 128 + 32 * cs) * NQ + qs;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint4 kv = rkl[(10 * 8 + k) * 64];
+            const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from, (int)(s[8 * r + k] ^ kw[r]));
+                if (NT == 2) {
+                    if ((o & kp) == 0x9e3779b9u && k == 7 && r == 3) out[0] = o;  // (timing probe: the cipher without its stores)
+                } else if (NT == 1)
+                    __builtin_nontemporal_store(o & kp, &out[(size_t)(8 * r + (7 - k)) * NQ]);
+                else
+                    out[(size_t)(8 * r + (7 - k)) * NQ] = o & kp;
+            }
+        }
+    }
+}
+
+// The same generator with its stores taken off the cipher wavefronts.  Beside the interpreter's level launches (RV_OVERLAP) the
+// compute unit's vector-memory queue is full of the levels' row gathers, and a cipher wavefront that has to push 32 store
+// instructions through it per block stands still for a third of its time (measured: masks + interpreter 3.25 ms with the stores,
+// 2.64 without).  Here a cipher wavefront writes its block -- 128 rows x 64 bytes -- into an LDS tile of its own and goes on; a NINTH
+// wavefront drains the tiles with 16-byte stores (8 instructions per block instead of 32) and is the only one that ever waits for
+// the memory pipeline.  Tile word (4*t + c)*16 + (ql ^ 8*(c >> 1)) holds mask row 32*c + t of quad ql: conflict-free for the
+// writers (lane = 4*ql + c) and for the drain's ds_read_b128.  One flag per tile: 0 = free, 1 = full (LDS operations of one
+// wavefront execute in order, so the flag follows the tile's words and the drain's release follows its reads).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t C4S_TILE_WORDS = 128 * 16;
+constexpr uint32_t C4S_LDS_BYTES = C4_LDS_BYTES + 8 * C4S_TILE_WORDS * 4 + 64;
+template <int NT>
+__global__ __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_aes_gf2_masks_col4s(
+    const uint4* __restrict__ img, const uint32_t* __restrict__ keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks, uint32_t blocks_per_wg,
+    uint32_t* __restrict__ masks, int xcd_map) {
+    extern __shared__ uint4 c4_lds[];
+    uint32_t* tiles = (uint32_t*)(c4_lds + C4_IMG_U4);
+    int* flags = (int*)(tiles + 8 * C4S_TILE_WORDS);
+    const uint32_t n_qg = NQ / 16;
+    uint32_t qg;
+    uint64_t chunk;
+    c4_place(n_qg, xcd_map, qg, chunk);
+    {
+        const uint4* src = img + (size_t)qg * C4_IMG_U4;
+        constexpr uint32_t T = 576, FULL = C4_IMG_U4 / T, REST = C4_IMG_U4 % T;
+        uint4 v[FULL];
+#pragma unroll
+        for (uint32_t i = 0; i < FULL; i++) v[i] = src[threadIdx.x + i * T];
+#pragma unroll
+        for (uint32_t i = 0; i < FULL; i++) c4_lds[threadIdx.x + i * T] = v[i];
+        if (REST != 0 && threadIdx.x < REST) c4_lds[threadIdx.x + FULL * T] = src[threadIdx.x + FULL * T];
+        if (threadIdx.x < 8) flags[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t j_lo = chunk * blocks_per_wg;
+    const uint64_t j_hi = (j_lo + blocks_per_wg < n_blocks) ? j_lo + blocks_per_wg : n_blocks;
+    if (wave == 8) {
+        __builtin_amdgcn_s_setprio(3);  // (a handful of instructions per block, all of them on the way to the memory pipeline)
+        // the drain: lane = (row slot L >> 2 of sixteen, piece g = L & 3 of four quad words); slot = 16*i + (L >> 2) = 4*t + c
+        const uint32_t g = lane & 3, c = (lane >> 2) & 3, t0 = lane >> 4;
+        const uint32_t rd = (lane >> 2) * 16 + 4 * (g ^ (2 * (c >> 1)));  // + i * 256 words
+        uint32_t* out0 = masks + (size_t)(32 * c + t0) * NQ + qg * 16 + 4 * g;  // + (jl * 128 + 4 * i) * NQ
+        for (uint64_t j0 = j_lo; j0 < j_hi; j0 += 8) {
+            for (uint32_t w = 0; w < 8 && j0 + w < j_hi; w++) {
+                while (__hip_atomic_load(&flags[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 1) __builtin_amdgcn_s_sleep(2);
+                const uint32_t* tile = tiles + w * C4S_TILE_WORDS + rd;
+                uint4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = *(const uint4*)(tile + i * 256);
+                __hip_atomic_store(&flags[w], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                uint32_t* out = out0 + (size_t)(j0 + w) * 128 * NQ;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (NT == 1)
+                        __builtin_nontemporal_store(u32x4{v[i].x, v[i].y, v[i].z, v[i].w}, (u32x4*)(out + (size_t)(4 * i) * NQ));
+                    else
+                        *(uint4*)(out + (size_t)(4 * i) * NQ) = v[i];
+                }
+            }
+        }
+        return;
+    }
+    const uint32_t c = lane & 3, ql = lane >> 2;
+    const uint4* rkl = c4_lds + lane;
+    const uint32_t kp = keep ? keep[qg * 16 + ql] : 0xFFFFFFFFu;
+    uint32_t* tile = tiles + wave * C4S_TILE_WORDS + c * 16 + (ql ^ (8 * (c >> 1)));  // + 64 * t words
+    for (uint64_t jl = j_lo + wave; jl < j_hi; jl += 8) {
+        const uint32_t j = (uint32_t)(first_block + jl);
+        uint32_t s[32];
+        c4_rounds_0_1(j, c, rkl, s);
+#pragma unroll 1
+        for (int r = 2; r < 10; r++) c4_round(s, rkl + r * 8 * 64);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            c4_sbox8(s[8 * r + 7], s[8 * r + 6], s[8 * r + 5], s[8 * r + 4], s[8 * r + 3], s[8 * r + 2], s[8 * r + 1], s[8 * r + 0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        while (__hip_atomic_load(&flags[wave], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) __builtin_amdgcn_s_sleep(1);
+        // byte 4*c + r, plane k -> mask row 8*(4*c + r) + 7 - k = 32*c + t, t = 8*r + 7 - k (gf2/domain.rs: MSB first inside a byte)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint4 kv = rkl[(10 * 8 + k) * 64];
+            const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) tile[64 * (8 * r + 7 - k)] = (s[8 * r + k] ^ kw[r]) & kp;
+        }
+        __hip_atomic_store(&flags[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+bool aes_col4_supports(uint32_t NQ) { return NQ % 16 == 0; }
+size_t aes_col4_image_bytes(uint32_t NQ) { return (size_t)(NQ / 16) * C4_LDS_BYTES; }
+
+void launch_rk_col4(hipStream_t st, const uint32_t* d_rk, uint32_t NQ, uint32_t* d_img) {
+    const uint32_t n = (NQ / 16) * C4_IMG_U4 * 4;
+    hipLaunchKernelGGL(k_rk_col4, dim3((n + 255) / 256), dim3(256), 0, st, d_rk, NQ, d_img);
+}
+
+template <int WAVES, int WPE, int NT>
+static void launch_c4(hipStream_t st, const uint32_t* d_img, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks, uint32_t* d_masks,
+                      uint64_t target_wgs) {
+    // (per device: the attribute belongs to the function ON the current device)
+    static bool raised[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute((const void*)k_aes_gf2_masks_col4<WAVES, WPE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4_LDS_BYTES);
+        raised[dev] = true;
+    }
+    const uint32_t n_qg = NQ / 16;
+    uint64_t per = (n_blocks * n_qg + target_wgs - 1) / target_wgs;
+    per = (per + WAVES - 1) / WAVES * WAVES;
+    static const int xcd_map = getenv("RV_C4_XCD") ? atoi(getenv("RV_C4_XCD")) : 1;
+    uint64_t chunks = (n_blocks + per - 1) / per;
+    if (xcd_map) chunks = (chunks + 7) / 8 * 8;  // (workgroups past the end find an empty range)
+    hipLaunchKernelGGL((k_aes_gf2_masks_col4<WAVES, WPE, NT>), dim3((unsigned)(chunks * n_qg)), dim3(WAVES * 64), C4_LDS_BYTES, st, (const uint4*)d_img, d_keep, NQ,
+                       first_block, n_blocks, (uint32_t)per, d_masks, xcd_map);
+}
+
+void launch_aes_gf2_masks_col4(hipStream_t st, const uint32_t* d_img, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks,
+                               uint32_t* d_masks) {
+    if (!n_blocks) return;
+    static const uint64_t target_wgs = [] {
+        if (const char* e = getenv("RV_AES_WGS")) return (uint64_t)std::max(atoi(e), 1);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return (uint64_t)cus;
+    }();
+    // experiment knobs (round 5): wavefronts per workgroup, 64-register build, nontemporal stores
+    static const int waves = getenv("RV_C4_WAVES") ? atoi(getenv("RV_C4_WAVES")) : 8;
+    static const int r64 = getenv("RV_C4_R64") ? atoi(getenv("RV_C4_R64")) : 0;
+    static const int nt = getenv("RV_C4_NT") ? atoi(getenv("RV_C4_NT")) : 0;
+    static const int sw = getenv("RV_C4_STOREWAVE") ? atoi(getenv("RV_C4_STOREWAVE")) : 1;
+    if (sw) {
+        static bool raised[64] = {false};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !raised[dev]) {
+            (void)hipFuncSetAttribute((const void*)k_aes_gf2_masks_col4s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4S_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)k_aes_gf2_masks_col4s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4S_LDS_BYTES);
+            raised[dev] = true;
+        }
+        const uint32_t n_qg = NQ / 16;
+        uint64_t per = (n_blocks * n_qg + target_wgs - 1) / target_wgs;
+        per = (per + 7) / 8 * 8;
+        static const int xcd_map = getenv("RV_C4_XCD") ? atoi(getenv("RV_C4_XCD")) : 1;
+        uint64_t chunks = (n_blocks + per - 1) / per;
+        if (xcd_map) chunks = (chunks + 7) / 8 * 8;
+        if (nt)
+            hipLaunchKernelGGL((k_aes_gf2_masks_col4s<1>), dim3((unsigned)(chunks * n_qg)), dim3(576), C4S_LDS_BYTES, st, (const uint4*)d_img, d_keep, NQ, first_block,
+                               n_blocks, (uint32_t)per, d_masks, xcd_map);
+        else
+            hipLaunchKernelGGL((k_aes_gf2_masks_col4s<0>), dim3((unsigned)(chunks * n_qg)), dim3(576), C4S_LDS_BYTES, st, (const uint4*)d_img, d_keep, NQ, first_block,
+                               n_blocks, (uint32_t)per, d_masks, xcd_map);
+        return;
+    }
+#define C4_GO(W, E, N) launch_c4<W, E, N>(st, d_img, d_keep, NQ, first_block, n_blocks, d_masks, target_wgs)
+    if (waves == 16) nt ? C4_GO(16, 6, 1) : C4_GO(16, 6, 0);
+    else if (r64) nt ? C4_GO(8, 8, 1) : C4_GO(8, 8, 0);
+    else if (nt == 2) C4_GO(8, 6, 2);
+    else if (nt == 3) C4_GO(8, 6, 3);
+    else nt ? C4_GO(8, 6, 1) : C4_GO(8, 6, 0);
+#undef C4_GO
+}
+
+}  // namespace rv

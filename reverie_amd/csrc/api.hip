@@ -141,6 +141,7 @@ struct rv_ctx {
     hipStream_t stream2 = nullptr;  // the interpreter (HBM-bound), pipelined against the mask generator
     hipStream_t stream3 = nullptr;  // the flat schedule's cleartext pass (k_clear), beside the mask generator
     hipStream_t stream_x = nullptr; // the flat schedule's XOR rows, running ahead of the Mul launches on `stream`
+    hipStream_t stream_m = nullptr; // RV_OVERLAP: the lane-distributed mask generator, beside the interpreter's level launches (made on first use)
     hipEvent_t clear_a = nullptr, clear_b = nullptr;  // profiling: around k_clear on stream3 (rv_profile slot RV_PH_CLEAR)
     bool clear_timed = false;
     std::vector<rv_ctx*> workers;            // rv_prove_batch on large circuits: one worker context per host thread
@@ -397,6 +398,7 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     if (ctx->stream_x) (void)hipStreamSynchronize(ctx->stream_x);
+    if (ctx->stream_m) (void)hipStreamSynchronize(ctx->stream_m);
     ctx->trim();
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -414,6 +416,7 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream_x) (void)hipStreamDestroy(ctx->stream_x);
+    if (ctx->stream_m) (void)hipStreamDestroy(ctx->stream_m);
     if (ctx->clear_a) (void)hipEventDestroy(ctx->clear_a);
     if (ctx->clear_b) (void)hipEventDestroy(ctx->clear_b);
     delete ctx;
@@ -1239,6 +1242,12 @@ struct rv_shard {
     uint8_t* d_rkbytes = nullptr;
     uint32_t* d_rk = nullptr;
     uint32_t* d_masks = nullptr;  // share rows: PRG masks, then computed rows
+    uint32_t* d_rk_c4 = nullptr;  // the lane-distributed generator's key image (aes_col4.hip), when it is the one that runs
+    // RV_OVERLAP: the generator runs chunk by chunk on ctx->stream_m BESIDE the level launches; a chunk is submitted (and its event
+    // waited for on the main stream) right before the first level that reads it -- see overlap_need()
+    bool overlap = false;
+    uint64_t ov_next = 0, ov_blocks = 0, ov_chunk = 0;  // next block to generate, all of them, blocks per chunk
+    const uint32_t* ov_keep = nullptr;
     uint8_t* d_wires = nullptr;   // corr bits [n_ssa][NQ/2]
     uint32_t* d_on = nullptr;
     uint8_t* d_pre = nullptr;     // [n_pre][NQ/2]
@@ -1301,7 +1310,7 @@ struct rv_shard {
         ev_clear = nullptr;
         void* ps[] = {d_seeds, d_keys, d_rkbytes, d_rk,    d_masks,  d_wires,   d_on,     d_pre,    d_wit,  d_cv[0],
                       d_cv[1], d_dig,  d_h,       d_err,   d_omit,   d_offs,    d_out,    d_masks64, d_wmask64,
-                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr, d_vb, d_sync, d_cvx, d_v64};
+                      d_wcorr64, d_on64, d_pre64, d_wit64, d_keys64, d_rk64,    d_omit64, d_masks_rep, d_on_rep, d_pre_rep, d_vbits, d_rk_rep, d_vclr, d_vb, d_sync, d_cvx, d_v64, d_rk_c4};
         for (void* p : ps) ctx->release(p);
         for (void* p : extra) ctx->release(p);
     }
@@ -1313,6 +1322,7 @@ extern "C" void rv_shard_destroy(rv_shard* s) {
     // work forked onto the second stream (the verifier's side copy of the proof, the two-stream pipeline): its buffers go back to
     // the arena below and the caller's host buffers leave scope -- nothing of it may still be in flight
     if (!s->misc_events.empty() || !s->mask_chunks.empty() || s->ev_setup || s->ec) (void)hipStreamSynchronize(s->ctx->stream2);
+    if (s->overlap && s->ctx->stream_m) (void)hipStreamSynchronize(s->ctx->stream_m);
     if (s->ev_clear || s->split) {
         if (s->ctx->stream3) (void)hipStreamSynchronize(s->ctx->stream3);
         if (s->ctx->stream_x) (void)hipStreamSynchronize(s->ctx->stream_x);
@@ -1321,6 +1331,28 @@ extern "C" void rv_shard_destroy(rv_shard* s) {
     delete s;
 }
 
+struct OvTrace {  // RV_OV_TRACE=1: timing events around every chunk and every group of levels, printed by overlap_trace_dump
+    std::vector<std::pair<std::string, hipEvent_t>> ev;
+    void mark(const char* what, uint64_t n, hipStream_t st) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, st);
+        ev.emplace_back(std::string(what) + " " + std::to_string(n), e);
+    }
+};
+static thread_local OvTrace* g_ov_trace = nullptr;
+static void overlap_trace_dump() {
+    if (!g_ov_trace) return;
+    for (auto& kv : g_ov_trace->ev) {
+        float ms = 0;
+        (void)hipEventSynchronize(kv.second);
+        (void)hipEventElapsedTime(&ms, g_ov_trace->ev[0].second, kv.second);
+        fprintf(stderr, "[ov] %9.1f us  %s\n", ms * 1e3, kv.first.c_str());
+    }
+    for (auto& kv : g_ov_trace->ev) (void)hipEventDestroy(kv.second);
+    delete g_ov_trace;
+    g_ov_trace = nullptr;
+}
 // key material -> bitsliced round keys, masks
 static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* d_keep64 = nullptr) {
     rv_ctx* ctx = s->ctx;
@@ -1340,6 +1372,19 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
     launch_key_schedule(ctx->stream, s->d_keys, s->R * 8, s->d_rkbytes);
     launch_bitslice_rk(ctx->stream, s->d_rkbytes, s->NQ, s->d_rk);
     ctx->count(2);
+    // which GF(2) generator: the lane-distributed one (aes_col4.hip) whenever it is to share the chip with the level launches
+    // (RV_OVERLAP), or on request (RV_AES_COL4=1); recorded batches keep the 128-plane kernel (its launch is replayable)
+    static const int col4_mode = [] {
+        const char* e = getenv("RV_AES_COL4");
+        return e ? atoi(e) : -1;
+    }();
+    const bool col4 = n_blocks && !g_recorder && aes_col4_supports(s->NQ) && (col4_mode > 0 || (col4_mode < 0 && s->overlap));
+    if (s->overlap && !col4) s->overlap = false;
+    if (col4) {
+        if ((rc = dalloc(ctx, aes_col4_image_bytes(s->NQ) / 4, &s->d_rk_c4))) return rc;
+        launch_rk_col4(ctx->stream, s->d_rk, s->NQ, s->d_rk_c4);
+        ctx->count();
+    }
     ctx->phase(RV_PH_MASKS);
     if (n_blocks64) {
         const uint32_t* rk64 = s->d_rk;  // prover: the same seeds feed both domains (proof/mod.rs:131-146)
@@ -1366,12 +1411,37 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
         s->ev_setup = ctx->get_sync_event();
         HIPCHK(hipEventRecord(s->ev_setup, ctx->stream));
     }
+    if (s->overlap) {
+        // nothing is generated here: the level loop submits the chunks (overlap_need), each on ctx->stream_m behind this point
+        if (!ctx->stream_m && hipStreamCreateWithFlags(&ctx->stream_m, hipStreamNonBlocking) != hipSuccess) return hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+        s->ev_setup = ctx->get_sync_event();
+        HIPCHK(hipEventRecord(s->ev_setup, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream_m, s->ev_setup, 0));
+        static const uint64_t n_chunks = [] {
+            const char* e = getenv("RV_OVERLAP_CHUNKS");
+            return (uint64_t)std::min(std::max(e ? atoi(e) : 16, 1), 256);
+        }();
+        s->ov_blocks = n_blocks;
+        s->ov_chunk = std::max<uint64_t>((n_blocks + n_chunks - 1) / n_chunks, 1024);
+        s->ov_keep = d_keep;
+        static const bool trace = getenv("RV_OV_TRACE") && atoi(getenv("RV_OV_TRACE")) != 0;
+        if (trace) {
+            overlap_trace_dump();  // (the previous proof's)
+            g_ov_trace = new OvTrace();
+            g_ov_trace->mark("main: keys done", 0, ctx->stream);
+        }
+        ctx->phase(-1);
+        return RV_OK;
+    }
     // gf2 masks in chunks, one event each (the interpreter starts as soon as its first levels' masks exist)
     {
         const uint64_t target = ctx->pipeline ? std::max<uint64_t>((n_blocks + 11) / 12, 2048) : std::max<uint64_t>(n_blocks, 1);
         for (uint64_t b0 = 0; b0 < n_blocks; b0 += target) {
             const uint64_t nb = std::min(target, n_blocks - b0);
-            launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, b0, nb, s->d_masks + (size_t)b0 * 128 * s->NQ, s->flat ? clear_wgs() : 0);
+            if (col4)
+                launch_aes_gf2_masks_col4(ctx->stream, s->d_rk_c4, d_keep, s->NQ, b0, nb, s->d_masks + (size_t)b0 * 128 * s->NQ);
+            else
+                launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, b0, nb, s->d_masks + (size_t)b0 * 128 * s->NQ, s->flat ? clear_wgs() : 0);
             ctx->count();
             if (ctx->pipeline) {
                 hipEvent_t e = ctx->get_sync_event();
@@ -1381,6 +1451,32 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
         }
     }
     ctx->phase(-1);
+    return RV_OK;
+}
+
+// RV_OVERLAP: make sure the masks of CTR blocks [0, need) are on their way and ordered before what the main stream queues next.
+// hipStreamWaitEvent orders behind the OTHER stream's tail at the time it is queued (runtime lessons of round 4), so a
+// chunk is submitted right before the first level that reads it and waited for at once: the host runs far ahead of the device,
+// every chunk sits in stream_m's queue long before its turn, and the generator runs back to back beside the levels.
+static int overlap_need(rv_shard* s, uint64_t need, hipStream_t sb) {
+    rv_ctx* ctx = s->ctx;
+    need = std::min(need, s->ov_blocks);
+    while (s->ov_next < need) {
+        if (g_ov_trace) g_ov_trace->mark("main: levels queued so far end; wait for chunk ending at block", s->ov_next, sb);
+        if (g_ov_trace) g_ov_trace->mark("  masks: chunk start at block", s->ov_next, ctx->stream_m);
+        // (the first chunk is what the proof waits for with nothing beside it: half size)
+        static const uint64_t first = getenv("RV_OVERLAP_FIRST") ? strtoull(getenv("RV_OVERLAP_FIRST"), nullptr, 0) : 0;
+        const uint64_t nb = std::min(s->ov_next == 0 ? (first ? first : std::max<uint64_t>(s->ov_chunk / 2, 512)) : s->ov_chunk, s->ov_blocks - s->ov_next);
+        launch_aes_gf2_masks_col4(ctx->stream_m, s->d_rk_c4, s->ov_keep, s->NQ, s->ov_next, nb, s->d_masks + (size_t)s->ov_next * 128 * s->NQ);
+        ctx->count();
+        s->ov_next += nb;
+        hipEvent_t e = ctx->get_sync_event();
+        HIPCHK(hipEventRecord(e, ctx->stream_m));
+        s->mask_chunks.emplace_back(s->ov_next, e);
+        if (g_ov_trace) g_ov_trace->mark("  masks: chunk end at block", s->ov_next, ctx->stream_m);
+        HIPCHK(hipStreamWaitEvent(sb, e, 0));
+        if (g_ov_trace) g_ov_trace->mark("main: chunk arrived, levels go on; block", s->ov_next, sb);
+    }
     return RV_OK;
 }
 
@@ -2160,6 +2256,14 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
     }
     for (size_t l = 0; l < n_levels; l++) {
         if (s->ec && (rc_ec = early_flush(s, l))) return rc_ec;
+        if (s->overlap) {
+            // (a run of levels in one launch needs its last level's masks)
+            size_t l_need = l;
+            if (s->c->lds_run_of_level[l] >= 0) l_need = std::max(l_need, (size_t)s->c->lds_runs[(size_t)s->c->lds_run_of_level[l]].run.l1 - 1);
+            if (s->c->run_of_level[l] >= 0) l_need = std::max(l_need, (size_t)s->c->narrow_runs[(size_t)s->c->run_of_level[l]].second - 1);
+            if ((rc_ec = overlap_need(s, cc.level_need_blocks[l_need], sb))) return rc_ec;
+            waited = s->mask_chunks.size();
+        }
         while (waited < s->mask_chunks.size() &&
                (waited == 0 ? 0 : s->mask_chunks[waited - 1].first) < cc.level_need_blocks[l]) {
             HIPCHK(hipStreamWaitEvent(sb, s->mask_chunks[waited].second, 0));
@@ -2214,6 +2318,8 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
         }
     }
     if (s->ec && (rc_ec = early_flush(s, n_levels))) return rc_ec;
+    if (s->overlap && (rc_ec = overlap_need(s, s->ov_blocks, sb))) return rc_ec;  // (masks no level reads: padding)
+    if (g_ov_trace) g_ov_trace->mark("main: last level done", n_levels, sb);
     return RV_OK;
 }
 
@@ -2458,6 +2564,14 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         if (hipEventRecord(s->ev_clear, ctx->stream3) != hipSuccess) return fail(RV_E_DEVICE);
     }
     s->z64f = !rep_path && c->z64f_ok && z64_fused_on() && z64_fused_supports(s->NQ) && !ctx->pipeline && !g_recorder;
+    {
+        // the mask generator beside the level launches (RV_OVERLAP=1; RV_OVERLAP_MIN = fewest CTR blocks): wide circuits only --
+        // a level must be long enough to hide a share of the cipher behind
+        static const int ov_mode = getenv("RV_OVERLAP") ? atoi(getenv("RV_OVERLAP")) : 0;
+        static const uint64_t ov_min = getenv("RV_OVERLAP_MIN") ? strtoull(getenv("RV_OVERLAP_MIN"), nullptr, 0) : 8192;
+        s->overlap = ov_mode != 0 && !rep_path && !s->flat && !s->split && !ctx->pipeline && !g_recorder && aes_col4_supports(s->NQ) &&
+                     cc.n_masks_pad / 128 >= ov_min && !(persist_mode() && persist_supports(s->NQ));
+    }
     ctx->phase(RV_PH_SETUP);
     ctx->count();
     launch_expand_seeds(ctx->stream, s->d_seeds, s->R, s->d_keys);

@@ -158,6 +158,13 @@ void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, u
 // reserve_cus: compute units to leave free (the flat schedule's cleartext pass runs beside the generator)
 void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
                           uint64_t n_blocks, uint32_t* d_masks, uint32_t reserve_cus = 0);
+// the lane-distributed generator (aes_col4.hip: a quad of lanes per bitsliced state, 80 registers, same rows): its key image
+// [NQ / 16][88 KiB] comes from the plane-major round keys of launch_bitslice_rk
+bool aes_col4_supports(uint32_t NQ);
+size_t aes_col4_image_bytes(uint32_t NQ);
+void launch_rk_col4(hipStream_t st, const uint32_t* d_rk, uint32_t NQ, uint32_t* d_img);
+void launch_aes_gf2_masks_col4(hipStream_t st, const uint32_t* d_img, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks,
+                               uint32_t* d_masks);
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,
                        uint8_t* d_out);
 // per-level class boundaries: [lo, mul11) G_MUL with one base per operand, [mul11, mul) other G_MUL,

@@ -595,6 +595,10 @@ __device__ __forceinline__ void run_level(const Gate* __restrict__ gates, const 
 // took 70 registers = seven; with the bound it is 61, without scratch.  Narrower rows keep the default: they would spill)
 template <int MODE, int NQ, bool GENERAL>
 __global__ __launch_bounds__(256, MODE == MODE_VERIFY_C ? (GENERAL ? 4 : 7) : (GENERAL || NQ != 64) ? 1 : 8) void k_interp_full(const Gate* __restrict__ gates, LevelRange r, InterpParams p, PfPlan pf) {
+    // a level's wavefronts are short-lived and wait on memory most of the time; when the lane-distributed mask generator shares the
+    // SIMD (api.hip: RV_OVERLAP) its two long-lived, always-ready wavefronts are the OLDEST and win every issue slot -- the level ran
+    // 3.3x slower beside it until its own wavefronts asked for priority
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);

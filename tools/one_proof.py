@@ -6,6 +6,6 @@ import circuits
 prog, wit, wc, st = circuits.layered_gf2()
 c = rv.Circuit(prog, wc)
 seeds = bytes(range(256)) * 16
-for i in range(2):
+for i in range(int(os.environ.get("N_PROOFS", "2"))):
     p = rv.Proof.new(c, wit, [], seeds=seeds)
 print("done", len(p), file=sys.stderr)
