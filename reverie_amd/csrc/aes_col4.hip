@@ -151,32 +151,20 @@ __device__ __forceinline__ void c4_rounds_0_1(uint32_t j, uint32_t c, const uint
     }
 }
 
-// Which (quad group, block range) a workgroup takes.  The n_qg workgroups of one block range write the n_qg 64-byte pieces of the
-// SAME mask rows; with xcd_map they sit on the same XCD (workgroups go round-robin over the eight XCDs: blockIdx % 8), so the pieces
-// meet in ONE L2 and leave it as whole lines instead of as four partial writes from four L2s (the grid is a multiple of 8 * n_qg)
-__device__ __forceinline__ void c4_place(uint32_t n_qg, int xcd_map, uint32_t& qg, uint64_t& chunk) {
-    if (xcd_map) {
-        const uint32_t in = blockIdx.x % (8 * n_qg);
-        qg = in / 8;
-        chunk = (uint64_t)(blockIdx.x / (8 * n_qg)) * 8 + in % 8;
-    } else {
-        qg = blockIdx.x % n_qg;
-        chunk = blockIdx.x / n_qg;
-    }
-}
-
 // A workgroup = 16 quad words (their key image in LDS for its lifetime) x a range of CTR blocks; a wavefront = one CTR block of
 // the 16 quads per trip.  WAVES wavefronts of 80 registers: with 8 the workgroup leaves three quarters of every SIMD's register
 // file and all of its other wavefront slots to whatever else is resident (the interpreter's level launches: api.hip, RV_OVERLAP).
-template <int WAVES, int WPE, int NT /* 1: nontemporal stores, 2: timing probe without stores */>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_aes_gf2_masks_col4(
+constexpr int C4_WAVES = 8;
+__global__ __launch_bounds__(C4_WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_aes_gf2_masks_col4(
     const uint4* __restrict__ img, const uint32_t* __restrict__ keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks, uint32_t blocks_per_wg,
-    uint32_t* __restrict__ masks, int xcd_map) {
+    uint32_t* __restrict__ masks) {
+    constexpr int WAVES = C4_WAVES;
     extern __shared__ uint4 c4_lds[];  // C4_IMG_U4 (dynamic: a static 88 KiB would make the compiler size the register budget for 2 waves)
     const uint32_t n_qg = NQ / 16;
-    uint32_t qg;
-    uint64_t chunk;
-    c4_place(n_qg, xcd_map, qg, chunk);
+    // (the n_qg workgroups that write the four 64-byte pieces of the same rows placed on ONE XCD, so that the pieces meet in one L2:
+    // measured, no difference -- the plain mapping stays)
+    const uint32_t qg = blockIdx.x % n_qg;
+    const uint64_t chunk = blockIdx.x / n_qg;
     {
         const uint4* src = img + (size_t)qg * C4_IMG_U4;
         constexpr uint32_t T = WAVES * 64, FULL = C4_IMG_U4 / T, REST = C4_IMG_U4 % T;
@@ -211,8 +199,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE,
         }
         // keystream bit order is MSB-first inside each byte (gf2/domain.rs: share 8i+j <- bit 7-j of byte i): byte 4*cs + r, plane k
         // -> mask index 8*(4*cs + r) + 7 - k
-        // (NT == 3, timing probe: every block lands in the same 8 MiB, which never leaves the caches)
-        uint32_t* out = masks + ((size_t)(NT == 3 ? (jl & 255) : jl) * 128 + 32 * cs) * NQ + qs;
+        uint32_t* out = masks + ((size_t)jl * 128 + 32 * cs) * NQ + qs;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint4 kv = rkl[(10 * 8 + k) * 64];
@@ -220,105 +207,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE,
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((int)from, (int)(s[8 * r + k] ^ kw[r]));
-                if (NT == 2) {
-                    if ((o & kp) == 0x9e3779b9u && k == 7 && r == 3) out[0] = o;  // (timing probe: the cipher without its stores)
-                } else if (NT == 1)
-                    __builtin_nontemporal_store(o & kp, &out[(size_t)(8 * r + (7 - k)) * NQ]);
-                else
-                    out[(size_t)(8 * r + (7 - k)) * NQ] = o & kp;
+                // nontemporal: the rows are read once, levels later (beside the level launches: 5.20 -> 5.13 ms per proof)
+                __builtin_nontemporal_store(o & kp, &out[(size_t)(8 * r + (7 - k)) * NQ]);
             }
         }
-    }
-}
-
-// The same generator with its stores taken off the cipher wavefronts.  Beside the interpreter's level launches (RV_OVERLAP) the
-// compute unit's vector-memory queue is full of the levels' row gathers, and a cipher wavefront that has to push 32 store
-// instructions through it per block stands still for a third of its time (measured: masks + interpreter 3.25 ms with the stores,
-// 2.64 without).  Here a cipher wavefront writes its block -- 128 rows x 64 bytes -- into an LDS tile of its own and goes on; a NINTH
-// wavefront drains the tiles with 16-byte stores (8 instructions per block instead of 32) and is the only one that ever waits for
-// the memory pipeline.  Tile word (4*t + c)*16 + (ql ^ 8*(c >> 1)) holds mask row 32*c + t of quad ql: conflict-free for the
-// writers (lane = 4*ql + c) and for the drain's ds_read_b128.  One flag per tile: 0 = free, 1 = full (LDS operations of one
-// wavefront execute in order, so the flag follows the tile's words and the drain's release follows its reads).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr uint32_t C4S_TILE_WORDS = 128 * 16;
-constexpr uint32_t C4S_LDS_BYTES = C4_LDS_BYTES + 8 * C4S_TILE_WORDS * 4 + 64;
-template <int NT>
-__global__ __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_aes_gf2_masks_col4s(
-    const uint4* __restrict__ img, const uint32_t* __restrict__ keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks, uint32_t blocks_per_wg,
-    uint32_t* __restrict__ masks, int xcd_map) {
-    extern __shared__ uint4 c4_lds[];
-    uint32_t* tiles = (uint32_t*)(c4_lds + C4_IMG_U4);
-    int* flags = (int*)(tiles + 8 * C4S_TILE_WORDS);
-    const uint32_t n_qg = NQ / 16;
-    uint32_t qg;
-    uint64_t chunk;
-    c4_place(n_qg, xcd_map, qg, chunk);
-    {
-        const uint4* src = img + (size_t)qg * C4_IMG_U4;
-        constexpr uint32_t T = 576, FULL = C4_IMG_U4 / T, REST = C4_IMG_U4 % T;
-        uint4 v[FULL];
-#pragma unroll
-        for (uint32_t i = 0; i < FULL; i++) v[i] = src[threadIdx.x + i * T];
-#pragma unroll
-        for (uint32_t i = 0; i < FULL; i++) c4_lds[threadIdx.x + i * T] = v[i];
-        if (REST != 0 && threadIdx.x < REST) c4_lds[threadIdx.x + FULL * T] = src[threadIdx.x + FULL * T];
-        if (threadIdx.x < 8) flags[threadIdx.x] = 0;
-        __syncthreads();
-    }
-    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t j_lo = chunk * blocks_per_wg;
-    const uint64_t j_hi = (j_lo + blocks_per_wg < n_blocks) ? j_lo + blocks_per_wg : n_blocks;
-    if (wave == 8) {
-        __builtin_amdgcn_s_setprio(3);  // (a handful of instructions per block, all of them on the way to the memory pipeline)
-        // the drain: lane = (row slot L >> 2 of sixteen, piece g = L & 3 of four quad words); slot = 16*i + (L >> 2) = 4*t + c
-        const uint32_t g = lane & 3, c = (lane >> 2) & 3, t0 = lane >> 4;
-        const uint32_t rd = (lane >> 2) * 16 + 4 * (g ^ (2 * (c >> 1)));  // + i * 256 words
-        uint32_t* out0 = masks + (size_t)(32 * c + t0) * NQ + qg * 16 + 4 * g;  // + (jl * 128 + 4 * i) * NQ
-        for (uint64_t j0 = j_lo; j0 < j_hi; j0 += 8) {
-            for (uint32_t w = 0; w < 8 && j0 + w < j_hi; w++) {
-                while (__hip_atomic_load(&flags[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 1) __builtin_amdgcn_s_sleep(2);
-                const uint32_t* tile = tiles + w * C4S_TILE_WORDS + rd;
-                uint4 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = *(const uint4*)(tile + i * 256);
-                __hip_atomic_store(&flags[w], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                uint32_t* out = out0 + (size_t)(j0 + w) * 128 * NQ;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (NT == 1)
-                        __builtin_nontemporal_store(u32x4{v[i].x, v[i].y, v[i].z, v[i].w}, (u32x4*)(out + (size_t)(4 * i) * NQ));
-                    else
-                        *(uint4*)(out + (size_t)(4 * i) * NQ) = v[i];
-                }
-            }
-        }
-        return;
-    }
-    const uint32_t c = lane & 3, ql = lane >> 2;
-    const uint4* rkl = c4_lds + lane;
-    const uint32_t kp = keep ? keep[qg * 16 + ql] : 0xFFFFFFFFu;
-    uint32_t* tile = tiles + wave * C4S_TILE_WORDS + c * 16 + (ql ^ (8 * (c >> 1)));  // + 64 * t words
-    for (uint64_t jl = j_lo + wave; jl < j_hi; jl += 8) {
-        const uint32_t j = (uint32_t)(first_block + jl);
-        uint32_t s[32];
-        c4_rounds_0_1(j, c, rkl, s);
-#pragma unroll 1
-        for (int r = 2; r < 10; r++) c4_round(s, rkl + r * 8 * 64);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            c4_sbox8(s[8 * r + 7], s[8 * r + 6], s[8 * r + 5], s[8 * r + 4], s[8 * r + 3], s[8 * r + 2], s[8 * r + 1], s[8 * r + 0]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        while (__hip_atomic_load(&flags[wave], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) __builtin_amdgcn_s_sleep(1);
-        // byte 4*c + r, plane k -> mask row 8*(4*c + r) + 7 - k = 32*c + t, t = 8*r + 7 - k (gf2/domain.rs: MSB first inside a byte)
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint4 kv = rkl[(10 * 8 + k) * 64];
-            const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
-#pragma unroll
-            for (int r = 0; r < 4; r++) tile[64 * (8 * r + 7 - k)] = (s[8 * r + k] ^ kw[r]) & kp;
-        }
-        __hip_atomic_store(&flags[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -330,27 +222,6 @@ void launch_rk_col4(hipStream_t st, const uint32_t* d_rk, uint32_t NQ, uint32_t*
     hipLaunchKernelGGL(k_rk_col4, dim3((n + 255) / 256), dim3(256), 0, st, d_rk, NQ, d_img);
 }
 
-template <int WAVES, int WPE, int NT>
-static void launch_c4(hipStream_t st, const uint32_t* d_img, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks, uint32_t* d_masks,
-                      uint64_t target_wgs) {
-    // (per device: the attribute belongs to the function ON the current device)
-    static bool raised[64] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !raised[dev]) {
-        (void)hipFuncSetAttribute((const void*)k_aes_gf2_masks_col4<WAVES, WPE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4_LDS_BYTES);
-        raised[dev] = true;
-    }
-    const uint32_t n_qg = NQ / 16;
-    uint64_t per = (n_blocks * n_qg + target_wgs - 1) / target_wgs;
-    per = (per + WAVES - 1) / WAVES * WAVES;
-    static const int xcd_map = getenv("RV_C4_XCD") ? atoi(getenv("RV_C4_XCD")) : 1;
-    uint64_t chunks = (n_blocks + per - 1) / per;
-    if (xcd_map) chunks = (chunks + 7) / 8 * 8;  // (workgroups past the end find an empty range)
-    hipLaunchKernelGGL((k_aes_gf2_masks_col4<WAVES, WPE, NT>), dim3((unsigned)(chunks * n_qg)), dim3(WAVES * 64), C4_LDS_BYTES, st, (const uint4*)d_img, d_keep, NQ,
-                       first_block, n_blocks, (uint32_t)per, d_masks, xcd_map);
-}
-
 void launch_aes_gf2_masks_col4(hipStream_t st, const uint32_t* d_img, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks,
                                uint32_t* d_masks) {
     if (!n_blocks) return;
@@ -360,41 +231,20 @@ void launch_aes_gf2_masks_col4(hipStream_t st, const uint32_t* d_img, const uint
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         return (uint64_t)cus;
     }();
-    // experiment knobs (round 5): wavefronts per workgroup, 64-register build, nontemporal stores
-    static const int waves = getenv("RV_C4_WAVES") ? atoi(getenv("RV_C4_WAVES")) : 8;
-    static const int r64 = getenv("RV_C4_R64") ? atoi(getenv("RV_C4_R64")) : 0;
-    static const int nt = getenv("RV_C4_NT") ? atoi(getenv("RV_C4_NT")) : 0;
-    static const int sw = getenv("RV_C4_STOREWAVE") ? atoi(getenv("RV_C4_STOREWAVE")) : 1;
-    if (sw) {
-        static bool raised[64] = {false};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !raised[dev]) {
-            (void)hipFuncSetAttribute((const void*)k_aes_gf2_masks_col4s<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4S_LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)k_aes_gf2_masks_col4s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4S_LDS_BYTES);
-            raised[dev] = true;
-        }
-        const uint32_t n_qg = NQ / 16;
-        uint64_t per = (n_blocks * n_qg + target_wgs - 1) / target_wgs;
-        per = (per + 7) / 8 * 8;
-        static const int xcd_map = getenv("RV_C4_XCD") ? atoi(getenv("RV_C4_XCD")) : 1;
-        uint64_t chunks = (n_blocks + per - 1) / per;
-        if (xcd_map) chunks = (chunks + 7) / 8 * 8;
-        if (nt)
-            hipLaunchKernelGGL((k_aes_gf2_masks_col4s<1>), dim3((unsigned)(chunks * n_qg)), dim3(576), C4S_LDS_BYTES, st, (const uint4*)d_img, d_keep, NQ, first_block,
-                               n_blocks, (uint32_t)per, d_masks, xcd_map);
-        else
-            hipLaunchKernelGGL((k_aes_gf2_masks_col4s<0>), dim3((unsigned)(chunks * n_qg)), dim3(576), C4S_LDS_BYTES, st, (const uint4*)d_img, d_keep, NQ, first_block,
-                               n_blocks, (uint32_t)per, d_masks, xcd_map);
-        return;
+    // (per device: the attribute belongs to the function ON the current device)
+    static bool raised[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        (void)hipFuncSetAttribute((const void*)k_aes_gf2_masks_col4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4_LDS_BYTES);
+        raised[dev] = true;
     }
-#define C4_GO(W, E, N) launch_c4<W, E, N>(st, d_img, d_keep, NQ, first_block, n_blocks, d_masks, target_wgs)
-    if (waves == 16) nt ? C4_GO(16, 6, 1) : C4_GO(16, 6, 0);
-    else if (r64) nt ? C4_GO(8, 8, 1) : C4_GO(8, 8, 0);
-    else if (nt == 2) C4_GO(8, 6, 2);
-    else if (nt == 3) C4_GO(8, 6, 3);
-    else nt ? C4_GO(8, 6, 1) : C4_GO(8, 6, 0);
-#undef C4_GO
+    const uint32_t n_qg = NQ / 16;
+    uint64_t per = (n_blocks * n_qg + target_wgs - 1) / target_wgs;
+    per = (per + C4_WAVES - 1) / C4_WAVES * C4_WAVES;
+    const uint64_t chunks = (n_blocks + per - 1) / per;
+    hipLaunchKernelGGL(k_aes_gf2_masks_col4, dim3((unsigned)(chunks * n_qg)), dim3(C4_WAVES * 64), C4_LDS_BYTES, st, (const uint4*)d_img, d_keep, NQ, first_block,
+                       n_blocks, (uint32_t)per, d_masks);
 }
 
 }  // namespace rv

@@ -2565,9 +2565,9 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     }
     s->z64f = !rep_path && c->z64f_ok && z64_fused_on() && z64_fused_supports(s->NQ) && !ctx->pipeline && !g_recorder;
     {
-        // the mask generator beside the level launches (RV_OVERLAP=1; RV_OVERLAP_MIN = fewest CTR blocks): wide circuits only --
-        // a level must be long enough to hide a share of the cipher behind
-        static const int ov_mode = getenv("RV_OVERLAP") ? atoi(getenv("RV_OVERLAP")) : 0;
+        // the mask generator beside the level launches (RV_OVERLAP=0 turns it off; RV_OVERLAP_MIN = fewest CTR blocks): wide circuits
+        // only -- a level must be long enough to hide a share of the cipher behind
+        static const int ov_mode = getenv("RV_OVERLAP") ? atoi(getenv("RV_OVERLAP")) : 1;
         static const uint64_t ov_min = getenv("RV_OVERLAP_MIN") ? strtoull(getenv("RV_OVERLAP_MIN"), nullptr, 0) : 8192;
         s->overlap = ov_mode != 0 && !rep_path && !s->flat && !s->split && !ctx->pipeline && !g_recorder && aes_col4_supports(s->NQ) &&
                      cc.n_masks_pad / 128 >= ov_min && !(persist_mode() && persist_supports(s->NQ));

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256, MODE == MODE_VERIFY_C ? (GENERAL ? 4 : 7) : (G
     // a level's wavefronts are short-lived and wait on memory most of the time; when the lane-distributed mask generator shares the
     // SIMD (api.hip: RV_OVERLAP) its two long-lived, always-ready wavefronts are the OLDEST and win every issue slot -- the level ran
     // 3.3x slower beside it until its own wavefronts asked for priority
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(1);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);

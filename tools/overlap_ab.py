@@ -16,7 +16,7 @@ p_and = float(os.environ.get("AB_P_AND", "0.5"))
 prog, wit, wc, st = circuits.layered_gf2(p_and=p_and)
 seeds = np.frombuffer(bytes(range(256)) * 16, np.uint8).reshape(256, 16)
 L = _lib.lib()
-c = rv.Circuit(prog, wc, whole_prover=True)
+c = rv.Circuit(prog, wc, whole_prover=os.environ.get("AB_HINT", "1") != "0")
 for _ in range(3):
     p = rv.Proof.new(c, wit, [], seeds=seeds)
 ctx = rv.Context.default()
