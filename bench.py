@@ -36,7 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PROFILE_TAG = "r04"    # profiles/<tag>_pmc_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r05"    # profiles/<tag>_pmc_traffic.json feeds roofline.traffic
 
 
 def rule_seeds():
@@ -152,6 +152,23 @@ class HostProver:
     def free(self, p):
         self.L.rv_free(p)
 
+    def run_each(self, steps, warm=2):
+        """every proof timed on its own (rv_prove returns with the bytes on the host) after `warm` untimed ones
+        -> (sorted seconds per proof, bytes of the last proof): the secondary records quote the MEDIAN with min / max, so that a
+        one-off (a buffer first mapped inside the loop, a neighbour's burst) cannot pass for the rate"""
+        last, ts = None, []
+        for i in range(warm + steps):
+            t0 = time.perf_counter()
+            p, n = self.prove()
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+            if last is not None:
+                self.free(last[0])
+            last = (p, n)
+        data = C.string_at(last[0], last[1])
+        self.free(last[0])
+        return sorted(ts), data
+
     def run(self, steps):
         """-> (seconds, bytes of the last proof)"""
         last = None
@@ -261,15 +278,16 @@ def secondary_records(ctx, seeds, quick):
     # warm-up of TWO proofs: run() holds the previous proof's buffer while the next one is made, and the second 640 MB page-locked
     # output buffer takes 45 ms to map the first time it is needed (with one warm-up proof that landed in the timed three: +15 ms
     # per proof in every earlier record of this number)
-    hp.run(2)
-    steps = 3
-    dt, data = hp.run(steps)
+    steps = 5
+    tz, data = hp.run_each(steps, warm=2)
+    dt = tz[len(tz) // 2] * steps  # (median per proof)
     p = reverie_amd.Proof(data)
     ok = bool(p.verify(circ))  # (the first call also sizes the context's buffer cache for the verifier's rows)
     t0 = time.perf_counter()
     ok = bool(p.verify(circ)) and ok
     tv = time.perf_counter() - t0
     rec = {"mul_gates": st["mul"], "levels": circ.info["levels"], "proof_bytes": len(data), "ms_per_proof": dt / steps * 1e3,
+           "ms_min_max": [tz[0] * 1e3, tz[-1] * 1e3],
            "mul_per_s": st["mul"] * steps / dt, "verifies_strict": ok, "verify_ms": tv * 1e3,
            "phase_ms": phase_ms(ctx, lambda: hp.run(2), 2),
            "note": "host to host; the 640 MB proof alone is ~11 ms of PCIe, of which the early-corrections path (the corrections vectors of all "
@@ -466,13 +484,14 @@ def main():
             "hash": (info["gf2_muls"] + info["gf2_inputs"] + info["gf2_asserts"]) * row + info["gf2_muls"] * row // 8,
         }
         interp_arg = "2" if vclr else "0"
-        kname = {"masks": "rv::k_aes_gf2_masks<16>", "interp": f"rv::k_interp_full<{interp_arg}, {row // 4}, {'true' if world == 1 else 'false'}>", "hash": "rv::k_b3_chunks<4>"}[dom]
+        kname = {"masks": "rv::k_aes_gf2_masks_col4", "interp": f"rv::k_interp_full<{interp_arg}, {row // 4}, {'true' if world == 1 else 'false'}>", "hash": "rv::k_b3_chunks<4>"}[dom]
+        kname_masks = "rv::k_aes_gf2_masks_col4"
         ach = alg[dom] / (phases[dom] * 1e-3) / 1e9 if phases[dom] > 0 else 0.0
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")
         if world == 1 and args.layers == 153 and args.p_and == 0.5 and os.path.exists(pmc_path):
             pk = json.load(open(pmc_path))["kernels"]
-            prefix = {"masks": "rv::k_aes_gf2_masks<", "interp": f"rv::k_interp_full<{interp_arg}", "hash": "rv::k_b3_chunks<"}[dom]
+            prefix = {"masks": "rv::k_aes_gf2_masks", "interp": f"rv::k_interp_full<{interp_arg}", "hash": "rv::k_b3_chunks<"}[dom]
             hits = [v["hbm_bytes_per_proof"] for k, v in pk.items() if k.startswith(prefix)]
             if hits:
                 traffic = sum(hits) / max(launches[dom], 1)
@@ -482,10 +501,15 @@ def main():
         # counted apart (rv_profile slot 6), and the copy-engine transfers they feed run beside the levels
         early_launches = int(prof.launches[6] // max(args.steps, 1))
         kernel_alone = None
-        if early_launches and world == 1 and not args.device_resident and not args.profile_run:
-            # the same kernel without that path (RV_EARLY=0: no packing kernels in the phase, no copy engine beside it), measured the
-            # same way right after the timed region
+        # round 5: the mask generator runs BESIDE the level launches (RV_OVERLAP, csrc/api.hip: its own stream, chunk by chunk), so the
+        # interpreter's phase of the timed proofs holds the level launches, their waits for mask chunks and -- on the other stream --
+        # the cipher's 2.57 GB of stores; the masks' own phase slot is empty
+        overlapped = world == 1 and os.environ.get("RV_OVERLAP", "1") != "0" and phases["masks"] < 0.25 * phases["interp"]
+        if (early_launches or overlapped) and world == 1 and not args.device_resident and not args.profile_run:
+            # the same kernel alone (RV_EARLY=0: no packing kernels in the phase, no copy engine beside it; RV_OVERLAP=0: the mask
+            # generator before the first level, nothing beside the levels), measured the same way right after the timed region
             os.environ["RV_EARLY"] = "0"
+            os.environ["RV_OVERLAP"] = "0"
             timed_bytes, last_bytes[0] = last_bytes[0], None  # (step() frees the previous proof's buffer: keep the timed proof's bytes aside)
             try:
                 n_alone = max(min(args.steps, 10), 3)
@@ -504,10 +528,13 @@ def main():
                 nl1 = max(int(prof1.launches[_lib.PHASES.index(dom)] // n_alone), 1)
                 kernel_alone = {"achieved": alg[dom] / (ms1 * 1e-3) / 1e9, "frac": alg[dom] / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "phase_ms": ms1, "launches_per_proof": nl1, "avg_launch_us": ms1 * 1e3 / nl1, "ms_per_proof_host_to_host": dt1 / n_alone * 1e3,
-                                "note": f"RV_EARLY=0, {n_alone} proofs after the timed region: the interpreter's phase holds the level launches only and "
-                                        "no copy engine runs beside them; the proof then pays the whole 50 MB device-to-host copy behind its last kernel"}
+                                "phase_ms_all": {n: prof1.ms[i] / n_alone for i, n in enumerate(_lib.PHASES)},
+                                "note": f"RV_EARLY=0 RV_OVERLAP=0, {n_alone} proofs after the timed region: the mask generator runs before the first "
+                                        "level, the interpreter's phase holds the level launches only and no copy engine runs beside them; the proof "
+                                        "then pays the whole 50 MB device-to-host copy behind its last kernel (this is the round-4 schedule)"}
             finally:
                 os.environ.pop("RV_EARLY", None)
+                os.environ.pop("RV_OVERLAP", None)
             if isinstance(last_bytes[0], tuple):
                 hp.free(last_bytes[0][0])
             last_bytes[0] = timed_bytes
@@ -521,6 +548,15 @@ def main():
                     "BLAKE3): no MFMA on this path.",
             "launches_per_proof": launches[dom], "avg_launch_us": phases[dom] * 1e3 / n_l,
             "algorithmic_bytes_per_launch": alg[dom] / n_l,
+            "kernel_alone": kernel_alone,
+            "concurrent": {"kernel": kname_masks, "stream": "the context's mask stream, chunk by chunk beside the level launches (RV_OVERLAP)",
+                           "algorithmic_bytes_per_proof": int(alg["masks"]),
+                           "phase_achieved_incl_masks": (alg[dom] + alg["masks"]) / (phases[dom] * 1e-3) / 1e9,
+                           "phase_frac_incl_masks": (alg[dom] + alg["masks"]) / (phases[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "the interpreter's phase (HIP events on the main stream) spans the level launches, their waits for mask chunks "
+                                   "and, beside them, the lane-distributed mask generator with its own 2.57 GB of row stores: achieved / frac above "
+                                   "price the LEVEL kernel's bytes over that whole span (it runs at about 0.75 of its stand-alone rate beside the "
+                                   "cipher), phase_*_incl_masks price both kernels' bytes over it; kernel_alone is the level kernel with nothing beside it"} if overlapped else None,
             "early_corrections": {"kernels_in_phase": early_launches, "kernel_alone": kernel_alone,
                                   "note": "the timed proofs take rv_prove's early-corrections path: the interpreter's phase also holds this many small kernels "
                                           "(k_pack_corr_all ~25 us + k_publish ~5 us per chunk of the corrections vectors, not counted in launches_per_proof) while the "
@@ -537,11 +573,14 @@ def main():
             sk = json.load(open(sq_path))["kernels"]
             peak_issue = 1024 * 0.5 * 2.4e9
             valu = {"peak": peak_issue, "unit": "wavefront VALU instructions/s", "kernels": {}}
-            for phase, prefixes in (("masks", ("rv::k_aes_gf2_masks<",)), ("hash", ("rv::k_b3_chunks<", "rv::k_b3_chunks_uni", "rv::k_b3_chunks_bits", "rv::k_b3_reduce<", "rv::k_b3_tree_tail"))):
+            mask_pf, interp_pf = ("rv::k_aes_gf2_masks",), ("rv::k_interp_full<",)
+            hash_pf = ("rv::k_b3_chunks<", "rv::k_b3_chunks_uni", "rv::k_b3_chunks_bits", "rv::k_b3_reduce<", "rv::k_b3_tree_tail")
+            # overlapped: the cipher and the level launches share the interpreter's phase (and the SIMDs): one entry for both
+            for phase, prefixes, ms in ((("masks+interp", mask_pf + interp_pf, phases["interp"]),) if overlapped else (("masks", mask_pf, phases["masks"]),)) + (("hash", hash_pf, phases["hash"]),):
                 insts = sum(v.get("SQ_INSTS_VALU_per_proof", 0.0) for k, v in sk.items() if k.startswith(prefixes))
-                if insts and phases[phase] > 0:
+                if insts and ms > 0:
                     valu["kernels"][phase] = {"kernels": [k for k in sk if k.startswith(prefixes)], "valu_insts_per_proof": insts,
-                                              "phase_ms": phases[phase], "issue_frac": insts / (phases[phase] * 1e-3) / peak_issue}
+                                              "phase_ms": ms, "issue_frac": insts / (ms * 1e-3) / peak_issue}
             valu["note"] = ("half of the BLAKE3 / bitsliced-AES instruction mix are 3-source VOP3 (v_bitop3, v_perm, v_add3, v_alignbit) "
                             "that issue at a quarter of a wavefront per clock, not half: tools/mb/valu_mb.hip; DESIGN.md section 4")
             roofline["valu"] = valu
@@ -625,26 +664,34 @@ def main():
                 result["host_to_host"] = {"value": n_and * n2 / d2, "unit": "AND gates/s", "ms_per_proof": d2 / n2 * 1e3,
                                           "bit_exact_vs_timed_proof": data2 == bytes(last)}
             else:
-                backend.prove_device(wit, [], seeds, dev_buf)
+                # (shard_times() above created and destroyed shards of four sizes: two warm-ups, every proof timed on its own, median)
+                for _ in range(2):
+                    backend.prove_device(wit, [], seeds, dev_buf)
                 sync_all()
-                t0 = time.perf_counter()
+                t2s = []
                 for _ in range(n2):
+                    t0 = time.perf_counter()
                     comm, omit, lens = backend.prove_device(wit, [], seeds, dev_buf)
-                sync_all()
-                d2 = time.perf_counter() - t0
+                    sync_all()
+                    t2s.append(time.perf_counter() - t0)
+                t2s.sort()
+                d2m = t2s[len(t2s) // 2]
                 dev_proof = assemble_device_parts(comm, [dev_buf], [lens])
-                result["device_resident"] = {"value": n_and * n2 / d2, "unit": "AND gates/s", "ms_per_proof": d2 / n2 * 1e3,
+                result["device_resident"] = {"value": n_and / d2m, "unit": "AND gates/s", "ms_per_proof": d2m * 1e3,
+                                             "ms_min_max": [t2s[0] * 1e3, t2s[-1] * 1e3], "proofs": n2,
                                              "bit_exact_vs_timed_proof": dev_proof == bytes(last),
-                                             "note": "rv_prove_device: the proof's openings stay in HBM (no D2H, no framing)"}
+                                             "note": "rv_prove_device: the proof's openings stay in HBM (no D2H, no framing); median of the "
+                                                     "proofs timed one by one after two warm-ups"}
             # rv_prove_batch, host to host: several proofs of the circuit per call
             B = 8
             rng = np.random.default_rng(7)
             bs = rng.integers(0, 256, (B, 256, 16), dtype=np.uint8)
             bs[0] = seeds
             bw = np.tile(np.asarray(wit, np.uint8), (B, 1))
-            reverie_amd.Proof.new_batch(circuit, bw, seeds=bs)
+            for _ in range(2):
+                reverie_amd.Proof.new_batch(circuit, bw, seeds=bs)
             d3s = []
-            for _ in range(3):
+            for _ in range(5):
                 t0 = time.perf_counter()
                 proofs = reverie_amd.Proof.new_batch(circuit, bw, seeds=bs)
                 d3s.append(time.perf_counter() - t0)
@@ -652,7 +699,8 @@ def main():
             result["prove_batch_host"] = {"value": n_and * B / d3, "unit": "AND gates/s", "ms_per_proof": d3 / B * 1e3, "proofs_per_call": B,
                                           "first_proof_bit_exact_vs_timed_proof": bytes(proofs[0]) == bytes(last),
                                           "last_proof_verifies_strict": bool(proofs[-1].verify(circuit)),
-                                          "note": "rv_prove_batch: witness bytes on the host -> B proofs' bytes on the host, one call (median of 3 calls)"}
+                                          "ms_per_proof_min_max": [min(d3s) / B * 1e3, max(d3s) / B * 1e3],
+                                          "note": "rv_prove_batch: witness bytes on the host -> B proofs' bytes on the host, one call (median of 5 calls after two warm-ups)"}
             del proofs
     if world > 1:
         # informational, outside the timed region: the same N GPUs proving N INDEPENDENT statements, one whole proof
@@ -684,12 +732,12 @@ def main():
         aprog, awit, awc, ast = circuits.layered_gf2(layers=args.layers, p_and=1.0)
         acirc = reverie_amd.Circuit(aprog, awc, ctx)
         ahp = HostProver(acirc, awit, [], seeds)
-        ahp.run(2)
-        na = 5
-        da, adata = ahp.run(na)
-        rec = {"value": ast["and"] * na / da, "unit": "AND gates/s", "ms_per_proof": da / na * 1e3, "and_gates": ast["and"],
+        na = 7
+        tas, adata = ahp.run_each(na, warm=2)
+        da = tas[len(tas) // 2]
+        rec = {"value": ast["and"] / da, "unit": "AND gates/s", "ms_per_proof": da * 1e3, "ms_min_max": [tas[0] * 1e3, tas[-1] * 1e3], "and_gates": ast["and"],
                "proof_bytes": len(adata), "verifies_strict": bool(reverie_amd.Proof(adata).verify(acirc)),
-               "note": "rv_prove host to host on the p_and = 1 variant of the workload"}
+               "note": "rv_prove host to host on the p_and = 1 variant of the workload (median of 7 proofs timed one by one after two warm-ups)"}
         if not args.no_cpu_baseline:
             import oracle_lib
 

@@ -161,12 +161,13 @@ typedef struct rv_circuit_info {
     /* ABI 4: share rows the GF(2) interpreter reads as gate operands (a Mul's two fresh mask rows not counted) and
      * computed rows it writes (materialised linear gates), per proof -- they depend on how linear gates were compiled */
     uint64_t gf2_operand_rows, gf2_rows_written;
-    /* ABI 6: page-locked host memory rv_prove's early-corrections path stages this circuit's corrections vectors in (0: the path
-     * does not apply to the circuit).  Allocated once per context, on the first proof that takes the path (its first mapping costs
-     * 0.15 - 1.5 s), and kept; RV_EARLY=0 proves without it. */
-    uint64_t early_staging_bytes;
-} rv_circuit_info;
+} rv_circuit_info; /* (no size field: this struct does not grow -- later additions get getters of their own, like the one below) */
 int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
+/* ABI 7 (ABI 6 had it as a field of rv_circuit_info): page-locked host memory rv_prove's early-corrections path stages this
+ * circuit's corrections vectors in (0: the path does not apply to the circuit), as the RV_EARLY_* environment stands at the call.
+ * Allocated once per context, on the first proof that takes the path (its first mapping costs 0.15 - 1.5 s), and kept;
+ * RV_EARLY=0 proves without it.  The query builds a plan of its own and leaves the circuit's (made by its first proof) alone. */
+int rv_circuit_early_staging_bytes(const rv_circuit *c, uint64_t *bytes);
 
 /* ---- Proof::new -------------------------------------------------------------------
  * wit_gf2: one byte per GF(2) witness element (0/1), consumed by Input gates in order
@@ -178,7 +179,7 @@ int rv_circuit_get_info(const rv_circuit *c, rv_circuit_info *info);
  *          rv_free recycles the buffer for the next proof); the pointer is ordinary readable/writable host memory.
  * Memory the call leaves on the context (kept for the next proof, released by rv_ctx_destroy): the device arena's cached blocks
  *          (rv_circuit_info::scratch_bytes), and -- for circuits that take the early-corrections path, pure GF(2) with >= 2^21
- *          Mul gates or pure Z64 with >= 2^17 -- page-locked staging of rv_circuit_info::early_staging_bytes (160 MB for the
+ *          Mul gates or pure Z64 with >= 2^17 -- page-locked staging of rv_circuit_early_staging_bytes() (160 MB for the
  *          10^7-gate GF(2) benchmark circuit, 2 GB for the 10^6-MUL Z64 one; its first mapping costs 0.15 - 1.5 s inside the first
  *          such proof) plus as much device memory for GF(2); RV_EARLY=0 in the environment proves without it. */
 int rv_prove(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64,

@@ -39,7 +39,7 @@ class CircuitInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_ops", "gf2_inputs", "gf2_muls", "gf2_asserts", "gf2_linear", "gf2_masks", "z64_inputs", "z64_muls",
         "z64_asserts", "z64_linear", "z64_masks", "b2a", "levels", "device_bytes", "scratch_bytes", "compile_us", "upload_us",
-        "gf2_operand_rows", "gf2_rows_written", "early_staging_bytes")]
+        "gf2_operand_rows", "gf2_rows_written")]
 
 
 class BristolInfo(C.Structure):
@@ -62,7 +62,7 @@ PHASES = ["setup", "masks", "interp", "hash", "join", "open"]
 # every symbol include/reverie_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "rv_strerror", "rv_last_error", "rv_abi_version", "rv_ctx_create", "rv_ctx_destroy", "rv_ctx_sync",
-    "rv_circuit_compile", "rv_circuit_compile_ex", "rv_hook_compile_info", "rv_hook_compile_compare", "rv_circuit_destroy", "rv_circuit_get_info", "rv_prove", "rv_verify", "rv_free",
+    "rv_circuit_compile", "rv_circuit_compile_ex", "rv_hook_compile_info", "rv_hook_compile_compare", "rv_circuit_destroy", "rv_circuit_get_info", "rv_circuit_early_staging_bytes", "rv_prove", "rv_verify", "rv_free",
     "rv_shard_commit", "rv_shard_digests_device", "rv_shard_digests", "rv_shard_open", "rv_shard_destroy",
     "rv_shard_open_device", "rv_combine_digests", "rv_challenge", "rv_assemble_proof", "rv_verify_shard",
     "rv_verify_finish", "rv_hook_prg_blocks", "rv_hook_expand_seed", "rv_hook_sharegen_gf2", "rv_hook_sharegen_z64",

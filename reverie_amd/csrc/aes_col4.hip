@@ -25,11 +25,14 @@
 namespace rv {
 
 #define XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+#ifndef C4_SBOX_INC
+#define C4_SBOX_INC "aes_sbox.inc"
+#endif
 
 __device__ __forceinline__ void c4_sbox8(uint32_t& b7, uint32_t& b6, uint32_t& b5, uint32_t& b4, uint32_t& b3, uint32_t& b2, uint32_t& b1,
                                          uint32_t& b0) {
     const uint32_t U0 = b7, U1 = b6, U2 = b5, U3 = b4, U4 = b3, U5 = b2, U6 = b1, U7 = b0;
-#include "aes_sbox.inc"
+#include C4_SBOX_INC
     b7 = S0;
     b6 = S1;
     b5 = S2;

@@ -45,11 +45,14 @@ static int hip_fail(hipError_t e, const char* what, const char* file, int line) 
     } while (0)
 
 extern "C" const char* rv_last_error(void) { return g_last_error.c_str(); }
-extern "C" uint32_t rv_abi_version(void) { return 6; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
+extern "C" uint32_t rv_abi_version(void) { return 7; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
                                                         //    streaming prover, rv_prove_multi, reconstruct hooks
                                                         // 4: rv_circuit_compile_ex (a pure addition)
                                                         // 5: rv_prove_ops / rv_verify_ops, rv_hook_compile_compare (pure additions)
                                                         // 6: rv_circuit_info grew by early_staging_bytes (callers must pass the larger struct)
+                                                        // 7: rv_circuit_info is its ABI-5 self again (a struct without a size field must not grow: a caller built
+                                                        //    against the older header would have had 8 bytes written past its buffer); the value has a getter of
+                                                        //    its own, rv_circuit_early_staging_bytes
 
 extern "C" const char* rv_strerror(int code) {
     switch (code) {
@@ -1170,7 +1173,16 @@ static uint64_t early_staging_bytes_of(const rv_circuit* c);  // (with the early
 extern "C" int rv_circuit_get_info(const rv_circuit* c, rv_circuit_info* info) {
     if (!c || !info) return RV_E_ARG;
     *info = c->cc.info;
-    info->early_staging_bytes = early_staging_bytes_of(c);
+    return RV_OK;
+}
+extern "C" int rv_circuit_early_staging_bytes(const rv_circuit* c, uint64_t* bytes) {
+    if (!c || !bytes) return RV_E_ARG;
+    try {
+        *bytes = early_staging_bytes_of(c);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
     return RV_OK;
 }
 
@@ -1558,154 +1570,157 @@ extern "C" uint64_t rv_hook_early_proofs(void) { return g_early_proofs.load(std:
 static std::atomic<uint64_t> g_verify_vc{0};
 extern "C" uint64_t rv_hook_verify_vc_count(void) { return g_verify_vc.load(std::memory_order_relaxed); }
 
-static const EarlyPlan* early_plan(const rv_circuit* c) {
-    std::call_once(c->ec_once, [c] {
-        EarlyPlan& P = c->ec_plan;
-        const Compiled& cc = c->cc;
-        // (read per circuit, not once per process: the tests lower them)
-        const uint64_t min_events = getenv("RV_EARLY_MIN") ? (uint64_t)atoll(getenv("RV_EARLY_MIN")) : (1ull << 21);
-        // (the progress stamp carries the chunk count in eight bits; a bad knob gives no plan, i.e. the plain path, not a failed proof)
-        const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? std::min(atoi(getenv("RV_EARLY_CHUNKS")), 255) : 4;
-        auto reps_env = [](uint32_t dflt) -> uint32_t {
-            const char* e = getenv("RV_EARLY_REPS");
-            if (!e) return dflt;
-            return (uint32_t)std::min(std::max(atoi(e), 0), (int)RV_TOTAL_REPS);
-        };
-        const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
-        if (!cc.gates64.empty()) {
-            // ---- Z64 ----
-            const size_t n_lv64 = cc.level_start64.empty() ? 0 : cc.level_start64.size() - 1;
-            const uint64_t min64 = getenv("RV_EARLY_MIN") ? min_events : (1ull << 17);
-            if (cc.row_prg_base || cc.n_pre || cc.pre_words64 != cc.n_corr64 || cc.n_corr64 < min64 || (cc.n_corr64 & 1) || !n_lv64 || n_chunks_env < 1) return;
-            std::vector<uint64_t> lo(n_lv64, UINT64_MAX);
-            for (size_t l = 0; l < n_lv64; l++)
-                for (uint32_t i = cc.level_start64[l]; i < cc.level_start64[l + 1]; i++) {
-                    const uint32_t op = cc.gates64[i].op;
-                    if (op == G64_B2A) return;
-                    if (op == G64_MUL) lo[l] = std::min<uint64_t>(lo[l], cc.gates64[i].ep);
-                }
-            std::vector<uint64_t> done(n_lv64);
-            uint64_t m = cc.pre_words64;
-            for (size_t l = n_lv64; l-- > 0;) {
-                done[l] = m;
-                m = std::min(m, lo[l]);
+// (the plan as the environment stands NOW: early_plan() below keeps the first one it builds for a circuit, rv_circuit_early_staging_bytes
+// builds one of its own to answer with -- a query must not freeze the knobs the first proof would have read)
+static void early_plan_build(const rv_circuit* c, EarlyPlan& P) {
+    const Compiled& cc = c->cc;
+    // (read per circuit, not once per process: the tests lower them)
+    const uint64_t min_events = getenv("RV_EARLY_MIN") ? (uint64_t)atoll(getenv("RV_EARLY_MIN")) : (1ull << 21);
+    // (the progress stamp carries the chunk count in eight bits; a bad knob gives no plan, i.e. the plain path, not a failed proof)
+    const int n_chunks_env = getenv("RV_EARLY_CHUNKS") ? std::min(atoi(getenv("RV_EARLY_CHUNKS")), 255) : 4;
+    auto reps_env = [](uint32_t dflt) -> uint32_t {
+        const char* e = getenv("RV_EARLY_REPS");
+        if (!e) return dflt;
+        return (uint32_t)std::min(std::max(atoi(e), 0), (int)RV_TOTAL_REPS);
+    };
+    const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
+    if (!cc.gates64.empty()) {
+        // ---- Z64 ----
+        const size_t n_lv64 = cc.level_start64.empty() ? 0 : cc.level_start64.size() - 1;
+        const uint64_t min64 = getenv("RV_EARLY_MIN") ? min_events : (1ull << 17);
+        if (cc.row_prg_base || cc.n_pre || cc.pre_words64 != cc.n_corr64 || cc.n_corr64 < min64 || (cc.n_corr64 & 1) || !n_lv64 || n_chunks_env < 1) return;
+        std::vector<uint64_t> lo(n_lv64, UINT64_MAX);
+        for (size_t l = 0; l < n_lv64; l++)
+            for (uint32_t i = cc.level_start64[l]; i < cc.level_start64[l + 1]; i++) {
+                const uint32_t op = cc.gates64[i].op;
+                if (op == G64_B2A) return;
+                if (op == G64_MUL) lo[l] = std::min<uint64_t>(lo[l], cc.gates64[i].ep);
             }
-            // how many repetitions' vectors fit through PCIe while the interpreter and the hashes run (rates of the 10^6-MUL
-            // benchmark circuit: ~10 ns per gate, ~6 ns per Mul of hashing); RV_EARLY=2: RV_EARLY_REPS (default 128) whatever the estimate
-            const uint64_t vec_bytes = 8 * cc.n_corr64;
-            uint32_t r_spec;
-            if (getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2) {
-                r_spec = reps_env(128);
-            } else {
-                // (~19 ns per gate of interpreter + mask generator -- fused or not --, ~6 ns per Mul of hashing)
-                const double t_window = (double)cc.gates64.size() * 19e-9 + (double)cc.n_corr64 * 6e-9;
-                // 0.9 of what the window could carry.  Round 3 staged 128 repetitions of the benchmark circuit in FOUR chunks (more
-                // made the proof slower: the last chunk, a quarter of everything, was still crossing PCIe at the challenge); in twelve
-                // chunks the last one fits the hash phase and all 256 repetitions pay: 54.4 -> 52.7 (192) -> 51.8 ms (256), proofs of
-                // both plans interleaved in one process (tools/z64_early_ab.py).  2 GB of page-locked staging instead of 1 GB.
-                r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.9 * t_window * 55e9 / (double)vec_bytes);
-            }
-            r_spec = std::min<uint32_t>(r_spec, RV_TOTAL_REPS) & ~7u;
-            if (r_spec < 64) return;
-            const uint64_t pitch = (vec_bytes + 127) & ~127ull;
-            const uint64_t K = getenv("RV_EARLY_CHUNKS") ? (uint64_t)n_chunks_env : 12;  // (Z64: twelve chunks unless told otherwise)
-            const uint64_t per = ((vec_bytes + K - 1) / K + 127) & ~127ull;
-            for (uint64_t b0 = 0; b0 < vec_bytes; b0 += per) {
-                EarlyPlan::Chunk ch{};
-                ch.byte0 = b0;
-                ch.nbytes = std::min(per, vec_bytes - b0);
-                ch.pitch = pitch;
-                ch.off = 0;
-                const uint64_t need = (ch.byte0 + ch.nbytes) / 8;
-                ch.ready_level = (uint32_t)(std::lower_bound(done.begin(), done.end(), need) - done.begin());
-                if (ch.ready_level >= n_lv64) return;
-                const uint64_t k = P.chunks.size();
-                if (ch.ready_level > n_lv64 * (k + 1) / K + n_lv64 / 4) return;
-                P.chunks.push_back(ch);
-            }
-            P.bytes = (size_t)r_spec * pitch;
-            P.z64 = true;
-            P.r_spec = r_spec;
-            P.ok = true;
-            return;
-        }
-        if (cc.row_prg_base || cc.n_pre < min_events || !n_levels || n_chunks_env < 1) return;
-        // The staged repetitions' vectors (1/8 byte per Mul each) must cross PCIe (~55 GB/s) while the interpreter and the hash kernels
-        // run, or the copies pile up behind the challenge and the proof gets SLOWER (all 256 on the all-AND variant of the 10^7-gate
-        // circuit, 320 MB against ~4.6 ms: 10.9 -> 11.0 - 11.6 ms).  So only as many repetitions as fit 0.9 of the estimated window
-        // (the benchmark circuits' rates: a level launch >= 13 us and ~0.25 ns per gate, the hashes ~0.21 ns per Mul); the opened
-        // repetitions beyond them are extracted and copied the plain way.  RV_EARLY=2: all of them (RV_EARLY_REPS overrides).
-        uint32_t r_spec = RV_TOTAL_REPS;
-        if (getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2) {
-            r_spec = reps_env(RV_TOTAL_REPS);
-        } else {
-            const double t_window = std::max((double)n_levels * 13e-6, (double)cc.gates.size() * 0.25e-9) + (double)cc.n_pre * 0.21e-9 + 0.3e-3;
-            r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.9 * t_window * 55e9 / ((double)cc.n_pre / 8.0));
-        }
-        r_spec = std::min<uint32_t>(r_spec, RV_TOTAL_REPS) & ~7u;
-        if (r_spec < 64) return;
-        // smallest row written per level, on a few threads (10^7 gate records are 0.4 GB)
-        std::vector<uint64_t> lo(n_levels, UINT64_MAX);
-        const int T = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
-        auto scan = [&](size_t l0, size_t l1) {
-            for (size_t l = l0; l < l1; l++) {
-                uint64_t m = UINT64_MAX;
-                for (uint32_t i = cc.level_start[l]; i < cc.level_start[l + 1]; i++)
-                    if (g_op(cc.gates[i]) == G_MUL) m = std::min<uint64_t>(m, cc.gates[i].ep);
-                lo[l] = m;
-            }
-        };
-        {
-            std::vector<std::thread> th;
-            size_t l0 = 0;
-            for (int t = 0; t < T; t++) {
-                // levels dealt by gate count
-                const uint32_t want = (uint32_t)((uint64_t)cc.gates.size() * (t + 1) / T);
-                size_t l1 = t + 1 == T ? n_levels : (size_t)(std::lower_bound(cc.level_start.begin(), cc.level_start.end(), want) - cc.level_start.begin());
-                l1 = std::min(std::max(l1, l0), n_levels);
-                if (l1 > l0) {
-                    if (t + 1 == T) scan(l0, l1); else th.emplace_back(scan, l0, l1);
-                }
-                l0 = l1;
-            }
-            for (auto& t : th) t.join();
-        }
-        // done[l] = rows final once levels 0 .. l have run
-        std::vector<uint64_t> done(n_levels);
-        uint64_t m = cc.n_pre;
-        for (size_t l = n_levels; l-- > 0;) {
+        std::vector<uint64_t> done(n_lv64);
+        uint64_t m = cc.pre_words64;
+        for (size_t l = n_lv64; l-- > 0;) {
             done[l] = m;
             m = std::min(m, lo[l]);
         }
-        const uint64_t l2c = cc.n_pre / 8 + 1;
-        const uint64_t K = (uint64_t)n_chunks_env;
-        const uint64_t per = ((l2c + K - 1) / K + 127) & ~127ull;
-        size_t off = 0;
-        for (uint64_t b0 = 0; b0 < l2c; b0 += per) {
+        // how many repetitions' vectors fit through PCIe while the interpreter and the hashes run (rates of the 10^6-MUL
+        // benchmark circuit: ~10 ns per gate, ~6 ns per Mul of hashing); RV_EARLY=2: RV_EARLY_REPS (default 128) whatever the estimate
+        const uint64_t vec_bytes = 8 * cc.n_corr64;
+        uint32_t r_spec;
+        if (getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2) {
+            r_spec = reps_env(128);
+        } else {
+            // (~19 ns per gate of interpreter + mask generator -- fused or not --, ~6 ns per Mul of hashing)
+            const double t_window = (double)cc.gates64.size() * 19e-9 + (double)cc.n_corr64 * 6e-9;
+            // 0.9 of what the window could carry.  Round 3 staged 128 repetitions of the benchmark circuit in FOUR chunks (more
+            // made the proof slower: the last chunk, a quarter of everything, was still crossing PCIe at the challenge); in twelve
+            // chunks the last one fits the hash phase and all 256 repetitions pay: 54.4 -> 52.7 (192) -> 51.8 ms (256), proofs of
+            // both plans interleaved in one process (tools/z64_early_ab.py).  2 GB of page-locked staging instead of 1 GB.
+            r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.9 * t_window * 55e9 / (double)vec_bytes);
+        }
+        r_spec = std::min<uint32_t>(r_spec, RV_TOTAL_REPS) & ~7u;
+        if (r_spec < 64) return;
+        const uint64_t pitch = (vec_bytes + 127) & ~127ull;
+        const uint64_t K = getenv("RV_EARLY_CHUNKS") ? (uint64_t)n_chunks_env : 12;  // (Z64: twelve chunks unless told otherwise)
+        const uint64_t per = ((vec_bytes + K - 1) / K + 127) & ~127ull;
+        for (uint64_t b0 = 0; b0 < vec_bytes; b0 += per) {
             EarlyPlan::Chunk ch{};
             ch.byte0 = b0;
-            ch.nbytes = std::min(per, l2c - b0);
-            ch.pitch = (ch.nbytes + 127) & ~127ull;
-            ch.off = off;
-            off += (size_t)256 * ch.pitch;
-            const uint64_t need = std::min<uint64_t>(8 * (ch.byte0 + ch.nbytes), cc.n_pre);
+            ch.nbytes = std::min(per, vec_bytes - b0);
+            ch.pitch = pitch;
+            ch.off = 0;
+            const uint64_t need = (ch.byte0 + ch.nbytes) / 8;
             ch.ready_level = (uint32_t)(std::lower_bound(done.begin(), done.end(), need) - done.begin());
-            if (ch.ready_level >= n_levels) return;  // (cannot happen: done[last] = n_pre)
+            if (ch.ready_level >= n_lv64) return;
             const uint64_t k = P.chunks.size();
-            if (ch.ready_level > n_levels * (k + 1) / K + n_levels / 4) return;  // completes too late to be worth sending ahead
+            if (ch.ready_level > n_lv64 * (k + 1) / K + n_lv64 / 4) return;
             P.chunks.push_back(ch);
         }
-        P.bytes = off;
+        P.bytes = (size_t)r_spec * pitch;
+        P.z64 = true;
         P.r_spec = r_spec;
         P.ok = true;
-    });
+        return;
+    }
+    if (cc.row_prg_base || cc.n_pre < min_events || !n_levels || n_chunks_env < 1) return;
+    // The staged repetitions' vectors (1/8 byte per Mul each) must cross PCIe (~55 GB/s) while the interpreter and the hash kernels
+    // run, or the copies pile up behind the challenge and the proof gets SLOWER (all 256 on the all-AND variant of the 10^7-gate
+    // circuit, 320 MB against ~4.6 ms: 10.9 -> 11.0 - 11.6 ms).  So only as many repetitions as fit 0.9 of the estimated window
+    // (the benchmark circuits' rates: a level launch >= 13 us and ~0.25 ns per gate, the hashes ~0.21 ns per Mul); the opened
+    // repetitions beyond them are extracted and copied the plain way.  RV_EARLY=2: all of them (RV_EARLY_REPS overrides).
+    uint32_t r_spec = RV_TOTAL_REPS;
+    if (getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 2) {
+        r_spec = reps_env(RV_TOTAL_REPS);
+    } else {
+        const double t_window = std::max((double)n_levels * 13e-6, (double)cc.gates.size() * 0.25e-9) + (double)cc.n_pre * 0.21e-9 + 0.3e-3;
+        r_spec = (uint32_t)std::min<double>(RV_TOTAL_REPS, 0.9 * t_window * 55e9 / ((double)cc.n_pre / 8.0));
+    }
+    r_spec = std::min<uint32_t>(r_spec, RV_TOTAL_REPS) & ~7u;
+    if (r_spec < 64) return;
+    // smallest row written per level, on a few threads (10^7 gate records are 0.4 GB)
+    std::vector<uint64_t> lo(n_levels, UINT64_MAX);
+    const int T = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
+    auto scan = [&](size_t l0, size_t l1) {
+        for (size_t l = l0; l < l1; l++) {
+            uint64_t m = UINT64_MAX;
+            for (uint32_t i = cc.level_start[l]; i < cc.level_start[l + 1]; i++)
+                if (g_op(cc.gates[i]) == G_MUL) m = std::min<uint64_t>(m, cc.gates[i].ep);
+            lo[l] = m;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        size_t l0 = 0;
+        for (int t = 0; t < T; t++) {
+            // levels dealt by gate count
+            const uint32_t want = (uint32_t)((uint64_t)cc.gates.size() * (t + 1) / T);
+            size_t l1 = t + 1 == T ? n_levels : (size_t)(std::lower_bound(cc.level_start.begin(), cc.level_start.end(), want) - cc.level_start.begin());
+            l1 = std::min(std::max(l1, l0), n_levels);
+            if (l1 > l0) {
+                if (t + 1 == T) scan(l0, l1); else th.emplace_back(scan, l0, l1);
+            }
+            l0 = l1;
+        }
+        for (auto& t : th) t.join();
+    }
+    // done[l] = rows final once levels 0 .. l have run
+    std::vector<uint64_t> done(n_levels);
+    uint64_t m = cc.n_pre;
+    for (size_t l = n_levels; l-- > 0;) {
+        done[l] = m;
+        m = std::min(m, lo[l]);
+    }
+    const uint64_t l2c = cc.n_pre / 8 + 1;
+    const uint64_t K = (uint64_t)n_chunks_env;
+    const uint64_t per = ((l2c + K - 1) / K + 127) & ~127ull;
+    size_t off = 0;
+    for (uint64_t b0 = 0; b0 < l2c; b0 += per) {
+        EarlyPlan::Chunk ch{};
+        ch.byte0 = b0;
+        ch.nbytes = std::min(per, l2c - b0);
+        ch.pitch = (ch.nbytes + 127) & ~127ull;
+        ch.off = off;
+        off += (size_t)256 * ch.pitch;
+        const uint64_t need = std::min<uint64_t>(8 * (ch.byte0 + ch.nbytes), cc.n_pre);
+        ch.ready_level = (uint32_t)(std::lower_bound(done.begin(), done.end(), need) - done.begin());
+        if (ch.ready_level >= n_levels) return;  // (cannot happen: done[last] = n_pre)
+        const uint64_t k = P.chunks.size();
+        if (ch.ready_level > n_levels * (k + 1) / K + n_levels / 4) return;  // completes too late to be worth sending ahead
+        P.chunks.push_back(ch);
+    }
+    P.bytes = off;
+    P.r_spec = r_spec;
+    P.ok = true;
+}
+static const EarlyPlan* early_plan(const rv_circuit* c) {
+    std::call_once(c->ec_once, [c] { early_plan_build(c, c->ec_plan); });
     return &c->ec_plan;
 }
 static uint64_t early_staging_bytes_of(const rv_circuit* c) {
     if (const char* e = getenv("RV_EARLY"))
         if (atoi(e) == 0) return 0;
-    const EarlyPlan* P = early_plan(c);
-    return P->ok ? (uint64_t)P->bytes : 0;
+    EarlyPlan P;
+    early_plan_build(c, P);
+    return P.ok ? (uint64_t)P.bytes : 0;
 }
 
 // Host-only view of the plan (tests): compiles the ops as rv_circuit_compile_ex would, builds the early-corrections plan and checks
@@ -2567,7 +2582,7 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     {
         // the mask generator beside the level launches (RV_OVERLAP=0 turns it off; RV_OVERLAP_MIN = fewest CTR blocks): wide circuits
         // only -- a level must be long enough to hide a share of the cipher behind
-        static const int ov_mode = getenv("RV_OVERLAP") ? atoi(getenv("RV_OVERLAP")) : 1;
+        const int ov_mode = getenv("RV_OVERLAP") ? atoi(getenv("RV_OVERLAP")) : 1;  // (read at every call: bench.py and the tools switch it)
         static const uint64_t ov_min = getenv("RV_OVERLAP_MIN") ? strtoull(getenv("RV_OVERLAP_MIN"), nullptr, 0) : 8192;
         s->overlap = ov_mode != 0 && !rep_path && !s->flat && !s->split && !ctx->pipeline && !g_recorder && aes_col4_supports(s->NQ) &&
                      cc.n_masks_pad / 128 >= ov_min && !(persist_mode() && persist_supports(s->NQ));

@@ -177,7 +177,7 @@ def parse():
     return gates
 
 
-LUT3_COST = 1.15
+LUT3_COST = float(os.environ.get("SBOX_LUT3_COST", "1.15"))  # a LUT3 in two-input ops (the cover is exact for this weight)
 
 
 def lut3_synthesis():
@@ -371,7 +371,7 @@ def main():
                 tt3 = sum(((tt >> (i >> 1)) & 1) << i for i in range(8))
                 expr = f"__builtin_amdgcn_bitop3_b32({a_}, {b_}, {b_}, 0x{tt3:02x})"
             out.append(f"const uint32_t {n} = {expr};")
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aes_sbox.inc")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ.get("SBOX_OUT", "aes_sbox.inc"))
     open(path, "w").write("\n".join(out) + "\n")
     tab = ", ".join("0x%02x" % sbox_def(x) for x in range(256))
     tpath = os.path.join(os.path.dirname(path), "aes_sbox_table.inc")

@@ -75,7 +75,11 @@ class Circuit:
     def info(self) -> dict:
         ci = _lib.CircuitInfo()
         _lib.check(_lib.lib().rv_circuit_get_info(self.handle, C.byref(ci)))
-        return {n: int(getattr(ci, n)) for n, _ in ci._fields_}
+        d = {n: int(getattr(ci, n)) for n, _ in ci._fields_}
+        esb = C.c_uint64()
+        _lib.check(_lib.lib().rv_circuit_early_staging_bytes(self.handle, C.byref(esb)))
+        d["early_staging_bytes"] = int(esb.value)
+        return d
 
     def record_sizes(self) -> Tuple[int, int]:
         """bytes of one OpenOnline record in the gf2 / z64 section of a proof of this circuit"""
