@@ -189,12 +189,17 @@ int rv_prove(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_
  * What the reference's own entry points take (proof/mod.rs:119-125,224-232: the op list, the witness, (z64, gf2) wire
  * counts): compile (RV_COMPILE_WHOLE_PROVER for the prover) + prove / verify + release, in one call -- the form a drop-in for
  * a single Proof::new uses.  The compile runs on several host threads (csrc/compile_par.cpp): a circuit the library has not
- * seen costs ~0.1 s per 10^7 gates before its first proof; callers that prove one circuit many times compile it once
- * (rv_circuit_compile_ex) and call rv_prove.  flags of rv_verify_ops: as rv_verify_ex. */
+ * seen costs ~0.1 s per 10^7 gates before its first proof.  Round 5: the context keeps the circuits these two calls compile, by
+ * CONTENT (128 bits hashed from the op array on host threads: ~3 ms per 10^7 ops) -- a second Proof::new on the same op list finds
+ * its gate stream on the device and costs the hash plus a proof (rv_prove's early-corrections path included); at most RV_OPS_CACHE
+ * circuits per context (environment, default 2, least recently used leaves; 0: nothing is kept), released by rv_ctx_destroy or
+ * rv_ctx_ops_cache_clear.  Callers that hold a circuit anyway compile it once (rv_circuit_compile_ex) and call rv_prove: no hash.
+ * flags of rv_verify_ops: as rv_verify_ex. */
 int rv_prove_ops(rv_ctx *ctx, const rv_op *ops, size_t n_ops, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64, size_t n_z64,
                  size_t z64_wires, size_t gf2_wires, const uint8_t *seeds, uint8_t **proof, size_t *proof_len);
 int rv_verify_ops(rv_ctx *ctx, const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, const uint8_t *proof, size_t proof_len,
                   uint32_t flags, int *ok);
+int rv_ctx_ops_cache_clear(rv_ctx *ctx); /* releases the circuits rv_prove_ops / rv_verify_ops keep (ABI 7) */
 
 /* ---- Proof::new with the openings left in device memory ------------------------------------
  * The whole prover (commit, Fiat-Shamir, openings) with ONE host synchronisation, for callers that keep working on
@@ -488,6 +493,8 @@ int rv_hook_shard_stream_digests(rv_shard *s, uint8_t *out);
  * ProverTranscript::extract returns, prover.rs:57-175 -- cross PCIe before the challenge exists).  The bytes are the same
  * either way; the tests use the counter to know which path they compared.  RV_EARLY=0 turns the path off. */
 uint64_t rv_hook_early_proofs(void);
+/* rv_prove_ops / rv_verify_ops calls of this process that found their op list's compiled circuit in the context's cache (ABI 7). */
+uint64_t rv_hook_ops_cache_hits(void);
 /* Verifications this process has run with one u64 of public corrections per share row instead of corr rows (csrc/kernels.hip:
  * MODE_VERIFY_C -- the verify-mode interpreter of whole proofs of pure GF(2) one-base gate streams; replaces nothing of the
  * reference's: verifier/online.rs:122-183 computes the same values).  The answer is the same either way; the tests use the

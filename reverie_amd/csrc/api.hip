@@ -181,6 +181,18 @@ struct rv_ctx {
     size_t rs_cap = 0;
     HelperPool* ec_pool = nullptr;
     double ec_wait_us[17] = {0};  // running averages of the early-corrections waits (per chunk stamp, [16] the challenge): mailbox_wait
+    // rv_prove_ops / rv_verify_ops: the circuits compiled from raw op lists, kept by content (ops_cache_get): the reference's
+    // Proof::new takes the op list at every call (proof/mod.rs:119-124), and a caller that proves one circuit again and again through
+    // that signature should pay the 70 - 90 ms host compile once, not per proof
+    struct OpsEntry {
+        uint64_t h[2];
+        size_t n_ops, z64_wires, gf2_wires;
+        uint32_t flags;
+        rv_circuit* c;
+        uint64_t stamp;
+    };
+    std::vector<OpsEntry> ops_cache;
+    uint64_t ops_clock = 0;
     std::vector<hipEvent_t> sync_pool;
     hipEvent_t get_sync_event() {
         if (!sync_pool.empty()) {
@@ -402,6 +414,8 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     if (ctx->stream_x) (void)hipStreamSynchronize(ctx->stream_x);
     if (ctx->stream_m) (void)hipStreamSynchronize(ctx->stream_m);
+    for (auto& e : ctx->ops_cache) rv_circuit_destroy(e.c);
+    ctx->ops_cache.clear();
     ctx->trim();
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -4307,19 +4321,133 @@ extern "C" int rv_verify_ex(rv_ctx* ctx, const rv_circuit* c, const uint8_t* pro
 }
 
 // Proof::new / Proof::verify on the raw op list (proof/mod.rs:119-125,224-232): compile + prove / verify + release
+// 128 bits of the op array's content, in parallel over host threads.  Per 16 bytes one 64 x 64 -> 128-bit multiply folded onto
+// itself (the mixing step of wyhash), four independent lanes per piece, pieces combined in order.  Not a cryptographic hash and it
+// need not be: a collision makes the PROVER use another circuit's gate stream, and that proof does not verify against the caller's.
+static std::atomic<uint64_t> g_ops_cache_hits{0};
+extern "C" uint64_t rv_hook_ops_cache_hits(void) { return g_ops_cache_hits.load(std::memory_order_relaxed); }
+static inline uint64_t ops_mum(uint64_t a, uint64_t b) {
+    const __uint128_t m = (__uint128_t)a * b;
+    return (uint64_t)m ^ (uint64_t)(m >> 64);
+}
+static void ops_hash_piece(const uint8_t* p, size_t n, uint64_t seed, uint64_t out[2]) {
+    constexpr uint64_t K0 = 0xa0761d6478bd642full, K1 = 0xe7037ed1a0b428dbull, K2 = 0x8ebc6af09c88c6e3ull, K3 = 0x589965cc75374cc3ull;
+    uint64_t a = seed ^ K0, b = seed ^ K1, c = seed ^ K2, d = seed ^ K3;
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        uint64_t w[8];
+        memcpy(w, p + i, 64);
+        a = ops_mum(w[0] ^ K1, w[1] ^ a);
+        b = ops_mum(w[2] ^ K2, w[3] ^ b);
+        c = ops_mum(w[4] ^ K3, w[5] ^ c);
+        d = ops_mum(w[6] ^ K0, w[7] ^ d);
+    }
+    for (; i < n; i += 8) {
+        uint64_t w = 0;
+        memcpy(&w, p + i, std::min<size_t>(8, n - i));
+        a = ops_mum(w ^ K1, a ^ K2 ^ (uint64_t)(n - i));
+    }
+    out[0] = ops_mum(a ^ K2, b ^ (uint64_t)n) ^ ops_mum(c ^ K0, d ^ K3);
+    out[1] = ops_mum(a ^ c ^ K1, b ^ d ^ K0) ^ (uint64_t)n * K3;
+}
+static void ops_hash(const void* ptr, size_t bytes, uint64_t out[2]) {
+    const uint8_t* p = (const uint8_t*)ptr;
+    constexpr size_t PIECE = (size_t)4 << 20;
+    const size_t n_pieces = std::max<size_t>((bytes + PIECE - 1) / PIECE, 1);
+    std::vector<uint64_t> d(2 * n_pieces);
+    static const unsigned n_thr = [] {
+        if (const char* e = getenv("RV_OPS_HASH_THREADS")) return (unsigned)std::max(atoi(e), 1);
+        return std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    }();
+    const unsigned T = (unsigned)std::min<size_t>(n_thr, n_pieces);
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t k; (k = next.fetch_add(1, std::memory_order_relaxed)) < n_pieces;) {
+            const size_t lo = k * PIECE, hi = std::min(bytes, lo + PIECE);
+            ops_hash_piece(p + lo, hi > lo ? hi - lo : 0, (uint64_t)k * 0x9e3779b97f4a7c15ull, &d[2 * k]);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    ops_hash_piece((const uint8_t*)d.data(), d.size() * 8, (uint64_t)bytes, out);
+}
+
+// the compiled circuit of an op list, from the context's cache or compiled now (and kept: at most RV_OPS_CACHE entries, default 2,
+// the least recently used one leaves; RV_OPS_CACHE=0: nothing is kept, *owned = the caller destroys it)
+static int ops_cache_get(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, rv_circuit** out, bool* hit,
+                         bool* owned) {
+    *hit = false;
+    *owned = true;
+    const size_t cap = getenv("RV_OPS_CACHE") ? (size_t)std::max(atoi(getenv("RV_OPS_CACHE")), 0) : 2;  // (read at every call: tests and bench switch it)
+    if (!ctx || cap == 0 || !ops || n_ops < 1024) return rv_circuit_compile_ex(ctx, ops, n_ops, z64_wires, gf2_wires, flags, out);
+    uint64_t h[2];
+    ops_hash(ops, n_ops * sizeof(rv_op), h);
+    {
+        // (the knobs that change what the compilers and circuit_upload make of an op list are part of the key: tests switch them between calls)
+        std::string knobs;
+        for (const char* k : {"RV_LAZY_K", "RV_LAZY_SLACK", "RV_LAZY_BALANCE", "RV_NARROW", "RV_COMPILE_SEQ", "RV_LDS_RUN", "RV_LDS_QS", "RV_FLAT", "RV_REP", "RV_PERSIST"}) {
+            const char* v = getenv(k);
+            knobs += v ? v : "";
+            knobs += ';';
+        }
+        uint64_t hk[2];
+        ops_hash_piece((const uint8_t*)knobs.data(), knobs.size(), 0x6b6e6f6273ull, hk);
+        h[0] ^= hk[0];
+        h[1] += hk[1];
+    }
+    for (auto& e : ctx->ops_cache)
+        if (e.h[0] == h[0] && e.h[1] == h[1] && e.n_ops == n_ops && e.z64_wires == z64_wires && e.gf2_wires == gf2_wires && e.flags == flags) {
+            e.stamp = ++ctx->ops_clock;
+            g_ops_cache_hits.fetch_add(1, std::memory_order_relaxed);
+            *out = e.c;
+            *hit = true;
+            *owned = false;
+            return RV_OK;
+        }
+    int rc = rv_circuit_compile_ex(ctx, ops, n_ops, z64_wires, gf2_wires, flags, out);
+    if (rc) return rc;
+    while (ctx->ops_cache.size() >= cap) {
+        size_t v = 0;
+        for (size_t i = 1; i < ctx->ops_cache.size(); i++)
+            if (ctx->ops_cache[i].stamp < ctx->ops_cache[v].stamp) v = i;
+        rv_circuit_destroy(ctx->ops_cache[v].c);
+        ctx->ops_cache.erase(ctx->ops_cache.begin() + (long)v);
+    }
+    ctx->ops_cache.push_back({{h[0], h[1]}, n_ops, z64_wires, gf2_wires, flags, *out, ++ctx->ops_clock});
+    *owned = false;
+    return RV_OK;
+}
+extern "C" int rv_ctx_ops_cache_clear(rv_ctx* ctx) {
+    if (!ctx) return RV_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto& e : ctx->ops_cache) rv_circuit_destroy(e.c);
+    ctx->ops_cache.clear();
+    return RV_OK;
+}
+
 extern "C" int rv_prove_ops(rv_ctx* ctx, const rv_op* ops, size_t n_ops, const uint8_t* wit_gf2, size_t n_gf2, const uint64_t* wit_z64, size_t n_z64,
                             size_t z64_wires, size_t gf2_wires, const uint8_t* seeds, uint8_t** proof, size_t* proof_len) {
     if (!proof || !proof_len) return RV_E_ARG;
     rv_circuit* c = nullptr;
-    int rc = rv_circuit_compile_ex(ctx, ops, n_ops, z64_wires, gf2_wires, RV_COMPILE_WHOLE_PROVER, &c);
+    bool hit = false, owned = true;
+    int rc;
+    try {
+        rc = ops_cache_get(ctx, ops, n_ops, z64_wires, gf2_wires, RV_COMPILE_WHOLE_PROVER, &c, &hit, &owned);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
     if (rc) return rc;
-    try {  // (one proof of a circuit nobody keeps: without the early-corrections staging)
-        rc = rv_prove_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, proof, proof_len, nullptr, 0, /*allow_early=*/false);
+    try {  // (the first proof of a circuit, or of one nobody keeps: without the early-corrections staging; a circuit seen before takes it)
+        rc = rv_prove_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, proof, proof_len, nullptr, 0, /*allow_early=*/hit);
     } catch (...) {
         g_last_error = "out of host memory";
         rc = RV_E_NOMEM;
     }
-    rv_circuit_destroy(c);
+    if (owned) rv_circuit_destroy(c);
     return rc;
 }
 
@@ -4327,10 +4455,17 @@ extern "C" int rv_verify_ops(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t
                              uint32_t flags, int* ok) {
     if (!ok) return RV_E_ARG;
     rv_circuit* c = nullptr;
-    int rc = rv_circuit_compile_ex(ctx, ops, n_ops, z64_wires, gf2_wires, 0, &c);
+    bool hit = false, owned = true;
+    int rc;
+    try {
+        rc = ops_cache_get(ctx, ops, n_ops, z64_wires, gf2_wires, 0, &c, &hit, &owned);
+    } catch (...) {
+        g_last_error = "out of host memory";
+        return RV_E_NOMEM;
+    }
     if (rc) return rc;
     rc = rv_verify_ex(ctx, c, proof, proof_len, flags, ok);
-    rv_circuit_destroy(c);
+    if (owned) rv_circuit_destroy(c);
     return rc;
 }
 

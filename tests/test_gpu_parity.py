@@ -1433,3 +1433,58 @@ def test_verifier_compact_corrections_vs_oracle(rv, oracle, rule_seeds, monkeypa
         except rv.ReverieError as e:
             got = (None, e.code)
         assert got == want
+
+
+def test_ops_cache_repeat_proof_new_on_the_same_op_list(rv, rule_seeds, monkeypatch):
+    """Proof::new takes the raw op list at every call (proof/mod.rs:119-124): rv_prove_ops keeps the compiled circuit by CONTENT in
+    the context (round 5), so the second call on the same ops is a cache hit with the same bytes; another circuit misses; the cache
+    holds RV_OPS_CACHE (default 2) circuits, least recently used out; RV_OPS_CACHE=0 keeps nothing; verify_ops shares the mechanism."""
+    import oracle_lib
+    from reverie_amd import _lib
+
+    L = _lib.lib()
+    ctx = rv.Context(0)
+
+    def circuit(seed, n=3000):
+        rng = np.random.default_rng(seed)
+        ops = [GF2.Input(i) for i in range(32)]
+        w = 32
+        for _ in range(n):
+            a, b = int(rng.integers(0, w)), int(rng.integers(0, w))
+            ops.append(GF2.Mul(w, a, b) if rng.integers(0, 2) else GF2.Add(w, a, b))
+            w += 1
+        return program(ops), [int(x) for x in rng.integers(0, 2, 32)], (0, w)
+
+    pa, wa, wca = circuit(1)
+    pb, wb, wcb = circuit(2)
+    pc, wc_, wcc = circuit(3)
+    want_a = oracle_lib.prove(pa, wa, [], wca, rule_seeds)
+    h0 = L.rv_hook_ops_cache_hits()
+    p1 = rv.Proof.new(pa, wa, [], wca, seeds=rule_seeds, ctx=ctx)
+    assert L.rv_hook_ops_cache_hits() == h0 and bytes(p1) == want_a
+    p2 = rv.Proof.new(pa, wa, [], wca, seeds=rule_seeds, ctx=ctx)
+    assert L.rv_hook_ops_cache_hits() == h0 + 1 and bytes(p2) == want_a
+    # a copy of the array with the same content is the same circuit; one changed operand is not
+    p3 = rv.Proof.new(pa.copy(), wa, [], wca, seeds=rule_seeds, ctx=ctx)
+    assert L.rv_hook_ops_cache_hits() == h0 + 2 and bytes(p3) == want_a
+    assert bytes(rv.Proof.new(pb, wb, [], wcb, seeds=rule_seeds, ctx=ctx)) == oracle_lib.prove(pb, wb, [], wcb, rule_seeds)
+    assert L.rv_hook_ops_cache_hits() == h0 + 2
+    # the verifier's compile (no prover hint) is an entry of its own: first call a miss, second a hit
+    assert p1.verify(pa, wca, ctx=ctx) and L.rv_hook_ops_cache_hits() == h0 + 2  # (evicts A's prover circuit or B's: cap 2)
+    assert p1.verify(pa, wca, ctx=ctx) and L.rv_hook_ops_cache_hits() == h0 + 3
+    # least recently used leaves: C comes in, then A's prover form must be compiled again (miss), bytes unchanged
+    assert bytes(rv.Proof.new(pc, wc_, [], wcc, seeds=rule_seeds, ctx=ctx)) == oracle_lib.prove(pc, wc_, [], wcc, rule_seeds)
+    h1 = L.rv_hook_ops_cache_hits()
+    assert bytes(rv.Proof.new(pa, wa, [], wca, seeds=rule_seeds, ctx=ctx)) == want_a
+    # RV_OPS_CACHE=0: nothing kept, nothing found
+    monkeypatch.setenv("RV_OPS_CACHE", "0")
+    h2 = L.rv_hook_ops_cache_hits()
+    assert bytes(rv.Proof.new(pa, wa, [], wca, seeds=rule_seeds, ctx=ctx)) == want_a
+    assert bytes(rv.Proof.new(pa, wa, [], wca, seeds=rule_seeds, ctx=ctx)) == want_a
+    assert L.rv_hook_ops_cache_hits() == h2
+    monkeypatch.delenv("RV_OPS_CACHE")
+    assert L.rv_ctx_ops_cache_clear(ctx.handle) == 0
+    h3 = L.rv_hook_ops_cache_hits()
+    assert bytes(rv.Proof.new(pa, wa, [], wca, seeds=rule_seeds, ctx=ctx)) == want_a and L.rv_hook_ops_cache_hits() == h3
+    assert h1 >= h0 + 3
+    ctx.close()
