@@ -495,6 +495,13 @@ int rv_hook_shard_stream_digests(rv_shard *s, uint8_t *out);
 uint64_t rv_hook_early_proofs(void);
 /* rv_prove_ops / rv_verify_ops calls of this process that found their op list's compiled circuit in the context's cache (ABI 7). */
 uint64_t rv_hook_ops_cache_hits(void);
+/* Shard commitments of this process whose GF(2) mask generator ran BESIDE the interpreter's level launches (round 5: the
+ * lane-distributed cipher of csrc/aes_col4.hip on a stream of its own, chunk by chunk; RV_OVERLAP=0 runs it before the first level;
+ * circuits below RV_OVERLAP_MIN = 8192 cipher blocks and rows narrower than 64 repetitions keep that order anyway).  Same bytes. */
+uint64_t rv_hook_overlap_commits(void);
+/* 1 in an experiment build of the library (csrc/Makefile: EXTRA=-DRV_EXPERIMENTS -- the prover schedules of rounds 2 and 4 that
+ * measured slower than the level path: RV_REP, RV_FLAT, RV_PERSIST, RV_EARLY_REC; rv_hook_flat_plan answers only there), else 0. */
+int rv_hook_experiments(void);
 /* Verifications this process has run with one u64 of public corrections per share row instead of corr rows (csrc/kernels.hip:
  * MODE_VERIFY_C -- the verify-mode interpreter of whole proofs of pure GF(2) one-base gate streams; replaces nothing of the
  * reference's: verifier/online.rs:122-183 computes the same values).  The answer is the same either way; the tests use the

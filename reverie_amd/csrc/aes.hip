@@ -428,6 +428,7 @@ __global__ __launch_bounds__(512, 2) void k_aes_gf2_masks(const uint32_t* __rest
 }
 
 
+#ifdef RV_EXPERIMENTS  // (the rep-sliced prover path, rep.hip: experiment builds only)
 // ------------------------------------------------------------------------------------
 // Rep-major mask generator (rep.hip's layout: masks[rep][m], one byte = the 8 players of that repetition).
 // rk_rep[(area*128 + 8*byte + bit) * R + rep]: bit of round-key byte of the 8 player keys of `rep`, player p at bit
@@ -523,6 +524,7 @@ void launch_aes_rep_masks(hipStream_t st, const uint32_t* d_rk_rep, uint32_t R, 
     parts = (uint32_t)std::min<uint64_t>(parts, std::max<uint64_t>(1, (trips + 7) / 8));
     hipLaunchKernelGGL(k_aes_rep_masks, dim3(R * parts), dim3(512), 0, st, d_rk_rep, R, n4, d_masks, mask_stride);
 }
+#endif  // RV_EXPERIMENTS
 
 // ---- launchers ----
 void launch_expand_seeds(hipStream_t st, const uint8_t* d_seeds, uint32_t n_reps, uint8_t* d_keys) {
@@ -703,13 +705,8 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
     uint32_t lo0[32], hi0[32], lo1[32], hi1[32];
     {
         uint32_t s[128], t[128];
-#ifdef RV_ZF_NOAES
-#pragma unroll
-        for (int i = 0; i < 128; i++) t[i] = m * (2 * i + 1);
-#else
         rounds_0_to_9<QW>(p.first_block + (m >> 1), s, t, rkl);
         sub_shift(s, t);
-#endif
         const uint32_t* rk10 = rkl + 10 * 128 * QW;
         // plane 8*i + k = bit k of keystream byte i; u64 h, bit b  <->  plane 64*h + b (k_aes_z64_masks)
 #pragma unroll
@@ -743,15 +740,6 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
     // the lane's four repetitions) they were spilled, and each reload sat between two repetitions' stores, waiting for them
     asm volatile("" : "+v"(q), "+v"(zo), "+v"(gi));
     if (!valid) return;
-#ifdef RV_ZF_NOMEM
-    {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int i = 0; i < 32; i++) acc += lo0[i] ^ hi0[i] ^ lo1[i] ^ hi1[i];
-        if (acc == 0x12345u) p.pre[gi] = acc;
-        return;
-    }
-#endif
     const Gate64 g = gates[gi];
     const uint64_t* ap = z_row(p, g.am, S) + zo;
     const uint64_t* bp = z_row(p, g.bm, S) + zo;
@@ -793,11 +781,9 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
         }
         cs[k] = c;
     }
-#ifndef RV_ZF_NOLNEW
 #pragma unroll
     for (int i = 0; i < 16; i++)
         z_st16(lnp + z_piece(i), ((uint64_t)hi1[2 * i] << 32) | lo1[2 * i], ((uint64_t)hi1[2 * i + 1] << 32) | lo1[2 * i + 1]);
-#endif
     if (VERIFY) {  // (requested here, once lambda_new has left and freed its registers)
         z_ld16(p.wcorr + (size_t)g.a * R + 4 * q, cxs[0], cxs[1]);
         z_ld16(p.wcorr + (size_t)g.a * R + 4 * q + 2, cxs[2], cxs[3]);
@@ -846,16 +832,8 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
         }
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t rep = 4 * q + k;
-#ifndef RV_ZF_NOON
         z_store_on(p.on + (size_t)rep * p.on_words + g.eo, w);
-#else
-        if (w[0] + w[1] + w[2] + w[3] + w[4] + w[5] + w[6] + w[7] == 0x1234567u) z_store_on(p.on + (size_t)rep * p.on_words + g.eo, w);
-#endif
-#ifndef RV_ZF_NOPRE
         p.pre[(size_t)rep * p.pre_words + g.ep] = delta;
-#else
-        if (delta == 0x1234567u) p.pre[(size_t)rep * p.pre_words + g.ep] = delta;
-#endif
         __builtin_amdgcn_sched_barrier(0);
     }
     if (VERIFY) {
@@ -1030,9 +1008,7 @@ __global__ __launch_bounds__(512, 2) void k_z64_fused(const Gate64* __restrict__
         const uint32_t lend = (uint32_t)(((uint64_t)(it + 1) * LI) / MI);
         for (; ld < lend; ld++) {
             const uint32_t gl = l_lo + (l0s + ld) * JW + jsub;
-#ifndef RV_ZF_NOLIN
             if (gl < l_hi) z64f_lin<VERIFY>(gates[gl], p, q, zo, writer);
-#endif
         }
     }
     for (; ld < LI; ld++) {

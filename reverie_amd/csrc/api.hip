@@ -45,6 +45,15 @@ static int hip_fail(hipError_t e, const char* what, const char* file, int line) 
     } while (0)
 
 extern "C" const char* rv_last_error(void) { return g_last_error.c_str(); }
+// 1: an experiment build (make EXTRA=-DRV_EXPERIMENTS: the rep-sliced path, the flat / split / chained schedules, the persistent level
+// kernels, RV_EARLY_REC); 0: the library build() makes, where those knobs do nothing
+extern "C" int rv_hook_experiments(void) {
+#ifdef RV_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" uint32_t rv_abi_version(void) { return 7; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
                                                         //    streaming prover, rv_prove_multi, reconstruct hooks
                                                         // 4: rv_circuit_compile_ex (a pure addition)
@@ -141,14 +150,13 @@ struct rv_ctx {
     int device = 0;
     size_t lds_bytes = 0;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     hipStream_t stream = nullptr;   // setup, AES masks, hashing, openings (VALU-heavy work)
-    hipStream_t stream2 = nullptr;  // the interpreter (HBM-bound), pipelined against the mask generator
+    hipStream_t stream2 = nullptr;  // side stream: the early-corrections copies, the verifier's proof copy and unpack kernels
     hipStream_t stream3 = nullptr;  // the flat schedule's cleartext pass (k_clear), beside the mask generator
     hipStream_t stream_x = nullptr; // the flat schedule's XOR rows, running ahead of the Mul launches on `stream`
     hipStream_t stream_m = nullptr; // RV_OVERLAP: the lane-distributed mask generator, beside the interpreter's level launches (made on first use)
     hipEvent_t clear_a = nullptr, clear_b = nullptr;  // profiling: around k_clear on stream3 (rv_profile slot RV_PH_CLEAR)
     bool clear_timed = false;
     std::vector<rv_ctx*> workers;            // rv_prove_batch on large circuits: one worker context per host thread
-    bool pipeline = false;          // RV_PIPELINE=1: mask generator and interpreter on two streams, chunk-wise (measured slower: DESIGN.md)
     // Small proofs (AES-128: 99 KB) leave through this page-locked, device-mapped buffer: the opening kernels write into it
     // and a one-lane kernel adds the error word, instead of two copy-engine operations of ~25 us each behind them
     static constexpr size_t STAGE_BYTES = (size_t)1 << 20;
@@ -362,7 +370,6 @@ static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level
         c->lds_bytes = (size_t)std::max(lds, 0);
         set_device_lds_limit(c->lds_bytes);
     }
-    if (const char* e = getenv("RV_PIPELINE")) c->pipeline = atoi(e) != 0;
     // The runtime multiplexes the streams of one priority over four hardware queues (a fifth stream would share the first one's),
     // and a queue that issues short kernels back to back keeps the dispatcher from a queue of the same or a lower priority.  The
     // main stream can therefore get the high priority (RV_MAIN_PRIO=1; default: all streams alike): its long kernels go out the moment their
@@ -389,6 +396,7 @@ static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level
     return RV_OK;
 }
 
+#ifdef RV_EXPERIMENTS
 // the side streams of the flat / split prover schedules (RV_FLAT != 0), on first use
 static int ctx_side_streams(rv_ctx* c) {
     if (c->stream3 && c->stream_x) return RV_OK;
@@ -403,6 +411,7 @@ static int ctx_side_streams(rv_ctx* c) {
         se = x_prio ? hipStreamCreateWithPriority(&c->stream_x, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking);
     return se == hipSuccess ? RV_OK : hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
 }
+#endif
 
 static void pinned_pool_trim();  // idle page-locked output buffers (defined with the pool below)
 
@@ -645,6 +654,7 @@ struct rv_circuit {
     bool chain_gen = false;
 };
 
+#ifdef RV_EXPERIMENTS
 // RV_FLAT: 0 (default) = the level-synchronous interpreter everywhere; 1 = the flat schedule for the prover of eligible circuits
 // of at least RV_FLAT_MIN gates (2^20: below, the cleartext pass does not hide behind the mask generator); 2 = for every eligible
 // circuit.  Read at every call (tests switch it).  Off by default: byte-identical, but on the 10^7-gate circuit the ~140 dependent
@@ -653,6 +663,7 @@ static int flat_mode() {
     const char* e = getenv("RV_FLAT");
     return e ? atoi(e) : 0;
 }
+#endif
 // workgroups of the cleartext pass = compute units the mask generator leaves free for them
 static uint32_t clear_wgs() {
     static const uint32_t v = [] {
@@ -711,6 +722,7 @@ static bool build_z64_fused(const Compiled& cc, std::vector<Gate64>& sorted, std
     return true;
 }
 
+#ifdef RV_EXPERIMENTS
 // LDS the rep-sliced interpreter may use for wire slots (a workgroup owns the CU: 160 KiB minus a little headroom)
 static uint32_t rep_lds_budget(const rv_ctx* ctx) {
     static const uint32_t v = [] {
@@ -720,12 +732,17 @@ static uint32_t rep_lds_budget(const rv_ctx* ctx) {
     const size_t dev = ctx->lds_bytes > 4096 ? ctx->lds_bytes - 4096 : 0;
     return (uint32_t)std::min<size_t>(v, dev);
 }
+#endif
 // RV_REP: 0 (default) = the row path everywhere; 1 = the rep-sliced path for whole proofs (all 256 repetitions on this
 // GPU) of circuits it accepts; 2 = for shards too.  Read at every call (tests switch it).  Off by default: measured on
 // MI355X it is byte-identical but not yet faster than the row path ("Rep-sliced path").
 static int rep_mode() {
+#ifdef RV_EXPERIMENTS
     const char* e = getenv("RV_REP");
     return e ? atoi(e) : 0;
+#else
+    return 0;  // (the rep-sliced path exists in experiment builds only: csrc/Makefile)
+#endif
 }
 
 static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
@@ -782,6 +799,7 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
     if (getenv("RV_COMPILE_STATS"))
         fprintf(stderr, "[rv circuit] compile_ops: %.3f s for %zu ops\n", std::chrono::duration<double>(t_compiled - t_begin).count(),
                 n_ops);
+#ifdef RV_EXPERIMENTS
     // the rep-sliced program of the prover (pure GF(2) circuits whose live wires fit the LDS): from this compile when it
     // keeps one base row per wire, else from a second compile that does
     if (rep_mode() && c->cc.gates64.empty() && !c->cc.gates.empty()) {
@@ -795,6 +813,7 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
             fprintf(stderr, "[rv circuit] rep-sliced path: %s%s (%u levels, %zu segments, %u LDS slots) at %.3f s\n", c->rep_ok ? "yes" : "no: ", why,
                     c->rp.n_levels, c->rp.segs.size(), c->rp.lds_slots, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     }
+#endif  // RV_EXPERIMENTS
     if ((rc = circuit_upload(ctx, c))) return rc;  // (destroys c on failure)
     if (getenv("RV_COMPILE_STATS"))
         fprintf(stderr, "[rv circuit] compiled + uploaded after %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
@@ -1048,6 +1067,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
         }
     }
     c->persist_gen = persist_general(cc.level_range.data(), cc.level_range.size());
+#ifdef RV_EXPERIMENTS
     if (c->vclr_ok && flat_mode()) {
         // the flat schedule of the prover: Mul records in program order, XOR rows by x-level, the rest
         static const uint64_t flat_min = getenv("RV_FLAT_MIN") ? (uint64_t)atoll(getenv("RV_FLAT_MIN")) : (1ull << 20);
@@ -1085,6 +1105,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
             decltype(c->flat.lite_k)().swap(c->flat.lite_k);
         }
     }
+#endif  // RV_EXPERIMENTS
     return RV_OK;
 #undef UPCHK
 }
@@ -1431,12 +1452,6 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
             ctx->count(1);
         }
     }
-    // everything the interpreter reads besides gf2 masks is queued on `stream` before this point
-    // (events only when two streams are in play: on one stream the order is the queue order)
-    if (ctx->pipeline) {
-        s->ev_setup = ctx->get_sync_event();
-        HIPCHK(hipEventRecord(s->ev_setup, ctx->stream));
-    }
     if (s->overlap) {
         // nothing is generated here: the level loop submits the chunks (overlap_need), each on ctx->stream_m behind this point
         if (!ctx->stream_m && hipStreamCreateWithFlags(&ctx->stream_m, hipStreamNonBlocking) != hipSuccess) return hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
@@ -1459,22 +1474,13 @@ static int shard_setup_prg(rv_shard* s, const uint32_t* d_keep, const uint32_t* 
         ctx->phase(-1);
         return RV_OK;
     }
-    // gf2 masks in chunks, one event each (the interpreter starts as soon as its first levels' masks exist)
-    {
-        const uint64_t target = ctx->pipeline ? std::max<uint64_t>((n_blocks + 11) / 12, 2048) : std::max<uint64_t>(n_blocks, 1);
-        for (uint64_t b0 = 0; b0 < n_blocks; b0 += target) {
-            const uint64_t nb = std::min(target, n_blocks - b0);
-            if (col4)
-                launch_aes_gf2_masks_col4(ctx->stream, s->d_rk_c4, d_keep, s->NQ, b0, nb, s->d_masks + (size_t)b0 * 128 * s->NQ);
-            else
-                launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, b0, nb, s->d_masks + (size_t)b0 * 128 * s->NQ, s->flat ? clear_wgs() : 0);
-            ctx->count();
-            if (ctx->pipeline) {
-                hipEvent_t e = ctx->get_sync_event();
-                HIPCHK(hipEventRecord(e, ctx->stream));
-                s->mask_chunks.emplace_back(b0 + nb, e);
-            }
-        }
+    // every GF(2) mask before the first level, on the main stream
+    if (n_blocks) {
+        if (col4)
+            launch_aes_gf2_masks_col4(ctx->stream, s->d_rk_c4, d_keep, s->NQ, 0, n_blocks, s->d_masks);
+        else
+            launch_aes_gf2_masks(ctx->stream, s->d_rk, d_keep, s->NQ, 0, n_blocks, s->d_masks, s->flat ? clear_wgs() : 0);
+        ctx->count();
     }
     ctx->phase(-1);
     return RV_OK;
@@ -1528,14 +1534,13 @@ static int shard_run_alloc(rv_shard* s, InterpParams& p, Interp64Params& p64) {
             HIPCHK(hipMemsetAsync(s->d_v64, 0, 8, ctx->stream));  // (SSA id 0 = the zero wire)
         } else {
             if ((rc = dalloc(ctx, (size_t)cc.n_ssa64 * s->R, &s->d_wcorr64))) return rc;
-            HIPCHK(hipMemsetAsync(s->d_wcorr64, 0, (size_t)s->R * 8, ctx->pipeline ? ctx->stream2 : ctx->stream));
+            HIPCHK(hipMemsetAsync(s->d_wcorr64, 0, (size_t)s->R * 8, ctx->stream));
         }
         if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.on_words64, 1) * s->R, &s->d_on64))) return rc;
         if ((rc = dalloc(ctx, (size_t)std::max<uint64_t>(cc.pre_words64, 1) * s->R, &s->d_pre64))) return rc;
-        HIPCHK(hipMemsetAsync(s->d_wmask64, 0, (size_t)s->R * 64, ctx->pipeline ? ctx->stream2 : ctx->stream));
+        HIPCHK(hipMemsetAsync(s->d_wmask64, 0, (size_t)s->R * 64, ctx->stream));
     }
-    hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
-    if (s->ev_setup && ctx->pipeline) HIPCHK(hipStreamWaitEvent(sb, s->ev_setup, 0));
+    hipStream_t sb = ctx->stream;
     // error flag and the zero row (first computed row: mask 0, corr 0), one launch
     launch_shard_init(sb, s->d_err, s->d_masks + (size_t)cc.zero_row * s->NQ, s->NQ,
                       s->d_wires + (size_t)cc.zero_row * (s->NQ / 2), s->NQ / 2);
@@ -1579,6 +1584,8 @@ static bool lds_run_for_batch(const rv_circuit* c, size_t level, size_t batch) {
 // byte ranges, each with the level it is complete after.  Only for pure GF(2) circuits with at least RV_EARLY_MIN
 // (default 2^21) Mul gates whose preprocessing rows complete roughly in step with the levels (a layered circuit; a
 // circuit whose first rows are written by its last level gains nothing and keeps the plain path).
+static std::atomic<uint64_t> g_overlap_commits{0};  // shard commitments whose mask generator ran beside the level launches (RV_OVERLAP)
+extern "C" uint64_t rv_hook_overlap_commits(void) { return g_overlap_commits.load(std::memory_order_relaxed); }
 static std::atomic<uint64_t> g_early_proofs{0};
 extern "C" uint64_t rv_hook_early_proofs(void) { return g_early_proofs.load(std::memory_order_relaxed); }
 static std::atomic<uint64_t> g_verify_vc{0};
@@ -1793,6 +1800,7 @@ extern "C" int rv_hook_early_plan(const rv_op* ops, size_t n_ops, size_t z64_wir
 // Host-only view of the flat prover schedule (tests; csrc/flat.h): built as circuit_upload builds it, then replayed against the
 // level-sorted gate stream it was made from.
 extern "C" int rv_hook_flat_plan(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, uint32_t bands, uint64_t out[24]) {
+#ifdef RV_EXPERIMENTS
     if (!out || (n_ops && !ops) || (flags & ~RV_COMPILE_WHOLE_PROVER)) return RV_E_ARG;
     try {
         Compiled cc;
@@ -1856,6 +1864,11 @@ extern "C" int rv_hook_flat_plan(const rv_op* ops, size_t n_ops, size_t z64_wire
         g_last_error = "out of host memory";
         return RV_E_NOMEM;
     }
+#else
+    (void)ops, (void)n_ops, (void)z64_wires, (void)gf2_wires, (void)flags, (void)bands, (void)out;
+    g_last_error = "rv_hook_flat_plan: the flat schedule exists in experiment builds only (make EXTRA=-DRV_EXPERIMENTS)";
+    return RV_E_UNSUPPORTED;
+#endif
 }
 
 // Early corrections, device side.  early_flush (called by the level loop) puts, behind the level that completes a chunk, the
@@ -1911,6 +1924,7 @@ static int early_flush(rv_shard* s, size_t levels_queued) {
     while (last < chunks.size() && chunks[last].ready_level < levels_queued) last++;
     return early_flush_chunks(s, last);
 }
+#ifdef RV_EXPERIMENTS
 // flat schedule: the chunks that lie inside the first `muls_queued` Mul gates of the program (preprocessing row = Mul ordinal)
 static int early_flush_muls(rv_shard* s, uint64_t muls_queued) {
     EarlyRun* e = s->ec;
@@ -1919,6 +1933,7 @@ static int early_flush_muls(rv_shard* s, uint64_t muls_queued) {
     while (last < chunks.size() && std::min<uint64_t>(8 * (chunks[last].byte0 + chunks[last].nbytes), s->c->cc.n_pre) <= muls_queued) last++;
     return early_flush_chunks(s, last);
 }
+#endif
 
 // The host's waits of the early-corrections path (a chunk's stamp, the challenge): the mailbox is written by the GPU, so there is
 // nothing to block on -- but the caller need not burn a core for the milliseconds a proof takes either.  The wait SLEEPS through
@@ -1988,6 +2003,7 @@ static int early_pump(rv_shard* s) {
     return RV_OK;
 }
 
+#ifdef RV_EXPERIMENTS  // the prover schedules that measured slower than the level path: experiment builds only
 // RV_PERSIST: 1 = the levels of a MODE_PROVE_V run go through k_interp_persist (no launch per level), 0 (default) = one launch per level.
 // Off: byte-identical, but the in-launch hand-off between levels (arrival counters + polling) costs more than the launch boundary
 // it replaces ("Persistent level kernel").
@@ -2223,15 +2239,18 @@ static int shard_run_split(rv_shard* s, const InterpParams& p) {
     HIPCHK(hipGetLastError());
     return RV_OK;
 }
+#endif  // RV_EXPERIMENTS
 
 static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const Interp64Params& p64) {
+#ifdef RV_EXPERIMENTS
     if (s->split) return shard_run_split(s, p);
     if (s->flat) return shard_run_flat(s, p);
     if (mode == MODE_PROVE_V && persist_mode() && persist_supports(s->NQ) && !g_recorder) return shard_run_persist(s, p);
+#endif
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
     const bool has64 = !cc.gates64.empty();
-    hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
+    hipStream_t sb = ctx->stream;
     const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
     ctx->phase(RV_PH_INTERP, sb);
     size_t waited = 0;  // mask chunks already waited for
@@ -2348,6 +2367,7 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
     }
     if (s->ec && (rc_ec = early_flush(s, n_levels))) return rc_ec;
     if (s->overlap && (rc_ec = overlap_need(s, s->ov_blocks, sb))) return rc_ec;  // (masks no level reads: padding)
+    if (s->overlap) g_overlap_commits.fetch_add(1, std::memory_order_relaxed);
     if (g_ov_trace) g_ov_trace->mark("main: last level done", n_levels, sb);
     return RV_OK;
 }
@@ -2355,13 +2375,6 @@ static int shard_run_levels(rv_shard* s, int mode, const InterpParams& p, const 
 static int shard_run_hash(rv_shard* s) {
     rv_ctx* ctx = s->ctx;
     const Compiled& cc = s->c->cc;
-    hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
-    if (sb != ctx->stream) {
-        hipEvent_t done = ctx->get_sync_event();
-        HIPCHK(hipEventRecord(done, sb));
-        HIPCHK(hipStreamWaitEvent(ctx->stream, done, 0));
-        s->misc_events.push_back(done);
-    }
     ctx->phase(RV_PH_HASH);
     uint32_t* dig = s->d_dig;
     const size_t DW = (size_t)s->R * 8;
@@ -2420,6 +2433,7 @@ static int shard_join(rv_shard* s) {
     return RV_OK;
 }
 
+#ifdef RV_EXPERIMENTS
 // (a lane's mask window may start a few bytes before its segment's first mask: slack in front of every repetition's masks)
 constexpr size_t REP_MASK_FRONT = 16;
 // The rep-sliced prover (rep.hip): a workgroup per repetition, live wires in LDS, rep-major masks and transcripts.
@@ -2492,6 +2506,7 @@ static int shard_commit_rep(rv_shard* s) {
     HIPCHK(hipGetLastError());
     return RV_OK;
 }
+#endif  // RV_EXPERIMENTS
 
 // defer_sync: do not wait for the device (nor look at the invalid-witness flag): the caller queues more work behind
 // the commitment and checks s->d_err itself after its own synchronisation
@@ -2559,7 +2574,8 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         return !e || atoi(e) != 0;
     }();
     const bool rep_path = c->rep_ok && (rep_mode() >= 2 || (rep_mode() == 1 && rep_count == RV_TOTAL_REPS));
-    const bool use_vclr = !rep_path && vclr_on && c->vclr_ok && (s->NQ == 64 || s->NQ == 32 || s->NQ == 16 || s->NQ == 8) && !ctx->pipeline;
+    const bool use_vclr = !rep_path && vclr_on && c->vclr_ok && (s->NQ == 64 || s->NQ == 32 || s->NQ == 16 || s->NQ == 8);
+#ifdef RV_EXPERIMENTS
     if (use_vclr && c->flat.ok && (flat_mode() == 1 || (flat_mode() == 3 && chain_supports(s->NQ))) && mul_flat_supports(s->NQ) && !g_recorder) {
         // split schedule: the level chain computes the values itself (shard_run_split)
         if ((rc = ctx_side_streams(ctx))) return fail(rc);
@@ -2592,21 +2608,28 @@ static int rv_shard_commit_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         }
         if (hipEventRecord(s->ev_clear, ctx->stream3) != hipSuccess) return fail(RV_E_DEVICE);
     }
-    s->z64f = !rep_path && c->z64f_ok && z64_fused_on() && z64_fused_supports(s->NQ) && !ctx->pipeline && !g_recorder;
+#endif  // RV_EXPERIMENTS
+    s->z64f = !rep_path && c->z64f_ok && z64_fused_on() && z64_fused_supports(s->NQ) && !g_recorder;
     {
         // the mask generator beside the level launches (RV_OVERLAP=0 turns it off; RV_OVERLAP_MIN = fewest CTR blocks): wide circuits
         // only -- a level must be long enough to hide a share of the cipher behind
         const int ov_mode = getenv("RV_OVERLAP") ? atoi(getenv("RV_OVERLAP")) : 1;  // (read at every call: bench.py and the tools switch it)
-        static const uint64_t ov_min = getenv("RV_OVERLAP_MIN") ? strtoull(getenv("RV_OVERLAP_MIN"), nullptr, 0) : 8192;
-        s->overlap = ov_mode != 0 && !rep_path && !s->flat && !s->split && !ctx->pipeline && !g_recorder && aes_col4_supports(s->NQ) &&
-                     cc.n_masks_pad / 128 >= ov_min && !(persist_mode() && persist_supports(s->NQ));
+        const uint64_t ov_min = getenv("RV_OVERLAP_MIN") ? strtoull(getenv("RV_OVERLAP_MIN"), nullptr, 0) : 8192;  // (per call: the tests lower it)
+        s->overlap = ov_mode != 0 && !rep_path && !s->flat && !s->split && !g_recorder && aes_col4_supports(s->NQ) &&
+                     cc.n_masks_pad / 128 >= ov_min;
+#ifdef RV_EXPERIMENTS
+        if (persist_mode() && persist_supports(s->NQ)) s->overlap = false;
+#endif
     }
     ctx->phase(RV_PH_SETUP);
     ctx->count();
     launch_expand_seeds(ctx->stream, s->d_seeds, s->R, s->d_keys);
+#ifdef RV_EXPERIMENTS
     if (rep_path) {
         if ((rc = shard_commit_rep(s))) return fail(rc);
-    } else {
+    } else
+#endif
+    {
         if ((rc = shard_setup_prg(s, nullptr))) return fail(rc);
         if (ec) s->ec = ec;  // (the caller made sure this path is taken: no rep-sliced prover, one stream)
         InterpParams p{};
@@ -2863,12 +2886,16 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
     ctx->count(any_on ? 4 : 1);
     launch_open_headers(ctx->stream, s->R, s->d_omit, s->d_seeds, s->d_keys, s->d_dig + 1 * DW, s->d_dig + 3 * DW, s->d_offs,
                         s->d_offs + s->R, L.l2r, L.l2c, L.l2i, L.l64r, L.l64c, L.l64i, d_out);
+#ifdef RV_EXPERIMENTS
     if (any_on && s->rep) {
         // rep-major transcripts: only the opened repetitions' bytes are read at all
         launch_rep_open(ctx->stream, s->d_on_rep, s->on_stride, s->c->d_rec_rows, cc.n_rec, 0, d_ol, s->d_omit, s->d_offs + 2 * s->R, d_out);
         launch_rep_open(ctx->stream, s->d_pre_rep, s->pre_stride, nullptr, cc.n_pre, 1, d_ol, s->d_omit, s->d_offs + 3 * s->R, d_out);
         launch_rep_open(ctx->stream, s->d_on_rep, s->on_stride, s->c->d_in_rows, cc.n_in, 1, d_ol, s->d_omit, s->d_offs + 4 * s->R, d_out);
-    } else if (any_on) {
+    } else
+#endif
+    if (any_on) {
+#ifdef RV_EXPERIMENTS
         if (rec_stage) {
             // slice by slice: extract into the staging block, then (second stream, behind an event) the slice's 2-D copy to the host
             // (host order: the event, then the other stream's wait for it -- a wait resolves to the stream's tail at queueing time)
@@ -2878,7 +2905,9 @@ static int shard_open_impl(rv_shard* s, const uint8_t* omit, void* dst, void** d
                 launch_publish(ctx->stream, nullptr, 0, nullptr, rec_stage->box_dev + 2, (rec_stage->seq << 8) | (uint32_t)(k + 1));
                 ctx->count(2);
             }
-        } else {
+        } else
+#endif
+        {
             launch_extract_bits(ctx->stream, s->d_on, s->c->d_rec_rows, cc.n_rec, s->NQ, 0, s->d_omit, s->d_offs + 2 * s->R, d_out);
         }
         if (corr2_rep_min < s->R) launch_extract_from_bits(ctx->stream, s->d_pre, cc.n_pre, s->NQ, d_ol, d_out, corr2_rep_min);
@@ -3054,7 +3083,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
     uint32_t* fs_dev = nullptr;
     OpenLayout EL{};
     const bool early_on = !(getenv("RV_EARLY") && atoi(getenv("RV_EARLY")) == 0);
-    if (early_on && allow_early && !dst && !g_recorder && !ctx->pipeline && rep_mode() == 0) {
+    if (early_on && allow_early && !dst && !g_recorder && rep_mode() == 0) {
         const EarlyPlan* pl = early_plan(c);
         if (pl->ok) {
             HIPCHK(hipSetDevice(ctx->device));
@@ -3114,6 +3143,7 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
     RecStage rs;
     bool rec_staged = false;
     const uint64_t rec_min = getenv("RV_EARLY_REC_MIN") ? (uint64_t)atoll(getenv("RV_EARLY_REC_MIN")) : (1ull << 20);  // (read per call: the tests lower it)
+#ifdef RV_EXPERIMENTS
     if (early && !er.plan->z64 && getenv("RV_EARLY_REC") && atoi(getenv("RV_EARLY_REC")) != 0 && c->cc.n_rec >= rec_min) {
         const uint64_t n_bytes = c->cc.n_rec / 8 + 1, g = extract_stage_granule(c->cc.n_rec);
         rs.pitch = (n_bytes + 255) & ~255ull;
@@ -3144,6 +3174,9 @@ static int rv_prove_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t* wit_gf
             rec_staged = true;
         }
     }
+#else
+    (void)rec_min;
+#endif
     int rc = rv_shard_commit_impl(ctx, c, wit_gf2, n_gf2, wit_z64, n_z64, seeds, 0, RV_TOTAL_REPS, &s, /*defer_sync=*/true, early ? &er : nullptr);
     if (rc) {
         for (hipEvent_t e : rs.ev) ctx->sync_pool.push_back(e);
@@ -3566,8 +3599,6 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
         ctx->prof.calls += batch;
         return RV_OK;
     }
-    const bool was_pipelined = ctx->pipeline;
-    ctx->pipeline = false;  // everything of a batch goes down ONE stream
     std::vector<rv_shard*> sh(batch, nullptr);
     std::vector<InterpParams> pp(batch);
     InterpParams* d_pp = nullptr;
@@ -3587,7 +3618,6 @@ static int rv_prove_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, c
         for (void* q : device_tmp) ctx->release(q);
         for (void* q : pinned_tmp) g_pinned.put(q);
         if (staging) g_pinned.put(staging);
-        ctx->pipeline = was_pipelined;
         if (code)
             for (size_t b = 0; b < batch; b++) rv_free(proofs[b]), proofs[b] = nullptr, proof_lens[b] = 0;
         return code;
@@ -3979,7 +4009,7 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
                  o_onq = seg(std::max<size_t>(on_quads.size(), 1) * 4), o_hkeys = seg(hkeys.size()), o_hco = seg(hco.size()),
                  o_hco64 = seg(hco64.size()), o_src = seg(src.size() * 8), o_proof = seg(proof_len);
     static const bool small_stage = !(getenv("RV_SMALL_STAGE") && atoi(getenv("RV_SMALL_STAGE")) == 0);
-    bool blob = small_stage && !has64 && !ctx->pipeline && !g_recorder && blob_bytes <= rv_ctx::IN_STAGE_BYTES;
+    bool blob = small_stage && !has64 && !g_recorder && blob_bytes <= rv_ctx::IN_STAGE_BYTES;
     if (blob && !ctx->h_in && hipHostMalloc((void**)&ctx->h_in, rv_ctx::IN_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         ctx->h_in = nullptr;
@@ -4019,7 +4049,7 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
         // d_proof / d_src may be filled from the SECOND stream further down (beside the mask kernels).  The arena hands blocks out
         // in the main stream's order, so the side stream first waits for everything the main stream holds NOW -- whatever used
         // these blocks last -- and nothing of this call's own kernels (they are queued after this point)
-        if (!ctx->pipeline && !g_recorder && proof_len >= ((size_t)4 << 20)) {
+        if (!g_recorder && proof_len >= ((size_t)4 << 20)) {
             ev_arena = ctx->get_sync_event();
             s->misc_events.push_back(ev_arena);
             if (hipEventRecord(ev_arena, ctx->stream) != hipSuccess) return fail(hip_fail(hipGetLastError(), "hipEventRecord", __FILE__, __LINE__));
@@ -4118,12 +4148,12 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     // level).  Its kernels take 40 ms instead of 53 on the 10^6-MUL circuit; the 640 MB proof's 12 ms of PCIe and the unpack
     // kernels, which used to hide beside the mask generator, hide beside the quad groups that hold no opened repetition (split64
     // below): rv_verify 59.5 -> 52.5 ms.
-    s->z64f = has64 && c->z64f_ok && z64_fused_on() && z64_fused_supports(NQ) && !ctx->pipeline && !g_recorder &&
+    s->z64f = has64 && c->z64f_ok && z64_fused_on() && z64_fused_supports(NQ) && !g_recorder &&
               !(getenv("RV_Z64_FUSED_VERIFY") && atoi(getenv("RV_Z64_FUSED_VERIFY")) == 0);
     if ((rc = shard_setup_prg(s, d_keep, d_keep64))) return fail(rc);
     // ---- the interpreter's stream: the proof itself (tens of MB from pageable memory: the host blocks in this
     //      copy while the mask kernels above already run) and the supplied-value rows unpacked from it
-    hipStream_t sb = ctx->pipeline ? ctx->stream2 : ctx->stream;
+    hipStream_t sb = ctx->stream;
     hipStream_t su = sb;  // the stream of the GF(2) unpack kernels
     // on ONE stream the proof's copy would queue up behind the mask kernels; from the second stream it runs beside them
     // (copy engine next to compute) and the unpack kernels wait for its event
@@ -4154,7 +4184,6 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
             }
         }
     }
-    if (s->ev_setup && ctx->pipeline) HC(hipStreamWaitEvent(sb, s->ev_setup, 0));  // d_omit / d_omit64 come from stream 1
     if (!split64) {  // (split64: a circuit without GF(2) gates has none of these)
         launch_unpack_bits(su, d_proof, d_src + 4 * R, d_src + 5 * R, s->d_omit, cc.n_in, NQ, 1, d_sup_in, sup_nq);
         launch_unpack_bits(su, d_proof, d_src + 2 * R, d_src + 3 * R, s->d_omit, cc.n_pre, NQ, 1, d_sup_corr, sup_nq);
@@ -4208,7 +4237,7 @@ static int rv_verify_shard_impl(rv_ctx* ctx, const rv_circuit* c, const uint8_t*
     int vmode = MODE_VERIFY;
     // (not for gate streams with multi-base levels -- the prover's lazy linear forms: their kernel variant runs at 4 - 5 wavefronts
     // per SIMD either way and measured 0.07 ms SLOWER with the compact corrections; one-base streams: -0.03 ... -0.08 ms)
-    if (vc_on && c->vclr_ok && !c->persist_gen && NQ == 64 && sup_nq == 16 && !on_quads.empty() && !ctx->pipeline && !g_recorder) {
+    if (vc_on && c->vclr_ok && !c->persist_gen && NQ == 64 && sup_nq == 16 && !on_quads.empty() && !g_recorder) {
         uint64_t* d_vc = nullptr;
         if ((rc = dalloc(ctx, (size_t)cc.n_rows, &d_vc))) return fail(rc);
         track(d_vc);
@@ -4602,8 +4631,6 @@ static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, 
     struct RecorderOff {
         ~RecorderOff() { g_recorder = nullptr; }
     } recorder_off;
-    const bool was_pipelined = ctx->pipeline;
-    ctx->pipeline = false;
     InterpParams* d_pp = nullptr;
     auto cleanup = [&](int code) {
         g_recorder = nullptr;
@@ -4616,7 +4643,6 @@ static int rv_verify_batch_impl(rv_ctx* ctx, const rv_circuit* c, size_t batch, 
         ctx->release(d_pp);
         for (void* q : device_tmp) ctx->release(q);
         for (void* q : pinned_tmp) g_pinned.put(q);
-        ctx->pipeline = was_pipelined;
         return code;
     };
     constexpr size_t HEAD = 256;  // (no slot pointer equals an arena block: the slabs are released exactly once)

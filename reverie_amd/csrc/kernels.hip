@@ -703,6 +703,10 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
     }
 }
 
+// Rounds 2 and 4 built four more launch structures for the GF(2) prover (persistent level kernels, the split and chained
+// schedules of flat.h).  All byte-identical, all measured slower: they are compiled only into experiment
+// builds (make EXTRA=-DRV_EXPERIMENTS), not into the library build() makes.
+#ifdef RV_EXPERIMENTS
 // ------------------------------------------------------------------------------------
 // k_interp_persist: the dependency levels of a circuit WITHOUT a launch each (round 4).
 //
@@ -1084,11 +1088,6 @@ void build_persist_levels(const LevelRange* lr, size_t n_levels, uint32_t NQ, bo
         out[l] = L;
     }
 }
-bool persist_general(const LevelRange* lr, size_t n_levels) {
-    for (size_t l = 0; l < n_levels; l++)
-        if (level_is_general(lr[l])) return true;
-    return false;
-}
 
 template <int NQ, bool GENERAL>
 static int launch_persist_nq(hipStream_t st, const Gate* d_gates, const PLevel* d_levels, uint32_t l0, uint32_t l1, uint64_t n_steps, const InterpParams& p,
@@ -1405,6 +1404,15 @@ void launch_chain(hipStream_t st, uint32_t n_wgs, bool general, const Gate* d_ga
     else
         hipLaunchKernelGGL((k_chain<64, false>), dim3(n_wgs), dim3(1024), 0, st, cp, p);
 }
+#endif  // RV_EXPERIMENTS
+
+// whether any level of the gate stream has enough multi-base gates for the kernel variants with their loops (the verifier's
+// choice of MODE_VERIFY_C looks at it too)
+bool persist_general(const LevelRange* lr, size_t n_levels) {
+    for (size_t l = 0; l < n_levels; l++)
+        if (level_is_general(lr[l])) return true;
+    return false;
+}
 
 // Narrow levels (deep circuits: ripple-carry adders, AES/SHA rounds) would be launch-bound at one
 // kernel per level (~4.6 us each).  A run of consecutive narrow levels is executed by ONE 1024-thread
@@ -1602,13 +1610,8 @@ struct B_k_b3_chunks {
             if (UNI) {
                 const char* rb = (const char*)(stream + e0 * 64);
                 const uint32_t qoff = q * 4u;
-#ifdef RV_B3_NOLOAD  // (experiment: the kernel without its message loads)
-#pragma unroll
-                for (int e = 0; e < 64; e++) w[e] = (uint32_t)(uintptr_t)rb * (e + 1) + qoff;
-#else
 #pragma unroll
                 for (int e = 0; e < 64; e++) w[e] = *(const uint32_t*)(rb + e * 256 + qoff);
-#endif
             } else {
 #pragma unroll
                 for (int e = 0; e < 64; e++) w[e] = stream[(e0 + e) * NQ + q];
@@ -1630,14 +1633,7 @@ struct B_k_b3_chunks {
                 m[i][k] = lo | (hi << 16);
             }
         }
-#ifdef RV_B3_NOCOMP  // (experiment: the kernel without its compressions)
-#pragma unroll
-        for (int i = 0; i < RPL; i++)
-#pragma unroll
-            for (int k = 0; k < 16; k++) cv[i][k & 7] ^= m[i][k] + flags;
-#else
         b3::compress_n<RPL>(cv, m, c + chunk_base, blen, flags);  // the lane's repetitions in lockstep
-#endif
     }
     const uint32_t R = NQ * 4;
 #pragma unroll
@@ -2570,6 +2566,7 @@ void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d
         launch<B_k_extract_rows<1>, 256>(k_extract_rows<1>, st, grid, dim3(256), (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
                            d_dst_off, d_out, 0, 0);
 }
+#ifdef RV_EXPERIMENTS  // (RecStage, api.hip: RV_EARLY_REC)
 // the same vectors (kind 0: the omitted players' broadcast bits) as a slice into a dense staging block: output bytes
 // [byte0, byte0 + n_bytes_slice) of every opened repetition's vector go to d_stage + slot * pitch + byte; byte0 a multiple of
 // extract_stage_granule(n_items)
@@ -2584,6 +2581,7 @@ void launch_extract_bits_stage(hipStream_t st, const void* d_stream, const uint3
     hipLaunchKernelGGL(k_extract_rows<0>, grid, dim3(256), 0, st, (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit, (const uint64_t*)nullptr, d_stage, pitch,
                        (uint32_t)(byte0 / tb));
 }
+#endif
 
 // Inverse for the verifier (Pack::unpack / PackSelected::unpack_selected): builds dense
 // rows from the proof's bit vectors.  kind 0: bit placed at the omitted player's position;

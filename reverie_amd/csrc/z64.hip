@@ -145,17 +145,11 @@ __global__ __launch_bounds__(256) void k_interp64(const Gate64* __restrict__ gat
                     if (om & 1) s.y += sup; else s.x += sup;
                 }
             }
-#ifndef RV_X_NOON
             st2_unaligned(p.on + (size_t)r * p.on_words + g.eo + 2 * pk, s);
-#endif
             uint64_t rec = sum8(s);
             if (MODE == MODE_VERIFY && !online) rec = 0;
             if (pk == 0) {
-#ifndef RV_X_NOPRE
                 p.pre[(size_t)r * p.pre_words + g.ep] = delta;
-#else
-                if (delta == 0x1234567u) p.pre[(size_t)r * p.pre_words + g.ep] = delta;
-#endif
                 *dc = rec + delta + cx * cy;
             }
             break;

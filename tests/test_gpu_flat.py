@@ -15,7 +15,12 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def rv():
     import reverie_amd
+    from reverie_amd import _lib
 
+    # these schedules measured slower than the level path and are compiled into experiment builds only (round 5):
+    #   make -C reverie_amd/csrc OUT=../_build_x EXTRA=-DRV_EXPERIMENTS && RV_LIB_PATH=reverie_amd/_build_x/libreverie_amd.so pytest ...
+    if not _lib.lib().rv_hook_experiments():
+        pytest.skip("the flat / split / chained prover schedules exist in experiment builds only (EXTRA=-DRV_EXPERIMENTS)")
     return reverie_amd
 
 

@@ -547,32 +547,53 @@ def test_prove_batch_equals_single_proofs(rv, oracle, rule_seeds):
         assert bytes(gm[b]) == oracle.prove(progm, w2, w64, wcm, seeds[b], threads=2)
 
 
-def test_two_stream_pipeline_mode(rv, oracle, rule_seeds, monkeypatch):
-    """RV_PIPELINE=1 (mask generator and interpreter on two streams, chunk-wise; no longer the default) must give the
-    same proofs: a layered circuit wide enough for several mask chunks, and a mixed GF(2)/Z64 one."""
-    import reverie_amd
+def test_mask_generator_beside_the_levels(rv, oracle, rule_seeds, monkeypatch):
+    """RV_OVERLAP (round 5, on by default for circuits of >= 8192 cipher blocks): the lane-distributed mask generator
+    (csrc/aes_col4.hip; replaces generator/share.rs:54-65 + gf2/domain.rs:66-378 like k_aes_gf2_masks) runs chunk by chunk on a
+    stream of its own BESIDE the level launches that read earlier chunks.  Threshold lowered so that circuits the oracle can prove
+    take the path: whole proofs (both compiler hints), 128- and 64-repetition shards, a mixed GF(2) / Z64 circuit beside; the
+    bytes with RV_OVERLAP=0; and the path really taken (rv_hook_overlap_commits)."""
+    from reverie_amd import _lib
+    from reverie_amd.dist import HipShardBackend
+    from reverie_amd.proof import challenge, combine_digests
 
-    monkeypatch.setenv("RV_PIPELINE", "1")
-    ctx = reverie_amd.Context(0)
-    monkeypatch.delenv("RV_PIPELINE")
-    live = []  # circuits must be destroyed before their context
-    try:
-        prog, wit, wc, st = circuits.layered_gf2(n_in=64, width=8192, layers=80, fold_to=16)
-        c = rv.Circuit(prog, wc, ctx)
-        live.append(c)
-        proof = rv.Proof.new(c, wit, [], seeds=rule_seeds)
-        assert bytes(proof) == oracle.prove(prog, wit, [], wc, rule_seeds, threads=4)
+    L = _lib.lib()
+    monkeypatch.setenv("RV_OVERLAP_MIN", "1000")
+    monkeypatch.setenv("RV_EARLY_MIN", "100000")  # (the early-corrections path beside it, as on the benchmark circuit)
+    prog, wit, wc, st = circuits.layered_gf2(n_in=64, width=8192, layers=80, fold_to=16)
+    want = oracle.prove(prog, wit, [], wc, rule_seeds, threads=4)
+    for hint in (True, False):
+        c = rv.Circuit(prog, wc, whole_prover=hint)
+        n0 = L.rv_hook_overlap_commits()
+        for _ in range(2):
+            proof = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+            assert bytes(proof) == want
+        assert L.rv_hook_overlap_commits() == n0 + 2
         assert proof.verify(c)
-        progm, w2, w64, wcm = circuits.random_mixed(np.random.default_rng(31), n_gates=400)
-        cm = rv.Circuit(progm, wcm, ctx)
-        live.append(cm)
-        pm = rv.Proof.new(cm, w2, w64, seeds=rule_seeds)
-        assert bytes(pm) == oracle.prove(progm, w2, w64, wcm, rule_seeds, threads=2)
-        assert pm.verify(cm)
-    finally:
-        for x in live:
-            x.close()
-        ctx.close()
+        monkeypatch.setenv("RV_OVERLAP", "0")
+        assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == want and L.rv_hook_overlap_commits() == n0 + 2
+        monkeypatch.delenv("RV_OVERLAP")
+        if not hint:
+            # repetition shards: 128 and 64 repetitions take the path (rows of 32 / 16 quad words), 32 keep the 128-plane generator
+            for per in (128, 64, 32):
+                be = HipShardBackend(c)
+                n1 = L.rv_hook_overlap_commits()
+                shards = [be.commit(wit, [], rule_seeds[b:b + per], b, per) for b in range(0, 256, per)]
+                assert L.rv_hook_overlap_commits() == n1 + (256 // per if per >= 64 else 0)
+                comm = combine_digests(np.concatenate([be.digests(s) for s in shards]))
+                omit = challenge(comm)
+                parts = [be.open(s, omit)[:2] for s in shards]
+                for s in shards:
+                    be.destroy(s)
+                from reverie_amd.dist import assemble
+
+                assert assemble(comm, parts) == want
+        c.close()
+    progm, w2, w64, wcm = circuits.random_mixed(np.random.default_rng(31), n_gates=400)
+    cm = rv.Circuit(progm, wcm)
+    pm = rv.Proof.new(cm, w2, w64, seeds=rule_seeds)
+    assert bytes(pm) == oracle.prove(progm, w2, w64, wcm, rule_seeds, threads=2) and pm.verify(cm)
+    cm.close()
 
 
 def test_prove_device_invalid_witness(rv, rule_seeds):
@@ -1007,6 +1028,10 @@ def test_rep_sliced_path(rv, oracle, rule_seeds, monkeypatch, mode):
     the cleartext pre-pass instead of stored corrections) must produce the same bytes as the oracle -- golden circuits,
     Bristol-style random circuits with constants and wire reuse, a layered circuit with several segments per level and
     misaligned transcript offsets, and (mode 2) repetition shards"""
+    from reverie_amd import _lib
+
+    if not _lib.lib().rv_hook_experiments():
+        pytest.skip("the rep-sliced path exists in experiment builds only (make EXTRA=-DRV_EXPERIMENTS)")
     from reverie_amd.dist import HipShardBackend, assemble
     from reverie_amd.proof import challenge, combine_digests
 
@@ -1227,7 +1252,8 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
     L = _lib.lib()
     monkeypatch.setenv("RV_EARLY_MIN", "1000")
     # round 4: the opened repetitions' broadcast-bit vectors leave in slices through the copy engine (RecStage, api.hip) -- on for
-    # every case here (threshold lowered), with 1 .. 7 slices; the RV_EARLY_REC=0 bytes (one kernel copy, round 3) at the end
+    # every case here (threshold lowered), with 1 .. 7 slices; the RV_EARLY_REC=0 bytes (one kernel copy, round 3) at the end.
+    # (RecStage exists in experiment builds only -- EXTRA=-DRV_EXPERIMENTS; the library build() makes ignores these three knobs)
     monkeypatch.setenv("RV_EARLY_REC_MIN", "1000")
     monkeypatch.setenv("RV_EARLY_REC", "1")
     # (the last case is mostly XOR: its outputs still depend on the inputs after 80 layers, so a flipped witness bit is caught)
