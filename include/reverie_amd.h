@@ -515,8 +515,9 @@ uint64_t rv_hook_verify_vc_count(void);
  * Returns the compiler's status. */
 int rv_hook_early_plan(const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, uint64_t out[22]);
 /* The flat prover schedule of a program (host only, no device; csrc/flat.h: the Mul gates of a pure GF(2) circuit in program
- * order behind its XOR rows, instead of one launch per dependency level -- what rv_prove runs for whole proofs and repetition
- * shards of eligible circuits; RV_FLAT=0 turns it off, proof bytes are the same either way).  out[0] = eligible (0 / 1),
+ * order behind its XOR rows, instead of one launch per dependency level).  An EXPERIMENT: byte-identical, measured slower than the
+ * level path, compiled into experiment builds only (csrc/Makefile: EXTRA=-DRV_EXPERIMENTS, where RV_FLAT=1/2/3
+ * selects it; default 0) -- in the library build() makes this hook returns RV_E_UNSUPPORTED.  out[0] = eligible (0 / 1),
  * [1] = Mul records, [2] = XOR gates, [3] = x-levels, [4] = Input / AssertZero gates, [5] = 1 when the plan checks against the
  * level-sorted gate stream (every gate present once, every XOR gate behind the XOR rows it reads, Mul record i = the gate with
  * preprocessing row i), [6] = the circuit's dependency levels, [7] = bands (`bands` asked for: equal ranges of the

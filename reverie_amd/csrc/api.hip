@@ -1136,6 +1136,23 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     c->ctx->release(c->d_lite_k);
     c->ctx->release(c->d_lite_levels);
     c->ctx->release(c->d_chain_levels);
+    // the early-corrections staging of a LARGE plan (2 GB of page-locked memory for the 10^6-MUL Z64 circuit) does not outlive the
+    // circuit that needed it: a context that moves on to small circuits would otherwise hold it until rv_ctx_destroy.
+    // Small stagings (the 160 MB of the 10^7-gate GF(2) circuit) stay: re-mapping them costs more than they weigh.
+    if (c->ec_plan.ok && c->ec_plan.bytes >= ((size_t)1 << 30)) {
+        auto drop = [](rv_ctx* x) {
+            if (x->h_ec_cap < ((size_t)1 << 30)) return;
+            (void)hipSetDevice(x->device);
+            (void)hipStreamSynchronize(x->stream);
+            (void)hipStreamSynchronize(x->stream2);
+            if (x->h_ec) (void)hipHostFree(x->h_ec);
+            if (x->d_ec) (void)hipFree(x->d_ec);
+            x->h_ec = x->d_ec = nullptr;
+            x->h_ec_cap = x->d_ec_cap = 0;
+        };
+        drop(c->ctx);
+        for (rv_ctx* w : c->ctx->workers) drop(w);
+    }
     delete c;
 }
 
