@@ -153,6 +153,8 @@ struct rv_ctx {
     hipStream_t stream2 = nullptr;  // side stream: the early-corrections copies, the verifier's proof copy and unpack kernels
     hipStream_t stream3 = nullptr;  // the flat schedule's cleartext pass (k_clear), beside the mask generator
     hipStream_t stream_x = nullptr; // the flat schedule's XOR rows, running ahead of the Mul launches on `stream`
+    bool has_prio = false;          // the context's streams carry a stream priority of their own (rv_prove_batch's worker contexts)
+    int prio = 0;
     hipStream_t stream_m = nullptr; // RV_OVERLAP: the lane-distributed mask generator, beside the interpreter's level launches (made on first use)
     hipEvent_t clear_a = nullptr, clear_b = nullptr;  // profiling: around k_clear on stream3 (rv_profile slot RV_PH_CLEAR)
     bool clear_timed = false;
@@ -380,11 +382,17 @@ static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level
     hipError_t se;
     if (main_prio_level >= 0 && prio_lo > prio_hi) {
         const int levels = prio_lo - prio_hi + 1;  // (numerically lower = higher priority)
-        se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi + main_prio_level % levels);
+        c->has_prio = true;
+        c->prio = prio_hi + main_prio_level % levels;
+        se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, c->prio);
     } else {
         se = main_prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     }
-    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    // (a worker context's side streams in the SAME priority class as its main stream: streams of different priorities never share a
+    // hardware queue, streams of one priority are dealt to four queues in creation order -- so the three streams of a worker keep to
+    // queues of their own class instead of landing, as default-priority streams, on the queue of ANOTHER worker's main stream: with the
+    // round-5 mask stream that happened in one bench process out of two, 5.0 -> 7.2 ms per proof of a batch)
+    if (se == hipSuccess) se = c->has_prio ? hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, c->prio) : hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     // (stream3 / stream_x -- the flat and split schedules' side streams -- are made by ctx_side_streams() when such a schedule first
     // runs: streams are dealt to the four hardware queues in creation order, so two idle ones per context put the main streams of
     // rv_prove_batch's worker contexts all on ONE queue and its proofs in flight ran one after the other: 4.9 -> 6.2 ms per proof)
