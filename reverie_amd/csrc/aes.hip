@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "internal.h"
+#include "z64_dev.h"
 #include "launch.h"
 
 namespace rv {
@@ -740,6 +741,7 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
     // the lane's four repetitions) they were spilled, and each reload sat between two repetitions' stores, waiting for them
     asm volatile("" : "+v"(q), "+v"(zo), "+v"(gi));
     if (!valid) return;
+    const uint32_t qc = q & 3u, qmh = (qc & 2u) ? ~0u : 0u, qml = (qc & 1u) ? ~0u : 0u;
     const Gate64 g = gates[gi];
     const uint64_t* ap = z_row(p, g.am, S) + zo;
     const uint64_t* bp = z_row(p, g.bm, S) + zo;
@@ -832,7 +834,8 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
         }
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t rep = 4 * q + k;
-        z_store_on(p.on + (size_t)rep * p.on_words + g.eo, w);
+        // (whole 64-byte segments per four lanes = four neighbouring quad words' repetition k: z64_dev.h)
+        z4_store_on_quad(p.on + (size_t)(4 * (q & ~3u) + k) * p.on_words + g.eo, 4 * p.on_words, w, qc, qmh, qml);
         p.pre[(size_t)rep * p.pre_words + g.ep] = delta;
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -261,6 +261,13 @@ struct Z64FParams {
     uint32_t sup_r;
 };
 bool z64_fused_supports(uint32_t NQ);
+#ifdef RV_EXPERIMENTS
+// round 5 (z64c4.hip, experiment builds): the PROVER's level with the lane-distributed cipher (aes_col4_dev.h) inside -- a wavefront = one
+// gate x 64 repetitions, the operand pieces in flight during the cipher; d_img = the key image of launch_rk_col4.  Same gate arrays and
+// parameters as above.
+bool z64_c4_supports(uint32_t NQ);
+void launch_z64_c4(hipStream_t st, const uint32_t* d_img, const struct Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p);
+#endif
 void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p);
 // BLAKE3 of R contiguous streams of n_words u64 each -> digests[R][8]
 uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,

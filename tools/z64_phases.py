@@ -9,7 +9,8 @@ ctx = reverie_amd.Context(0)
 L = _lib.lib()
 seeds = bench.rule_seeds()
 n_mul = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-prog, w64, wc, st = circuits.layered_z64(n_mul=n_mul)
+n_in = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+prog, w64, wc, st = circuits.layered_z64(n_mul=n_mul, n_in=n_in)
 c = reverie_amd.Circuit(prog, wc, ctx)
 hp = bench.HostProver(c, [], w64, seeds)
 hp.run(2)  # (two: the second page-locked output buffer is mapped outside the timed proofs)
