@@ -742,7 +742,10 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
     asm volatile("" : "+v"(q), "+v"(zo), "+v"(gi));
     if (!valid) return;
     const uint32_t qc = q & 3u, qmh = (qc & 2u) ? ~0u : 0u, qml = (qc & 1u) ? ~0u : 0u;
+    const uint32_t row = gi - (uint32_t)__builtin_amdgcn_readfirstlane((int)gi);  // (= lane / 16 when QW == 16; computed HERE, not carried through the cipher)
     const Gate64 g = gates[gi];
+    const uint32_t ep0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g.ep);
+    const bool pre_run = QW == 16 && __builtin_amdgcn_ballot_w64(g.ep == ep0 + row) == ~0ull;  // (a wavefront with a gate missing: false)
     const uint64_t* ap = z_row(p, g.am, S) + zo;
     const uint64_t* bp = z_row(p, g.bm, S) + zo;
     uint64_t* lnp = p.masks + (size_t)(g.m + 1) * S + zo;
@@ -836,7 +839,21 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
         const uint32_t rep = 4 * q + k;
         // (whole 64-byte segments per four lanes = four neighbouring quad words' repetition k: z64_dev.h)
         z4_store_on_quad(p.on + (size_t)(4 * (q & ~3u) + k) * p.on_words + g.eo, 4 * p.on_words, w, qc, qmh, qml);
-        p.pre[(size_t)rep * p.pre_words + g.ep] = delta;
+        // the preprocessing transcript: one word per gate and repetition.  The wavefront's four gates (its four rows of 16 lanes) are
+        // consecutive Mul gates of the level; where their words are consecutive in the streams too (pre_run: always, unless gates of
+        // other levels sit between them in program order) the row of lanes k collects the four gates' words of repetition 4q + k and
+        // stores 32 contiguous bytes, instead of 64 lanes storing 8 bytes each into 64 x 4 places
+        if (pre_run) {
+            uint64_t v4[4];
+            z4_row_gather(delta, v4);
+            if (row == (uint32_t)k) {
+                uint64_t* pp = p.pre + (size_t)rep * p.pre_words + ep0;
+                z4_st16_stream(pp, v4[0], v4[1]);
+                z4_st16_stream(pp + 2, v4[2], v4[3]);
+            }
+        } else {
+            p.pre[(size_t)rep * p.pre_words + g.ep] = delta;
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     if (VERIFY) {

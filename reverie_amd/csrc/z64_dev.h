@@ -11,12 +11,14 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t z4_dpp(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
 
 
-// the transcripts are read again in the hash phase only: nontemporal (measured: no difference, 36.86 / 36.82 ms of level launches per
-// 10^6 Mul; lambda_new, an operand a level later, stored nontemporal as well: 37.0; the same on k_z64_fused's transcripts: 38.4 -> 39.8)
+// 16 bytes of a transcript stream: the streams are only 8-byte aligned (global_store_dwordx4 takes any dword-aligned address:
+// tools/mb/unaligned16_mb.hip).  Nontemporal -- the transcripts are read again in the hash phase only (measured: no difference, 36.86 /
+// 36.82 ms of level launches per 10^6 Mul in k_z64_c4; lambda_new, an operand a level later, stored nontemporal as well: 37.0)
 typedef uint64_t z4_u64x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void z4_st16_nt(uint64_t* p, uint64_t a, uint64_t b) {
-    z4_u64x2 v = {a, b};
-    __builtin_nontemporal_store(v, (z4_u64x2*)p);
+typedef z4_u64x2 z4_u64x2_a8 __attribute__((aligned(8)));
+__device__ __forceinline__ void z4_st16_stream(uint64_t* p, uint64_t a, uint64_t b) {
+    const z4_u64x2 v = {a, b};
+    __builtin_nontemporal_store(v, (z4_u64x2_a8*)p);
 }
 
 // A Mul's eight transcript words per repetition are 64 bytes of the repetition's stream, the wavefront's 64 repetitions 64 streams: with
@@ -49,16 +51,24 @@ __device__ __forceinline__ void z4_store_on_quad(uint64_t* oq, uint64_t stride, 
         }
     }
     uint64_t* op = oq + 2 * c;
-    if ((((uintptr_t)oq | (stride * 8)) & 15) == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) z4_st16_nt(op + k * stride, ((uint64_t)e[k][1] << 32) | e[k][0], ((uint64_t)e[k][3] << 32) | e[k][2]);
-    } else {  // (the stream is only 8-byte aligned)
+    for (int k = 0; k < 4; k++) z4_st16_stream(op + k * stride, ((uint64_t)e[k][1] << 32) | e[k][0], ((uint64_t)e[k][3] << 32) | e[k][2]);
+}
+
+// v of the four lanes (row 0..3, l) -- the wavefront's four rows of 16 lanes -- in every one of them (gfx950's v_permlane16_swap /
+// v_permlane32_swap: registers only)
+__device__ __forceinline__ void z4_row_gather(uint64_t v, uint64_t* out) {
+    const uint32_t w[2] = {(uint32_t)v, (uint32_t)(v >> 32)};
+    uint32_t r[4][2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            __builtin_nontemporal_store(((uint64_t)e[k][1] << 32) | e[k][0], &op[k * stride]);
-            __builtin_nontemporal_store(((uint64_t)e[k][3] << 32) | e[k][2], &op[k * stride + 1]);
-        }
+    for (int h = 0; h < 2; h++) {
+        const auto s16 = __builtin_amdgcn_permlane16_swap(w[h], w[h], false, false);    // [v0 v0 v2 v2], [v1 v1 v3 v3] by rows
+        const auto e = __builtin_amdgcn_permlane32_swap(s16[0], s16[0], false, false);  // v0 everywhere, v2 everywhere
+        const auto o = __builtin_amdgcn_permlane32_swap(s16[1], s16[1], false, false);  // v1, v3
+        r[0][h] = e[0], r[2][h] = e[1], r[1][h] = o[0], r[3][h] = o[1];
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = ((uint64_t)r[k][1] << 32) | r[k][0];
 }
 
 }  // namespace rv
