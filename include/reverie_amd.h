@@ -276,6 +276,13 @@ int rv_stream_feed(rv_stream *s, const rv_op *ops, size_t n_ops, const uint8_t *
 int rv_stream_commit(rv_stream *s, uint8_t comm[RV_HASH_SIZE] /* nullable */);
 int rv_stream_finish(rv_stream *s, uint8_t **proof, size_t *proof_len);
 void rv_stream_abort(rv_stream *s);
+/* A promise, made during pass 1: pass 2 will be fed in exactly pass 1's pieces (the same rv_stream_feed calls).  Pass 1 then keeps
+ * the transcripts of the stream's LAST chunks on the device, as many as fit a budget (RV_STREAM_KEEP_MB; default an eighth of the
+ * device's memory, at most 32 GiB; 0 = none; rv_stream_info.kept_mib), and pass 2 takes the openings of those chunks from them
+ * instead of running them a second time: the earlier chunks run twice, as every chunk does without the promise.  Device memory
+ * stays bounded by wire store + one chunk + the proof + that budget.  A pass 2 that breaks the promise gets RV_E_ARG from the feed
+ * that would have to run a chunk after one that did not.  rv_prove_streaming makes the promise itself. */
+int rv_stream_same_cuts(rv_stream *s);
 typedef struct rv_stream_info {
     uint64_t n_ops, chunks, levels; /* of pass 1 (running totals while it is in progress) */
     uint64_t gf2_masks, z64_masks, gf2_muls, z64_muls;
@@ -283,7 +290,8 @@ typedef struct rv_stream_info {
     uint64_t peak_chunk_bytes;  /* largest single chunk's working set (rows, transcripts, gate records) */
     uint64_t hash_state_bytes;  /* incremental BLAKE3 trees + unhashed stream tails */
     uint64_t proof_bytes;       /* 0 before rv_stream_commit */
-    uint32_t pass, reserved;
+    uint32_t pass;
+    uint32_t kept_mib;          /* most MiB of pass-1 transcripts held for pass 2 (RV_STREAM_KEEP_MB; the field was `reserved`, always 0) */
 } rv_stream_info;
 int rv_stream_get_info(const rv_stream *s, rv_stream_info *info);
 /* Both passes over an op array that already sits in host memory: Proof::new with bounded DEVICE memory.

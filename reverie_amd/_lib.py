@@ -49,7 +49,7 @@ class BristolInfo(C.Structure):
 
 class StreamInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_ops", "chunks", "levels", "gf2_masks", "z64_masks", "gf2_muls", "z64_muls", "wire_store_bytes",
-                                          "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")] + [("pass_", C.c_uint32), ("reserved", C.c_uint32)]
+                                          "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")] + [("pass_", C.c_uint32), ("kept_mib", C.c_uint32)]
 
 
 class Profile(C.Structure):
@@ -70,7 +70,7 @@ SYMBOLS = [
     "rv_bristol_parse", "rv_circuit_record_sizes", "rv_program_from_bincode", "rv_program_to_bincode", "rv_prove_batch", "rv_prove_device",
     "rv_verify_ex", "rv_verify_shard_ex", "rv_verify_finish_ex", "rv_verify_batch",
     "rv_hook_gf2_reconstruct", "rv_hook_z64_reconstruct", "rv_hook_early_proofs", "rv_hook_ops_cache_hits", "rv_hook_overlap_commits", "rv_hook_experiments", "rv_hook_early_plan", "rv_hook_flat_plan", "rv_hook_verify_vc_count",
-    "rv_stream_begin", "rv_stream_feed", "rv_stream_commit", "rv_stream_finish", "rv_stream_abort", "rv_stream_get_info",
+    "rv_stream_begin", "rv_stream_feed", "rv_stream_commit", "rv_stream_finish", "rv_stream_abort", "rv_stream_get_info", "rv_stream_same_cuts",
     "rv_prove_streaming", "rv_prove_ops", "rv_verify_ops", "rv_stream_verify_begin", "rv_stream_verify_finish", "rv_verify_streaming",
     "rv_comm_unique_id", "rv_comm_create", "rv_comm_create_all", "rv_comm_destroy", "rv_prove_sharded", "rv_prove_multi",
 ]

@@ -54,7 +54,7 @@ extern "C" int rv_hook_experiments(void) {
     return 0;
 #endif
 }
-extern "C" uint32_t rv_abi_version(void) { return 7; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
+extern "C" uint32_t rv_abi_version(void) { return 8; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
                                                         //    streaming prover, rv_prove_multi, reconstruct hooks
                                                         // 4: rv_circuit_compile_ex (a pure addition)
                                                         // 5: rv_prove_ops / rv_verify_ops, rv_hook_compile_compare (pure additions)
@@ -62,6 +62,7 @@ extern "C" uint32_t rv_abi_version(void) { return 7; }  // 3: verification stric
                                                         // 7: rv_circuit_info is its ABI-5 self again (a struct without a size field must not grow: a caller built
                                                         //    against the older header would have had 8 bytes written past its buffer); the value has a getter of
                                                         //    its own, rv_circuit_early_staging_bytes
+                                                        // 8: rv_stream_same_cuts (a pure addition); rv_stream_info.reserved (always 0) is now kept_mib
 
 extern "C" const char* rv_strerror(int code) {
     switch (code) {

@@ -40,6 +40,11 @@ class StreamingProver:
         z = np.ascontiguousarray(np.asarray(wit_z64, dtype=np.uint64))
         _lib.check(_lib.lib().rv_stream_feed(self.handle, _ptr(ops), C.c_size_t(len(ops)), _ptr(g), C.c_size_t(len(g)), _ptr(z), C.c_size_t(len(z))))
 
+    def same_cuts(self):
+        """rv_stream_same_cuts: pass 2 will be fed in pass 1's pieces -- pass 1 keeps the last chunks' transcripts within
+        RV_STREAM_KEEP_MB and pass 2 takes their openings from them instead of running them again"""
+        _lib.check(_lib.lib().rv_stream_same_cuts(self.handle))
+
     def commit(self) -> bytes:
         comm = np.zeros(32, np.uint8)
         _lib.check(_lib.lib().rv_stream_commit(self.handle, _ptr(comm)))

@@ -31,7 +31,7 @@ def test_header_symbols_exported(L):
     assert declared == set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.rv_abi_version() == 7
+    assert L.rv_abi_version() == 8
     assert C.sizeof(_lib.ShardParts) == 4 * 8 + 4 * 8 + 8
 
 

@@ -38,10 +38,12 @@ def _pieces(prog, w2, w64, cuts):
     return out
 
 
-def _stream(rv, prog, w2, w64, wc, seeds, cuts1, cuts2=None):
+def _stream(rv, prog, w2, w64, wc, seeds, cuts1, cuts2=None, same_cuts=False):
     from reverie_amd.stream import StreamingProver
 
     sp = StreamingProver(wc, seeds=seeds)
+    if same_cuts:
+        sp.same_cuts()
     for part, a, b in _pieces(prog, w2, w64, cuts1):
         sp.feed(part, a, b)
     comm = sp.commit()
@@ -369,3 +371,43 @@ def test_stream_verify_full_size_bounded_memory(rv, rule_seeds):
     bad[len(bad) // 3] ^= 0x10
     ok, _ = verify_streaming(prog, wc, bytes(bad))
     assert not ok
+
+
+@pytest.mark.parametrize("keep_mb", ["0", "1", None])
+def test_stream_kept_transcripts(rv, oracle, monkeypatch, keep_mb):
+    """rv_stream_same_cuts: pass 1 keeps the LAST chunks' transcripts on the device within RV_STREAM_KEEP_MB and pass 2 takes their
+    openings from them (stream.inc: rv_stream::Kept) -- budget 0: every chunk runs twice, as without the promise; 1 MiB: the first
+    chunks run twice, the last ones are kept; default: all kept.  GF(2) + Z64 + B2A; a broken promise is RV_E_ARG."""
+    from reverie_amd._lib import ReverieError
+
+    if keep_mb is None:
+        monkeypatch.delenv("RV_STREAM_KEEP_MB", raising=False)
+    else:
+        monkeypatch.setenv("RV_STREAM_KEEP_MB", keep_mb)
+    rng = np.random.default_rng(808)
+    prog, w2, w64, wc = circuits.random_mixed(rng, n_gates=2500)
+    hint = prog[prog["domain"] == 3]
+    wc = (max([wc[0]] + [int(x) for x in hint["a"]]), max([wc[1]] + [int(x) for x in hint["b"]]))
+    seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
+    want = oracle.prove(prog, w2, w64, wc, seeds)
+    n = len(prog)
+    cuts = sorted(int(x) for x in rng.integers(1, n, 12))
+    proof, info = _stream(rv, prog, w2, w64, wc, seeds, cuts, same_cuts=True)
+    assert bytes(proof) == want
+    assert (info["kept_mib"] == 0) == (keep_mb == "0")
+    other = sorted(int(x) for x in rng.integers(1, n, 5)) + cuts[:4]
+    proof, info = _stream(rv, prog, w2, w64, wc, seeds, cuts, other)  # (no promise: nothing kept, any cuts)
+    assert bytes(proof) == want and info["kept_mib"] == 0
+    if keep_mb is None:  # a chunk of pass 2 that has to run after one that was served from kept transcripts
+        with pytest.raises(ReverieError) as e:
+            _stream(rv, prog, w2, w64, wc, seeds, cuts, cuts[:6] + [cuts[6] + 1] + cuts[7:], same_cuts=True)
+        assert e.value.code == 9  # RV_E_ARG
+    # a long GF(2) stream through the one-call form (which makes the promise): many chunks, 1 MiB holds the last few
+    from reverie_amd.stream import prove_streaming
+
+    prog, wit, wc, st = circuits.layered_gf2(layers=12, width=8192, n_in=512, recycle=True)
+    want = bytes(rv.Proof.new(prog, wit, [], wc, seeds=seeds))
+    proof, info = prove_streaming(prog, wit, [], wc, seeds=seeds, max_chunk_ops=20000)
+    assert bytes(proof) == want and info["chunks"] >= 5
+    if keep_mb == "1":
+        assert info["kept_mib"] == 1
