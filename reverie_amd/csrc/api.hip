@@ -177,6 +177,36 @@ struct rv_ctx {
     // ahead of the main thread (circuit_stage), which then only issues the copies (stream.inc)
     std::vector<uint8_t*> h_ring;
     size_t h_ring_cap = 0;
+    // ... and pass 2's small ring: a chunk's host-built tables (proof offsets, item -> row lists) go to the device as ONE copy out
+    // of a page-locked slot; a slot is written again only after the copy out of it has finished (its event).  Kept by the context:
+    // unmapping four slots at the end of every stream was 20 ms of a 110 ms streamed proof.
+    static constexpr int OPEN_SLOTS = 4;
+    uint8_t* h_open[OPEN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    size_t h_open_cap[OPEN_SLOTS] = {0, 0, 0, 0};
+    hipEvent_t ev_open[OPEN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned open_next = 0;
+    uint8_t* open_slot(size_t bytes, int* slot) {
+        const int k = (int)(open_next++ % OPEN_SLOTS);
+        if (ev_open[k]) (void)hipEventSynchronize(ev_open[k]);
+        if (h_open_cap[k] < bytes) {
+            if (h_open[k]) (void)hipHostFree(h_open[k]);
+            h_open[k] = nullptr;
+            h_open_cap[k] = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            if (hipHostMalloc((void**)&h_open[k], want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            h_open_cap[k] = want;
+        }
+        if (!ev_open[k] && hipEventCreateWithFlags(&ev_open[k], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ev_open[k] = nullptr;
+            return nullptr;
+        }
+        *slot = k;
+        return h_open[k];
+    }
     // early corrections (rv_prove_impl): page-locked staging for EVERY repetition's corrections vector, the mapped
     // mailbox the challenge arrives in ([0] = sequence number, from word 16 on the data), the helper threads
     uint8_t* h_ec = nullptr;
@@ -440,6 +470,10 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     if (ctx->h_up) (void)hipHostFree(ctx->h_up);
     for (uint8_t* p : ctx->h_ring) (void)hipHostFree(p);
+    for (int k = 0; k < rv_ctx::OPEN_SLOTS; k++) {
+        if (ctx->ev_open[k]) (void)hipEventDestroy(ctx->ev_open[k]);
+        if (ctx->h_open[k]) (void)hipHostFree(ctx->h_open[k]);
+    }
     if (ctx->h_ec) (void)hipHostFree(ctx->h_ec);
     if (ctx->d_ec) (void)hipFree(ctx->d_ec);
     if (ctx->h_fs) (void)hipHostFree(ctx->h_fs);
