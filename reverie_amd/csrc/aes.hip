@@ -688,15 +688,17 @@ __device__ __forceinline__ void z_store_on(uint64_t* op, const uint64_t* w) {
     }
 }
 
-// Row layout of this path ("swizzled"): inside a workgroup's block of 16 quad words (512 u64), the 16-byte piece i (slots 2i,
-// 2i + 1 of a quad word's 32) of quad ql sits at u64 offset i * 32 + ql * 2 -- piece-major, so that the 16 lanes of a gate
+// Row layout of this path ("swizzled"): inside a workgroup's block of QW = 16 quad words (512 u64), the 16-byte piece i (slots 2i,
+// 2i + 1 of a quad word's 32) of quad ql sits at u64 offset i * 2 QW + ql * 2 -- piece-major, so that the 16 lanes of a gate
 // read 256 contiguous bytes per load instruction while each lane still collects the 32 slots of ITS quad word (the bitsliced
 // cipher fixes which lane holds which slot).  With a lane's pieces in the natural order (256 contiguous bytes per lane, 256
 // bytes apart between lanes) every load instruction touched 64 lines and the eight wavefronts of a compute unit evicted each
 // other's lines from L1 between the instructions that shared them: 72 ms per proof instead of the 52 of the two-kernel path.
 // Every row this path reads it also wrote (wmask rows, the Mul gates' lambda_new rows) -- except the Input gates' mask rows,
 // which come from k_aes_z64_masks in the natural order and are rewritten in place by the Input gate itself (z64f_oth).
-__device__ __forceinline__ uint32_t z_piece(uint32_t i) { return i * 32; }
+// (QW = quad words per workgroup block: 16, or 8 for shards whose rows are not a multiple of 16 quad words -- 32 repetitions)
+template <int QW>
+__device__ __forceinline__ uint32_t z_piece(uint32_t i) { return i * (2 * QW); }
 
 template <int QW, bool VERIFY>
 __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint32_t gi, bool valid, const Z64FParams& p, const uint32_t* rkl, uint32_t q,
@@ -766,8 +768,8 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
     for (int k = 0; k < 2; k++) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            z_ld16(ap + z_piece(4 * k + i), lx[k][2 * i], lx[k][2 * i + 1]);
-            z_ld16(bp + z_piece(4 * k + i), ly[k][2 * i], ly[k][2 * i + 1]);
+            z_ld16(ap + z_piece<QW>(4 * k + i), lx[k][2 * i], lx[k][2 * i + 1]);
+            z_ld16(bp + z_piece<QW>(4 * k + i), ly[k][2 * i], ly[k][2 * i + 1]);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -788,7 +790,7 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
     }
 #pragma unroll
     for (int i = 0; i < 16; i++)
-        z_st16(lnp + z_piece(i), ((uint64_t)hi1[2 * i] << 32) | lo1[2 * i], ((uint64_t)hi1[2 * i + 1] << 32) | lo1[2 * i + 1]);
+        z_st16(lnp + z_piece<QW>(i), ((uint64_t)hi1[2 * i] << 32) | lo1[2 * i], ((uint64_t)hi1[2 * i + 1] << 32) | lo1[2 * i + 1]);
     if (VERIFY) {  // (requested here, once lambda_new has left and freed its registers)
         z_ld16(p.wcorr + (size_t)g.a * R + 4 * q, cxs[0], cxs[1]);
         z_ld16(p.wcorr + (size_t)g.a * R + 4 * q + 2, cxs[2], cxs[3]);
@@ -831,8 +833,8 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
         if (k + 2 < 4) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                z_ld16(ap + z_piece(4 * (k + 2) + i), lx[bf][2 * i], lx[bf][2 * i + 1]);
-                z_ld16(bp + z_piece(4 * (k + 2) + i), ly[bf][2 * i], ly[bf][2 * i + 1]);
+                z_ld16(ap + z_piece<QW>(4 * (k + 2) + i), lx[bf][2 * i], lx[bf][2 * i + 1]);
+                z_ld16(bp + z_piece<QW>(4 * (k + 2) + i), ly[bf][2 * i], ly[bf][2 * i + 1]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -866,7 +868,7 @@ __device__ __forceinline__ void z64f_mul(const Gate64* __restrict__ gates, uint3
 
 // Add / Sub / AddConst / SubConst / MulConst: the mask row (z64/share.rs:110-136 player by player; elementwise, so the
 // row layout does not matter) and the value
-template <bool VERIFY>
+template <int QW, bool VERIFY>
 __device__ __forceinline__ void z64f_lin(const Gate64& g, const Z64FParams& p, uint32_t q, uint32_t zo, bool writer) {
     const uint64_t S = (uint64_t)p.NQ * 32;
     const uint64_t* ap = z_row(p, g.am, S) + zo;
@@ -896,22 +898,22 @@ __device__ __forceinline__ void z64f_lin(const Gate64& g, const Z64FParams& p, u
         uint64_t x[32], y[32];  // (every load before the first store: see z64f_mul)
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            z_ld16(ap + z_piece(i), x[2 * i], x[2 * i + 1]);
-            z_ld16(bp + z_piece(i), y[2 * i], y[2 * i + 1]);
+            z_ld16(ap + z_piece<QW>(i), x[2 * i], x[2 * i + 1]);
+            z_ld16(bp + z_piece<QW>(i), y[2 * i], y[2 * i + 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; i++)
-            z_st16(dp + z_piece(i), sub ? x[2 * i] - y[2 * i] : x[2 * i] + y[2 * i], sub ? x[2 * i + 1] - y[2 * i + 1] : x[2 * i + 1] + y[2 * i + 1]);
+            z_st16(dp + z_piece<QW>(i), sub ? x[2 * i] - y[2 * i] : x[2 * i] + y[2 * i], sub ? x[2 * i + 1] - y[2 * i + 1] : x[2 * i + 1] + y[2 * i + 1]);
         if (writer) p.v[g.dst] = sub ? va - vb : va + vb;
     } else {
         const uint64_t f = g.op == G64_MULC ? g.imm : 1;
         uint64_t x[32];
 #pragma unroll
-        for (int i = 0; i < 16; i++) z_ld16(ap + z_piece(i), x[2 * i], x[2 * i + 1]);
+        for (int i = 0; i < 16; i++) z_ld16(ap + z_piece<QW>(i), x[2 * i], x[2 * i + 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; i++) z_st16(dp + z_piece(i), x[2 * i] * f, x[2 * i + 1] * f);
+        for (int i = 0; i < 16; i++) z_st16(dp + z_piece<QW>(i), x[2 * i] * f, x[2 * i + 1] * f);
         if (writer) p.v[g.dst] = g.op == G64_MULC ? va * g.imm : (g.op == G64_ADDC ? va + g.imm : va - g.imm);
     }
 }
@@ -919,7 +921,7 @@ __device__ __forceinline__ void z64f_lin(const Gate64& g, const Z64FParams& p, u
 // Input (masked input = witness - reconstruct(fresh mask) into the online transcript; its mask row, written by
 // k_aes_z64_masks in the natural order, is rewritten in this path's layout), AssertZero (the wire's mask shares into the
 // online transcript; the VALUE must be zero, prover.rs:221-228), Const
-template <bool VERIFY>
+template <int QW, bool VERIFY>
 __device__ __forceinline__ void z64f_oth(const Gate64& g, const Z64FParams& p, uint32_t q, uint32_t zo, bool writer) {
     const uint64_t S = (uint64_t)p.NQ * 32;
     const uint32_t R = p.NQ * 4;
@@ -951,7 +953,7 @@ __device__ __forceinline__ void z64f_oth(const Gate64& g, const Z64FParams& p, u
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < 16; i++) z_st16(row + zo + z_piece(i), l[2 * i], l[2 * i + 1]);
+        for (int i = 0; i < 16; i++) z_st16(row + zo + z_piece<QW>(i), l[2 * i], l[2 * i + 1]);
         if (writer) p.v[g.dst] = wv;
     } else if (g.op == G64_ASSERT) {
         const uint64_t* ap = z_row(p, g.am, S) + zo;
@@ -959,7 +961,7 @@ __device__ __forceinline__ void z64f_oth(const Gate64& g, const Z64FParams& p, u
         for (int k = 0; k < 4; k++) {
             uint64_t l[8];
 #pragma unroll
-            for (int i = 0; i < 4; i++) z_ld16(ap + z_piece(4 * k + i), l[2 * i], l[2 * i + 1]);
+            for (int i = 0; i < 4; i++) z_ld16(ap + z_piece<QW>(4 * k + i), l[2 * i], l[2 * i + 1]);
             if (VERIFY) {
                 const uint32_t om = (om4 >> (8 * k)) & 0xFFu;
                 if (om < 8) {
@@ -980,7 +982,7 @@ __device__ __forceinline__ void z64f_oth(const Gate64& g, const Z64FParams& p, u
     } else if (g.op == G64_CONST) {
         uint64_t* dp = p.wmask + (size_t)g.dst * S + zo;
 #pragma unroll
-        for (int i = 0; i < 16; i++) z_st16(dp + z_piece(i), 0, 0);
+        for (int i = 0; i < 16; i++) z_st16(dp + z_piece<QW>(i), 0, 0);
         if (VERIFY) {
             z_st16(p.wcorr + (size_t)g.dst * R + 4 * q, g.imm, g.imm);
             z_st16(p.wcorr + (size_t)g.dst * R + 4 * q + 2, g.imm, g.imm);
@@ -1028,20 +1030,24 @@ __global__ __launch_bounds__(512, 2) void k_z64_fused(const Gate64* __restrict__
         const uint32_t lend = (uint32_t)(((uint64_t)(it + 1) * LI) / MI);
         for (; ld < lend; ld++) {
             const uint32_t gl = l_lo + (l0s + ld) * JW + jsub;
-            if (gl < l_hi) z64f_lin<VERIFY>(gates[gl], p, q, zo, writer);
+            if (gl < l_hi) z64f_lin<QW, VERIFY>(gates[gl], p, q, zo, writer);
         }
     }
     for (; ld < LI; ld++) {
         const uint32_t gl = l_lo + (l0s + ld) * JW + jsub;
-        if (gl < l_hi) z64f_lin<VERIFY>(gates[gl], p, q, zo, writer);
+        if (gl < l_hi) z64f_lin<QW, VERIFY>(gates[gl], p, q, zo, writer);
     }
-    for (uint32_t go = o_lo + wave * JW + jsub; go < o_hi; go += STEP) z64f_oth<VERIFY>(gates[go], p, q, zo, writer);
+    for (uint32_t go = o_lo + wave * JW + jsub; go < o_hi; go += STEP) z64f_oth<QW, VERIFY>(gates[go], p, q, zo, writer);
 }
 
-bool z64_fused_supports(uint32_t NQ) { return NQ >= 16 && NQ % 16 == 0; }
+// quad words per workgroup block: 16 where the rows are whole blocks of 16 (shards of 64 repetitions and more), else 8 (32-repetition
+// shards, NQ = 8: VERDICT r4 #3), else 0 = this path does not take the shard
+uint32_t z64_fused_qw(uint32_t NQ) { return NQ >= 16 && NQ % 16 == 0 ? 16u : (NQ >= 8 && NQ % 8 == 0 ? 8u : 0u); }
+bool z64_fused_supports(uint32_t NQ) { return z64_fused_qw(NQ) != 0; }
 
-void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p) {
-    constexpr uint32_t QW = 16, JW = 64 / QW, STEP = 8 * JW;
+template <int QW>
+static void launch_z64_fused_qw(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p) {
+    constexpr uint32_t JW = 64 / QW, STEP = 8 * JW;
     static const uint32_t cus = [] {
         if (const char* e = getenv("RV_Z64F_WGS")) return (uint32_t)std::max(atoi(e), 1);
         int dev = 0, n = 0;
@@ -1067,6 +1073,12 @@ void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv
         hipLaunchKernelGGL((k_z64_fused<QW, true>), dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_gates, lv, mul_per, lin_per, oth_per, lin_bias, p);
     else
         hipLaunchKernelGGL((k_z64_fused<QW, false>), dim3((unsigned)(chunks * n_qg)), dim3(512), 0, st, d_gates, lv, mul_per, lin_per, oth_per, lin_bias, p);
+}
+void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p) {
+    if (z64_fused_qw(p.NQ) == 16)
+        launch_z64_fused_qw<16>(st, d_gates, lv, p);
+    else
+        launch_z64_fused_qw<8>(st, d_gates, lv, p);
 }
 
 void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys, uint64_t first_block, uint64_t n_blocks,

@@ -261,6 +261,7 @@ struct Z64FParams {
     uint32_t sup_r;
 };
 bool z64_fused_supports(uint32_t NQ);
+uint32_t z64_fused_qw(uint32_t NQ);  // quad words per workgroup block of that path for rows of NQ quad words (16 or 8; 0: not taken)
 #ifdef RV_EXPERIMENTS
 // round 5 (z64c4.hip, experiment builds): the PROVER's level with the lane-distributed cipher (aes_col4_dev.h) inside -- a wavefront = one
 // gate x 64 repetitions, the operand pieces in flight during the cipher; d_img = the key image of launch_rk_col4.  Same gate arrays and

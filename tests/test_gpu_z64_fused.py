@@ -140,7 +140,7 @@ def test_fused_invalid_witness_and_reuse(rv, oracle, rule_seeds, monkeypatch):
 
 @pytest.mark.parametrize("reps", [32, 64, 128])
 def test_fused_shards_vs_oracle(rv, oracle, monkeypatch, reps):
-    """repetition shards: 64 and 128 repetitions run the fused launches (one / two quad groups), 32 fall back (rows of 8 quad words)"""
+    """repetition shards: 64 and 128 repetitions run the fused launches in blocks of 16 quad words (one / two quad groups), 32 in a block of 8 (round 5)"""
     from reverie_amd.dist import HipShardBackend, assemble
     from reverie_amd.proof import challenge, combine_digests
 
