@@ -177,6 +177,7 @@ struct rv_ctx {
     // ahead of the main thread (circuit_stage), which then only issues the copies (stream.inc)
     std::vector<uint8_t*> h_ring;
     size_t h_ring_cap = 0;
+    std::vector<hipEvent_t> ring_ev;  // per slot: recorded behind the copies out of it (a worker waits for it before it fills the slot again)
     // ... and pass 2's small ring: a chunk's host-built tables (proof offsets, item -> row lists) go to the device as ONE copy out
     // of a page-locked slot; a slot is written again only after the copy out of it has finished (its event).  Kept by the context:
     // unmapping four slots at the end of every stream was 20 ms of a 110 ms streamed proof.
@@ -470,6 +471,8 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     if (ctx->h_up) (void)hipHostFree(ctx->h_up);
     for (uint8_t* p : ctx->h_ring) (void)hipHostFree(p);
+    for (hipEvent_t e : ctx->ring_ev)
+        if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < rv_ctx::OPEN_SLOTS; k++) {
         if (ctx->ev_open[k]) (void)hipEventDestroy(ctx->ev_open[k]);
         if (ctx->h_open[k]) (void)hipHostFree(ctx->h_open[k]);
@@ -630,6 +633,8 @@ struct rv_circuit {
     rv_ctx* ctx = nullptr;
     const uint8_t* staged = nullptr;  // circuit_stage: the arrays circuit_upload sends first, already in page-locked memory
     size_t staged_bytes = 0;
+    int staged_slot = -1;             // ... in this slot of rv_ctx::h_ring
+    bool upload_pending = false;      // circuit_upload(async_staged) left the copies in flight on the context's stream
     Compiled cc;  // gates kept on the host too (level table, counts)
     Gate* d_gates = nullptr;
     uint32_t* d_rec_rows = nullptr;
@@ -805,7 +810,7 @@ static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
 
 static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags,
                                   rv_circuit** out);
-static int circuit_upload(rv_ctx* ctx, rv_circuit* c);
+static int circuit_upload(rv_ctx* ctx, rv_circuit* c, bool async_staged = false);
 
 extern "C" int rv_circuit_compile_ex(rv_ctx* ctx, const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags,
                                      rv_circuit** out) {
@@ -882,7 +887,7 @@ static size_t circuit_stage_bytes(const Compiled& cc) {
     circuit_stage_each(cc, [&](const void*, size_t b) { n += (b + 255) & ~(size_t)255; });
     return n;
 }
-static void circuit_stage(rv_circuit* c, uint8_t* dst) {
+static void circuit_stage(rv_circuit* c, uint8_t* dst, int slot = -1) {
     size_t off = 0;
     circuit_stage_each(c->cc, [&](const void* p, size_t b) {
         if (b) memcpy(dst + off, p, b);
@@ -890,10 +895,14 @@ static void circuit_stage(rv_circuit* c, uint8_t* dst) {
     });
     c->staged = dst;
     c->staged_bytes = off;
+    c->staged_slot = slot;
 }
 
 // the compiled gate stream (c->cc) to HBM + the narrow-run plan; c is destroyed on failure
-static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
+// async_staged (the streaming feeds): a piece whose arrays ALL came out of its page-locked ring slot is not waited for -- the
+// slot's event is recorded behind the copies instead (the worker that fills the slot next waits for it), and the caller's kernels
+// follow on the same stream
+static int circuit_upload(rv_ctx* ctx, rv_circuit* c, bool async_staged) {
     const auto t_compiled = std::chrono::steady_clock::now();
     int rc;
 // (c is destroyed on EVERY failure: the callers rely on it)
@@ -929,11 +938,14 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
             (void)hipGetLastError();
     }
     size_t stage_off = 0;
+    bool all_staged = c->staged != nullptr;
     auto up = [&](const void* src, size_t bytes, void** dst) -> int {
         int r = ctx->alloc(bytes, dst);
         if (r) return r;
         if (!bytes) return RV_OK;
-        if (c->staged && stage_off + bytes <= c->staged_bytes) {  // (a streaming piece: copied here by a worker thread)
+        const bool from_slot = c->staged && stage_off + bytes <= c->staged_bytes;
+        all_staged = all_staged && from_slot;
+        if (from_slot) {  // (a streaming piece: copied here by a worker thread)
             src = c->staged + stage_off;
             stage_off += (bytes + 255) & ~(size_t)255;
         } else if (stage_on && ctx->h_up && stage_off + bytes <= ctx->h_up_cap && stage_need <= rv_ctx::UP_STAGE_MAX) {
@@ -963,7 +975,12 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c) {
             return rc;
         }
     }
-    UPCHK(hipStreamSynchronize(ctx->stream));
+    if (async_staged && all_staged && !c->rep_ok && c->staged_slot >= 0 && (size_t)c->staged_slot < ctx->ring_ev.size() && ctx->ring_ev[c->staged_slot]) {
+        UPCHK(hipEventRecord(ctx->ring_ev[c->staged_slot], ctx->stream));
+        c->upload_pending = true;
+    } else {
+        UPCHK(hipStreamSynchronize(ctx->stream));
+    }
     c->staged = nullptr;  // (the slot belongs to the next piece from here on)
     c->staged_bytes = 0;
     if (c->rep_ok) {  // the device holds them now

@@ -26,6 +26,7 @@ struct Lin {
 struct Builder {
     Compiled& out;
     bool counting;  // pass 1: only number the SSA wires and count how often each is read
+    bool have_uses = true;  // false: there was no pass 1 (streaming chunks) -- every wire counts as read
     int lazy_k = 1; // largest base set a wire may keep symbolically (1 = aliases and constants only)
     uint32_t lazy_slack = 1;  // extra row reads a symbolic wire may cost over materialising it (f readers x (n - 1) rows vs n + 1)
     // deep narrow circuits: when a sum outgrows lazy_k rows, up to `balance` of its LATEST rows stay symbolic and only the strictly
@@ -50,11 +51,11 @@ struct Builder {
     uint32_t max_level = 0;
     bool any = false;
 
-    Builder(Compiled& o, bool counting_, std::vector<uint32_t>& uses_) : out(o), counting(counting_), uses(uses_) {
+    Builder(Compiled& o, bool counting_, std::vector<uint32_t>& uses_, size_t size_hint = 0) : out(o), counting(counting_), uses(uses_) {
         if (!counting) {
             // pass 1 left one entry per SSA wire in `uses`: size the big vectors once (10^7 gates x 48 B would otherwise
             // be copied several times over while the vector grows)
-            const size_t n = uses.size();
+            const size_t n = std::max(uses.size(), size_hint);
             lin.reserve(n + 1);
             gates.reserve(n);
             level.reserve(n);
@@ -185,7 +186,7 @@ struct Builder {
             }
         }
         const uint8_t c = A.c ^ B.c;
-        const uint32_t f = uses[n_ssa];  // how often the result will be read
+        const uint32_t f = have_uses ? uses[n_ssa] : 1u;  // how often the result will be read
         // keep it symbolic when that costs no more row traffic than materialising it:
         // f readers x (n - 1) extra rows  vs  n reads + 1 write
         // (lazy_slack: no such limit for the circuits that are bound by their dependency levels, see compile_ops_seq)
@@ -669,7 +670,11 @@ int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
             fprintf(stderr, "[rv compile] %-28s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     };
     std::vector<uint32_t> uses;
-    {
+    // A streaming chunk is compiled once with every XOR materialised (lazy_k = 1 below): the read counts would only serve to drop the
+    // XOR gates nobody reads (13.5 % of them on the layered workload -- the GPU runs them in passing), and the counting pass is
+    // 3 of a piece's 18 - 22 ms on a worker thread, where the streaming prover's first pass is bound
+    const bool count_reads = !chunk || force_lazy_k || getenv("RV_LAZY_K") || getenv("RV_CHUNK_COUNT_READS");
+    if (count_reads) {
         // pass 1: SSA numbering + read counts (the materialisation rule needs each wire's fan-out)
         Compiled scratch;
         Builder b1(scratch, true, uses);
@@ -705,7 +710,8 @@ int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
     for (;;) {
         out = Compiled();
         delete bp;
-        bp = new Builder(out, false, uses);
+        bp = new Builder(out, false, uses, count_reads ? 0 : n_ops + gf2_wires + z64_wires + 64);
+        bp->have_uses = count_reads;
         bp->lazy_k = lazy_k;
         bp->lazy_slack = lazy_slack_for(lazy_k, forced);
         bp->balance = balance;

@@ -1,6 +1,6 @@
 """Randomised parity run for the fused Z64 prover (csrc/aes.hip: k_z64_fused): random Z64 programs of random shapes (every eligible op,
 wire reuse, Input gates anywhere, even / odd Input counts -- odd ones must fall back), layered circuits of random widths, whole proofs
-and 64 / 128-repetition shards, against the oracle.   python tools/fuzz_z64f.py [n_cases] [seed]"""
+and 32 / 64 / 128-repetition shards, against the oracle.   python tools/fuzz_z64f.py [n_cases] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -52,7 +52,7 @@ for case in range(n_cases):
     else:
         from reverie_amd.dist import HipShardBackend, assemble
         from reverie_amd.proof import challenge, combine_digests
-        reps = int(rng.choice([64, 128]))
+        reps = int(rng.choice([32, 64, 128]))
         be = HipShardBackend(c)
         shards = [be.commit([], w64, seeds[b:b + reps], b, reps) for b in range(0, 256, reps)]
         try:
