@@ -22,19 +22,22 @@ def streaming_record(ctx, prog, wit, wc, st, seeds, want: bytes, chunk_ops: int 
     rprog, rwit, rwc, rst = circuits.layered_gf2(layers=layers, p_and=p_and, recycle=True)
     from reverie_amd.stream import verify_streaming
 
-    # median of three calls (the first one also sizes the context's staging buffers and starts the worker threads)
+    # median of the five calls after a warm-up (which also sizes the context's staging buffers and starts the worker threads); the
+    # record is bound by 24 host threads compiling pieces: 65 - 77 ms in three consecutive bench runs on one box
     dts, tvs = [], []
-    for _ in range(3):
+    for _ in range(6):
         t0 = time.perf_counter()
         proof, info = prove_streaming(rprog, rwit, [], rwc, seeds=seeds, max_chunk_ops=chunk_ops, ctx=ctx)
         dts.append(time.perf_counter() - t0)
         tv = time.perf_counter()
         vok, vinfo = verify_streaming(rprog, rwc, proof, max_chunk_ops=chunk_ops, ctx=ctx)
         tvs.append(time.perf_counter() - tv)
-    dt, tv = sorted(dts)[1], sorted(tvs)[1]
-    rec = {"value": rst["and"] / dt, "unit": "AND gates/s", "ms": dt * 1e3, "first_call_ms": dts[0] * 1e3, "chunk_ops": chunk_ops, "chunks": info["chunks"],
+    first_dt, first_tv = dts[0], tvs[0]
+    dts, tvs = dts[1:], tvs[1:]
+    dt, tv = sorted(dts)[2], sorted(tvs)[2]
+    rec = {"value": rst["and"] / dt, "unit": "AND gates/s", "ms": dt * 1e3, "ms_min_max": [min(dts) * 1e3, max(dts) * 1e3], "first_call_ms": first_dt * 1e3, "chunk_ops": chunk_ops, "chunks": info["chunks"],
            "gf2_wires": rwc[1], "bit_exact_vs_rv_prove": bytes(proof) == want,
-           "verify_streaming": {"ms": tv * 1e3, "first_call_ms": tvs[0] * 1e3, "ok": vok, "device_bytes_beside_the_proof": vinfo["wire_store_bytes"] + vinfo["peak_chunk_bytes"] + vinfo["hash_state_bytes"],
+           "verify_streaming": {"ms": tv * 1e3, "ms_min_max": [min(tvs) * 1e3, max(tvs) * 1e3], "first_call_ms": first_tv * 1e3, "ok": vok, "device_bytes_beside_the_proof": vinfo["wire_store_bytes"] + vinfo["peak_chunk_bytes"] + vinfo["hash_state_bytes"],
                                 "note": "rv_verify_streaming (strict): one pass over the op array, chunks in verify mode against the proof"},
            "device_bytes": dict({k: info[k] for k in ("wire_store_bytes", "peak_chunk_bytes", "hash_state_bytes", "proof_bytes")},
                                 kept_transcript_bytes=info["kept_mib"] << 20),
