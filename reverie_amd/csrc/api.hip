@@ -766,14 +766,6 @@ static bool build_z64_fused(const Compiled& cc, std::vector<Gate64>& sorted, std
         uint64_t at[3] = {lo, lo + n[0], lo + n[0] + n[1]};
         levels[l] = Z64FLevel{(uint32_t)lo, (uint32_t)at[1], (uint32_t)at[2], (uint32_t)hi};
         for (uint64_t i = lo; i < hi; i++) sorted[at[cls(cc.gates64[i].op)]++] = cc.gates64[i];
-        // (experiment RV_Z64F_SORT=1: a level's Mul and linear gates in the order of their first operand's row -- gates that share it
-        // run next to each other, and the second read of the row finds it in L2)
-        static const bool by_operand = getenv("RV_Z64F_SORT") && atoi(getenv("RV_Z64F_SORT")) != 0;
-        if (by_operand) {
-            auto key = [](const Gate64& g) { return g.am; };
-            std::stable_sort(sorted.begin() + lo, sorted.begin() + (lo + n[0]), [&](const Gate64& x, const Gate64& y) { return key(x) < key(y); });
-            std::stable_sort(sorted.begin() + (lo + n[0]), sorted.begin() + (lo + n[0] + n[1]), [&](const Gate64& x, const Gate64& y) { return key(x) < key(y); });
-        }
     }
     return true;
 }
