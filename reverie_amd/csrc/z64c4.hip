@@ -1,11 +1,14 @@
 // The Z64 prover's dependency level with the LANE-DISTRIBUTED cipher inside (round 5).  EXPERIMENT BUILDS ONLY (make
-// EXTRA=-DRV_EXPERIMENTS, RV_Z64_C4=1): byte-identical proofs (tests/test_gpu_z64_fused.py), but on the 10^6-Mul circuit 37.9 - 38.3 ms of
-// level launches against 36.2 - 36.6 for k_z64_fused (aes.hip), which stays the library's kernel.  What this file found and k_z64_fused
-// took over: the transcript stores (z64_dev.h: whole 64-byte segments per four lanes; 44.3 -> 36.9 ms here, 38.4 -> 36.2 there).  Both
-// kernels now sit where the cipher's instruction stream (27 - 31 ms alone) and 124 GB of row and transcript traffic per proof (3.4 TB/s
-// of scattered 4 KiB - 16 KiB pieces, reads = the algorithmic 65 GB exactly) meet; measured here and not kept: nontemporal transcript
-// stores (no difference), the linear gate's rows requested with the Mul's (167 registers, 12 wavefronts: 39.7), 8 wavefronts (41.0),
-// a priority that falls with the trips done (42.9 against 44.9 before the store fix).
+// EXTRA=-DRV_EXPERIMENTS, RV_Z64_C4=1): byte-identical proofs (tests/test_gpu_z64_fused.py) and, on the 10^6-Mul circuit, a TIE with
+// k_z64_fused (aes.hip), which stays the library's kernel: 35.7 ms of level launches against 35.8 - 36.1, the hash phase behind it 6.25
+// against 6.04 (the chip comes out of this kernel at a lower clock), 48.7 - 48.8 ms per proof either way.  What this file found and
+// k_z64_fused took over: the transcript stores (z64_dev.h: whole 64-byte segments per four lanes; 44.3 -> 36.9 ms here, 38.4 -> 36.2
+// there); its own preprocessing words leave in runs of eight through LDS (a wavefront takes consecutive gates: 37.9 -> 35.7).  Both
+// kernels sit where the cipher's instruction stream (27 - 31 ms alone) and 120 GB of row and transcript traffic per proof (3.4 TB/s of
+// scattered 4 KiB - 16 KiB pieces, reads = the algorithmic 65 GB exactly) meet; measured here and not kept: nontemporal transcript
+// stores (no difference), the linear gate's rows requested with the Mul's (167 registers, 12 wavefronts: 39.7), 12 wavefronts (37.1:
+// what a co-resident hash kernel would need), 8 wavefronts (41.0), a priority that falls with the trips done (42.9 against 44.9 before
+// the store fix).
 //
 // Replaces, for one dependency level (all under /root/reference/src/): generator/share.rs:54-65 + algebra/z64/domain.rs:64-83
 // (the two fresh masks of every Mul: one AES-128-CTR block per (repetition, player) stream), interpreter/single.rs:25-157
@@ -74,7 +77,7 @@ __device__ __forceinline__ void z4_store_on(uint64_t* op, const uint64_t* w) {
 constexpr uint32_t Z4_PIECE = 128;
 
 // Mul (interpreter/single.rs:25-69 with the prover's transcript, prover.rs:181-219): lambda_ab, lambda_new = the gate's cipher block
-__device__ __forceinline__ void z4_mul(const Gate64& g, const Z64FParams& p, const uint4* rkl, uint32_t c, uint32_t rep, uint32_t zo, bool writer) {
+__device__ __forceinline__ uint64_t z4_mul(const Gate64& g, const Z64FParams& p, const uint4* rkl, uint32_t c, uint32_t rep, uint32_t zo, bool writer) {
     const uint64_t S = (uint64_t)p.NQ * 32;
     // the operand pieces first: they land while the cipher runs
     const uint64_t* ap = z4_row(p, g.am, S) + zo;
@@ -147,8 +150,8 @@ __device__ __forceinline__ void z4_mul(const Gate64& g, const Z64FParams& p, con
 #pragma unroll
     for (int i = 0; i < 4; i++) z4_st16(lnp + Z4_PIECE * i, lnw[2 * i], lnw[2 * i + 1]);
     z4_store_on_quad(p.on + (size_t)(rep & ~3u) * p.on_words + g.eo, p.on_words, w, co, mh, ml);
-    __builtin_nontemporal_store(a * b - cs, &p.pre[(size_t)rep * p.pre_words + g.ep]);
     if (writer) p.v[g.dst] = va * vb;
+    return a * b - cs;  // the preprocessing transcript's word of (this gate, this repetition): k_z64_c4 collects a run of them
 }
 
 // Add / Sub / AddConst / SubConst / MulConst (z64/share.rs:110-136 player by player) and the value
@@ -219,7 +222,12 @@ __device__ __forceinline__ void z4_oth(const Gate64& g, const Z64FParams& p, uin
 // step.  Mul steps and linear steps alternate inside a wavefront, so that the level's row traffic runs beside other wavefronts' ciphers.
 // (the linear gate's operand rows requested together with the Mul's, its result stored after the cipher -- no wavefront ever waits for a
 // row it has just asked for -- needs 167 registers = 12 wavefronts: 39.7 ms per 10^6 Mul against 36.8; 8 wavefronts 41.0)
-constexpr int Z4_WAVES = 16;
+#ifndef Z4_NW
+#define Z4_NW 16
+#endif
+constexpr int Z4_WAVES = Z4_NW;
+constexpr uint32_t Z4_PRE_RUN = 8;  // words per repetition a wavefront collects before it stores them (16 wavefronts x 4 KiB of LDS)
+constexpr size_t Z4_LDS_BYTES = C4_LDS_BYTES + (size_t)Z4_WAVES * Z4_PRE_RUN * 64 * 8;
 __global__ __launch_bounds__(Z4_WAVES * 64) void k_z64_c4(const uint4* __restrict__ img, const Gate64* __restrict__ gates, Z64FLevel lv, uint32_t mul_per,
                                                         uint32_t lin_per, uint32_t oth_per, Z64FParams p) {
     extern __shared__ uint4 z4_lds[];
@@ -246,14 +254,40 @@ __global__ __launch_bounds__(Z4_WAVES * 64) void k_z64_c4(const uint4* __restric
     const bool writer = rep == 0;
     const uint4* rkl = z4_lds + lane;
     const uint32_t n_m = m_hi - m_lo, n_l = l_hi - l_lo;
-    const uint32_t MI = n_m > wave ? (n_m - wave + Z4_WAVES - 1) / Z4_WAVES : 0u;
+    // A wavefront takes CONSECUTIVE Mul gates: their words of the preprocessing transcript are then consecutive in every repetition's
+    // stream, and a run of up to eight of them goes through LDS (Z4_PRE_RUN words x 64 lanes per wavefront, behind the key image) and
+    // leaves as whole 64-byte segments per four lanes -- instead of 64 lanes storing 8 bytes each into 64 streams per gate
+    const uint32_t base = n_m / Z4_WAVES, rem = n_m % Z4_WAVES;
+    const uint32_t MI = base + (wave < rem ? 1u : 0u), m_first = m_lo + wave * base + min(wave, rem);
     const uint32_t LI = n_l > wave ? (n_l - wave + Z4_WAVES - 1) / Z4_WAVES : 0u;
+    uint64_t* run = (uint64_t*)(z4_lds + C4_IMG_U4) + (size_t)wave * Z4_PRE_RUN * 64;
+    uint32_t run_n = 0;
+    uint64_t run_ep = 0;
+    auto flush = [&]() {
+        if (run_n == Z4_PRE_RUN) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {  // lane -> repetition 16 i + lane / 4 of the wavefront's 64, words 2 (lane % 4), + 1 of the run
+                const uint32_t r = 16 * i + (lane >> 2), w2 = 2 * (lane & 3);
+                z4_st16_stream(p.pre + (size_t)(64 * qg + r) * p.pre_words + run_ep + w2, run[(size_t)w2 * 64 + r], run[(size_t)(w2 + 1) * 64 + r]);
+            }
+        } else {
+            for (uint32_t t = 0; t < run_n; t++) __builtin_nontemporal_store(run[(size_t)t * 64 + lane], &p.pre[(size_t)rep * p.pre_words + run_ep + t]);
+        }
+        run_n = 0;
+    };
     uint32_t ld = 0;
     for (uint32_t it = 0; it < MI; it++) {
-        z4_mul(gates[m_lo + wave + Z4_WAVES * it], p, rkl, c, rep, zo, writer);
+        const Gate64& g = gates[m_first + it];
+        const uint64_t ep = g.ep;
+        if (run_n && (run_n == Z4_PRE_RUN || ep != run_ep + run_n)) flush();
+        if (!run_n) run_ep = ep;
+        const uint64_t w = z4_mul(g, p, rkl, c, rep, zo, writer);
+        run[(size_t)run_n * 64 + lane] = w;
+        run_n++;
         const uint32_t lend = (uint32_t)(((uint64_t)(it + 1) * LI) / MI);
         for (; ld < lend; ld++) z4_lin(gates[l_lo + wave + Z4_WAVES * ld], p, zo, writer);
     }
+    if (run_n) flush();
     for (; ld < LI; ld++) z4_lin(gates[l_lo + wave + Z4_WAVES * ld], p, zo, writer);
     for (uint32_t go = o_lo + wave; go < o_hi; go += Z4_WAVES) z4_oth(gates[go], p, rep, zo, writer);
 }
@@ -271,7 +305,7 @@ void launch_z64_c4(hipStream_t st, const uint32_t* d_img, const Gate64* d_gates,
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !raised[dev]) {
-        (void)hipFuncSetAttribute((const void*)k_z64_c4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C4_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)k_z64_c4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z4_LDS_BYTES);
         raised[dev] = true;
     }
     const uint32_t n_qg = p.qgn;
@@ -283,7 +317,7 @@ void launch_z64_c4(hipStream_t st, const uint32_t* d_img, const Gate64* d_gates,
     const uint64_t chunks = std::max<uint64_t>(std::min<uint64_t>(per_qg, ((uint64_t)n_mul + n_lin + n_oth + Z4_WAVES - 1) / Z4_WAVES), 1);
     const uint32_t mul_per = (uint32_t)((n_mul + chunks - 1) / chunks), lin_per = (uint32_t)((n_lin + chunks - 1) / chunks),
                    oth_per = (uint32_t)((n_oth + chunks - 1) / chunks);
-    hipLaunchKernelGGL(k_z64_c4, dim3((unsigned)(chunks * n_qg)), dim3(Z4_WAVES * 64), C4_LDS_BYTES, st, (const uint4*)d_img, d_gates, lv, mul_per, lin_per,
+    hipLaunchKernelGGL(k_z64_c4, dim3((unsigned)(chunks * n_qg)), dim3(Z4_WAVES * 64), Z4_LDS_BYTES, st, (const uint4*)d_img, d_gates, lv, mul_per, lin_per,
                        oth_per, p);
 }
 
