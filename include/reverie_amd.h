@@ -189,11 +189,15 @@ int rv_prove(rv_ctx *ctx, const rv_circuit *c, const uint8_t *wit_gf2, size_t n_
  * What the reference's own entry points take (proof/mod.rs:119-125,224-232: the op list, the witness, (z64, gf2) wire
  * counts): compile (RV_COMPILE_WHOLE_PROVER for the prover) + prove / verify + release, in one call -- the form a drop-in for
  * a single Proof::new uses.  The compile runs on several host threads (csrc/compile_par.cpp): a circuit the library has not
- * seen costs ~0.1 s per 10^7 gates before its first proof.  Round 5: the context keeps the circuits these two calls compile, by
- * CONTENT (128 bits hashed from the op array on host threads: ~3 ms per 10^7 ops) -- a second Proof::new on the same op list finds
- * its gate stream on the device and costs the hash plus a proof (rv_prove's early-corrections path included); at most RV_OPS_CACHE
- * circuits per context (environment, default 2, least recently used leaves; 0: nothing is kept), released by rv_ctx_destroy or
- * rv_ctx_ops_cache_clear.  Callers that hold a circuit anyway compile it once (rv_circuit_compile_ex) and call rv_prove: no hash.
+ * seen costs ~0.1 s per 10^7 gates before its first proof.  The context keeps the circuits these two calls compile and finds them
+ * again BY CONTENT: every kept circuit owns a copy of the op array it was compiled from (24 bytes per op of host memory) and a hit is
+ * a full comparison of the caller's array against it on host threads (~4 ms per 10^7 ops) -- no hash is trusted, so neither the prover
+ * nor the verifier can be handed another statement's gate stream (round 5 keyed the cache by an unkeyed 128-bit hash: constructible
+ * collisions made rv_verify_ops accept a proof for a different circuit).  A second Proof::new on the same op list finds its gate stream
+ * on the device and costs the comparison plus a proof (rv_prove's early-corrections path included).  At most RV_OPS_CACHE circuits per
+ * context (environment, default 2; the least recently used one leaves BEFORE a new one is compiled; 0: nothing is kept), released by
+ * rv_ctx_destroy or rv_ctx_ops_cache_clear.  Both calls therefore MUTATE the context (one call at a time per context, like every entry
+ * point).  Callers that hold a circuit anyway compile it once (rv_circuit_compile_ex) and call rv_prove: no comparison.
  * flags of rv_verify_ops: as rv_verify_ex. */
 int rv_prove_ops(rv_ctx *ctx, const rv_op *ops, size_t n_ops, const uint8_t *wit_gf2, size_t n_gf2, const uint64_t *wit_z64, size_t n_z64,
                  size_t z64_wires, size_t gf2_wires, const uint8_t *seeds, uint8_t **proof, size_t *proof_len);

@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <mutex>
 #include <thread>
@@ -227,7 +228,8 @@ struct rv_ctx {
     // Proof::new takes the op list at every call (proof/mod.rs:119-124), and a caller that proves one circuit again and again through
     // that signature should pay the 70 - 90 ms host compile once, not per proof
     struct OpsEntry {
-        uint64_t h[2];
+        std::shared_ptr<std::vector<uint8_t>> ops;  // the op array the circuit was compiled from: a hit is a comparison against it
+        std::string knobs;
         size_t n_ops, z64_wires, gf2_wires;
         uint32_t flags;
         rv_circuit* c;
