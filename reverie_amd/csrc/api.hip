@@ -156,7 +156,7 @@ struct rv_ctx {
     hipStream_t stream3 = nullptr;  // the flat schedule's cleartext pass (k_clear), beside the mask generator
     hipStream_t stream_x = nullptr; // the flat schedule's XOR rows, running ahead of the Mul launches on `stream`
     bool has_prio = false;          // the context's streams carry a stream priority of their own (rv_prove_batch's worker contexts)
-    int prio = 0;
+    int prio = 0, mask_prio = 0;    // ... the main stream's (and stream2's), the mask generator stream's
     hipStream_t stream_m = nullptr; // RV_OVERLAP: the lane-distributed mask generator, beside the interpreter's level launches (made on first use)
     hipEvent_t clear_a = nullptr, clear_b = nullptr;  // profiling: around k_clear on stream3 (rv_profile slot RV_PH_CLEAR)
     bool clear_timed = false;
@@ -338,11 +338,15 @@ struct rv_ctx {
             free_blocks.erase(it);
             return RV_OK;
         }
+        static const bool trace = getenv("RV_PINNED_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(out, bytes);
         if (e != hipSuccess) {
             trim();
             e = hipMalloc(out, bytes);
         }
+        if (trace) fprintf(stderr, "[rv arena] hipMalloc %zu KiB: %.2f ms (ctx %p)\n", bytes >> 10,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), (void*)this);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             g_last_error = "hipMalloc failed";
@@ -378,10 +382,12 @@ static int dalloc(rv_ctx* ctx, size_t count, T** out) {
 // streams of ONE priority to four hardware queues in creation order, so which of a process's streams share a queue depends on how
 // many it happened to create before -- and when the workers' main streams fell on one queue, their proofs in flight ran one after the
 // other (a bench run with 10.2 ms per proof instead of 4.9 - 5.1).  Streams of different priorities never share a queue.
-static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level /* -1: default priority */);
+// main_prio_level / mask_prio_level: the priority class (0 = the device's highest) of the main stream and of the mask generator's stream;
+// -1 = the default priority.  A context with classes of its own (rv_prove_batch's workers) makes its second stream on first use.
+static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level /* -1: default priority */, int mask_prio_level = -1);
 extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) { return ctx_create_impl(device_ordinal, out, -1); }
 
-static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level) {
+static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level, int mask_prio_level) {
     if (!out) return RV_E_ARG;
     *out = nullptr;
     int n = 0;
@@ -418,15 +424,14 @@ static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level
         const int levels = prio_lo - prio_hi + 1;  // (numerically lower = higher priority)
         c->has_prio = true;
         c->prio = prio_hi + main_prio_level % levels;
+        c->mask_prio = mask_prio_level >= 0 ? prio_hi + mask_prio_level % levels : c->prio;
         se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, c->prio);
     } else {
         se = main_prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     }
-    // (a worker context's side streams in the SAME priority class as its main stream: streams of different priorities never share a
-    // hardware queue, streams of one priority are dealt to four queues in creation order -- so the three streams of a worker keep to
-    // queues of their own class instead of landing, as default-priority streams, on the queue of ANOTHER worker's main stream: with the
-    // round-5 mask stream that happened in one bench process out of two, 5.0 -> 7.2 ms per proof of a batch)
-    if (se == hipSuccess) se = c->has_prio ? hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, c->prio) : hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    // (a worker context of rv_prove_batch makes no second stream before something asks for one (ctx_stream2): an idle stream still
+    // holds a share of a hardware queue of its class, and which queue the NEXT stream of that class gets depends on it)
+    if (se == hipSuccess && !c->has_prio) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     // (stream3 / stream_x -- the flat and split schedules' side streams -- are made by ctx_side_streams() when such a schedule first
     // runs: streams are dealt to the four hardware queues in creation order, so two idle ones per context put the main streams of
     // rv_prove_batch's worker contexts all on ONE queue and its proofs in flight ran one after the other: 4.9 -> 6.2 ms per proof)
@@ -436,6 +441,13 @@ static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level
     }
     *out = c;
     return RV_OK;
+}
+
+// the context's second stream (worker contexts: made on first use, in the main stream's priority class)
+static int ctx_stream2(rv_ctx* c) {
+    if (c->stream2) return RV_OK;
+    const hipError_t se = c->has_prio ? hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, c->prio) : hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    return se == hipSuccess ? RV_OK : hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
 }
 
 #ifdef RV_EXPERIMENTS
@@ -461,7 +473,7 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     if (ctx->stream_x) (void)hipStreamSynchronize(ctx->stream_x);
     if (ctx->stream_m) (void)hipStreamSynchronize(ctx->stream_m);
@@ -487,7 +499,7 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     delete ctx->ec_pool;
     for (rv_ctx* w : ctx->workers) rv_ctx_destroy(w);
     (void)hipStreamDestroy(ctx->stream);
-    (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream_x) (void)hipStreamDestroy(ctx->stream_x);
     if (ctx->stream_m) (void)hipStreamDestroy(ctx->stream_m);
@@ -518,6 +530,10 @@ struct PinnedPool {
     std::vector<Buf> bufs;
     static constexpr size_t MIN_BYTES = 1u << 20;  // below this plain malloc is as fast
     static constexpr size_t KEEP_FREE = 3;         // idle buffers kept for reuse
+    static bool trace() {
+        static const bool on = getenv("RV_PINNED_TRACE") != nullptr;
+        return on;
+    }
     void* get(size_t n) {
         if (n < MIN_BYTES) return nullptr;
         std::lock_guard<std::mutex> g(mu);
@@ -530,10 +546,13 @@ struct PinnedPool {
         }
         void* p = nullptr;
         const size_t cap = (n + (n >> 3) + 0xFFFFF) & ~(size_t)0xFFFFF;  // 12 % headroom, whole MiB
+        const auto t0 = std::chrono::steady_clock::now();
         if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;  // caller falls back to malloc
         }
+        if (trace()) fprintf(stderr, "[rv pinned] hipHostMalloc %zu MiB: %.2f ms (%zu buffers)\n", cap >> 20,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), bufs.size() + 1);
         bufs.push_back(Buf{p, cap, true});
         return p;
     }
@@ -566,7 +585,10 @@ struct PinnedPool {
             for (size_t k = 0; k < bufs.size(); k++)
                 if (!bufs[k].used && (victim == bufs.size() || bufs[k].cap < bufs[victim].cap)) victim = k;
             if (victim == bufs.size()) break;
+            const auto t0 = std::chrono::steady_clock::now();
             (void)hipHostFree(bufs[victim].p);
+            if (trace()) fprintf(stderr, "[rv pinned] hipHostFree %zu MiB: %.2f ms\n", bufs[victim].cap >> 20,
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             bufs.erase(bufs.begin() + (long)victim);
             idle--;
         }
@@ -1206,7 +1228,7 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
             if (x->h_ec_cap < ((size_t)1 << 30)) return;
             (void)hipSetDevice(x->device);
             (void)hipStreamSynchronize(x->stream);
-            (void)hipStreamSynchronize(x->stream2);
+            if (x->stream2) (void)hipStreamSynchronize(x->stream2);
             if (x->h_ec) (void)hipHostFree(x->h_ec);
             if (x->d_ec) (void)hipFree(x->d_ec);
             x->h_ec = x->d_ec = nullptr;

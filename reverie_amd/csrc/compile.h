@@ -32,7 +32,16 @@ namespace rv {
 // kernel, never value-initialised a second time by the container.
 void* big_alloc(size_t bytes);  // nullptr when out of memory; contents are zero
 void big_free(void* p, size_t bytes);
-void big_free_later(void* p, size_t bytes);  // the same from a background thread (nobody waits for an unmap)
+void big_free_later(void* p, size_t bytes);
+// +1 / -1 around a library call that drives the GPU (LibBusy below): the background thread of big_free_later unmaps nothing meanwhile --
+// its munmap calls stall other threads' HIP calls for 10 - 100 ms (round 6: rv_prove_batch's workers right after a compile)
+void lib_busy(int d);
+struct LibBusy {
+    LibBusy() { lib_busy(+1); }
+    ~LibBusy() { lib_busy(-1); }
+    LibBusy(const LibBusy&) = delete;
+    LibBusy& operator=(const LibBusy&) = delete;
+};  // the same from a background thread (nobody waits for an unmap)
 template <class T>
 struct BigAlloc {
     using value_type = T;

@@ -280,6 +280,10 @@ void* big_alloc(size_t bytes) {
 // it frees nothing while a compile is running (compile_busy) and not before the releases have been quiet for a while -- the
 // upload and the first proof follow a compile at once, and a loop of compiles would otherwise fault its fresh pages
 // against the previous round's unmapping (20 - 30 ms per compile on the 10^7-gate circuit).  Above a cap it frees at once.
+static void big_free_impl(void* p, size_t bytes, bool pause);
+// library calls in flight (compiles, proofs, verifications: lib_busy in compile.h): the background thread gives nothing back while one runs
+static std::atomic<int> g_lib_busy{0};
+void lib_busy(int d) { g_lib_busy.fetch_add(d, std::memory_order_relaxed); }
 namespace {
 struct Reaper {
     // more than this queued: free at once, in the one burst it then takes.  An eighth of the machine's memory, 4 .. 32 GiB: the
@@ -311,7 +315,7 @@ struct Reaper {
             take.swap(q);
             queued = 0;
             lk.unlock();
-            for (auto& e : take) big_free(e.first, e.second);
+            for (auto& e : take) big_free_impl(e.first, e.second, /*pause=*/true);
             lk.lock();
         }
     }
@@ -341,8 +345,8 @@ Reaper& reaper() {
     return r;
 }
 struct CompileBusy {  // while one lives, the background thread unmaps nothing
-    CompileBusy() { reaper().set_busy(+1); }
-    ~CompileBusy() { reaper().set_busy(-1); }
+    CompileBusy() { reaper().set_busy(+1), lib_busy(+1); }
+    ~CompileBusy() { reaper().set_busy(-1), lib_busy(-1); }
 };
 }  // namespace
 void big_free_later(void* p, size_t bytes) {
@@ -353,15 +357,42 @@ void big_free_later(void* p, size_t bytes) {
     else
         reaper().push(p, bytes);
 }
-void big_free(void* p, size_t bytes) {
+// Unmapping holds the address-space lock exclusively while the pages go back, ~25 ms per GB -- and every other thread of the process that
+// faults a page, grows its heap or maps anything waits that long (round 6: the worker threads of rv_prove_batch stalled 15 - 100 ms in
+// their kernel launches whenever the background thread returned the scratch of compiles done shortly before: 4.8 -> 8.7 ms per proof in
+// the driver's bench).  So a block goes back in pieces of 16 MiB, the pages of a piece first through MADV_DONTNEED (shared lock), and
+// from the background thread with a pause after every piece: nobody waits longer than one piece takes.
+static void unmap_gently(void* p, size_t len, bool pause) {
+    constexpr size_t PIECE = (size_t)16 << 20;
+    uint8_t* q = (uint8_t*)p;
+    while (len) {
+        // (background thread: between the library's calls only -- but not for ever: a service that proves without a break gets its
+        // memory back within ~2 s per block all the same)
+        for (int spins = 0; pause && g_lib_busy.load(std::memory_order_relaxed) > 0 && spins < 10000; spins++) {
+            timespec ts{0, 200 * 1000};
+            nanosleep(&ts, nullptr);
+        }
+        const size_t n = std::min(len, PIECE);
+        (void)madvise(q, n, MADV_DONTNEED);
+        munmap(q, n);
+        q += n;
+        len -= n;
+        if (pause && len) {
+            timespec ts{0, 50 * 1000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+}
+static void big_free_impl(void* p, size_t bytes, bool pause) {
     if (!p) return;
     if (bytes < ((size_t)4 << 20)) {
         free(p);
         return;
     }
     const size_t HP = (size_t)2 << 20;
-    munmap(p, (bytes + HP - 1) & ~(HP - 1));
+    unmap_gently(p, (bytes + HP - 1) & ~(HP - 1), pause);
 }
+void big_free(void* p, size_t bytes) { big_free_impl(p, bytes, false); }
 
 int compile_threads() {
     if (const char* e = getenv("RV_COMPILE_THREADS")) return std::max(1, atoi(e));

@@ -9,7 +9,7 @@ import pytest
 
 import circuits
 from conftest import GOLDEN
-from reverie_amd.ops import GF2, OP_DTYPE, program
+from reverie_amd.ops import GF2, OP_DTYPE, Z64, program
 
 pytestmark = pytest.mark.gpu
 
@@ -1553,7 +1553,6 @@ def test_ops_cache_is_by_content_colliding_op_lists(rv, rule_seeds):
         assert not rv.Proof(proof_a).verify(pb, wcb, ctx=ctx, strict=strict)
         assert rv.Proof(proof_b).verify(pb.copy(), wcb, ctx=ctx, strict=strict)
     # the prover side: each list proves ITS statement
-    ctx.ops_cache_clear() if hasattr(ctx, "ops_cache_clear") else None
     assert bytes(rv.Proof.new(pb, wit, [], wcb, seeds=rule_seeds, ctx=ctx)) == proof_b
     assert bytes(rv.Proof.new(pa, wit, [], wca, seeds=rule_seeds, ctx=ctx)) == proof_a
     assert bytes(rv.Proof.new(pb, wit, [], wcb, seeds=rule_seeds, ctx=ctx)) == proof_b
