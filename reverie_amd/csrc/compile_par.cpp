@@ -283,7 +283,16 @@ void* big_alloc(size_t bytes) {
 static void big_free_impl(void* p, size_t bytes, bool pause);
 // library calls in flight (compiles, proofs, verifications: lib_busy in compile.h): the background thread gives nothing back while one runs
 static std::atomic<int> g_lib_busy{0};
-void lib_busy(int d) { g_lib_busy.fetch_add(d, std::memory_order_relaxed); }
+static std::atomic<int64_t> g_lib_idle_since_ns{0};  // when the last call in flight returned (steady clock)
+static int64_t steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void lib_busy(int d) {
+    if (d < 0) g_lib_idle_since_ns.store(steady_ns(), std::memory_order_relaxed);
+    g_lib_busy.fetch_add(d, std::memory_order_relaxed);
+}
+// nothing in flight, and nothing for a few milliseconds: a loop of back-to-back calls leaves no gap the unmapper would take
+static bool lib_quiet() {
+    return g_lib_busy.load(std::memory_order_relaxed) <= 0 && steady_ns() - g_lib_idle_since_ns.load(std::memory_order_relaxed) > 3 * 1000 * 1000;
+}
 namespace {
 struct Reaper {
     // more than this queued: free at once, in the one burst it then takes.  An eighth of the machine's memory, 4 .. 32 GiB: the
@@ -368,7 +377,7 @@ static void unmap_gently(void* p, size_t len, bool pause) {
     while (len) {
         // (background thread: between the library's calls only -- but not for ever: a service that proves without a break gets its
         // memory back within ~2 s per block all the same)
-        for (int spins = 0; pause && g_lib_busy.load(std::memory_order_relaxed) > 0 && spins < 10000; spins++) {
+        for (int spins = 0; pause && !lib_quiet() && spins < 10000; spins++) {
             timespec ts{0, 200 * 1000};
             nanosleep(&ts, nullptr);
         }
