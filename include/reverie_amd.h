@@ -114,7 +114,7 @@ enum {
     RV_PH_JOIN = 4,   /* k_join                                                        */
     RV_PH_OPEN = 5,   /* k_fs_challenge + k_open_headers + k_extract_rows / k_extract_from_bits / k_extract64 */
     RV_PH_EARLY = 6,  /* launches only (their time is inside RV_PH_INTERP): k_pack_corr_all + k_publish of rv_prove's early-corrections path */
-    RV_PH_CLEAR = 7,  /* k_clear of the flat prover schedule: runs on a stream of its own beside the mask generator (its time is not part of a proof's critical path unless it outlasts RV_PH_MASKS) */
+    RV_PH_CLEAR = 7,  /* unused since round 6 (the flat prover schedule's cleartext pass): the slot stays so that rv_profile keeps its size */
     RV_PH_COUNT = 8
 };
 typedef struct rv_profile {
@@ -511,9 +511,6 @@ uint64_t rv_hook_ops_cache_hits(void);
  * lane-distributed cipher of csrc/aes_col4.hip on a stream of its own, chunk by chunk; RV_OVERLAP=0 runs it before the first level;
  * circuits below RV_OVERLAP_MIN = 8192 cipher blocks and rows narrower than 64 repetitions keep that order anyway).  Same bytes. */
 uint64_t rv_hook_overlap_commits(void);
-/* 1 in an experiment build of the library (csrc/Makefile: EXTRA=-DRV_EXPERIMENTS -- the prover schedules of rounds 2 and 4 that
- * measured slower than the level path: RV_REP, RV_FLAT, RV_PERSIST, RV_EARLY_REC; rv_hook_flat_plan answers only there), else 0. */
-int rv_hook_experiments(void);
 /* Verifications this process has run with one u64 of public corrections per share row instead of corr rows (csrc/kernels.hip:
  * MODE_VERIFY_C -- the verify-mode interpreter of whole proofs of pure GF(2) one-base gate streams; replaces nothing of the
  * reference's: verifier/online.rs:122-183 computes the same values).  The answer is the same either way; the tests use the
@@ -526,16 +523,6 @@ uint64_t rv_hook_verify_vc_count(void);
  * after a chunk's ready level writes one of its rows and the ready level itself does, [6 + k] = chunk k's ready level (k < 16).
  * Returns the compiler's status. */
 int rv_hook_early_plan(const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, uint64_t out[22]);
-/* The flat prover schedule of a program (host only, no device; csrc/flat.h: the Mul gates of a pure GF(2) circuit in program
- * order behind its XOR rows, instead of one launch per dependency level).  An EXPERIMENT: byte-identical, measured slower than the
- * level path, compiled into experiment builds only (csrc/Makefile: EXTRA=-DRV_EXPERIMENTS, where RV_FLAT=1/2/3
- * selects it; default 0) -- in the library build() makes this hook returns RV_E_UNSUPPORTED.  out[0] = eligible (0 / 1),
- * [1] = Mul records, [2] = XOR gates, [3] = x-levels, [4] = Input / AssertZero gates, [5] = 1 when the plan checks against the
- * level-sorted gate stream (every gate present once, every XOR gate behind the XOR rows it reads, Mul record i = the gate with
- * preprocessing row i), [6] = the circuit's dependency levels, [7] = bands (`bands` asked for: equal ranges of the
- * program's Mul gates, each with the XOR rows no earlier band needed), [8 + k] = x-levels of band k (k < 16).
- * Returns the compiler's status. */
-int rv_hook_flat_plan(const rv_op *ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, uint32_t flags, uint32_t bands, uint64_t out[24]);
 
 #ifdef __cplusplus
 }

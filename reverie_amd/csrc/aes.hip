@@ -429,103 +429,6 @@ __global__ __launch_bounds__(512, 2) void k_aes_gf2_masks(const uint32_t* __rest
 }
 
 
-#ifdef RV_EXPERIMENTS  // (the rep-sliced prover path, rep.hip: experiment builds only)
-// ------------------------------------------------------------------------------------
-// Rep-major mask generator (rep.hip's layout: masks[rep][m], one byte = the 8 players of that repetition).
-// rk_rep[(area*128 + 8*byte + bit) * R + rep]: bit of round-key byte of the 8 player keys of `rep`, player p at bit
-// 7 - p of EVERY byte of the word (the four counter blocks of a lane share the keys).
-// ------------------------------------------------------------------------------------
-__global__ void k_bitslice_rk_rep(const uint8_t* __restrict__ rkbytes, uint32_t R, uint32_t* __restrict__ rk) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (RK_BYTES / 4) * R) return;
-    const uint32_t rep = t % R, bg = t / R;
-    uint32_t v[8];
-#pragma unroll
-    for (uint32_t p = 0; p < 8; p++) v[p] = *(const uint32_t*)(rkbytes + RK_BYTES * (size_t)(rep * 8 + p) + 4 * bg);
-    for (uint32_t k = 0; k < 32; k++) {
-        uint32_t w = 0;
-#pragma unroll
-        for (uint32_t p = 0; p < 8; p++) w |= ((v[p] >> k) & 1u) << (7 - p);
-        rk[(size_t)(32 * bg + k) * R + rep] = w * 0x01010101u;
-    }
-}
-void launch_bitslice_rk_rep(hipStream_t st, const uint8_t* d_rkbytes, uint32_t R, uint32_t* d_rk) {
-    const uint32_t n = (RK_BYTES / 4) * R;
-    hipLaunchKernelGGL(k_bitslice_rk_rep, dim3((n + 255) / 256), dim3(256), 0, st, d_rkbytes, R, d_rk);
-}
-
-// A workgroup = one repetition (its 11 bitsliced round keys: 5.5 KiB of LDS); lane = 4 consecutive CTR blocks x 8
-// players, a wavefront = 256 consecutive blocks = 32 KiB of mask bytes per trip.  The cipher leaves bit plane b of
-// the four blocks in one register; the epilogue turns 4 planes x 4 blocks into 4 x 4 mask bytes (v_perm), and the
-// wavefront's bytes pass through an LDS tile so that every store instruction writes whole 128-byte runs (a lane
-// storing its own 16-byte pieces 512 bytes apart is what held the Z64 generator at 1.2 TB/s).
-constexpr uint32_t AES_REP_ROW = 128 + 16;  // bytes per staged lane row (+16: the column reads spread over the banks)
-__global__ __launch_bounds__(512, 2) void k_aes_rep_masks(const uint32_t* __restrict__ rk, uint32_t R, uint64_t n_blocks4 /* groups of 4 blocks */,
-                                                       uint8_t* __restrict__ masks, uint64_t mask_stride) {
-    __shared__ uint32_t lds_rk[11 * 128];
-    __shared__ __attribute__((aligned(16))) uint8_t tile[8][64 * AES_REP_ROW];
-    const uint32_t rep = blockIdx.x % R;
-    const uint32_t part = blockIdx.x / R, n_parts = gridDim.x / R;
-    stage_round_keys<1>(rk, R, rep, lds_rk);
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t* my_tile = tile[wave];
-    uint8_t* out_rep = masks + (size_t)rep * mask_stride;
-    // this workgroup's share of the repetition's lane-trips (64 x 4 blocks each), dealt wave by wave
-    const uint64_t trips = (n_blocks4 + 63) / 64;
-    for (uint64_t trip = (uint64_t)part * 8 + wave; trip < trips; trip += (uint64_t)n_parts * 8) {
-        const uint64_t j = trip * 64 + lane;  // blocks 4j .. 4j+3
-        uint32_t s[128], t[128];
-        if (j < n_blocks4) {
-            rounds_0_to_9<1, true>(j, s, t, lds_rk);
-            sub_shift(s, t);
-        }
-        const uint32_t* rk10 = lds_rk + 10 * 128;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            // mask index inside block 4j + c: b = 8 * byte + (7 - bit)  (keystream bits MSB-first, gf2/domain.rs)
-            if (j < n_blocks4) {
-#pragma unroll
-                for (int g = 0; g < 32; g++) {
-                    uint32_t v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int b = 4 * g + e, i = b >> 3, k = 7 - (b & 7);
-                        v[e] = t[8 * i + k] ^ rk10[8 * i + k];
-                    }
-                    const uint32_t sel = 0x0c0c0400u + (uint32_t)(3 - c) * 0x0101u;  // byte c counted from the MSB
-                    const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], sel), hi = __builtin_amdgcn_perm(v[3], v[2], sel);
-                    *(uint32_t*)(my_tile + lane * AES_REP_ROW + 4 * g) = lo | (hi << 16);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();  // (the tile is wave-private: DS operations of one wavefront complete in order)
-            // the wavefront's tile: row = source lane (block 4j_src + c), 128 bytes each -> eight lanes per row
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t src = 8 * q + (lane >> 3), piece = lane & 7;
-                const uint64_t js = trip * 64 + src;
-                const uint4 d = *(const uint4*)(my_tile + src * AES_REP_ROW + 16 * piece);
-                if (js < n_blocks4) *(uint4*)(out_rep + 128 * (4 * js + c) + 16 * piece) = d;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-void launch_aes_rep_masks(hipStream_t st, const uint32_t* d_rk_rep, uint32_t R, uint64_t n_blocks, uint8_t* d_masks, uint64_t mask_stride) {
-    if (!n_blocks) return;
-    const uint64_t n4 = (n_blocks + 3) / 4;
-    static const uint32_t cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return (uint32_t)n;
-    }();
-    // one workgroup per CU and generation: parts of a repetition's trips when there are fewer repetitions than CUs
-    uint32_t parts = std::max<uint32_t>(1, cus / R);
-    const uint64_t trips = (n4 + 63) / 64;
-    parts = (uint32_t)std::min<uint64_t>(parts, std::max<uint64_t>(1, (trips + 7) / 8));
-    hipLaunchKernelGGL(k_aes_rep_masks, dim3(R * parts), dim3(512), 0, st, d_rk_rep, R, n4, d_masks, mask_stride);
-}
-#endif  // RV_EXPERIMENTS
 
 // ---- launchers ----
 void launch_expand_seeds(hipStream_t st, const uint8_t* d_seeds, uint32_t n_reps, uint8_t* d_keys) {
@@ -599,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void k_aes_z64_masks(const uint32_t* __rest
 
 template <int QW>
 static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
-                            uint64_t n_blocks, uint32_t* d_masks, uint32_t reserve_cus) {
+                            uint64_t n_blocks, uint32_t* d_masks) {
     const uint32_t n_qg = NQ / QW;
     constexpr uint32_t JW = 64 / QW;
     // Target workgroup count: a workgroup takes a whole CU (88 KiB LDS, 512 x 256 registers), so ONE workgroup per CU
@@ -616,7 +519,7 @@ static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t
     // chip is its 1/batch of the workgroups, at least one per quad group -- each workgroup fills 88 KiB of LDS with
     // round keys before its first block
     const uint64_t wgs = g_recorder ? std::max<uint64_t>(n_qg, target_wgs / std::max(g_recorder->batch, 1u))
-                                    : (target_wgs > 2 * (uint64_t)reserve_cus ? target_wgs - reserve_cus : target_wgs);
+                                    : target_wgs;
     uint64_t per = (n_blocks * n_qg + wgs - 1) / wgs;
     per = ((per + 8 * JW - 1) / (8 * JW)) * (8 * JW);
     const uint64_t chunks = (n_blocks + per - 1) / per;
@@ -625,14 +528,14 @@ static void launch_masks_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t
 }
 
 void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
-                          uint64_t n_blocks, uint32_t* d_masks, uint32_t reserve_cus) {
+                          uint64_t n_blocks, uint32_t* d_masks) {
     if (!n_blocks) return;
     if (NQ % 16 == 0)
-        launch_masks_qw<16>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks, reserve_cus);
+        launch_masks_qw<16>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
     else if (NQ % 8 == 0)
-        launch_masks_qw<8>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks, reserve_cus);
+        launch_masks_qw<8>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
     else
-        launch_masks_qw<2>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks, reserve_cus);
+        launch_masks_qw<2>(st, d_rk, d_keep, NQ, first_block, n_blocks, d_masks);
 }
 template <int QW>
 static void launch_z64_qw(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block, uint64_t n_blocks,

@@ -22,10 +22,8 @@
 
 #include "b3.h"
 #include "compile.h"
-#include "flat.h"
 #include "internal.h"
 #include "launch.h"
-#include "repprog.h"
 #include "ldsrun.h"
 
 using namespace rv;
@@ -46,15 +44,6 @@ static int hip_fail(hipError_t e, const char* what, const char* file, int line) 
     } while (0)
 
 extern "C" const char* rv_last_error(void) { return g_last_error.c_str(); }
-// 1: an experiment build (make EXTRA=-DRV_EXPERIMENTS: the rep-sliced path, the flat / split / chained schedules, the persistent level
-// kernels, RV_EARLY_REC); 0: the library build() makes, where those knobs do nothing
-extern "C" int rv_hook_experiments(void) {
-#ifdef RV_EXPERIMENTS
-    return 1;
-#else
-    return 0;
-#endif
-}
 extern "C" uint32_t rv_abi_version(void) { return 8; }  // 3: verification strict by default (RV_VERIFY_REFERENCE_COMPAT), rv_bristol_parse takes n_expected,
                                                         //    streaming prover, rv_prove_multi, reconstruct hooks
                                                         // 4: rv_circuit_compile_ex (a pure addition)
@@ -153,13 +142,9 @@ struct rv_ctx {
     size_t lds_bytes = 0;  // hipDeviceAttributeMaxSharedMemoryPerBlock
     hipStream_t stream = nullptr;   // setup, AES masks, hashing, openings (VALU-heavy work)
     hipStream_t stream2 = nullptr;  // side stream: the early-corrections copies, the verifier's proof copy and unpack kernels
-    hipStream_t stream3 = nullptr;  // the flat schedule's cleartext pass (k_clear), beside the mask generator
-    hipStream_t stream_x = nullptr; // the flat schedule's XOR rows, running ahead of the Mul launches on `stream`
     bool has_prio = false;          // the context's streams carry a stream priority of their own (rv_prove_batch's worker contexts)
     int prio = 0, mask_prio = 0;    // ... the main stream's (and stream2's), the mask generator stream's
     hipStream_t stream_m = nullptr; // RV_OVERLAP: the lane-distributed mask generator, beside the interpreter's level launches (made on first use)
-    hipEvent_t clear_a = nullptr, clear_b = nullptr;  // profiling: around k_clear on stream3 (rv_profile slot RV_PH_CLEAR)
-    bool clear_timed = false;
     std::vector<rv_ctx*> workers;            // rv_prove_batch on large circuits: one worker context per host thread
     // Small proofs (AES-128: 99 KB) leave through this page-locked, device-mapped buffer: the opening kernels write into it
     // and a one-lane kernel adds the error word, instead of two copy-engine operations of ~25 us each behind them
@@ -217,11 +202,6 @@ struct rv_ctx {
     size_t d_ec_cap = 0;
     uint32_t* h_fs = nullptr;
     uint32_t fs_seq = 0;
-    // ... and the staging of the opened repetitions' broadcast-bit vectors on their way out (RecStage below): [40][pitch] on the
-    // device and page-locked on the host
-    uint8_t* d_rs = nullptr;
-    uint8_t* h_rs = nullptr;
-    size_t rs_cap = 0;
     HelperPool* ec_pool = nullptr;
     double ec_wait_us[17] = {0};  // running averages of the early-corrections waits (per chunk stamp, [16] the challenge): mailbox_wait
     // rv_prove_ops / rv_verify_ops: the circuits compiled from raw op lists, kept by content (ops_cache_get): the reference's
@@ -316,12 +296,6 @@ struct rv_ctx {
             if (hipEventElapsedTime(&ms, m.a, m.b) == hipSuccess) prof.ms[m.phase] += ms;
             prof.launches[m.phase] += m.launches;
         }
-        if (clear_timed) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, clear_a, clear_b) == hipSuccess) prof.ms[RV_PH_CLEAR] += ms;
-            prof.launches[RV_PH_CLEAR]++;
-            clear_timed = false;
-        }
         for (auto& kv : ev_refs) ev_pool.push_back(kv.first);  // (an event may be the end of one mark and the start of the next)
         ev_refs.clear();
         marks.clear();
@@ -412,13 +386,10 @@ static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level
         c->lds_bytes = (size_t)std::max(lds, 0);
         set_device_lds_limit(c->lds_bytes);
     }
-    // The runtime multiplexes the streams of one priority over four hardware queues (a fifth stream would share the first one's),
-    // and a queue that issues short kernels back to back keeps the dispatcher from a queue of the same or a lower priority.  The
-    // main stream can therefore get the high priority (RV_MAIN_PRIO=1; default: all streams alike): its long kernels go out the moment their
-    // dependencies are met, and the flat schedule's short XOR launches (stream_x) fill in beside them.  (Measured: no gain; off.)
+    // The runtime multiplexes the streams of one priority class over four hardware queues (a fifth stream shares the first one's);
+    // streams of different classes never share one (batch.inc: the workers of rv_prove_batch get classes of their own).
     int prio_lo = 0, prio_hi = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0, (void)hipGetLastError();
-    static const bool main_prio = getenv("RV_MAIN_PRIO") && atoi(getenv("RV_MAIN_PRIO")) != 0;
     hipError_t se;
     if (main_prio_level >= 0 && prio_lo > prio_hi) {
         const int levels = prio_lo - prio_hi + 1;  // (numerically lower = higher priority)
@@ -427,14 +398,11 @@ static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level
         c->mask_prio = mask_prio_level >= 0 ? prio_hi + mask_prio_level % levels : c->prio;
         se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, c->prio);
     } else {
-        se = main_prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     }
     // (a worker context of rv_prove_batch makes no second stream before something asks for one (ctx_stream2): an idle stream still
     // holds a share of a hardware queue of its class, and which queue the NEXT stream of that class gets depends on it)
     if (se == hipSuccess && !c->has_prio) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
-    // (stream3 / stream_x -- the flat and split schedules' side streams -- are made by ctx_side_streams() when such a schedule first
-    // runs: streams are dealt to the four hardware queues in creation order, so two idle ones per context put the main streams of
-    // rv_prove_batch's worker contexts all on ONE queue and its proofs in flight ran one after the other: 4.9 -> 6.2 ms per proof)
     if (se != hipSuccess) {
         delete c;
         return hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
@@ -450,22 +418,6 @@ static int ctx_stream2(rv_ctx* c) {
     return se == hipSuccess ? RV_OK : hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
 }
 
-#ifdef RV_EXPERIMENTS
-// the side streams of the flat / split prover schedules (RV_FLAT != 0), on first use
-static int ctx_side_streams(rv_ctx* c) {
-    if (c->stream3 && c->stream_x) return RV_OK;
-    int prio_lo = 0, prio_hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0, (void)hipGetLastError();
-    hipError_t se = hipSuccess;
-    if (!c->stream3) se = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
-    // (RV_X_PRIO=1: the chain stream at the high priority -- its short dependent launches then win the dispatcher whenever
-    // wavefront slots are free)
-    static const bool x_prio = getenv("RV_X_PRIO") && atoi(getenv("RV_X_PRIO")) != 0;
-    if (se == hipSuccess && !c->stream_x)
-        se = x_prio ? hipStreamCreateWithPriority(&c->stream_x, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking);
-    return se == hipSuccess ? RV_OK : hip_fail(se, "hipStreamCreate", __FILE__, __LINE__);
-}
-#endif
 
 static void pinned_pool_trim();  // idle page-locked output buffers (defined with the pool below)
 
@@ -474,8 +426,6 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
-    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
-    if (ctx->stream_x) (void)hipStreamSynchronize(ctx->stream_x);
     if (ctx->stream_m) (void)hipStreamSynchronize(ctx->stream_m);
     for (auto& e : ctx->ops_cache) rv_circuit_destroy(e.c);
     ctx->ops_cache.clear();
@@ -494,17 +444,11 @@ extern "C" void rv_ctx_destroy(rv_ctx* ctx) {
     if (ctx->h_ec) (void)hipHostFree(ctx->h_ec);
     if (ctx->d_ec) (void)hipFree(ctx->d_ec);
     if (ctx->h_fs) (void)hipHostFree(ctx->h_fs);
-    if (ctx->h_rs) (void)hipHostFree(ctx->h_rs);
-    if (ctx->d_rs) (void)hipFree(ctx->d_rs);
     delete ctx->ec_pool;
     for (rv_ctx* w : ctx->workers) rv_ctx_destroy(w);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
-    if (ctx->stream_x) (void)hipStreamDestroy(ctx->stream_x);
     if (ctx->stream_m) (void)hipStreamDestroy(ctx->stream_m);
-    if (ctx->clear_a) (void)hipEventDestroy(ctx->clear_a);
-    if (ctx->clear_b) (void)hipEventDestroy(ctx->clear_b);
     delete ctx;
     pinned_pool_trim();
 }
@@ -684,12 +628,6 @@ struct rv_circuit {
     // MODE_PROVE_V (cleartext wire values instead of corr rows, internal.h) is possible: pure GF(2), no Random / B2A
     // gates, every level launched on its own (no single-workgroup narrow runs)
     bool vclr_ok = false;
-    // rep-sliced prover path (repprog.h): present when the circuit is eligible
-    bool rep_ok = false;
-    RepProgram rp;  // host copy without the big vectors (only counts are read after the upload)
-    RepLevel* d_rep_levels = nullptr;
-    RepSeg* d_rep_segs = nullptr;
-    RepRec* d_rep_recs = nullptr;
     // LDS runs (ldsrun.h): narrow stretches whose live wires fit the LDS; preferred over narrow_runs when the shard's
     // row width is a multiple of the run's slice width
     struct LdsPlan {
@@ -701,49 +639,8 @@ struct rv_circuit {
     LdsRec* d_lds_recs = nullptr;
     mutable std::once_flag ec_once;
     mutable EarlyPlan ec_plan;
-    // k_interp_persist: per row width the levels' step tables (built and uploaded at first use), and whether any level has enough
-    // multi-base gates for the kernel variant with their loops
-    struct PersistTab {
-        std::vector<PLevel> h;
-        PLevel* d = nullptr;
-    };
-    mutable std::mutex persist_mu;
-    mutable std::map<uint32_t, PersistTab> persist_tab;
-    bool persist_gen = false;
-    // flat prover schedule (flat.h): present when the circuit is eligible (the big vectors live on the device only)
-    FlatPlan flat;
-    Gate* d_xgates = nullptr;
-    MulRec* d_muls = nullptr;
-    Gate* d_others = nullptr;
-    uint32_t n_others = 0, n_other_inputs = 0;  // (the Input gates first)
-    ClearRec* d_clear_s = nullptr;
-    ClearRecK* d_clear_k = nullptr;
-    ClearLevel* d_clear_levels = nullptr;
-    ClearRec* d_lite_s = nullptr;
-    ClearRecK* d_lite_k = nullptr;
-    ClearLevel* d_lite_levels = nullptr;
-    PLevel* d_chain_levels = nullptr;  // k_chain: step tables of the levels' XOR classes (rows of 64 quad words)
-    bool chain_gen = false;
+    bool persist_gen = false;  // some level has enough multi-base Mul / Xor gates for the kernel variant with their loops (kernels.hip: level_is_general)
 };
-
-#ifdef RV_EXPERIMENTS
-// RV_FLAT: 0 (default) = the level-synchronous interpreter everywhere; 1 = the flat schedule for the prover of eligible circuits
-// of at least RV_FLAT_MIN gates (2^20: below, the cleartext pass does not hide behind the mask generator); 2 = for every eligible
-// circuit.  Read at every call (tests switch it).  Off by default: byte-identical, but on the 10^7-gate circuit the ~140 dependent
-// x-level launches of its XOR rows cost what the level boundaries saved ("Flat schedule").
-static int flat_mode() {
-    const char* e = getenv("RV_FLAT");
-    return e ? atoi(e) : 0;
-}
-#endif
-// workgroups of the cleartext pass = compute units the mask generator leaves free for them
-static uint32_t clear_wgs() {
-    static const uint32_t v = [] {
-        const char* e = getenv("RV_CLEAR_WGS");
-        return e ? (uint32_t)std::min(std::max(atoi(e), 1), 64) : 8u;
-    }();
-    return v;
-}
 
 // RV_Z64_FUSED: 1 (default) = the prover of eligible Z64 circuits runs its mask generator inside the interpreter's level launches
 // (internal.h: Z64FParams); 0 = masks to HBM first, k_interp64 behind.  Read at every call (tests switch it).
@@ -792,29 +689,6 @@ static bool build_z64_fused(const Compiled& cc, std::vector<Gate64>& sorted, std
         for (uint64_t i = lo; i < hi; i++) sorted[at[cls(cc.gates64[i].op)]++] = cc.gates64[i];
     }
     return true;
-}
-
-#ifdef RV_EXPERIMENTS
-// LDS the rep-sliced interpreter may use for wire slots (a workgroup owns the CU: 160 KiB minus a little headroom)
-static uint32_t rep_lds_budget(const rv_ctx* ctx) {
-    static const uint32_t v = [] {
-        const char* e = getenv("RV_REP_LDS");
-        return e ? (uint32_t)atoi(e) : 156u * 1024u;
-    }();
-    const size_t dev = ctx->lds_bytes > 4096 ? ctx->lds_bytes - 4096 : 0;
-    return (uint32_t)std::min<size_t>(v, dev);
-}
-#endif
-// RV_REP: 0 (default) = the row path everywhere; 1 = the rep-sliced path for whole proofs (all 256 repetitions on this
-// GPU) of circuits it accepts; 2 = for shards too.  Read at every call (tests switch it).  Off by default: measured on
-// MI355X it is byte-identical but not yet faster than the row path ("Rep-sliced path").
-static int rep_mode() {
-#ifdef RV_EXPERIMENTS
-    const char* e = getenv("RV_REP");
-    return e ? atoi(e) : 0;
-#else
-    return 0;  // (the rep-sliced path exists in experiment builds only: csrc/Makefile)
-#endif
 }
 
 static size_t scratch_bytes_for(const Compiled& cc, uint32_t R) {
@@ -871,21 +745,6 @@ static int rv_circuit_compile_impl(rv_ctx* ctx, const rv_op* ops, size_t n_ops, 
     if (getenv("RV_COMPILE_STATS"))
         fprintf(stderr, "[rv circuit] compile_ops: %.3f s for %zu ops\n", std::chrono::duration<double>(t_compiled - t_begin).count(),
                 n_ops);
-#ifdef RV_EXPERIMENTS
-    // the rep-sliced program of the prover (pure GF(2) circuits whose live wires fit the LDS): from this compile when it
-    // keeps one base row per wire, else from a second compile that does
-    if (rep_mode() && c->cc.gates64.empty() && !c->cc.gates.empty()) {
-        const char* why = "";
-        c->rep_ok = build_rep_program(c->cc, rep_lds_budget(ctx), c->rp, &why);
-        if (!c->rep_ok && strstr(why, "base")) {
-            Compiled one;
-            if (compile_ops(ops, n_ops, z64_wires, gf2_wires, one, nullptr, 1) == RV_OK) c->rep_ok = build_rep_program(one, rep_lds_budget(ctx), c->rp, &why);
-        }
-        if (getenv("RV_COMPILE_STATS"))
-            fprintf(stderr, "[rv circuit] rep-sliced path: %s%s (%u levels, %zu segments, %u LDS slots) at %.3f s\n", c->rep_ok ? "yes" : "no: ", why,
-                    c->rp.n_levels, c->rp.segs.size(), c->rp.lds_slots, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
-    }
-#endif  // RV_EXPERIMENTS
     if ((rc = circuit_upload(ctx, c))) return rc;  // (destroys c on failure)
     if (getenv("RV_COMPILE_STATS"))
         fprintf(stderr, "[rv circuit] compiled + uploaded after %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
@@ -991,15 +850,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c, bool async_staged) {
         rv_circuit_destroy(c);
         return rc;
     }
-    if (c->rep_ok) {
-        if ((rc = up(c->rp.levels.data(), c->rp.levels.size() * sizeof(RepLevel), (void**)&c->d_rep_levels)) ||
-            (rc = up(c->rp.segs.data(), c->rp.segs.size() * sizeof(RepSeg), (void**)&c->d_rep_segs)) ||
-            (rc = up(c->rp.recs.data(), c->rp.recs.size() * sizeof(RepRec), (void**)&c->d_rep_recs))) {
-            rv_circuit_destroy(c);
-            return rc;
-        }
-    }
-    if (async_staged && all_staged && !c->rep_ok && c->staged_slot >= 0 && (size_t)c->staged_slot < ctx->ring_ev.size() && ctx->ring_ev[c->staged_slot]) {
+    if (async_staged && all_staged && c->staged_slot >= 0 && (size_t)c->staged_slot < ctx->ring_ev.size() && ctx->ring_ev[c->staged_slot]) {
         UPCHK(hipEventRecord(ctx->ring_ev[c->staged_slot], ctx->stream));
         c->upload_pending = true;
     } else {
@@ -1007,11 +858,6 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c, bool async_staged) {
     }
     c->staged = nullptr;  // (the slot belongs to the next piece from here on)
     c->staged_bytes = 0;
-    if (c->rep_ok) {  // the device holds them now
-        std::vector<RepRec>().swap(c->rp.recs);
-        std::vector<RepSeg>().swap(c->rp.segs);
-        std::vector<RepLevel>().swap(c->rp.levels);
-    }
     c->cc.info.upload_us = (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_compiled).count();
     {
         const size_t n_levels = cc.level_start.empty() ? 0 : cc.level_start.size() - 1;
@@ -1151,45 +997,6 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c, bool async_staged) {
         }
     }
     c->persist_gen = persist_general(cc.level_range.data(), cc.level_range.size());
-#ifdef RV_EXPERIMENTS
-    if (c->vclr_ok && flat_mode()) {
-        // the flat schedule of the prover: Mul records in program order, XOR rows by x-level, the rest
-        static const uint64_t flat_min = getenv("RV_FLAT_MIN") ? (uint64_t)atoll(getenv("RV_FLAT_MIN")) : (1ull << 20);
-        const uint32_t bands = getenv("RV_FLAT_BANDS") ? (uint32_t)std::max(atoi(getenv("RV_FLAT_BANDS")), 1) : 8u;
-        if ((flat_mode() >= 2 || cc.gates.size() >= flat_min) && build_flat_plan(cc, c->flat, bands)) {
-            c->n_others = (uint32_t)c->flat.others.size();
-            c->n_other_inputs = c->flat.n_other_inputs;
-            if ((rc = up(c->flat.xgates.data(), c->flat.xgates.size() * sizeof(Gate), (void**)&c->d_xgates)) ||
-                (rc = up(c->flat.muls.data(), c->flat.muls.size() * sizeof(MulRec), (void**)&c->d_muls)) ||
-                (rc = up(c->flat.others.data(), c->flat.others.size() * sizeof(Gate), (void**)&c->d_others)) ||
-                (rc = up(c->flat.clear_s.data(), c->flat.clear_s.size() * sizeof(ClearRec), (void**)&c->d_clear_s)) ||
-                (rc = up(c->flat.clear_k.data(), c->flat.clear_k.size() * sizeof(ClearRecK), (void**)&c->d_clear_k)) ||
-                (rc = up(c->flat.clear_levels.data(), c->flat.clear_levels.size() * sizeof(ClearLevel), (void**)&c->d_clear_levels)) ||
-                (rc = up(c->flat.lite_s.data(), c->flat.lite_s.size() * sizeof(ClearRec), (void**)&c->d_lite_s)) ||
-                (rc = up(c->flat.lite_k.data(), c->flat.lite_k.size() * sizeof(ClearRecK), (void**)&c->d_lite_k)) ||
-                (rc = up(c->flat.lite_levels.data(), c->flat.lite_levels.size() * sizeof(ClearLevel), (void**)&c->d_lite_levels))) {
-                rv_circuit_destroy(c);
-                return rc;
-            }
-            c->chain_gen = chain_general(cc.level_range.data(), cc.level_range.size());
-            std::vector<PLevel> xl(cc.level_range.size());
-            build_chain_levels(cc.level_range.data(), cc.level_range.size(), 64, c->chain_gen, xl.data());
-            if ((rc = up(xl.data(), xl.size() * sizeof(PLevel), (void**)&c->d_chain_levels))) {
-                rv_circuit_destroy(c);
-                return rc;
-            }
-            UPCHK(hipStreamSynchronize(ctx->stream));
-            decltype(c->flat.xgates)().swap(c->flat.xgates);  // the device holds them now
-            decltype(c->flat.muls)().swap(c->flat.muls);
-            std::vector<Gate>().swap(c->flat.others);
-            decltype(c->flat.clear_s)().swap(c->flat.clear_s);
-            decltype(c->flat.clear_k)().swap(c->flat.clear_k);
-            std::vector<ClearLevel>().swap(c->flat.clear_levels);
-            decltype(c->flat.lite_s)().swap(c->flat.lite_s);
-            decltype(c->flat.lite_k)().swap(c->flat.lite_k);
-        }
-    }
-#endif  // RV_EXPERIMENTS
     return RV_OK;
 #undef UPCHK
 }
@@ -1205,21 +1012,7 @@ extern "C" void rv_circuit_destroy(rv_circuit* c) {
     c->ctx->release(c->d_in_offs64);
     c->ctx->release(c->d_level_start);
     c->ctx->release(c->d_level_range);
-    c->ctx->release(c->d_rep_levels);
-    c->ctx->release(c->d_rep_segs);
-    c->ctx->release(c->d_rep_recs);
     c->ctx->release(c->d_lds_recs);
-    for (auto& kv : c->persist_tab) c->ctx->release(kv.second.d);
-    c->ctx->release(c->d_xgates);
-    c->ctx->release(c->d_muls);
-    c->ctx->release(c->d_others);
-    c->ctx->release(c->d_clear_s);
-    c->ctx->release(c->d_clear_k);
-    c->ctx->release(c->d_clear_levels);
-    c->ctx->release(c->d_lite_s);
-    c->ctx->release(c->d_lite_k);
-    c->ctx->release(c->d_lite_levels);
-    c->ctx->release(c->d_chain_levels);
     // the early-corrections staging of a LARGE plan (2 GB of page-locked memory for the 10^6-MUL Z64 circuit) does not outlive the
     // circuit that needed it: a context that moves on to small circuits would otherwise hold it until rv_ctx_destroy.
     // Small stagings (the 160 MB of the 10^7-gate GF(2) circuit) stay: re-mapping them costs more than they weigh.

@@ -110,12 +110,9 @@ struct Interp64Params {
 // by the interpreter itself level by level).  The three 32-byte corr-row accesses of a gate become one-byte accesses at
 // wave-uniform addresses.  Not for circuits with Random gates / B2A (values that differ between repetitions) and only
 // in the one-launch-per-level kernels (a level reads what the previous LAUNCH wrote).
-// MODE_PROVE_F: the flat prover schedule (flat.h) -- the level kernels run only what is left of the gate stream once the Mul
-// gates have a kernel of their own and the wire values a pass of their own: XOR rows (shares only) and the Input / AssertZero
-// transcript rows.  No corr rows, no value bytes, no checks.
 // MODE_VERIFY_C: the verifier of a whole proof with one u64 of public corrections per share row (the opened repetitions' quad
 // words, InterpParams::vc) instead of corr rows; full-width rows, every level launched on its own, no Random / B2A gates.
-enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1, MODE_PROVE_V = 2, MODE_PROVE_F = 3, MODE_VERIFY_C = 4 };
+enum Mode : int { MODE_PROVE = 0, MODE_VERIFY = 1, MODE_PROVE_V = 2, /* 3: the flat schedule of rounds 4 - 5, gone */ MODE_VERIFY_C = 4 };
 // bit set in the device error word when an AssertZero of an online-verified repetition does not reconstruct to zero
 // (VerifierTranscriptOnline.okay, online.rs:175-177; only the strict verifier looks at it)
 constexpr int RV_DEV_ZERO_CHECK = 0x100;
@@ -155,9 +152,8 @@ constexpr uint32_t RK_AREAS = 13;
 constexpr uint64_t RV_MAX_CTR_BLOCKS = 1ull << 24;
 void launch_key_schedule(hipStream_t st, const uint8_t* d_keys, uint32_t n_slots, uint8_t* d_rkbytes /*[n][RK_BYTES]*/);
 void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, uint32_t* d_rk /*[RK_AREAS][128][NQ]*/);
-// reserve_cus: compute units to leave free (the flat schedule's cleartext pass runs beside the generator)
 void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
-                          uint64_t n_blocks, uint32_t* d_masks, uint32_t reserve_cus = 0);
+                          uint64_t n_blocks, uint32_t* d_masks);
 // the lane-distributed generator (aes_col4.hip: a quad of lanes per bitsliced state, 80 registers, same rows): its key image
 // [NQ / 16][88 KiB] comes from the plane-major round keys of launch_bitslice_rk
 bool aes_col4_supports(uint32_t NQ);
@@ -172,23 +168,8 @@ void launch_aes_blocks(hipStream_t st, const uint8_t* d_rkbytes, uint32_t n_keys
 struct LevelRange {
     uint32_t lo, mul11, mul, xor2, xork, hi;
 };
-// k_interp_persist (kernels.hip): a level's wave-steps as launch_interp would deal them out, and where they sit in the circuit's
-// sequence of steps
-struct PLevel {
-    LevelRange r;
-    uint32_t n_full[4];  // full unrolled steps of classes 0..3
-    uint32_t n_steps;    // wave-steps of the level (full steps + the leftover gates', 64 / NQ gates each)
-    uint32_t step0;      // wave-steps of all the levels before it
-};
-constexpr uint32_t PERSIST_SYNC_WORDS = 64;        // per launch: 32 arrival counters, the abort word, padding to 256 bytes
-constexpr int RV_DEV_PERSIST_ABORT = 0x20000000;   // device error word: a persistent launch gave up waiting (reported as RV_E_DEVICE)
-void build_persist_levels(const LevelRange* lr, size_t n_levels, uint32_t NQ, bool general, PLevel* out);
+// some level has enough multi-base Mul / Xor gates for the kernel variant with their loops (kernels.hip: level_is_general)
 bool persist_general(const LevelRange* lr, size_t n_levels);
-bool persist_supports(uint32_t NQ);
-// flow: the dataflow form (k_interp_flow): no counters, a gate waits for the ready bits of its own operands' value bytes -- the
-// whole vclr array must be zero before the first launch of a proof, but for the zero row's byte (0x80: ready, value 0)
-void launch_interp_persist(hipStream_t st, uint32_t NQ, bool general, const Gate* d_gates, const PLevel* d_levels, uint32_t l0, uint32_t l1, uint64_t n_steps,
-                           const InterpParams& p, uint32_t* d_sync, bool flow = false);
 // next: the level launched after this one by launch_interp too (nullable) -- the tail of this launch prefetches
 // its first gate records
 void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRange& r, const InterpParams& p,
@@ -208,11 +189,6 @@ void launch_store_word(hipStream_t st, const int* d_src, int* dst_mapped);
 void launch_pack_corr_all(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint64_t byte0, uint64_t n_bytes, uint64_t pitch, uint8_t* d_out);
 void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
                       uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit /*[256]*/, uint32_t rep_limit);
-void launch_copy_gaps2(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t h1_at, uint64_t h1_len,
-                       uint64_t h2_at, uint64_t h2_len, uint32_t n_rec, const uint8_t* d_omit /*[256]*/, uint32_t rep_limit);
-uint32_t extract_stage_granule(uint64_t n_items);
-void launch_extract_bits_stage(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ, const uint8_t* d_omit,
-                               uint8_t* d_stage, uint64_t pitch, uint64_t byte0, uint64_t n_bytes_slice);
 void launch_publish(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, uint32_t* flag_mapped, uint32_t seq);
 void launch_store_words(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, const int* d_err, int* dst_err_mapped);
 // a narrow stretch with its live wires in LDS (ldsrun.h); d_pp != null: `batch` proofs, parameters from the device array
@@ -262,13 +238,6 @@ struct Z64FParams {
 };
 bool z64_fused_supports(uint32_t NQ);
 uint32_t z64_fused_qw(uint32_t NQ);  // quad words per workgroup block of that path for rows of NQ quad words (16 or 8; 0: not taken)
-#ifdef RV_EXPERIMENTS
-// round 5 (z64c4.hip, experiment builds): the PROVER's level with the lane-distributed cipher (aes_col4_dev.h) inside -- a wavefront = one
-// gate x 64 repetitions, the operand pieces in flight during the cipher; d_img = the key image of launch_rk_col4.  Same gate arrays and
-// parameters as above.
-bool z64_c4_supports(uint32_t NQ);
-void launch_z64_c4(hipStream_t st, const uint32_t* d_img, const struct Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p);
-#endif
 void launch_z64_fused(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p);
 // BLAKE3 of R contiguous streams of n_words u64 each -> digests[R][8]
 uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
@@ -346,19 +315,5 @@ void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, cons
                          uint64_t lens2_rec, uint64_t lens2_corr, uint64_t lens2_in, uint64_t lens64_rec, uint64_t lens64_corr,
                          uint64_t lens64_in, uint8_t* d_out);
 
-// ---- rep-sliced prover path (rep.hip, repprog.h) ----
-struct RepLevel;
-struct RepSeg;
-struct RepRec;
-struct RepParams;
-void launch_bitslice_rk_rep(hipStream_t st, const uint8_t* d_rkbytes, uint32_t R, uint32_t* d_rk /*[RK_AREAS][128][R]*/);
-void launch_aes_rep_masks(hipStream_t st, const uint32_t* d_rk_rep, uint32_t R, uint64_t n_blocks, uint8_t* d_masks, uint64_t mask_stride);
-void launch_rep_clear(hipStream_t st, const RepLevel* d_levels, uint32_t n_levels, const RepSeg* d_segs, const RepRec* d_recs, const uint8_t* d_wit,
-                      uint32_t* d_vbits, int* d_err, uint32_t lds_slots);
-void launch_rep_interp(hipStream_t st, const RepParams& P, uint32_t R, uint32_t lds_slots);
-void launch_rep_open(hipStream_t st, const uint8_t* d_stream, uint64_t stride, const uint32_t* d_rows, uint64_t n_items, int kind,
-                     const OnlineList* d_ol, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
-uint32_t launch_b3_bytes(hipStream_t st, const uint8_t* d_streams, uint64_t stride_bytes, uint64_t n_bytes, uint32_t R, uint32_t* d_cv_a,
-                         uint32_t* d_cv_b, uint32_t* d_digest);
 
 }  // namespace rv

@@ -18,7 +18,6 @@
 #include <algorithm>
 
 #include "b3.h"
-#include "flat.h"
 #include "gf2dev.h"
 #include "internal.h"
 #include "launch.h"
@@ -151,7 +150,6 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
             corr = onm ? (p.sup_in[(size_t)g.x * p.sup_nq + q] & onm) : 0u;  // (rows of quads without an opened repetition are never written)
         }
         if (!is_verify(MODE) || onm) p.on[(size_t)g.eo * NQ + q] = corr;
-        if (MODE == MODE_PROVE_F) break;  // (the wire's value is k_clear's business)
         if (MODE == MODE_PROVE_V) {
             if (q == 0) st_v<COH>(&p.vclr[g.dst], p.wit[g.x] ? 1 : 0);
         } else if (MODE == MODE_VERIFY_C) {
@@ -163,7 +161,6 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
     }
     case G_XORK: {
         st_row<COH>(&p.rows[(size_t)g.dst * NQ + q], gather_rows_c<COH>(p.rows, g.a, NQ, q) ^ gather_rows_c<COH>(p.rows, g.b, NQ, q));
-        if (MODE == MODE_PROVE_F) break;
         if (MODE == MODE_PROVE_V) {
             if (q == 0) st_v<COH>(&p.vclr[g.dst], (uint8_t)((g_ca(g) ^ gather_vclr_c<COH>(p.vclr, g.a) ^ gather_vclr_c<COH>(p.vclr, g.b)) & 1u));
             break;
@@ -181,7 +178,6 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         break;
     }
     case G_RANDOM: {
-        if (MODE == MODE_PROVE_F) break;
         if (MODE == MODE_VERIFY_C) {
             if (q == 0) p.vc[g.dst] = 0;
             break;
@@ -190,7 +186,6 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         break;
     }
     case G_MUL: {
-        if (MODE == MODE_PROVE_F) break;  // (k_mul_flat runs the Mul gates of a flat schedule)
         const uint32_t lx = gather_rows_c<COH>(p.rows, g.a, NQ, q), ly = gather_rows_c<COH>(p.rows, g.b, NQ, q);
         const uint32_t lab = p.rows[(size_t)g.m * NQ + q], lnew = p.rows[(size_t)(g.m + 1) * NQ + q];
         const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
@@ -235,7 +230,6 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         break;
     }
     case G_RECON: {
-        if (MODE == MODE_PROVE_F) break;
         // B2A's recorded reconstruction (combine.rs:181-183): value = reconstruct(mask) + corr
         uint32_t m = gather_rows(p.rows, g.a, NQ, q);
         if (is_verify(MODE) && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
@@ -251,7 +245,6 @@ __device__ __forceinline__ void interp_one_impl(const Gate& g, const InterpParam
         uint32_t m = gather_rows_c<COH>(p.rows, g.a, NQ, q);
         if (is_verify(MODE) && onm) m ^= p.sup_rec[(size_t)g.x * p.sup_nq + q];
         if (!is_verify(MODE) || onm) p.on[(size_t)g.eo * NQ + q] = m;
-        if (MODE == MODE_PROVE_F) break;  // (k_clear checks the wire's value)
         if (MODE == MODE_PROVE_V) {
             // the wire's value itself must be zero (prover.rs:221-228), the same in every repetition
             if (q == 0 && ((gather_vclr_c<COH>(p.vclr, g.a) ^ g_ca(g)) & 1u) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
@@ -491,10 +484,8 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
             // only the slots the gate uses (N == 2: both by construction)
             if (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) {
                 rr[u][i] = ld_row<COH>(&p.rows[(size_t)id * NQ + q]);
-                // H corr bytes per row: the first H lanes of the gate's lane group carry them (MODE_PROVE_V: one value byte;
-                // MODE_PROVE_F: shares only)
-                if (MODE == MODE_PROVE_F) {
-                } else if (MODE == MODE_PROVE_V) {
+                // H corr bytes per row: the first H lanes of the gate's lane group carry them (MODE_PROVE_V: one value byte)
+                if (MODE == MODE_PROVE_V) {
                     if (q == 0) cc[u][i] = ld_v<COH>(&p.vclr[id]);
                 } else if (MODE == MODE_VERIFY_C) {
                     if (q < 2) cc[u][i] = ((const uint32_t*)p.vc)[2 * (size_t)id + q];  // (lanes 0, 1: the word's two halves)
@@ -518,8 +509,7 @@ __device__ __forceinline__ void xorU(const Gate* __restrict__ gates, uint32_t g0
 #pragma unroll
     for (int u = 0; u < U; u++) {
         st_row<COH>(&p.rows[(size_t)g[u].dst * NQ + q], x[u]);
-        if (MODE == MODE_PROVE_F) {
-        } else if (MODE == MODE_PROVE_V) {
+        if (MODE == MODE_PROVE_V) {
             if (q == 0) st_v<COH>(&p.vclr[g[u].dst], (uint8_t)((bx[u] ^ g_ca(g[u])) & 1u));
         } else if (MODE == MODE_VERIFY_C) {
             if (q < 2) ((uint32_t*)p.vc)[2 * (size_t)g[u].dst + q] = bx[u] ^ (g_ca(g[u]) ? 0xFFFFFFFFu : 0u);
@@ -675,12 +665,7 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
     uint64_t blocks = (waves + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    if (mode == MODE_PROVE_F) {
-        if (general)
-            hipLaunchKernelGGL((k_interp_full<MODE_PROVE_F, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
-        else
-            hipLaunchKernelGGL((k_interp_full<MODE_PROVE_F, NQ, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
-    } else if (mode == MODE_PROVE_V) {
+    if (mode == MODE_PROVE_V) {
         if (general)
             hipLaunchKernelGGL((k_interp_full<MODE_PROVE_V, NQ, true>), dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r, p, pf);
         else
@@ -703,708 +688,8 @@ static void launch_interp_full(hipStream_t st, int mode, const Gate* d_gates, co
     }
 }
 
-// Rounds 2 and 4 built four more launch structures for the GF(2) prover (persistent level kernels, the split and chained
-// schedules of flat.h).  All byte-identical, all measured slower: they are compiled only into experiment
-// builds (make EXTRA=-DRV_EXPERIMENTS), not into the library build() makes.
-#ifdef RV_EXPERIMENTS
-// ------------------------------------------------------------------------------------
-// k_interp_persist: the dependency levels of a circuit WITHOUT a launch each (round 4).
-//
-// One launch per level costs a kernel boundary (~2.5 us behind a streaming kernel) plus the fill and drain of ~1.5
-// generations of short-lived wavefronts: 163 levels x ~12.8 us on the 10^7-gate circuit, and ~7 us per level however narrow
-// the rows of a repetition shard are.  Here the grid is as many workgroups as the chip holds at once and stays for levels
-// [l0, l1): the wave-steps of a level (the same 4-gate class steps run_level deals out) are dealt to the wavefronts round-robin,
-// continuing where the previous level stopped.  A wavefront with a step in level l first makes sure every step of the levels
-// before it has ended -- `done` = 32 counters (one atomic per wavefront and level, spread over 32 words so that no word
-// sees more than a few arrivals per microsecond) whose sum it polls with one 128-byte load -- and adds its own steps when its
-// stores have drained.  Nothing waits for a slower wavefront that has no business with it, no workgroup is launched or retired
-// at a level boundary, and a wavefront whose level-l work is done starts its level-(l + 1) step's gate records at once.
-//
-// What crosses compute units inside the launch (operand rows that are XOR outputs, the cleartext value bytes) goes through
-// write-through stores and L1-bypassing loads (COH = true above).  Fresh PRG masks and transcripts do not: the former were
-// written by the mask generator's launch, the latter are read by later launches.
-// Every wait is bounded (PERSIST_SPIN_TICKS): a wavefront that gives up sets the abort word, everybody leaves, and the proof
-// fails with RV_E_DEVICE instead of hanging the queue (a grid larger than the chip can hold at once would do that).
-// ------------------------------------------------------------------------------------
-constexpr uint32_t PERSIST_SHARDS = 32;
-constexpr long long PERSIST_SPIN_TICKS = 200000000ll;  // wall_clock64: 100 MHz -> 2 s
-
-__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;  // lanes 0..31 hold the sum of lanes 0..31
-}
-
-// true when the steps [0, need) of the launch have all ended (seen: the last total this wavefront read); false = abort
-__device__ __forceinline__ bool persist_wait(uint32_t* sync, uint32_t need, uint32_t& seen, uint32_t lane) {
-    if (seen >= need) return true;
-    const long long t0 = wall_clock64();
-    for (uint32_t spins = 0;; spins++) {
-        uint32_t v = 0;
-        if (lane < PERSIST_SHARDS) v = __hip_atomic_load(sync + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum32(v));
-        if (total >= need) {
-            seen = total;
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(2);
-        if ((spins & 255u) == 255u) {
-            uint32_t ab = 0;
-            if (lane == 0) ab = __hip_atomic_load(sync + PERSIST_SHARDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ab = (uint32_t)__builtin_amdgcn_readfirstlane((int)ab);
-            if (ab || wall_clock64() - t0 > PERSIST_SPIN_TICKS) {
-                if (lane == 0) __hip_atomic_store(sync + PERSIST_SHARDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-    }
-}
-
-// ---- dataflow form (k_interp_flow): no counters at all.  Every share row that the interpreter writes, and every PRG row whose
-// wire VALUE it computes (Mul / Input outputs), has one byte in `vclr`: bit 7 = "the row and its value are final", bit 0 = the
-// cleartext value.  A gate reads its operands' bytes first (write-through stores, L1-bypassing loads: a stale copy can only say
-// "not yet", each byte is written once per proof), waits on exactly those, and only then gathers the rows; an XOR gate stores its
-// row, drains, and sets the byte.  The steps are dealt to the resident wavefronts in (level, class) order as above, so a producer's
-// step is always handed out before its consumers': the waits end whatever the timing, and nothing that is not a real dependency
-// is ever waited for -- the wavefronts run through the level boundaries.
-constexpr uint32_t V_READY = 0x80u;
-
-struct FlowCtl {
-    uint32_t* sync;   // [0] abort word
-    long long t0;
-    uint32_t spins;
-    // false: give up (another wavefront did, or this one has waited PERSIST_SPIN_TICKS)
-    __device__ __forceinline__ bool again(uint32_t lane) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 127u) != 0) return true;
-        uint32_t ab = 0;
-        if (lane == 0) ab = __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ab = (uint32_t)__builtin_amdgcn_readfirstlane((int)ab);
-        if (ab || wall_clock64() - t0 > PERSIST_SPIN_TICKS) {
-            if (lane == 0) __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-        return true;
-    }
-};
-
-template <int NQ, int U, int KA, int KB>
-__device__ __forceinline__ bool mulD(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q, FlowCtl& fc, uint32_t lane) {
-    constexpr uint32_t GPW = 64 / NQ;
-    Gate g[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
-    uint32_t lab[U], lnew[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {  // the fresh masks depend on nothing
-        lab[u] = __builtin_nontemporal_load(&p.rows[(size_t)g[u].m * NQ + q]);
-        lnew[u] = p.rows[(size_t)(g[u].m + 1) * NQ + q];
-    }
-    uint32_t bx[U], by[U];
-    for (;;) {
-        uint32_t ca[U][KA], cb[U][KB];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
-#pragma unroll
-            for (int i = 0; i < KA; i++) ca[u][i] = (i == 0 || i < na) ? ld_v<1>(&p.vclr[g[u].a[i]]) : V_READY;
-#pragma unroll
-            for (int i = 0; i < KB; i++) cb[u][i] = (i == 0 || i < nb) ? ld_v<1>(&p.vclr[g[u].b[i]]) : V_READY;
-        }
-        uint32_t all = V_READY;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            bx[u] = 0, by[u] = 0;
-#pragma unroll
-            for (int i = 0; i < KA; i++) all &= ca[u][i], bx[u] ^= ca[u][i];
-#pragma unroll
-            for (int i = 0; i < KB; i++) all &= cb[u][i], by[u] ^= cb[u][i];
-        }
-        if (__all((all & V_READY) != 0)) break;
-        if (!fc.again(lane)) return false;
-    }
-    uint32_t lx[U], ly[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
-        lx[u] = 0, ly[u] = 0;
-#pragma unroll
-        for (int i = 0; i < KA; i++)
-            if (i == 0 || i < na) lx[u] ^= ld_row<1>(&p.rows[(size_t)g[u].a[i] * NQ + q]);
-#pragma unroll
-        for (int i = 0; i < KB; i++)
-            if (i == 0 || i < nb) ly[u] ^= ld_row<1>(&p.rows[(size_t)g[u].b[i] * NQ + q]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const uint32_t a = recon32(lx[u]), b = recon32(ly[u]), c = recon32(lab[u]);
-        const uint32_t vx = (bx[u] ^ g_ca(g[u])) & 1u, vy = (by[u] ^ g_cb(g[u])) & 1u;
-        const uint32_t cx = a ^ (vx ? 0xFFFFFFFFu : 0u), cy = b ^ (vy ? 0xFFFFFFFFu : 0u);  // corr = value - reconstruct(mask)
-        const uint32_t delta = (a & b) ^ c;
-        const uint32_t s = (ly[u] & cx) ^ (lx[u] & cy) ^ lab[u] ^ lnew[u];
-        __builtin_nontemporal_store(s, &p.on[(size_t)g[u].eo * NQ + q]);
-        store_bits(p.pre, g[u].ep, NQ, q, delta);
-        if (q == 0) st_v<1>(&p.vclr[g[u].dst], (uint8_t)(V_READY | (vx & vy)));  // (the output's mask is a PRG row: only its value is new)
-    }
-    return true;
-}
-
-template <int NQ, int U, int N>
-__device__ __forceinline__ bool xorD(const Gate* __restrict__ gates, uint32_t g0, const InterpParams& p, uint32_t sub, uint32_t q, FlowCtl& fc, uint32_t lane) {
-    constexpr uint32_t GPW = 64 / NQ;
-    Gate g[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) g[u] = gates[g0 + u * GPW + sub];
-    uint32_t bx[U];
-    for (;;) {
-        uint32_t all = V_READY;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
-            bx[u] = 0;
-#pragma unroll
-            for (int i = 0; i < N; i++) {
-                const uint32_t id = (N == 2) ? g[u].a[i] : (i < RV_LIN_K ? g[u].a[i] : g[u].b[i - RV_LIN_K]);
-                const uint32_t c = (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) ? ld_v<1>(&p.vclr[id]) : V_READY;
-                all &= c, bx[u] ^= c;
-            }
-        }
-        if (__all((all & V_READY) != 0)) break;
-        if (!fc.again(lane)) return false;
-    }
-    uint32_t x[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int na = (int)g_na(g[u]), nb = (int)g_nb(g[u]);
-        x[u] = 0;
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            const uint32_t id = (N == 2) ? g[u].a[i] : (i < RV_LIN_K ? g[u].a[i] : g[u].b[i - RV_LIN_K]);
-            if (N == 2 || (i < RV_LIN_K ? i < na : i - RV_LIN_K < nb)) x[u] ^= ld_row<1>(&p.rows[(size_t)id * NQ + q]);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) st_row<1>(&p.rows[(size_t)g[u].dst * NQ + q], x[u]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have left before their bytes say so
-#pragma unroll
-    for (int u = 0; u < U; u++)
-        if (q == 0) st_v<1>(&p.vclr[g[u].dst], (uint8_t)(V_READY | ((bx[u] ^ g_ca(g[u])) & 1u)));
-    return true;
-}
-
-// one gate per lane group (the gates that do not fill an unrolled step)
-__device__ __forceinline__ bool oneD(const Gate& g, bool active, const InterpParams& p, uint32_t NQ, uint32_t q, FlowCtl& fc, uint32_t lane) {
-    const uint32_t op = active ? g_op(g) : 0xFFu;
-    uint32_t va = 0, vb = 0;
-    for (;;) {
-        uint32_t all = V_READY;
-        va = 0, vb = 0;
-        if (op == G_XORK || op == G_MUL || op == G_ASSERT) {
-#pragma unroll
-            for (int i = 0; i < RV_LIN_K; i++) {  // (unused slots hold the zero row: ready, value 0)
-                const uint32_t a = ld_v<1>(&p.vclr[g.a[i]]), b = (op == G_ASSERT) ? V_READY : ld_v<1>(&p.vclr[g.b[i]]);
-                all &= a & b, va ^= a, vb ^= b;
-            }
-        }
-        if (__all((all & V_READY) != 0)) break;
-        if (!fc.again(lane)) return false;
-    }
-    bool wrote_row = false;
-    if (op == G_INPUT) {
-        const uint32_t lam = p.rows[(size_t)g.m * NQ + q];
-        const uint32_t w = p.wit[g.x] ? 0xFFFFFFFFu : 0u;
-        p.on[(size_t)g.eo * NQ + q] = w ^ recon32(lam);
-        if (q == 0) st_v<1>(&p.vclr[g.dst], (uint8_t)(V_READY | (w & 1u)));
-    } else if (op == G_XORK) {
-        st_row<1>(&p.rows[(size_t)g.dst * NQ + q], gather_rows_c<1>(p.rows, g.a, NQ, q) ^ gather_rows_c<1>(p.rows, g.b, NQ, q));
-        wrote_row = true;
-    } else if (op == G_MUL) {
-        const uint32_t lx = gather_rows_c<1>(p.rows, g.a, NQ, q), ly = gather_rows_c<1>(p.rows, g.b, NQ, q);
-        const uint32_t lab = p.rows[(size_t)g.m * NQ + q], lnew = p.rows[(size_t)(g.m + 1) * NQ + q];
-        const uint32_t a = recon32(lx), b = recon32(ly), c = recon32(lab);
-        const uint32_t vx = (va ^ g_ca(g)) & 1u, vy = (vb ^ g_cb(g)) & 1u;
-        const uint32_t cx = a ^ (vx ? 0xFFFFFFFFu : 0u), cy = b ^ (vy ? 0xFFFFFFFFu : 0u);
-        p.on[(size_t)g.eo * NQ + q] = (ly & cx) ^ (lx & cy) ^ lab ^ lnew;
-        store_bits(p.pre, g.ep, NQ, q, (a & b) ^ c);
-        if (q == 0) st_v<1>(&p.vclr[g.dst], (uint8_t)(V_READY | (vx & vy)));
-    } else if (op == G_ASSERT) {
-        p.on[(size_t)g.eo * NQ + q] = gather_rows_c<1>(p.rows, g.a, NQ, q);
-        if (q == 0 && ((va ^ g_ca(g)) & 1u) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
-    }
-    if (__any(wrote_row)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (wrote_row && q == 0) st_v<1>(&p.vclr[g.dst], (uint8_t)(V_READY | ((va ^ vb ^ g_ca(g)) & 1u)));
-    }
-    return true;
-}
-
-template <int NQ, bool GENERAL>
-__global__ __launch_bounds__(256, GENERAL ? 1 : 8) void k_interp_flow(const Gate* __restrict__ gates, const PLevel* __restrict__ levels, uint32_t l0, uint32_t l1,
-                                                                      InterpParams p, uint32_t* __restrict__ sync) {
-    constexpr uint32_t GPW = 64 / NQ;
-    constexpr int U = interp_unroll(NQ, GENERAL);
-    constexpr uint32_t STEP = (uint32_t)U * GPW;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t q = lane % NQ, sub = lane / NQ;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t W = gridDim.x * (blockDim.x >> 6);
-    const uint32_t base0 = levels[l0].step0;
-    FlowCtl fc{sync + PERSIST_SHARDS, wall_clock64(), 0u};
-    bool ok = true;
-    PLevel Ln = levels[l0];
-    for (uint32_t l = l0; l < l1 && ok; l++) {
-        const PLevel L = Ln;
-        Ln = levels[l + 1 < l1 ? l + 1 : l];
-        const uint32_t rot = (L.step0 - base0) % W;
-        uint32_t t = wave >= rot ? wave - rot : wave + W - rot;
-        const uint32_t begin[5] = {L.r.lo, L.r.mul11, L.r.mul, L.r.xor2, L.r.xork}, end[5] = {L.r.mul11, L.r.mul, L.r.xor2, L.r.xork, L.r.hi};
-        for (; t < L.n_steps && ok; t += W) {
-            uint32_t tt = t;
-            if (tt < L.n_full[0]) {
-                ok = mulD<NQ, U, 1, 1>(gates, begin[0] + tt * STEP, p, sub, q, fc, lane);
-                continue;
-            }
-            tt -= L.n_full[0];
-            if (GENERAL && tt < L.n_full[1]) {
-                ok = mulD<NQ, U, RV_LIN_K, RV_LIN_K>(gates, begin[1] + tt * STEP, p, sub, q, fc, lane);
-                continue;
-            }
-            tt -= L.n_full[1];
-            if (tt < L.n_full[2]) {
-                ok = xorD<NQ, U, 2>(gates, begin[2] + tt * STEP, p, sub, q, fc, lane);
-                continue;
-            }
-            tt -= L.n_full[2];
-            if (GENERAL && tt < L.n_full[3]) {
-                ok = xorD<NQ, U, 2 * RV_LIN_K>(gates, begin[3] + tt * STEP, p, sub, q, fc, lane);
-                continue;
-            }
-            tt -= L.n_full[3];
-            uint32_t c0 = 0, e0 = 0, found = 0;
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const uint32_t rest = begin[c] + (c < 4 ? L.n_full[c] * STEP : 0u);
-                const uint32_t n = (end[c] - rest + GPW - 1) / GPW;
-                if (!found) {
-                    if (tt < n) c0 = rest + tt * GPW, e0 = end[c], found = 1;
-                    else tt -= n;
-                }
-            }
-            const uint32_t gi = c0 + sub;
-            const bool active = found && gi < e0;
-            ok = oneD(gates[active ? gi : L.r.lo], active, p, NQ, q, fc, lane);
-        }
-    }
-    if (!ok && lane == 0) atomicOr(p.err, RV_DEV_PERSIST_ABORT);
-}
-
-template <int MODE, int NQ, bool GENERAL>
-__global__ __launch_bounds__(256, GENERAL ? 1 : 8) void k_interp_persist(const Gate* __restrict__ gates, const PLevel* __restrict__ levels, uint32_t l0, uint32_t l1,
-                                                                         InterpParams p, uint32_t* __restrict__ sync) {
-    constexpr uint32_t GPW = 64 / NQ;
-    constexpr int U = interp_unroll(NQ, GENERAL);
-    constexpr uint32_t STEP = (uint32_t)U * GPW;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t q = lane % NQ, sub = lane / NQ;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t W = gridDim.x * (blockDim.x >> 6);
-    const uint32_t base0 = levels[l0].step0;  // steps are counted from the launch's first level
-    uint32_t seen = 0;
-    PLevel Ln = levels[l0];
-    for (uint32_t l = l0; l < l1; l++) {
-        const PLevel L = Ln;
-        Ln = levels[l + 1 < l1 ? l + 1 : l];  // (the next level's table entry travels while this level runs)
-        const uint32_t first_step = L.step0 - base0;
-        // the wavefront's first step in this level: steps are dealt round-robin across the levels
-        const uint32_t rot = first_step % W;
-        uint32_t t = wave >= rot ? wave - rot : wave + W - rot;
-        if (t >= L.n_steps) continue;
-        if (!persist_wait(sync, first_step, seen, lane)) {
-            if (lane == 0) atomicOr(p.err, RV_DEV_PERSIST_ABORT);
-            return;
-        }
-        const uint32_t begin[5] = {L.r.lo, L.r.mul11, L.r.mul, L.r.xor2, L.r.xork}, end[5] = {L.r.mul11, L.r.mul, L.r.xor2, L.r.xork, L.r.hi};
-        uint32_t mine = 0;
-        for (; t < L.n_steps; t += W, mine++) {
-            uint32_t tt = t;
-            if (tt < L.n_full[0]) {
-                mulU<MODE, NQ, U, 1, 1, 1>(gates, begin[0] + tt * STEP, p, sub, q, 0u);
-                continue;
-            }
-            tt -= L.n_full[0];
-            if (GENERAL && tt < L.n_full[1]) {
-                mulU<MODE, NQ, U, RV_LIN_K, RV_LIN_K, 1>(gates, begin[1] + tt * STEP, p, sub, q, 0u);
-                continue;
-            }
-            tt -= L.n_full[1];
-            if (tt < L.n_full[2]) {
-                xorU<MODE, NQ, U, 2, 1>(gates, begin[2] + tt * STEP, p, sub, q);
-                continue;
-            }
-            tt -= L.n_full[2];
-            if (GENERAL && tt < L.n_full[3]) {
-                xorU<MODE, NQ, U, 2 * RV_LIN_K, 1>(gates, begin[3] + tt * STEP, p, sub, q);
-                continue;
-            }
-            tt -= L.n_full[3];
-            // the gates that do not fill an unrolled step, GPW at a time, class after class
-            uint32_t c0 = 0, e0 = 0, found = 0;
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const uint32_t rest = begin[c] + (c < 4 ? L.n_full[c] * STEP : 0u);
-                const uint32_t n = (end[c] - rest + GPW - 1) / GPW;
-                if (!found) {
-                    if (tt < n) c0 = rest + tt * GPW, e0 = end[c], found = 1;
-                    else tt -= n;
-                }
-            }
-            const uint32_t gi = c0 + sub;
-            if (found && gi < e0) interp_one_impl<MODE, 1>(gates[gi], p, NQ, q, 0u);
-        }
-        // this wavefront's share of the level has ended once its write-through stores have left
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(sync + (wave % PERSIST_SHARDS), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// per-level step tables of a compiled circuit (host): the same class steps launch_interp_full would deal out
-void build_persist_levels(const LevelRange* lr, size_t n_levels, uint32_t NQ, bool general, PLevel* out) {
-    const uint32_t GPW = 64 / NQ;
-    const uint32_t STEP = (uint32_t)interp_unroll((int)NQ, general) * GPW;
-    uint64_t step0 = 0;
-    for (size_t l = 0; l < n_levels; l++) {
-        PLevel L{};
-        L.r = lr[l];
-        const uint32_t begin[5] = {L.r.lo, L.r.mul11, L.r.mul, L.r.xor2, L.r.xork}, end[5] = {L.r.mul11, L.r.mul, L.r.xor2, L.r.xork, L.r.hi};
-        uint32_t n = 0;
-        for (int c = 0; c < 5; c++) {
-            const uint32_t full = (c == 4 || (!general && (c == 1 || c == 3))) ? 0u : (end[c] - begin[c]) / STEP;
-            if (c < 4) L.n_full[c] = full;
-            n += full + ((end[c] - (begin[c] + full * STEP)) + GPW - 1) / GPW;
-        }
-        L.n_steps = n;
-        L.step0 = (uint32_t)step0;
-        step0 += n;
-        out[l] = L;
-    }
-}
-
-template <int NQ, bool GENERAL>
-static int launch_persist_nq(hipStream_t st, const Gate* d_gates, const PLevel* d_levels, uint32_t l0, uint32_t l1, uint64_t n_steps, const InterpParams& p,
-                             uint32_t* d_sync, bool flow) {
-    // as many workgroups as are resident at once, one short of the occupancy query's answer per compute unit (it is one too
-    // high for some register counts: MI355X_MICROARCH.md, residency) -- every wavefront of the grid must be running for the
-    // waits to end
-    static const uint32_t max_blocks = [] {
-        int dev = 0, cus = 0, occ = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_interp_persist<MODE_PROVE_V, NQ, GENERAL>, 256, 0) != hipSuccess || occ <= 0) {
-            (void)hipGetLastError();
-            occ = 2;
-        }
-        if (const char* e = getenv("RV_PERSIST_OCC")) occ = std::max(atoi(e), 1);
-        else if (occ > 2) occ -= 1;
-        return (uint32_t)(occ * cus);
-    }();
-    static const uint32_t max_blocks_flow = [] {
-        int dev = 0, cus = 0, occ = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_interp_flow<NQ, GENERAL>, 256, 0) != hipSuccess || occ <= 0) {
-            (void)hipGetLastError();
-            occ = 2;
-        }
-        if (const char* e = getenv("RV_PERSIST_OCC")) occ = std::max(atoi(e), 1);
-        else if (occ > 2) occ -= 1;
-        return (uint32_t)(occ * cus);
-    }();
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((n_steps + 3) / 4, 1), flow ? max_blocks_flow : max_blocks);
-    if (flow)
-        hipLaunchKernelGGL((k_interp_flow<NQ, GENERAL>), dim3(blocks), dim3(256), 0, st, d_gates, d_levels, l0, l1, p, d_sync);
-    else
-        hipLaunchKernelGGL((k_interp_persist<MODE_PROVE_V, NQ, GENERAL>), dim3(blocks), dim3(256), 0, st, d_gates, d_levels, l0, l1, p, d_sync);
-    return 0;
-}
-
-bool persist_supports(uint32_t NQ) { return NQ == 64 || NQ == 32 || NQ == 16 || NQ == 8; }
-
-// levels [l0, l1) in one launch (MODE_PROVE_V); d_sync: PERSIST_SYNC_WORDS zeroed words of this launch's own
-void launch_interp_persist(hipStream_t st, uint32_t NQ, bool general, const Gate* d_gates, const PLevel* d_levels, uint32_t l0, uint32_t l1, uint64_t n_steps,
-                           const InterpParams& p, uint32_t* d_sync, bool flow) {
-    if (l1 <= l0) return;
-    switch (NQ) {
-    case 64: general ? launch_persist_nq<64, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow) : launch_persist_nq<64, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow); break;
-    case 32: general ? launch_persist_nq<32, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow) : launch_persist_nq<32, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow); break;
-    case 16: general ? launch_persist_nq<16, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow) : launch_persist_nq<16, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow); break;
-    case 8: general ? launch_persist_nq<8, true>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow) : launch_persist_nq<8, false>(st, d_gates, d_levels, l0, l1, n_steps, p, d_sync, flow); break;
-    default: break;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// k_level_split: one dependency level of the split prover schedule's CHAIN (flat.h): the level's XOR gates as the level
-// kernels run them (rows and value bytes), and -- a lane per gate, bytes only -- the cleartext values of its Mul / Input /
-// AssertZero gates.  The Mul gates' row work (four rows in, a transcript row out) is not here: k_mul_flat runs it in program
-// order on the main stream, a band behind this chain.  Value byte of a share row: bit 0 = the wire's value; a Mul's output row
-// also carries its operands' values in bits 1 and 2 for k_mul_flat.
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ void lite_finish(const InterpParams& p, uint32_t meta, uint32_t dst, uint32_t xa, uint32_t xb) {
-    const uint32_t op = meta & 7u, ca = (meta >> 3) & 1u, cb = (meta >> 4) & 1u;
-    if (op == G_MUL) {
-        const uint32_t vx = (xa ^ ca) & 1u, vy = (xb ^ cb) & 1u;
-        p.vclr[dst] = (uint8_t)((vx & vy) | (vx << 1) | (vy << 2));
-    } else if (op == G_INPUT) {
-        p.vclr[dst] = (uint8_t)(xa ? 1 : 0);
-    } else if (op == G_ASSERT) {
-        if (((xa ^ xb ^ ca) & 1u) != 0) atomicOr(p.err, RV_E_WITNESS_INVALID);
-    } else if (op == G_XORK) {
-        p.vclr[dst] = (uint8_t)((xa ^ xb ^ ca) & 1u);
-    }
-}
-template <int NQ, bool GENERAL>
-__global__ __launch_bounds__(256) void k_level_split(const Gate* __restrict__ gates, LevelRange xr, ClearLevel lite, const ClearRec* __restrict__ recs,
-                                                     const ClearRecK* __restrict__ recs_k, uint32_t lite_blocks, InterpParams p) {
-    if (blockIdx.x < lite_blocks) {
-        const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-        const uint32_t ns = lite.s1 - lite.s0, ng = lite.g1 - lite.g0;
-        if (t < ns) {
-            const uint4 r = *(const uint4*)(recs + lite.s0 + t);  // dst a0 b0 meta
-            const uint32_t meta = r.w;
-            uint32_t xa = 0, xb = 0;
-            if ((meta & 7u) == G_INPUT) {
-                xa = p.wit[r.y];
-            } else {
-                if ((meta >> 8) & 3u) xa = p.vclr[r.y];
-                if ((meta >> 10) & 3u) xb = p.vclr[r.z];
-            }
-            lite_finish(p, meta, r.x, xa, xb);
-        } else if (t - ns < ng) {
-            const uint4* qq = (const uint4*)(recs_k + lite.g0 + (t - ns));
-            const uint4 r0 = qq[0], r1 = qq[1];  // dst meta a0 a1 | a2 b0 b1 b2
-            const uint32_t meta = r0.y, na = (meta >> 8) & 3u, nb = (meta >> 10) & 3u;
-            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-            if (na > 0) t0 = p.vclr[r0.z];
-            if (na > 1) t1 = p.vclr[r0.w];
-            if (na > 2) t2 = p.vclr[r1.x];
-            if (nb > 0) t3 = p.vclr[r1.y];
-            if (nb > 1) t4 = p.vclr[r1.z];
-            if (nb > 2) t5 = p.vclr[r1.w];
-            lite_finish(p, meta, r0.x, t0 ^ t1 ^ t2, t3 ^ t4 ^ t5);
-        }
-        return;
-    }
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(((blockIdx.x - lite_blocks) * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t n_waves = (gridDim.x - lite_blocks) * (blockDim.x >> 6);
-    run_level<MODE_PROVE_V, NQ, true, GENERAL>(gates, xr, p, wave, n_waves, lane, 0u);
-}
-
-template <int NQ>
-static void launch_level_split_nq(hipStream_t st, const Gate* d_gates, const LevelRange& r, const ClearLevel& lite, const ClearRec* d_lite_s,
-                                  const ClearRecK* d_lite_k, const InterpParams& p) {
-    constexpr uint32_t GPW = 64 / NQ;
-    // the XOR classes of the level only (its Mul gates have a kernel of their own, everything else goes by value records)
-    const LevelRange xr{r.mul, r.mul, r.mul, r.xor2, r.xork, r.xork};
-    const bool general = level_is_general(xr);
-    const uint32_t u = (uint32_t)interp_unroll(NQ, general);
-    const uint64_t n_lite = (uint64_t)(lite.s1 - lite.s0) + (lite.g1 - lite.g0);
-    const uint32_t lite_blocks = (uint32_t)((n_lite + 255) / 256);
-    const uint64_t waves = ((uint64_t)(xr.hi - xr.lo) + u * GPW - 1) / (u * GPW);
-    const uint32_t xblocks = (uint32_t)std::min<uint64_t>((waves + 3) / 4, 4096);
-    if (!lite_blocks && !xblocks) return;
-    if (general)
-        hipLaunchKernelGGL((k_level_split<NQ, true>), dim3(lite_blocks + xblocks), dim3(256), 0, st, d_gates, xr, lite, d_lite_s, d_lite_k, lite_blocks, p);
-    else
-        hipLaunchKernelGGL((k_level_split<NQ, false>), dim3(lite_blocks + xblocks), dim3(256), 0, st, d_gates, xr, lite, d_lite_s, d_lite_k, lite_blocks, p);
-}
-void launch_level_split(hipStream_t st, const Gate* d_gates, const LevelRange& r, const ClearLevel& lite, const ClearRec* d_lite_s, const ClearRecK* d_lite_k,
-                        const InterpParams& p) {
-    switch (p.NQ) {
-    case 64: return launch_level_split_nq<64>(st, d_gates, r, lite, d_lite_s, d_lite_k, p);
-    case 32: return launch_level_split_nq<32>(st, d_gates, r, lite, d_lite_s, d_lite_k, p);
-    case 16: return launch_level_split_nq<16>(st, d_gates, r, lite, d_lite_s, d_lite_k, p);
-    case 8: return launch_level_split_nq<8>(st, d_gates, r, lite, d_lite_s, d_lite_k, p);
-    default: break;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// k_chain: the split schedule's level chain as ONE launch per band, on ONE XCD (round 4).
-//
-// A dependency level of the chain is small (the 10^7-gate circuit: ~9 400 XOR gates and ~30 000 value bytes), and what makes
-// it expensive as a launch of its own is latency: a kernel boundary, then two dependent trips to memory.  The workgroups of one
-// XCD share an L2: what one compute unit stores (plain, write-through to L2) another finds there a few hundred nanoseconds
-// later if it bypasses its own L1 (sc1 loads), and an atomic without the sc1 bit executes in that L2.  So the chain runs on the
-// workgroups that land on ONE XCD -- the first workgroup of a proof's first chain launch claims its own XCD for the proof
-// (`chosen`), every workgroup on another XCD leaves at once -- with the levels separated by an L2-local hand-off instead of a
-// launch: per level a ticket counter (a ticket = 16 wave-steps of XOR gates or 1 024 value records, taken by a whole workgroup)
-// and a count of finished tickets.  Nobody needs to know how many workgroups take part, or when they start: correct for any
-// placement (one workgroup suffices), fast when the hardware deals workgroups to the XCDs round-robin as it is observed to.
-// Meanwhile the other seven XCDs run the previous band's Mul gates (k_mul_flat leaves the chosen XCD alone).
-// Every wait is bounded (PERSIST_SPIN_TICKS): abort word, RV_DEV_PERSIST_ABORT, the proof fails with RV_E_DEVICE.
-// ------------------------------------------------------------------------------------
-constexpr uint32_t CHAIN_NONE = 0xFFFFFFFFu;
-
-__device__ __forceinline__ uint32_t xcc_id() {
-    uint32_t v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 0xFu;
-}
-
-struct ChainParams {
-    const Gate* gates;
-    const PLevel* xlevels;      // per dependency level: the step table of its XOR classes (build_persist_levels over XOR-only ranges)
-    const ClearLevel* lite;     // per dependency level: its value records
-    const ClearRec* lite_s;
-    const ClearRecK* lite_k;
-    uint32_t l0, l1;
-    uint32_t* chosen;           // one word per proof: the chain's XCD (CHAIN_NONE until the first workgroup claims one)
-    uint32_t* ctr;              // [2 * (l1 - l0)] zeroed: per level the next ticket, the finished tickets (L2-local)
-    uint32_t* abort_word;
-};
-
-template <int NQ, bool GENERAL>
-__global__ __launch_bounds__(1024) void k_chain(ChainParams cp, InterpParams p) {
-    __shared__ uint32_t s_tk, s_go;
-    constexpr uint32_t GPW = 64 / NQ;
-    constexpr int U = interp_unroll(NQ, GENERAL);
-    constexpr uint32_t STEP = (uint32_t)U * GPW;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wiw = tid >> 6;
-    const uint32_t q = lane % NQ, sub = lane / NQ;
-    if (tid == 0) {
-        const uint32_t mine = xcc_id();
-        uint32_t c = __hip_atomic_load(cp.chosen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c == CHAIN_NONE) {
-            uint32_t expect = CHAIN_NONE;
-            __hip_atomic_compare_exchange_strong(cp.chosen, &expect, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c = expect == CHAIN_NONE ? mine : expect;
-        }
-        s_go = c == mine;
-        // (statistics: workgroups of this launch that take part / that left, per proof)
-        __hip_atomic_fetch_add(cp.chosen + (c == mine ? 1 : 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_go) return;
-    const long long t0 = wall_clock64();
-    for (uint32_t l = cp.l0; l < cp.l1; l++) {
-        const PLevel L = cp.xlevels[l];
-        const ClearLevel C = cp.lite[l];
-        uint32_t* tk = cp.ctr + 2 * (l - cp.l0);
-        const uint32_t n_lite = (C.s1 - C.s0) + (C.g1 - C.g0), ns = C.s1 - C.s0;
-        const uint32_t tx = (L.n_steps + 15) / 16, tl = (n_lite + 1023) / 1024, n_tickets = tx + tl;
-        const uint32_t begin[5] = {L.r.lo, L.r.mul11, L.r.mul, L.r.xor2, L.r.xork}, end[5] = {L.r.mul11, L.r.mul, L.r.xor2, L.r.xork, L.r.hi};
-        for (;;) {
-            __syncthreads();
-            if (tid == 0) s_tk = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (no sc1: executes in this XCD's L2)
-            __syncthreads();
-            const uint32_t k = s_tk;
-            if (k >= n_tickets) break;
-            if (k < tx) {
-                // 16 wave-steps of the level's XOR gates, one per wavefront
-                const uint32_t t = k * 16 + wiw;
-                if (t < L.n_steps) {
-                    uint32_t tt = t;
-                    if (tt < L.n_full[2]) {
-                        xorU<MODE_PROVE_V, NQ, U, 2, 2>(cp.gates, begin[2] + tt * STEP, p, sub, q);
-                    } else if (GENERAL && (tt -= L.n_full[2]) < L.n_full[3]) {
-                        xorU<MODE_PROVE_V, NQ, U, 2 * RV_LIN_K, 2>(cp.gates, begin[3] + tt * STEP, p, sub, q);
-                    } else {
-                        if (!GENERAL) tt -= L.n_full[2];
-                        else tt -= L.n_full[3];
-                        uint32_t c0 = 0, e0 = 0, found = 0;
-#pragma unroll
-                        for (int c = 2; c < 4; c++) {  // (the table holds XOR classes only)
-                            const uint32_t rest = begin[c] + L.n_full[c] * STEP;
-                            const uint32_t n = (end[c] - rest + GPW - 1) / GPW;
-                            if (!found) {
-                                if (tt < n) c0 = rest + tt * GPW, e0 = end[c], found = 1;
-                                else tt -= n;
-                            }
-                        }
-                        const uint32_t gi = c0 + sub;
-                        if (found && gi < e0) interp_one_impl<MODE_PROVE_V, 2>(cp.gates[gi], p, NQ, q, 0u);
-                    }
-                }
-            } else {
-                // 1 024 value records of the level's other gates, a lane each
-                const uint32_t t = (k - tx) * 1024 + tid;
-                if (t < ns) {
-                    const uint4 r = *(const uint4*)(cp.lite_s + C.s0 + t);  // dst a0 b0 meta
-                    const uint32_t meta = r.w;
-                    uint32_t xa = 0, xb = 0;
-                    if ((meta & 7u) == G_INPUT) {
-                        xa = p.wit[r.y];
-                    } else {
-                        if ((meta >> 8) & 3u) xa = ld_v<2>(&p.vclr[r.y]);
-                        if ((meta >> 10) & 3u) xb = ld_v<2>(&p.vclr[r.z]);
-                    }
-                    lite_finish(p, meta, r.x, xa, xb);
-                } else if (t < n_lite) {
-                    const uint4* qq = (const uint4*)(cp.lite_k + C.g0 + (t - ns));
-                    const uint4 r0 = qq[0], r1 = qq[1];  // dst meta a0 a1 | a2 b0 b1 b2
-                    const uint32_t meta = r0.y, na = (meta >> 8) & 3u, nb = (meta >> 10) & 3u;
-                    uint32_t t0v = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-                    if (na > 0) t0v = ld_v<2>(&p.vclr[r0.z]);
-                    if (na > 1) t1 = ld_v<2>(&p.vclr[r0.w]);
-                    if (na > 2) t2 = ld_v<2>(&p.vclr[r1.x]);
-                    if (nb > 0) t3 = ld_v<2>(&p.vclr[r1.y]);
-                    if (nb > 1) t4 = ld_v<2>(&p.vclr[r1.z]);
-                    if (nb > 2) t5 = ld_v<2>(&p.vclr[r1.w]);
-                    lite_finish(p, meta, r0.x, t0v ^ t1 ^ t2, t3 ^ t4 ^ t5);
-                }
-            }
-            // the ticket has ended once every wavefront's stores have reached the L2
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(tk + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (l + 1 == cp.l1) break;
-        // the next level starts when every ticket of this one has ended (one poller per workgroup)
-        if (tid == 0) {
-            uint32_t ok = 1;
-            for (uint32_t spins = 0; __hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_tickets; spins++) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((spins & 255u) == 255u) {
-                    if (__hip_atomic_load(cp.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > PERSIST_SPIN_TICKS) {
-                        __hip_atomic_store(cp.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        atomicOr(p.err, RV_DEV_PERSIST_ABORT);
-                        ok = 0;
-                        break;
-                    }
-                }
-            }
-            s_go = ok;
-        }
-        __syncthreads();
-        if (!s_go) return;
-    }
-}
-
-// step tables of the levels' XOR classes (host)
-void build_chain_levels(const LevelRange* lr, size_t n_levels, uint32_t NQ, bool general, PLevel* out) {
-    std::vector<LevelRange> xr(n_levels);
-    for (size_t l = 0; l < n_levels; l++) xr[l] = LevelRange{lr[l].mul, lr[l].mul, lr[l].mul, lr[l].xor2, lr[l].xork, lr[l].xork};
-    build_persist_levels(xr.data(), n_levels, NQ, general, out);
-}
-bool chain_general(const LevelRange* lr, size_t n_levels) {
-    for (size_t l = 0; l < n_levels; l++)
-        if (lr[l].xork - lr[l].xor2 >= 64) return true;
-    return false;
-}
-
-bool chain_supports(uint32_t NQ) { return NQ == 64; }
-
-// levels [l0, l1) of the chain; d_ctr: 2 * (l1 - l0) zeroed words; n_wgs workgroups of 1 024 threads are launched (those that land
-// on the proof's chain XCD do the work)
-void launch_chain(hipStream_t st, uint32_t n_wgs, bool general, const Gate* d_gates, const PLevel* d_xlevels, const ClearLevel* d_lite, const ClearRec* d_lite_s,
-                  const ClearRecK* d_lite_k, uint32_t l0, uint32_t l1, uint32_t* d_chosen, uint32_t* d_ctr, uint32_t* d_abort, const InterpParams& p) {
-    if (l1 <= l0) return;
-    const ChainParams cp{d_gates, d_xlevels, d_lite, d_lite_s, d_lite_k, l0, l1, d_chosen, d_ctr, d_abort};
-    if (general)
-        hipLaunchKernelGGL((k_chain<64, true>), dim3(n_wgs), dim3(1024), 0, st, cp, p);
-    else
-        hipLaunchKernelGGL((k_chain<64, false>), dim3(n_wgs), dim3(1024), 0, st, cp, p);
-}
-#endif  // RV_EXPERIMENTS
+// (Rounds 2 and 4 built four more launch structures for the GF(2) prover -- persistent level kernels, the flat, split and chained
+// schedules.  All byte-identical, all measured slower: DESIGN.md Appendix A; their last version is commit 56a26f2.)
 
 // whether any level of the gate stream has enough multi-base gates for the kernel variants with their loops (the verifier's
 // choice of MODE_VERIFY_C looks at it too)
@@ -1524,9 +809,7 @@ void launch_interp(hipStream_t st, int mode, const Gate* d_gates, const LevelRan
     const uint64_t want = (uint64_t)(r.hi - r.lo) * p.NQ;
     uint64_t blocks = (want + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (mode == MODE_PROVE_F)
-        hipLaunchKernelGGL(k_interp<MODE_PROVE_F>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);
-    else if (mode == MODE_PROVE)
+    if (mode == MODE_PROVE)
         hipLaunchKernelGGL(k_interp<MODE_PROVE>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);
     else
         hipLaunchKernelGGL(k_interp<MODE_VERIFY>, dim3((unsigned)blocks), dim3(256), 0, st, d_gates, r.lo, r.hi, p);
@@ -2566,22 +1849,6 @@ void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d
         launch<B_k_extract_rows<1>, 256>(k_extract_rows<1>, st, grid, dim3(256), (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
                            d_dst_off, d_out, 0, 0);
 }
-#ifdef RV_EXPERIMENTS  // (RecStage, api.hip: RV_EARLY_REC)
-// the same vectors (kind 0: the omitted players' broadcast bits) as a slice into a dense staging block: output bytes
-// [byte0, byte0 + n_bytes_slice) of every opened repetition's vector go to d_stage + slot * pitch + byte; byte0 a multiple of
-// extract_stage_granule(n_items)
-uint32_t extract_stage_granule(uint64_t n_items) { return std::max(ex_tb_for(n_items / 8 + 1), 16u); }  // (16: the copy engine's fast 2-D path)
-void launch_extract_bits_stage(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ, const uint8_t* d_omit,
-                               uint8_t* d_stage, uint64_t pitch, uint64_t byte0, uint64_t n_bytes_slice) {
-    const uint64_t n_bytes = n_items / 8 + 1;
-    const uint32_t tb = extract_stage_granule(n_items);
-    const uint64_t end = std::min(byte0 + n_bytes_slice, n_bytes);
-    if (end <= byte0) return;
-    const dim3 grid((unsigned)((end - byte0 + tb - 1) / tb));
-    hipLaunchKernelGGL(k_extract_rows<0>, grid, dim3(256), 0, st, (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit, (const uint64_t*)nullptr, d_stage, pitch,
-                       (uint32_t)(byte0 / tb));
-}
-#endif
 
 // Inverse for the verifier (Pack::unpack / PackSelected::unpack_selected): builds dense
 // rows from the proof's bit vectors.  kind 0: bit placed at the omitted player's position;
@@ -2900,52 +2167,6 @@ __global__ __launch_bounds__(256) void k_copy_gaps(const uint8_t* __restrict__ i
     for (uint64_t i = a16 + 16 * tid; i < b16; i += 16 * nth) *(uint4*)(dst_mapped + i) = *(const uint4*)(img + i);
     for (uint64_t i = b16 + tid; i < b; i += nth) dst_mapped[i] = img[i];
 }
-// The same with TWO holes per online record: [h1_at, h1_at + h1_len) in every one of the n_rec records (the broadcast-bit vectors:
-// they reach the host through the copy engine, slice by slice) and [h2_at, h2_at + h2_len) in the first m (the corrections vectors,
-// m as above).  What is left -- headers, keys, length words, input vectors, the preprocessing sections -- is a few dozen KB.
-// Piece p (blockIdx.y): 0 = the image's head up to the first record; 1 + 3 j + {0, 1, 2} = record j before hole 1 / between the
-// holes / behind hole 2; the last = everything behind the records.
-__global__ __launch_bounds__(256) void k_copy_gaps2(const uint8_t* __restrict__ img, uint8_t* __restrict__ dst_mapped, uint64_t total, uint64_t first,
-                                                    uint64_t rec, uint64_t h1_at, uint64_t h1_len, uint64_t h2_at, uint64_t h2_len, uint32_t n_rec,
-                                                    const uint8_t* __restrict__ omit, uint32_t rep_limit) {
-    __shared__ uint32_t s_m;
-    if (threadIdx.x < 64) {
-        uint32_t cnt = 0;
-        for (uint32_t r = threadIdx.x; r < rep_limit && r < RV_TOTAL_REPS; r += 64) cnt += omit[r] < 8 ? 1u : 0u;
-        for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (threadIdx.x == 0) s_m = cnt < n_rec ? cnt : n_rec;
-    }
-    __syncthreads();
-    const uint32_t m = s_m, p = blockIdx.y;
-    uint64_t a, b;
-    if (p == 0) {
-        a = 0, b = first;
-    } else if (p == 1 + 3 * n_rec) {
-        a = first + (uint64_t)n_rec * rec, b = total;
-    } else {
-        const uint32_t j = (p - 1) / 3, k = (p - 1) % 3;
-        const uint64_t r0 = first + (uint64_t)j * rec;
-        if (k == 0) a = r0, b = r0 + h1_at;
-        else if (k == 1) a = r0 + h1_at + h1_len, b = j < m ? r0 + h2_at : r0 + rec;
-        else a = j < m ? r0 + h2_at + h2_len : r0 + rec, b = r0 + rec;
-    }
-    if (b <= a) return;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
-    if (b - a < 4096) {  // (nearly all pieces: a few hundred bytes)
-        for (uint64_t i = a + tid; i < b; i += nth) dst_mapped[i] = img[i];
-        return;
-    }
-    uint64_t a16 = (a + 15) & ~15ull, b16 = b & ~15ull;
-    for (uint64_t i = a + tid; i < a16; i += nth) dst_mapped[i] = img[i];
-    for (uint64_t i = a16 + 16 * tid; i < b16; i += 16 * nth) *(uint4*)(dst_mapped + i) = *(const uint4*)(img + i);
-    for (uint64_t i = b16 + tid; i < b; i += nth) dst_mapped[i] = img[i];
-}
-void launch_copy_gaps2(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t h1_at, uint64_t h1_len,
-                       uint64_t h2_at, uint64_t h2_len, uint32_t n_rec, const uint8_t* d_omit, uint32_t rep_limit) {
-    hipLaunchKernelGGL(k_copy_gaps2, dim3(rep_limit < RV_TOTAL_REPS ? 16 : 1, 3 * n_rec + 2), dim3(256), 0, st, d_img, dst_mapped, total, first, rec, h1_at, h1_len, h2_at,
-                       h2_len, n_rec, d_omit, rep_limit);
-}
-
 void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
                       uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit, uint32_t rep_limit) {
     // (the last piece may be most of the image -- Z64 with few staged repetitions --: enough workgroups per piece to fill PCIe alone)

@@ -284,16 +284,6 @@ void launch_b3_contig_chunks(hipStream_t st, const uint64_t* d_streams, uint64_t
                        stride_words * 8, n_bytes, R, n, d_cv, chunk_base, root_ok);
 }
 
-// byte streams [R][stride_bytes] (stride a multiple of 16), the first n_bytes of each hashed -> digests [R][8]
-uint32_t launch_b3_bytes(hipStream_t st, const uint8_t* d_streams, uint64_t stride_bytes, uint64_t n_bytes, uint32_t R, uint32_t* d_cv_a,
-                         uint32_t* d_cv_b, uint32_t* d_digest) {
-    const uint64_t n = n_bytes == 0 ? 1 : (n_bytes + 1023) / 1024;
-    const uint64_t threads = n * R;
-    hipLaunchKernelGGL(k_b3_chunks_contig, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_streams, stride_bytes, n_bytes,
-                       R, n, d_cv_a, (uint64_t)0, 1u);
-    return 1 + b3_reduce_tree(st, d_cv_a, d_cv_b, n, R, d_digest);
-}
-
 uint32_t launch_b3_contig(hipStream_t st, const uint64_t* d_streams, uint64_t n_words, uint32_t R, uint32_t* d_cv_a, uint32_t* d_cv_b,
                       uint32_t* d_digest) {
     const uint64_t n_bytes = n_words * 8;

@@ -1022,54 +1022,6 @@ def test_library_communicator_world1(rv, oracle, rule_seeds):
     _lib.lib().rv_comm_destroy(C.c_void_p(cm[0]))
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_rep_sliced_path(rv, oracle, rule_seeds, monkeypatch, mode):
-    """RV_REP=1/2: the rep-sliced prover (a workgroup per repetition, live wires in LDS, rep-major masks and transcripts,
-    the cleartext pre-pass instead of stored corrections) must produce the same bytes as the oracle -- golden circuits,
-    Bristol-style random circuits with constants and wire reuse, a layered circuit with several segments per level and
-    misaligned transcript offsets, and (mode 2) repetition shards"""
-    from reverie_amd import _lib
-
-    if not _lib.lib().rv_hook_experiments():
-        pytest.skip("the rep-sliced path exists in experiment builds only (make EXTRA=-DRV_EXPERIMENTS)")
-    from reverie_amd.dist import HipShardBackend, assemble
-    from reverie_amd.proof import challenge, combine_digests
-
-    monkeypatch.setenv("RV_REP", mode)
-    for name in ("adder64", "gf2_mix", "empty"):
-        m, prog, w2, w64, wc, gold = load_case(name)
-        assert bytes(rv.Proof.new(prog, w2, w64, wc, seeds=rule_seeds)) == gold
-    rng = np.random.default_rng(77)
-    for trial in range(4):
-        prog, wit, wc = circuits.random_gf2(rng, n_in=int(rng.integers(1, 40)), n_gates=int(rng.integers(50, 3000)), n_wires=int(rng.integers(8, 200)))
-        prog = prog[prog["opcode"] != 1]  # (Random gates keep a circuit on the row path)
-        seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
-        try:
-            want = oracle.prove(prog, wit, [], wc, seeds)
-        except oracle.OracleError:
-            continue  # removing the Random gates broke an assertion
-        assert bytes(rv.Proof.new(prog, wit, [], wc, seeds=seeds)) == want, trial
-    for n_in, width, layers in ((37, 1024, 9), (4096, 4096, 5)):
-        prog, wit, wc, st = circuits.layered_gf2(n_in=n_in, width=width, layers=layers)
-        want = oracle.prove(prog, wit, [], wc, rule_seeds)
-        c = rv.Circuit(prog, wc)
-        assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == want
-        bad = wit.copy()
-        bad[0] ^= 1
-        with pytest.raises(rv.ReverieError) as e:
-            rv.Proof.new(c, bad, [], seeds=rule_seeds)
-        assert e.value.code == 1
-        if mode == "2":
-            be = HipShardBackend(c)
-            shards = [be.commit(wit, [], rule_seeds[b:b + 64], b, 64) for b in range(0, 256, 64)]
-            comm = combine_digests(np.concatenate([be.digests(s) for s in shards]))
-            omit = challenge(comm)
-            parts = [be.open(s, omit)[:2] for s in shards]
-            for s in shards:
-                be.destroy(s)
-            assert assemble(comm, parts) == want
-
-
 def _hourglass(seed=5):
     """600 inputs (a wide level), 40 narrow layers of 32 gates reading them, then 1024 Mul gates (a wide level again) that
     read wires of the narrow part and inputs, folded by Add gates into asserts: the narrow stretch has live-in AND
@@ -1251,17 +1203,11 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
 
     L = _lib.lib()
     monkeypatch.setenv("RV_EARLY_MIN", "1000")
-    # round 4: the opened repetitions' broadcast-bit vectors leave in slices through the copy engine (RecStage, api.hip) -- on for
-    # every case here (threshold lowered), with 1 .. 7 slices; the RV_EARLY_REC=0 bytes (one kernel copy, round 3) at the end.
-    # (RecStage exists in experiment builds only -- EXTRA=-DRV_EXPERIMENTS; the library build() makes ignores these three knobs)
-    monkeypatch.setenv("RV_EARLY_REC_MIN", "1000")
-    monkeypatch.setenv("RV_EARLY_REC", "1")
     # (the last case is mostly XOR: its outputs still depend on the inputs after 80 layers, so a flipped witness bit is caught)
     cases = [(64, 8192, 40, 0.5, "10", 16), (37, 4736, 70, 0.6, "3", 37), (64, 8192, 36, 1.0, "1", 16), (128, 16384, 24, 0.5, "16", 16),
              (64, 16384, 80, 0.1, "4", 16)]
     for case_no, (n_in, width, layers, p_and, chunks, fold_to) in enumerate(cases):
         monkeypatch.setenv("RV_EARLY_CHUNKS", chunks)
-        monkeypatch.setenv("RV_EARLY_REC_SLICES", str((4, 1, 7, 3, 2)[case_no]))
         # (cases 1 and 3: only the first 96 / 200 repetitions are staged, the opened ones beyond them take the plain way)
         if case_no in (1, 3):
             monkeypatch.setenv("RV_EARLY_REPS", "96" if case_no == 1 else "200")
@@ -1281,13 +1227,10 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
         again = rv.Proof.new(c, wit, [], seeds=rule_seeds)  # the staging buffers and the mailbox are reused
         assert bytes(again) == want
         assert got.verify(c)
-        monkeypatch.setenv("RV_EARLY_REC", "0")
-        assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == want
-        monkeypatch.setenv("RV_EARLY_REC", "1")
         monkeypatch.setenv("RV_EARLY", "0")
         plain = rv.Proof.new(c, wit, [], seeds=rule_seeds)
         assert c.info["early_staging_bytes"] == 0  # (RV_EARLY=0)
-        assert L.rv_hook_early_proofs() == n0 + 3
+        assert L.rv_hook_early_proofs() == n0 + 2
         assert bytes(plain) == want
         monkeypatch.setenv("RV_EARLY", "2")
         if p_and < 0.2:
@@ -1296,7 +1239,7 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
             with pytest.raises(rv.ReverieError) as e:
                 rv.Proof.new(c, bad, [], seeds=rule_seeds)
             assert e.value.code == 1
-            assert L.rv_hook_early_proofs() == n0 + 3
+            assert L.rv_hook_early_proofs() == n0 + 2
             assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == want  # ... and the context is fine afterwards
         c.close()
 

@@ -200,20 +200,3 @@ def test_fused_verifier_vs_oracle(rv, oracle, rule_seeds, monkeypatch, fused_ver
             bad_prog[idx[-1]]["imm"] ^= 1
             want = (oracle.verify(bad_prog, wc, good), oracle.verify(bad_prog, wc, good, strict=True))
             assert (rv.Proof(good).verify(bad_prog, wc, strict=False), rv.Proof(good).verify(bad_prog, wc, strict=True)) == want
-
-
-@pytest.mark.parametrize("n_in,width,n_mul", [(64, 33, 500), (1024, 129, 3000), (64, 2048, 20000)])
-def test_lane_distributed_cipher_level_kernel(rv, oracle, rule_seeds, monkeypatch, n_in, width, n_mul):
-    """experiment builds (make EXTRA=-DRV_EXPERIMENTS; RV_LIB_PATH): k_z64_c4 (z64c4.hip, RV_Z64_C4=1) writes the proof k_z64_fused writes"""
-    from reverie_amd import _lib
-
-    if not _lib.lib().rv_hook_experiments():
-        pytest.skip("k_z64_c4 is compiled into experiment builds only")
-    prog, w64, wc, st = circuits.layered_z64(n_in=n_in, width=width, n_mul=n_mul, fold_to=min(16, width))
-    want = oracle.prove(prog, [], w64, wc, rule_seeds, threads=8)
-    monkeypatch.setenv("RV_Z64_C4", "1")
-    assert _prove(rv, prog, w64, wc, rule_seeds, monkeypatch, 1) == want
-    rng = np.random.default_rng(6464)
-    prog, w64, wc = random_z64(rng, n_in=8, n_gates=1200, n_wires=90)
-    seeds = rng.integers(0, 256, (256, 16), dtype=np.uint8)
-    assert _prove(rv, prog, w64, wc, seeds, monkeypatch, 1) == oracle.prove(prog, [], w64, wc, seeds, threads=8)
