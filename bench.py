@@ -36,7 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PROFILE_TAG = "r05"    # profiles/<tag>_pmc_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r06"    # profiles/<tag>_pmc_traffic.json feeds roofline.traffic
 
 
 def rule_seeds():
@@ -583,7 +583,45 @@ def main():
                                               "phase_ms": ms, "issue_frac": insts / (ms * 1e-3) / peak_issue}
             valu["note"] = ("half of the BLAKE3 / bitsliced-AES instruction mix are 3-source VOP3 (v_bitop3, v_perm, v_add3, v_alignbit) "
                             "that issue at a quarter of a wavefront per clock, not half: tools/mb/valu_mb.hip; DESIGN.md section 4")
+            # the ceiling the instruction mix itself allows (tools/valu_mix.py over the shipped ISA: N / (N_full + 2 N_half))
+            mix_path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_valu_mix.json")
+            mix = json.load(open(mix_path))["kernels"] if os.path.exists(mix_path) else {}
+            valu["mix"] = {k: {"half_rate_share": v["half_rate_share"], "issue_ceiling": v["issue_ceiling"]} for k, v in mix.items()}
             roofline["valu"] = valu
+            # the line's roofline names the binding resource of the dominant phase.  Beside each other the cipher and
+            # the level launches are paced by integer-VALU issue (the cipher takes the longer share of the phase and is at the ceiling
+            # of its mix when alone); the level kernel's HBM view stays as roofline.hbm
+            ph = valu["kernels"].get("masks+interp")
+            if overlapped and ph:
+                c4 = "rv::k_aes_gf2_masks_col4"
+                c4_insts = sum(v.get("SQ_INSTS_VALU_per_proof", 0.0) for k, v in sk.items() if k.startswith(mask_pf))
+                ceil_c4 = mix.get(c4, {}).get("issue_ceiling")
+                ceil_lv = mix.get(kname, {}).get("issue_ceiling")
+                lv_insts = ph["valu_insts_per_proof"] - c4_insts
+                # (the phase's ceiling: both kernels' instructions at their own mixes' rates)
+                ceil_phase = (ph["valu_insts_per_proof"] / (c4_insts / ceil_c4 + lv_insts / ceil_lv)) if ceil_c4 and ceil_lv else None
+                c4_traffic = None
+                if world == 1 and args.layers == 153 and args.p_and == 0.5 and os.path.exists(pmc_path):
+                    hits = [v["hbm_bytes_per_proof"] for k, v in json.load(open(pmc_path))["kernels"].items() if k.startswith("rv::k_aes_gf2_masks")]
+                    c4_traffic = sum(hits) / max(int(prof.launches[_lib.PHASES.index("masks")] // max(args.steps, 1)), 1) if hits else None
+                hbm_view = roofline
+                roofline = {
+                    "bound": "valu", "kernel": c4, "achieved": ph["valu_insts_per_proof"] / (ph["phase_ms"] * 1e-3) / 1e9, "peak": peak_issue / 1e9,
+                    "unit": "G wavefront VALU instructions/s", "frac": ph["issue_frac"], "ceiling_frac": ceil_phase,
+                    "ceiling_frac_kernel": ceil_c4, "traffic": c4_traffic,
+                    "note": "the proof's dominant phase = the lane-distributed mask generator (bitsliced AES-128-CTR, the kernel with the largest share of "
+                            "the trace) on its own stream BESIDE the interpreter's level launches; both are paced by integer-VALU issue: achieved = "
+                            "wavefront VALU instructions of both kernels per proof (SQ_INSTS_VALU, profiles/%s_sq_counters.json) / the phase's HIP-event "
+                            "time in THIS run; peak = 1024 SIMDs x 1/2 instruction per clock x 2.4 GHz; ceiling_frac = what the instruction mix allows "
+                            "(61 %% of the cipher's instructions are 3-source VOP3 at half rate: profiles/%s_valu_mix.json) -- the cipher alone reaches it, "
+                            "the pair does not because the level launches are latency-bound (roofline.hbm.kernel_alone); no MFMA on this path.  "
+                            "traffic = PMC HBM bytes per generator launch" % (PROFILE_TAG, PROFILE_TAG),
+                    "phase_ms": phases, "phase_launches": launches, "gpu_ms_per_proof": sum(phases.values()),
+                    "valu": valu, "hbm": hbm_view,
+                }
+                # (kept at the top level for the tools that read them)
+                for k in ("kernel_alone", "concurrent", "early_corrections", "launches_per_proof", "avg_launch_us", "algorithmic_bytes_per_proof"):
+                    roofline[k] = hbm_view.get(k)
         boundary = (("rv_prove_sharded (library communicator: RCCL all-gather of digests on the library's stream, ncclSend/ncclRecv of "
                      "the openings); rank 0 ends with bincode(Proof) bytes in host memory" if lib_comm is not None else
                      "sharded rv_shard_* + torch.distributed all-gather; rank 0 ends with bincode(Proof) bytes in host memory"

@@ -41,7 +41,8 @@ def table(b, src):
     rows = [
         ("**headline: one proof, host bytes to host bytes** (`rv_prove`, 10^7 gates / 5.01·10^6 AND)", "%s AND/s" % sci(b.get("value")), "%s ms" % fmt(b.get("ms_per_step"))),
         ("  GPU phases: masks / interpreter / digests / openings", "", " / ".join(fmt(ph.get(k)) for k in ("masks", "interp", "hash", "open")) + " ms"),
-        ("  interpreter kernel vs HBM roofline (%s)" % g(b, "roofline", "kernel", default="?"), "%s of 8 TB/s" % fmt(g(b, "roofline", "frac")), "%s us per launch x %s" % (fmt(g(b, "roofline", "avg_launch_us"), 1), g(b, "roofline", "launches_per_proof"))),
+        ("  masks || levels phase vs the integer-VALU issue peak (%s + level launches)" % g(b, "roofline", "kernel", default="?"), "%s of 1.23 T wavefront instructions/s (mix ceiling %s)" % (fmt(g(b, "roofline", "frac")), fmt(g(b, "roofline", "ceiling_frac"))), "%s ms" % fmt(g(b, "roofline", "phase_ms", "interp"))),
+        ("  interpreter kernel vs HBM roofline (%s)" % g(b, "roofline", "hbm", "kernel", default="?"), "%s of 8 TB/s" % fmt(g(b, "roofline", "hbm", "frac")), "%s us per launch x %s" % (fmt(g(b, "roofline", "avg_launch_us"), 1), g(b, "roofline", "launches_per_proof"))),
         ("  the level kernel with nothing beside it (`RV_OVERLAP=0 RV_EARLY=0`, same run)", "%s of 8 TB/s" % fmt(g(b, "roofline", "kernel_alone", "frac")), "%s us per launch; such a proof: %s ms" % (fmt(g(b, "roofline", "kernel_alone", "avg_launch_us"), 1), fmt(g(b, "roofline", "kernel_alone", "ms_per_proof_host_to_host")))),
         ("  level launches + mask generator beside them, both kernels' bytes over the phase", "%s of 8 TB/s" % fmt(g(b, "roofline", "concurrent", "phase_frac_incl_masks")), ""),
         ("  issue fraction, mask generator + level launches / transcript hashes", "", "%s / %s" % (fmt(g(b, "roofline", "valu", "kernels", "masks+interp", "issue_frac", default=g(b, "roofline", "valu", "kernels", "masks", "issue_frac"))), fmt(g(b, "roofline", "valu", "kernels", "hash", "issue_frac")))),
