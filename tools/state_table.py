@@ -53,6 +53,7 @@ def table(b, src):
         ("first proof of an unseen circuit (`rv_prove_ops`)", "%s AND/s" % sci(g(b, "first_proof", "and_per_s")), "%s ms" % fmt(g(b, "first_proof", "first_proof_ms"), 1)),
         ("  the same call again on the same op list (the context keeps compiled circuits by content)", "%s AND/s" % sci(g(b, "first_proof", "repeat_and_per_s")), "%s ms" % fmt(g(b, "first_proof", "repeat_proof_ms"))),
         ("streaming prover / verifier (`rv_prove_streaming`, `rv_verify_streaming`)", "%s AND/s" % sci(g(b, "streaming", "value")), "%s / %s ms" % (fmt(g(b, "streaming", "ms"), 1), fmt(g(b, "streaming", "verify_streaming", "ms"), 1))),
+        ("  the same with NO transcripts kept between the passes (`RV_STREAM_KEEP_MB=0`: wire store + one chunk + the proof on the device)", "%s AND/s" % sci(g(b, "streaming", "bounded_memory", "value")), "%s ms" % fmt(g(b, "streaming", "bounded_memory", "ms"), 1)),
         ("Z64, 10^6 MUL (config 5)", "%s MUL/s" % sci(g(b, "secondary", "z64", "mul_per_s")), "%s ms (verify %s)" % (fmt(g(b, "secondary", "z64", "ms_per_proof")), fmt(g(b, "secondary", "z64", "verify_ms")))),
         ("AES-128 / SHA-256, one proof", "%s / %s AND/s" % (sci(g(b, "secondary", "aes128", "single_proof_and_per_s")), sci(g(b, "secondary", "sha256", "single_proof_and_per_s"))),
          "%s / %s ms" % (fmt(g(b, "secondary", "aes128", "single_proof_ms"), 3), fmt(g(b, "secondary", "sha256", "single_proof_ms"), 3))),
