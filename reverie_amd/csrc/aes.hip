@@ -952,13 +952,12 @@ template <int QW>
 static void launch_z64_fused_qw(hipStream_t st, const Gate64* d_gates, const Z64FLevel& lv, const Z64FParams& p) {
     constexpr uint32_t JW = 64 / QW, STEP = 8 * JW;
     static const uint32_t cus = [] {
-        if (const char* e = getenv("RV_Z64F_WGS")) return (uint32_t)std::max(atoi(e), 1);
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return (uint32_t)n;
     }();
     // a Mul step (cipher batch + rows) in linear steps (rows only): what the wavefronts with one Mul step more get fewer of
-    static const uint32_t lin_bias = getenv("RV_Z64F_LIN_BIAS") ? (uint32_t)std::min(std::max(atoi(getenv("RV_Z64F_LIN_BIAS")), 0), 64) : 3u;  // (measured 0 / 3 / 5 / 8: 38.6 / 38.3 / 38.9 / 38.8 ms)
+    constexpr uint32_t lin_bias = 3;  // (measured 0 / 3 / 5 / 8: 38.6 / 38.3 / 38.9 / 38.8 ms)
     const uint32_t n_qg = p.qgn;  // (quad groups of this launch)
     const uint32_t n_mul = lv.mul1 - lv.mul0, n_lin = lv.lin1 - lv.mul1, n_oth = lv.oth1 - lv.lin1;
     if (!(n_mul + n_lin + n_oth) || !n_qg) return;

@@ -359,6 +359,7 @@ static int dalloc(rv_ctx* ctx, size_t count, T** out) {
 // main_prio_level / mask_prio_level: the priority class (0 = the device's highest) of the main stream and of the mask generator's stream;
 // -1 = the default priority.  A context with classes of its own (rv_prove_batch's workers) makes its second stream on first use.
 static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level /* -1: default priority */, int mask_prio_level = -1);
+// (main stream and mask-generator stream of a caller's context in the DEFAULT priority class: the highest / lowest classes measured the same, round 6)
 extern "C" int rv_ctx_create(int device_ordinal, rv_ctx** out) { return ctx_create_impl(device_ordinal, out, -1); }
 
 static int ctx_create_impl(int device_ordinal, rv_ctx** out, int main_prio_level, int mask_prio_level) {
@@ -806,7 +807,7 @@ static int circuit_upload(rv_ctx* ctx, rv_circuit* c, bool async_staged) {
     for (size_t b : {cc.gates.size() * sizeof(Gate), cc.rec_rows.size() * 4, cc.in_rows.size() * 4, cc.gates64.size() * sizeof(Gate64),
                      cc.rec_offs64.size() * 8, cc.in_offs64.size() * 8, cc.level_start.size() * 4, cc.level_range.size() * sizeof(LevelRange)})
         stage_need += (b + 255) & ~(size_t)255;
-    static const bool stage_on = !(getenv("RV_UPLOAD_STAGE") && atoi(getenv("RV_UPLOAD_STAGE")) == 0);
+    constexpr bool stage_on = true;
     if (stage_on && stage_need <= rv_ctx::UP_STAGE_MAX && stage_need > ctx->h_up_cap) {
         if (ctx->h_up) {
             (void)hipStreamSynchronize(ctx->stream);  // (no copy out of the old buffer may still be pending)

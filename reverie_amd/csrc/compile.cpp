@@ -673,7 +673,7 @@ int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
     // A streaming chunk is compiled once with every XOR materialised (lazy_k = 1 below): the read counts would only serve to drop the
     // XOR gates nobody reads (13.5 % of them on the layered workload -- the GPU runs them in passing), and the counting pass is
     // 3 of a piece's 18 - 22 ms on a worker thread, where the streaming prover's first pass is bound
-    const bool count_reads = !chunk || force_lazy_k || getenv("RV_LAZY_K") || getenv("RV_CHUNK_COUNT_READS");
+    const bool count_reads = !chunk || force_lazy_k || getenv("RV_LAZY_K");
     if (count_reads) {
         // pass 1: SSA numbering + read counts (the materialisation rule needs each wire's fan-out)
         Compiled scratch;

@@ -270,7 +270,7 @@ void* big_alloc(size_t bytes) {
     if (p > raw) munmap(raw, (size_t)(p - raw));
     const size_t tail = (size_t)((raw + len + HP) - (p + len));
     if (tail) munmap(p + len, tail);
-    static const bool thp = !(getenv("RV_THP") && atoi(getenv("RV_THP")) == 0);
+    constexpr bool thp = true;
     if (thp) (void)madvise(p, len, MADV_HUGEPAGE);
     return p;
 }
@@ -1192,14 +1192,6 @@ int compile_ops_par(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
         info.gf2_rows_written += f.rows_written;
     }
     lap("tables done");
-    if (stats && getenv("RV_COMPILE_STATS_MEM")) {  // (walks the whole address space: tens of milliseconds)
-        if (FILE* f = fopen("/proc/self/smaps_rollup", "r")) {
-            char line[256];
-            while (fgets(line, sizeof line, f))
-                if (!strncmp(line, "AnonHugePages", 13) || !strncmp(line, "Rss", 3)) fprintf(stderr, "[rv compile/par] %s", line);
-            fclose(f);
-        }
-    }
     return RV_OK;
 }
 

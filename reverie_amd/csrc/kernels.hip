@@ -1254,14 +1254,8 @@ size_t b3_stream_scratch_words(uint64_t n_events, uint32_t R) {
 }
 
 // (chunk, quad word) lanes below which a lane takes ONE repetition instead of four: four times the wavefronts, each a quarter as
-// long -- for transcripts that would not fill the chip's wavefront slots otherwise (RV_B3_RPL1_LANES: an experiment knob)
-static uint64_t b3_rpl1_lanes() {
-    static const uint64_t v = [] {
-        const char* e = getenv("RV_B3_RPL1_LANES");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)128 * 1024;  // (64-repetition shards of the 10^7-gate circuit: digests 0.47 -> 0.38 ms)
-    }();
-    return v;
-}
+// long -- for transcripts that would not fill the chip's wavefront slots otherwise
+static uint64_t b3_rpl1_lanes() { return (uint64_t)128 * 1024; }  // (64-repetition shards of the 10^7-gate circuit: digests 0.47 -> 0.38 ms)
 
 // chunk chaining values only ([n_chunks][R][8] into d_cv); chunk_base / root_ok: see B_k_b3_chunks
 void launch_b3_stream_chunks(hipStream_t st, const uint32_t* d_stream, uint64_t n_events, uint32_t NQ, uint32_t* d_cv, const uint32_t* d_quads,
