@@ -385,7 +385,9 @@ int rv_shard_open_gathered(rv_shard *s, const void *all_digests_device, void *ds
  * loads without it and reuses a copy the process already has (PyTorch's).
  *   one process per GPU : rank 0 calls rv_comm_unique_id and hands the 128 bytes to the others out of band (MPI,
  *                         torch.distributed, a file); every rank calls rv_comm_create with its own context
- *   one process, n GPUs : rv_comm_create_all(ctxs, n, comms), then rv_prove_multi (a host thread per GPU)
+ *   one process, n GPUs : rv_comm_create_all(ctxs, n, comms), then rv_prove_multi (a host thread per GPU; its ranks send nothing to
+ *                         rank 0: every rank copies its own sections straight into ONE page-locked proof buffer over its own PCIe
+ *                         link -- the all-gather of digests stays the only collective)
  * rv_prove_sharded is a COLLECTIVE call: every rank calls it with the same statement and the same 256 seeds (all of
  * them, not only its share; NULL is not allowed -- the ranks could not agree on OS randomness); *proof is set on rank
  * 0 only (NULL / 0 elsewhere) and is byte-identical to rv_prove's.  If one rank fails before the collective the
