@@ -322,9 +322,10 @@ struct Reaper {
                 cv.wait_for(lk, std::chrono::milliseconds(50));
             std::vector<std::pair<void*, size_t>> take;
             take.swap(q);
+            const bool urgent = stop || queued > CAP_BYTES;  // (over the cap, or the library is unloading: at once, whatever runs beside it)
             queued = 0;
             lk.unlock();
-            for (auto& e : take) big_free_impl(e.first, e.second, /*pause=*/true);
+            for (auto& e : take) big_free_impl(e.first, e.second, /*pause=*/!urgent);
             lk.lock();
         }
     }
