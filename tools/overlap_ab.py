@@ -8,6 +8,10 @@ CHILD = r'''
 import os, sys, time, zlib
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, ctypes as C
+if os.environ.get("AB_TORCH"):
+    import torch
+    torch.cuda.synchronize()
+    _buf = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
 import reverie_amd as rv
 from reverie_amd import _lib
 import circuits
