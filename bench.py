@@ -443,10 +443,15 @@ def main():
     L.rv_ctx_profile(ctx.handle, 1, 1, None)
     sync_all()
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         step()
+        step_marks.append(time.perf_counter())
     sync_all()
     dt = time.perf_counter() - t0
+    if os.environ.get("RV_BENCH_STEP_TIMES") and rank == 0:  # (diagnostic: the K steps one by one; the timed region is unchanged)
+        prev = [t0] + step_marks[:-1]
+        print("step ms: " + " ".join("%.3f" % ((b - a) * 1e3) for a, b in zip(prev, step_marks)), file=sys.stderr)
     prof = _lib.Profile()
     L.rv_ctx_profile(ctx.handle, 0, 0, C.byref(prof))
     if world > 1:

@@ -18,7 +18,11 @@ import circuits
 reps = int(sys.argv[1])
 p_and = float(os.environ.get("AB_P_AND", "0.5"))
 prog, wit, wc, st = circuits.layered_gf2(p_and=p_and)
-seeds = np.frombuffer(bytes(range(256)) * 16, np.uint8).reshape(256, 16)
+# (random seeds, as bench.py's: with the counting pattern bytes(range(256)) * 16 only 16 of the 256 repetitions' seeds differ, and the
+# GPU then runs the same kernels 4 % faster -- masks || levels 3.17 against 3.27 ms, hashes 1.06 against 1.16 -- less switching, higher
+# clocks: tools/mb/bench_bisect.py.  AB_SEEDS=count restores the old pattern)
+seeds = (np.frombuffer(bytes(range(256)) * 16, np.uint8).reshape(256, 16) if os.environ.get("AB_SEEDS") == "count"
+         else np.random.default_rng(0x5EED).integers(0, 256, (256, 16), dtype=np.uint8))
 L = _lib.lib()
 c = rv.Circuit(prog, wc, whole_prover=os.environ.get("AB_HINT", "1") != "0")
 for _ in range(3):
@@ -26,7 +30,10 @@ for _ in range(3):
 ctx = rv.Context.default()
 L.rv_ctx_profile(ctx.handle, 1, 1, None)
 ts = []
+gap = float(os.environ.get("AB_GAP_MS", "0")) * 1e-3   # host idle between proofs (bench.py's loop has none)
 for i in range(reps):
+    if gap:
+        time.sleep(gap)
     t = time.perf_counter()
     p = rv.Proof.new(c, wit, [], seeds=seeds)
     ts.append((time.perf_counter() - t) * 1e3)
