@@ -137,6 +137,15 @@ struct HelperPool {
 // context: one device, one stream, a caching arena (hipMalloc of GB-sized buffers costs
 // milliseconds; proofs over the same circuit reuse the same sizes)
 // ------------------------------------------------------------------------------------
+// a kept copy of an op array (opscache.inc): plain uninitialised memory -- a std::vector would zero 240 MB before the copy overwrites them
+struct OpsCopy {
+    uint8_t* p;
+    size_t bytes;
+    explicit OpsCopy(size_t n);
+    ~OpsCopy();
+    OpsCopy(const OpsCopy&) = delete;
+    OpsCopy& operator=(const OpsCopy&) = delete;
+};
 struct rv_ctx {
     int device = 0;
     size_t lds_bytes = 0;  // hipDeviceAttributeMaxSharedMemoryPerBlock
@@ -208,7 +217,7 @@ struct rv_ctx {
     // Proof::new takes the op list at every call (proof/mod.rs:119-124), and a caller that proves one circuit again and again through
     // that signature should pay the 70 - 90 ms host compile once, not per proof
     struct OpsEntry {
-        std::shared_ptr<std::vector<uint8_t>> ops;  // the op array the circuit was compiled from: a hit is a comparison against it
+        std::shared_ptr<OpsCopy> ops;  // the op array the circuit was compiled from: a hit is a comparison against it
         std::string knobs;
         size_t n_ops, z64_wires, gf2_wires;
         uint32_t flags;
