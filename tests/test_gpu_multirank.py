@@ -24,9 +24,12 @@ def build_shim():
     return SHIM
 
 
+@pytest.mark.parametrize("sendrecv", ["0", "1"])
 @pytest.mark.parametrize("worlds", [("2", "4"), ("8",)])
-def test_rv_prove_multi_with_several_ranks_on_one_gpu(worlds):
-    env = dict(os.environ, RV_RCCL_PATH=build_shim())
+def test_rv_prove_multi_with_several_ranks_on_one_gpu(worlds, sendrecv):
+    """sendrecv = 1: the gather rv_prove_sharded uses between PROCESSES (sections to rank 0 by ncclSend / ncclRecv, RV_MULTI_SENDRECV);
+    0: rv_prove_multi's own (round 6: every rank copies its sections into one page-locked buffer)"""
+    env = dict(os.environ, RV_RCCL_PATH=build_shim(), RV_MULTI_SENDRECV=sendrecv)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), *worlds], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -40,7 +43,7 @@ def test_rv_prove_multi_full_size_config4():
     """BASELINE config 4 at full size (10^7 gates, 5 014 185 AND) through the multi-rank C path with 2 and 8 ranks sharing the GPU:
     every rank holds the replicated gate stream (0.3 GB) and a 128- / 32-repetition shard; rank 0's framed 50 MB proof must be
     the oracle's and rv_prove's, byte for byte (reference: proof/mod.rs:127-172)"""
-    env = dict(os.environ, RV_RCCL_PATH=build_shim(), MULTI_FULL="1")
+    env = dict(os.environ, RV_RCCL_PATH=build_shim(), MULTI_FULL="1", RV_MULTI_SENDRECV="1")  # (the send / recv gather at full size; the shared buffer: the test above)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), "2", "8"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
