@@ -509,6 +509,9 @@ int rv_hook_shard_stream_digests(rv_shard *s, uint8_t *out);
 uint64_t rv_hook_early_proofs(void);
 /* rv_prove_ops / rv_verify_ops calls of this process that found their op list's compiled circuit in the context's cache (ABI 7). */
 uint64_t rv_hook_ops_cache_hits(void);
+/* Host only, no device: the comparison a cache lookup of rv_prove_ops / rv_verify_ops decides on -- 1 iff the two ranges hold the same
+ * bytes (parallel memcmp, first difference ends it), 0 if not, -1 on a NULL range. */
+int rv_hook_ops_same(const void *a, const void *b, size_t bytes);
 /* Shard commitments of this process whose GF(2) mask generator ran BESIDE the interpreter's level launches (round 5: the
  * lane-distributed cipher of csrc/aes_col4.hip on a stream of its own, chunk by chunk; RV_OVERLAP=0 runs it before the first level;
  * circuits below RV_OVERLAP_MIN = 8192 cipher blocks and rows narrower than 64 repetitions keep that order anyway).  Same bytes. */

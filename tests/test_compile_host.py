@@ -338,3 +338,28 @@ def test_parallel_compiler_survives_a_failing_worker(monkeypatch):
         assert compile_once() == 6  # RV_E_NOMEM
     monkeypatch.delenv("RV_TEST_POOL_THROW")
     assert compile_once() == 0 and ci.gf2_muls == st["and"]
+
+
+def test_ops_cache_comparison_is_by_content(L):
+    """The compiled-circuit cache of rv_prove_ops / rv_verify_ops finds a circuit by comparing the op arrays themselves (round 6; round 5's
+    unkeyed 128-bit hash had constructible collisions: VERDICT r5 weak #2).  rv_hook_ops_same is that comparison: equal arrays, a copy, one
+    differing byte anywhere in a 40 MB array (first / middle / last 4 MiB piece), and the verdict's colliding pair (op 2's imm = the hash's
+    public constant, op 3 differs) must all come out right."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, 40 * 1024 * 1024 + 12345, dtype=np.uint8)
+    b = a.copy()
+    same = lambda x, y: L.rv_hook_ops_same(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_size_t(x.nbytes))  # noqa: E731
+    assert same(a, a) == 1 and same(a, b) == 1
+    for pos in (0, 1, (4 << 20) - 1, 4 << 20, 17 << 20, len(a) // 2, len(a) - 2, len(a) - 1):
+        b[pos] ^= 0x40
+        assert same(a, b) == 0, pos
+        b[pos] ^= 0x40
+    assert same(a, b) == 1
+
+    def circuit(assertion):
+        ops = [GF2.Input(0), GF2.Input(1), Z64.AddConst(0, 0, 0xE7037ED1A0B428DB), GF2.AssertZero(0) if assertion else GF2.AddConst(2, 0, 1)]
+        ops += [GF2.Mul(3 + i, 0, 1) for i in range(2044)]
+        return program(ops)
+
+    pa, pb = circuit(True), circuit(False)
+    assert pa.nbytes == pb.nbytes == 2048 * 24 and same(pa, pb) == 0 and same(pa, pa.copy()) == 1
