@@ -307,6 +307,11 @@ def test_early_plan_pcie_window(L, monkeypatch):
     monkeypatch.setenv("RV_EARLY_MIN", "1000")
     prog, _, wc, st = circuits.layered_gf2(n_in=64, width=1 << 20, layers=4, p_and=1.0, fold_to=16)
     assert st["and"] == 4 << 20
+    # (round 6: with the mask generator beside the levels the phase lasts as long as the cipher needs -- 0.6 ns per Mul, and 32 bytes per Mul
+    # cross the link in 0.58: everything fits; with the masks before the first level the window is the levels' own time again)
+    p = early_plan(L, prog, wc)
+    assert p["ok"] and p["check"] and p["reps"] == 256, p
+    monkeypatch.setenv("RV_OVERLAP", "0")
     p = early_plan(L, prog, wc)
     assert p["ok"] and p["check"] and 64 <= p["reps"] < 256 and p["reps"] % 8 == 0, p
     monkeypatch.setenv("RV_EARLY", "2")
