@@ -9,7 +9,7 @@ import reverie_amd as rv
 import circuits
 p_and = float(os.environ.get("AB_P_AND", "0.5"))
 prog, wit, wc, st = circuits.layered_gf2(p_and=p_and)
-seeds = np.frombuffer(bytes(range(256)) * 16, np.uint8).reshape(256, 16)
+seeds = np.random.default_rng(0x5EED).integers(0, 256, (256, 16), dtype=np.uint8)  # (random, as bench.py: the counting pattern has 16 distinct seeds and runs 4 % faster)
 args = [a for a in sys.argv[1:] if not a.startswith("rounds=")]
 rounds = int(([a for a in sys.argv[1:] if a.startswith("rounds=")] or ["rounds=15"])[0].split("=")[1])
 variants = [("default", {})] + [(a, dict(kv.split("=") for kv in a.split())) for a in args]
