@@ -64,7 +64,23 @@ def host_info():
     except OSError:
         pass
     logical = os.cpu_count() or 1
-    return {"cpu_model": model, "logical_cpus": logical, "physical_cores": len(cores) or logical}
+    return {"cpu_model": model, "logical_cpus": logical, "physical_cores": len(cores) or logical, "cpu_quota": cpu_quota()}
+
+
+def cpu_quota():
+    """CPUs this process's cgroup may use at a time (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1), None when unlimited or
+    unreadable.  The benchmark boxes grant 16 of their 256 logical CPUs: threads beyond the quota only take turns."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(prog, w2, w64, wc, seeds, units, unit, what, runs=5):
@@ -75,6 +91,8 @@ def cpu_baseline(prog, w2, w64, wc, seeds, units, unit, what, runs=5):
 
     hi = host_info()
     threads = max(1, min(32, hi["physical_cores"]))
+    if hi["cpu_quota"]:
+        threads = max(1, min(threads, int(hi["cpu_quota"] + 0.5)))  # (more threads than granted CPUs would only take turns)
     times, proof = [], None
     for _ in range(runs):
         t0 = time.perf_counter()
@@ -84,8 +102,8 @@ def cpu_baseline(prog, w2, w64, wc, seeds, units, unit, what, runs=5):
     return {
         "value": units / med, "unit": unit, "cores": threads, "kind": "port",
         "sample": f"{what}: {runs} proofs, median {med:.3f} s (min {min(times):.3f}, max {max(times):.3f}); "
-                  f"{threads} threads = one per packed group (32 groups), capped by the physical cores",
-        "cpu_model": hi["cpu_model"], "physical_cores": hi["physical_cores"], "logical_cpus": hi["logical_cpus"],
+                  f"{threads} threads over the 32 packed groups (one each at most), capped by the physical cores and by the cgroup's CPU quota",
+        "cpu_model": hi["cpu_model"], "physical_cores": hi["physical_cores"], "logical_cpus": hi["logical_cpus"], "cpu_quota": hi["cpu_quota"],
         "simd": "AES-NI, AVX2 (movemask bit transpose, 8-way BLAKE3)", "proof_bytes": len(proof),
     }, proof
 
