@@ -149,6 +149,7 @@ int compile_ops_seq(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2
 constexpr int RV_COMPILE_FALLBACK = -1;
 int compile_ops_par(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, int force_lazy_k, int n_threads);
 int compile_threads();
+unsigned cpu_budget();  // logical CPUs capped by the cgroup's CPU quota
 // 0 when the two compiled circuits are identical field by field, else a number naming the first difference (test hook)
 int compiled_diff(const Compiled& a, const Compiled& b);
 

@@ -404,11 +404,38 @@ static void big_free_impl(void* p, size_t bytes, bool pause) {
 }
 void big_free(void* p, size_t bytes) { big_free_impl(p, bytes, false); }
 
+// CPUs this process may use at a time: the logical CPUs, capped by the cgroup's CPU quota (cpu.max of cgroup v2, cfs_quota_us /
+// cfs_period_us of v1).  The compiler's data-flow pass spin-waits: with more threads than granted CPUs the kernel throttles the whole
+// group for the rest of each period (the benchmark boxes grant 16 of 256 logical CPUs -- 16 / 24 / 32 / 64 threads: 82 / 93 / 104 /
+// 480 ms for a cold proof of the 10^7-gate circuit).
+unsigned cpu_budget() {
+    static const unsigned budget = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        auto cap = [&](double quota, double period) {
+            if (quota > 0 && period > 0) n = std::min(n, std::max(1u, (unsigned)(quota / period + 0.5)));
+        };
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            double p = 0;
+            if (fscanf(f, "%31s %lf", q, &p) == 2 && strcmp(q, "max") != 0) cap(atof(q), p);
+            fclose(f);
+        } else {
+            double q = 0, p = 0;
+            FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+            FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+            if (fq && fp && fscanf(fq, "%lf", &q) == 1 && fscanf(fp, "%lf", &p) == 1) cap(q, p);
+            if (fq) fclose(fq);
+            if (fp) fclose(fp);
+        }
+        return n;
+    }();
+    return budget;
+}
+
 int compile_threads() {
     if (const char* e = getenv("RV_COMPILE_THREADS")) return std::max(1, atoi(e));
-    const unsigned hc = std::thread::hardware_concurrency();
-    // (16: measured on the 128-core host of the GPU box -- 0.12 s for the 10^7-gate circuit with 16 or 32 threads, 32 with more spread)
-    return (int)std::min(16u, std::max(1u, hc));
+    // (16: measured on the GPU boxes -- 8 / 16 threads 119 / 82 ms cold, and 16 is their whole CPU quota)
+    return (int)std::min(16u, cpu_budget());
 }
 
 int compile_ops_par(const rv_op* ops, size_t n_ops, size_t z64_wires, size_t gf2_wires, Compiled& out, int force_lazy_k, int n_threads) {
