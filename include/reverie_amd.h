@@ -507,6 +507,10 @@ int rv_hook_shard_stream_digests(rv_shard *s, uint8_t *out);
  * ProverTranscript::extract returns, prover.rs:57-175 -- cross PCIe before the challenge exists).  The bytes are the same
  * either way; the tests use the counter to know which path they compared.  RV_EARLY=0 turns the path off. */
 uint64_t rv_hook_early_proofs(void);
+/* ... and those of them whose opened repetitions' broadcast vectors (the omitted player's shares, prover.rs:57-175) were written into
+ * the page-locked proof buffer by the extraction kernel itself (csrc/internal.h: OpenDirect; RV_OPEN_DIRECT=0/1 turns it off).  Same
+ * bytes either way. */
+uint64_t rv_hook_open_direct_proofs(void);
 /* rv_prove_ops / rv_verify_ops calls of this process that found their op list's compiled circuit in the context's cache (ABI 7). */
 uint64_t rv_hook_ops_cache_hits(void);
 /* Host only, no device: the comparison a cache lookup of rv_prove_ops / rv_verify_ops decides on -- 1 iff the two ranges hold the same

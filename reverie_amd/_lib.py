@@ -69,7 +69,7 @@ SYMBOLS = [
     "rv_hook_blake3", "rv_hook_shard_stream_digests", "rv_ctx_profile", "rv_shard_digests_to_device", "rv_shard_open_size", "rv_shard_open_into", "rv_shard_open_self", "rv_shard_open_gathered",
     "rv_bristol_parse", "rv_circuit_record_sizes", "rv_program_from_bincode", "rv_program_to_bincode", "rv_prove_batch", "rv_prove_device",
     "rv_verify_ex", "rv_verify_shard_ex", "rv_verify_finish_ex", "rv_verify_batch",
-    "rv_hook_gf2_reconstruct", "rv_hook_z64_reconstruct", "rv_hook_early_proofs", "rv_hook_ops_cache_hits", "rv_hook_ops_same", "rv_hook_overlap_commits", "rv_hook_early_plan", "rv_hook_verify_vc_count",
+    "rv_hook_gf2_reconstruct", "rv_hook_z64_reconstruct", "rv_hook_early_proofs", "rv_hook_open_direct_proofs", "rv_hook_ops_cache_hits", "rv_hook_ops_same", "rv_hook_overlap_commits", "rv_hook_early_plan", "rv_hook_verify_vc_count",
     "rv_stream_begin", "rv_stream_feed", "rv_stream_commit", "rv_stream_finish", "rv_stream_abort", "rv_stream_get_info", "rv_stream_same_cuts",
     "rv_prove_streaming", "rv_prove_ops", "rv_verify_ops", "rv_stream_verify_begin", "rv_stream_verify_finish", "rv_verify_streaming",
     "rv_comm_unique_id", "rv_comm_create", "rv_comm_create_all", "rv_comm_destroy", "rv_prove_sharded", "rv_prove_multi",
@@ -121,7 +121,7 @@ def lib():
             fn = getattr(L, name)
             if name in ("rv_ctx_destroy", "rv_circuit_destroy", "rv_shard_destroy", "rv_free", "rv_stream_abort", "rv_comm_destroy"):
                 fn.restype = None
-            elif name in ("rv_hook_early_proofs", "rv_hook_verify_vc_count", "rv_hook_ops_cache_hits", "rv_hook_overlap_commits"):
+            elif name in ("rv_hook_early_proofs", "rv_hook_open_direct_proofs", "rv_hook_verify_vc_count", "rv_hook_ops_cache_hits", "rv_hook_overlap_commits"):
                 fn.restype = C.c_uint64
             elif name not in ("rv_strerror", "rv_last_error", "rv_abi_version"):
                 fn.restype = C.c_int

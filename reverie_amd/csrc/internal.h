@@ -187,8 +187,17 @@ bool launch_b3_pair_small(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, 
 void launch_store_word(hipStream_t st, const int* d_src, int* dst_mapped);
 // early corrections (kernels.hip, api.hip: rv_prove on large GF(2) circuits)
 void launch_pack_corr_all(hipStream_t st, const uint8_t* d_bits, uint64_t n_items, uint64_t byte0, uint64_t n_bytes, uint64_t pitch, uint8_t* d_out);
+// OpenDirect: the first n_direct tiles of the opened repetitions' broadcast vectors (tile = `tile` bytes, a power of two, of every
+// opened repetition; vector at record + rvec_at, rvec_len bytes) are written to the page-locked proof buffer by the extraction kernel
+// itself -- its first workgroups; whole 16-byte aligned words only -- and k_copy_gaps leaves those words out (it still copies the
+// word across every tile boundary).  n_direct = 0: off.
+struct OpenDirect {
+    uint32_t n_direct = 0, tile = 0;
+    uint64_t rvec_at = 0, rvec_len = 0;
+};
 void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
-                      uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit /*[256]*/, uint32_t rep_limit);
+                      uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit /*[256]*/, uint32_t rep_limit, OpenDirect od = OpenDirect());
+uint32_t extract_tile_bytes(uint64_t n_items);  // the tile of launch_extract_bits for vectors of n_items bits
 void launch_publish(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, uint32_t* flag_mapped, uint32_t seq);
 void launch_store_words(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, const int* d_err, int* dst_err_mapped);
 // a narrow stretch with its live wires in LDS (ldsrun.h); d_pp != null: `batch` proofs, parameters from the device array
@@ -298,8 +307,10 @@ struct FsLayout {
 void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint32_t rep_begin, uint32_t R, uint8_t* d_comm,
                          uint8_t* d_omit, uint8_t* d_omit_all, uint64_t* d_offs, OnlineList* d_ol, uint32_t* d_res);
 // kind 0: omitted player's bit of a share row; 1: smeared byte of a row
+// d_out2 / n_direct (kind 0, rv_prove's early path): the first n_direct tiles ALSO go to d_out2 (the proof buffer's device address), same offsets
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,
-                         uint32_t NQ, int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out);
+                         uint32_t NQ, int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out, uint8_t* d_out2 = nullptr,
+                         uint32_t n_direct = 0);
 void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d_src_off, const uint64_t* d_src_len,
                         const uint8_t* d_omit, uint64_t n_items, uint32_t NQ, int kind, uint32_t* d_rows_out, uint32_t out_nq /* row stride in quad words */,
                         uint64_t first_item = 0 /* the vectors' item row 0 of the output is */);

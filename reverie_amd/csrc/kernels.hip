@@ -1474,6 +1474,11 @@ void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, 
 // writes per 16 lines read: the kernel was bound by write transactions, not by HBM bytes.)
 // ------------------------------------------------------------------------------------
 constexpr uint32_t EX_TB = 128;
+// (k_extract_rows: its own tile, for A/B builds)
+#ifndef RV_EXR_TB
+#define RV_EXR_TB 256
+#endif
+constexpr uint32_t EXR_TB = RV_EXR_TB;
 
 // slot of every opened repetition (rank among the opened ones) and its output offset, into LDS
 // stage_pitch != 0: the output is a dense staging block, slot k's bytes at k * stage_pitch (dst_off is not read)
@@ -1496,11 +1501,39 @@ __device__ __forceinline__ uint32_t ex_slots(const uint8_t* __restrict__ omit, c
 }
 
 // contiguous write-out of the collected bytes: s_buf[slot][0 .. nb)
+template <uint32_t TB = EX_TB>
 __device__ __forceinline__ void ex_flush(const uint8_t* s_buf, const uint64_t* s_dst, uint32_t n_slots, uint64_t t0, uint32_t nb,
                                          uint8_t* __restrict__ out, uint32_t k0 = 0) {
-    for (uint32_t idx = threadIdx.x + k0 * EX_TB; idx < n_slots * EX_TB; idx += blockDim.x) {
-        const uint32_t k = idx / EX_TB, i = idx % EX_TB;
-        if (i < nb && s_dst[k] != ~0ull) out[s_dst[k] + t0 + i] = s_buf[k * EX_TB + i];  // (~0: a slot that is left out)
+    for (uint32_t idx = threadIdx.x + k0 * TB; idx < n_slots * TB; idx += blockDim.x) {
+        const uint32_t k = idx / TB, i = idx % TB;
+        if (i < nb && s_dst[k] != ~0ull) out[s_dst[k] + t0 + i] = s_buf[k * TB + i];  // (~0: a slot that is left out)
+    }
+}
+
+// the same to page-locked HOST memory (internal.h: OpenDirect), in whole 16-byte aligned words: every word that STARTS inside the
+// slot's run of nb bytes and ends inside the nbx >= nb bytes the workgroup has extracted (a run starts at an odd offset of the proof;
+// byte stores cross the link as partial writes one by one, and with them the proof was SLOWER than without the direct path).  What is
+// left -- the partial words at a vector's two ends -- k_copy_gaps copies from the image.  `out` is 16-byte aligned; TB = the stride
+// of s_buf.
+template <uint32_t TB>
+__device__ __forceinline__ void ex_flush_host(const uint8_t* s_buf, const uint64_t* s_dst, uint32_t n_slots, uint64_t t0, uint32_t nb, uint32_t nbx,
+                                              uint8_t* __restrict__ out) {
+    constexpr uint32_t W = TB / 16 + 1;
+    for (uint32_t idx = threadIdx.x; idx < n_slots * W; idx += blockDim.x) {
+        const uint32_t k = idx / W, w = idx % W;
+        if (s_dst[k] == ~0ull) continue;
+        const uint64_t d0 = s_dst[k] + t0;
+        const uint64_t wa = (d0 & ~15ull) + 16ull * w;
+        if (wa >= d0 + nb) continue;
+        const uint8_t* sp = s_buf + k * TB;
+        if (wa >= d0 && wa + 16 <= d0 + nbx) {
+            const uint32_t o = (uint32_t)(wa - d0);
+            uint32_t x[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                x[q] = (uint32_t)sp[o + 4 * q] | ((uint32_t)sp[o + 4 * q + 1] << 8) | ((uint32_t)sp[o + 4 * q + 2] << 16) | ((uint32_t)sp[o + 4 * q + 3] << 24);
+            *(uint4*)(out + wa) = make_uint4(x[0], x[1], x[2], x[3]);
+        }
     }
 }
 
@@ -1509,9 +1542,12 @@ struct B_k_extract_rows {
     // stage_pitch / block0: a SLICE of the vectors (workgroups block0 .. block0 + gridDim.x of the whole launch) into a dense staging
     // block [slot][stage_pitch] instead of the proof image (rv_prove's early path: the slices leave through the copy engine while
     // the next ones are extracted)
-    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out, uint64_t stage_pitch, uint32_t block0) const {
-    __shared__ uint8_t s_buf[RV_ONLINE_REPS * EX_TB];
-    __shared__ uint32_t s_rows[8 * EX_TB];
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EXR_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out, uint64_t stage_pitch, uint32_t block0, uint8_t* __restrict__ out2 = nullptr, uint32_t n_direct = 0) const {
+    // (internal.h: OpenDirect) a workgroup that also writes to the proof buffer on the host sends every 16-byte aligned word that
+    // STARTS in its tile, so it extracts up to LA bytes of the next tile as well: no word is left for two workgroups to share
+    constexpr uint32_t LA = 16, SB = EXR_TB + LA;
+    __shared__ uint8_t s_buf[RV_ONLINE_REPS * SB];
+    __shared__ uint32_t s_rows[8 * SB];
     __shared__ uint8_t s_slot[256];
     __shared__ uint64_t s_dst[RV_ONLINE_REPS];
     __shared__ uint32_t s_cnt[4];
@@ -1520,8 +1556,10 @@ struct B_k_extract_rows {
     const uint64_t n_bytes = n_items / 8 + 1;
     const uint64_t t0 = (uint64_t)(blockIdx.x + block0) * tb;
     const uint32_t nb = (uint32_t)((n_bytes - t0 < tb) ? n_bytes - t0 : tb);
+    const bool direct = out2 && blockIdx.x + block0 < n_direct;
+    const uint32_t nbx = direct ? (uint32_t)((n_bytes - t0 < nb + LA) ? n_bytes - t0 : nb + LA) : nb;  // bytes extracted
     // this workgroup's row ids, one coalesced pass (ordinals past the end repeat the last item; masked below)
-    for (uint32_t i = threadIdx.x; i < 8 * nb; i += 256) {
+    for (uint32_t i = threadIdx.x; i < 8 * nbx; i += 256) {
         uint64_t it = 8 * t0 + i;
         if (it >= n_items) it = n_items ? n_items - 1 : 0;
         s_rows[i] = rows ? rows[it] : (uint32_t)it;
@@ -1547,7 +1585,7 @@ struct B_k_extract_rows {
     const uint32_t n_aq = s_naq;
     if (!n_aq) return;
     const uint32_t dtl = 256 / n_aq, da = 256 % n_aq;
-    for (uint32_t tl = threadIdx.x / n_aq, a = threadIdx.x % n_aq; tl < nb;) {
+    for (uint32_t tl = threadIdx.x / n_aq, a = threadIdx.x % n_aq; tl < nbx;) {
         const uint32_t q = s_aq[a];
         uint32_t sl[4], om[4];
 #pragma unroll
@@ -1572,7 +1610,7 @@ struct B_k_extract_rows {
             uint32_t acc = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) acc |= ((w[j] >> sh) & 1u) << (7 - j);
-            s_buf[sl[i] * EX_TB + tl] = (uint8_t)acc;
+            s_buf[sl[i] * SB + tl] = (uint8_t)acc;
         }
         a += da;
         tl += dtl;
@@ -1582,12 +1620,13 @@ struct B_k_extract_rows {
         }
     }
     __syncthreads();
-    ex_flush(s_buf, s_dst, n_slots, t0, nb, out);
+    ex_flush<SB>(s_buf, s_dst, n_slots, t0, nb, out);
+    if (direct) ex_flush_host<SB>(s_buf, s_dst, n_slots, t0, nb, nbx, out2);
 }
 };
 template <int KIND>
-__global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out, uint64_t stage_pitch, uint32_t block0) {
-    B_k_extract_rows<KIND>{}(stream, rows, n_items, NQ, tb, omit, dst_off, out, stage_pitch, block0);
+__global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out, uint64_t stage_pitch, uint32_t block0, uint8_t* __restrict__ out2, uint32_t n_direct) {
+    B_k_extract_rows<KIND>{}(stream, rows, n_items, NQ, tb, omit, dst_off, out, stage_pitch, block0, out2, n_direct);
 }
 
 // Bit-per-rep source (the preprocessing stream, [n][NQ/2] bytes; nibble bit k of quad q <-> repetition 4q+3-k):
@@ -1651,10 +1690,10 @@ __global__ __launch_bounds__(256) void k_extract_from_bits(const uint8_t* __rest
     B_k_extract_from_bits{}(bits, n_items, NQ, tb, olp, out, rep_min);
 }
 
-static uint32_t ex_tb_for(uint64_t n_bytes) {
+static uint32_t ex_tb_for(uint64_t n_bytes, uint32_t cap = EX_TB) {
     // output bytes per workgroup: the full EX_TB when that still yields several workgroups per CU, fewer for
     // short vectors (a workgroup walks its bytes in a serial loop)
-    uint32_t tb = EX_TB;
+    uint32_t tb = cap;
     while (tb > 8 && (n_bytes + tb - 1) / tb < 2048) tb /= 2;
     return tb;
 }
@@ -1831,17 +1870,19 @@ void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, 
     launch<B_k_fs_challenge, 64>(k_fs_challenge, st, dim3(1), dim3(64), d_h, L, rep_begin, R, d_comm, d_omit, d_omit_all, d_offs, d_ol, d_res);
 }
 
+uint32_t extract_tile_bytes(uint64_t n_items) { return ex_tb_for(n_items / 8 + 1, EXR_TB); }
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows, uint64_t n_items, uint32_t NQ,
-                         int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out) {
+                         int kind, const uint8_t* d_omit, const uint64_t* d_dst_off, uint8_t* d_out, uint8_t* d_out2, uint32_t n_direct) {
     const uint64_t n_bytes = n_items / 8 + 1;
-    const uint32_t tb = ex_tb_for(n_bytes);
+    const uint32_t tb = ex_tb_for(n_bytes, EXR_TB);
     const dim3 grid((unsigned)((n_bytes + tb - 1) / tb));
+    if (!n_direct) d_out2 = nullptr;
     if (kind == 0)
         launch<B_k_extract_rows<0>, 256>(k_extract_rows<0>, st, grid, dim3(256), (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
-                           d_dst_off, d_out, 0, 0);
+                           d_dst_off, d_out, 0, 0, d_out2, n_direct);
     else
         launch<B_k_extract_rows<1>, 256>(k_extract_rows<1>, st, grid, dim3(256), (const uint32_t*)d_stream, d_rows, n_items, NQ, tb, d_omit,
-                           d_dst_off, d_out, 0, 0);
+                           d_dst_off, d_out, 0, 0, (uint8_t*)nullptr, 0u);
 }
 
 // Inverse for the verifier (Pack::unpack / PackSelected::unpack_selected): builds dense
@@ -2140,7 +2181,7 @@ void launch_pack_corr_all(hipStream_t st, const uint8_t* d_bits, uint64_t n_item
 // both bases 16-byte aligned.
 __global__ __launch_bounds__(256) void k_copy_gaps(const uint8_t* __restrict__ img, uint8_t* __restrict__ dst_mapped, uint64_t total, uint64_t first,
                                                    uint64_t rec, uint64_t corr_at, uint64_t corr_len, uint32_t n_rec, const uint8_t* __restrict__ omit,
-                                                   uint32_t rep_limit) {
+                                                   uint32_t rep_limit, OpenDirect od) {
     __shared__ uint32_t s_m;
     if (threadIdx.x < 64) {
         uint32_t cnt = 0;
@@ -2158,14 +2199,33 @@ __global__ __launch_bounds__(256) void k_copy_gaps(const uint8_t* __restrict__ i
     if (a16 > b16) a16 = b16 = b;  // shorter than one aligned word: bytes only
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = a + tid; i < a16; i += nth) dst_mapped[i] = img[i];
-    for (uint64_t i = a16 + 16 * tid; i < b16; i += 16 * nth) *(uint4*)(dst_mapped + i) = *(const uint4*)(img + i);
+    if (od.n_direct && j < m) {
+        // record j's broadcast vector lies in this piece: the words inside the tiles the extraction kernel has sent already are left
+        // out (the image holds every tile, so a word across the boundary is simply copied)
+        const uint64_t v0 = first + (uint64_t)j * rec + od.rvec_at;
+        const uint64_t v1 = std::min(v0 + (uint64_t)od.n_direct * od.tile, v0 + od.rvec_len);  // [v0, v1): the tiles sent already
+        const uint64_t ve = v0 + od.rvec_len;
+        for (uint64_t i = a16 + 16 * tid; i < b16; i += 16 * nth) {
+            // a whole word of the vector that starts in one of those tiles is there (k_extract_rows: LA)
+            if (i >= v0 && i < v1 && i + 16 <= ve) {
+                const uint64_t last = std::min(v1, ve - 15);                        // first word start that is NOT there (or beyond)
+                const uint64_t nsk = (last - i + 16 * nth - 1) / (16 * nth);  // this thread's words up to it
+                i += (nsk - 1) * 16 * nth;
+                continue;
+            }
+            *(uint4*)(dst_mapped + i) = *(const uint4*)(img + i);
+        }
+    } else {
+        for (uint64_t i = a16 + 16 * tid; i < b16; i += 16 * nth) *(uint4*)(dst_mapped + i) = *(const uint4*)(img + i);
+    }
     for (uint64_t i = b16 + tid; i < b; i += nth) dst_mapped[i] = img[i];
 }
 void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
-                      uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit, uint32_t rep_limit) {
+                      uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit, uint32_t rep_limit, OpenDirect od) {
+    if (!od.n_direct || od.tile < 16 || (od.tile & (od.tile - 1))) od = OpenDirect();
     // (the last piece may be most of the image -- Z64 with few staged repetitions --: enough workgroups per piece to fill PCIe alone)
     hipLaunchKernelGGL(k_copy_gaps, dim3(rep_limit < RV_TOTAL_REPS ? 64 : 8, n_rec + 1), dim3(256), 0, st, d_img, dst_mapped, total, first, rec, corr_at, corr_len,
-                       n_rec, d_omit, rep_limit);
+                       n_rec, d_omit, rep_limit, od);
 }
 
 // n_words of device memory into host-mapped memory, then (ordered behind them at system scope) a sequence number the

@@ -1244,6 +1244,35 @@ def test_early_corrections_path(rv, oracle, rule_seeds, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("direct", ["0/1", "1/1", "1/2", "1/7"])
+def test_early_corrections_openings_direct(rv, oracle, rule_seeds, monkeypatch, direct):
+    """The early path's second half (csrc/internal.h: OpenDirect): the opened repetitions' broadcast vectors written into the
+    page-locked proof buffer by the extraction kernel itself -- whole 16-byte aligned words, each workgroup every word that STARTS in
+    its tile -- and k_copy_gaps bringing the rest of the image: the oracle's bytes with none, all, half and a seventh of the tiles
+    sent that way, with all and with only 96 of the repetitions staged (the records beyond them keep their corrections in the
+    image), Mul counts that are and are not multiples of 8."""
+    from reverie_amd import _lib
+
+    L = _lib.lib()
+    monkeypatch.setenv("RV_EARLY_MIN", "1000")
+    monkeypatch.setenv("RV_EARLY", "2")
+    monkeypatch.setenv("RV_OPEN_DIRECT", direct)
+    # (vectors of 32 KiB and more: tiles of 16 bytes, the smallest the path takes)
+    for n_in, width, layers, p_and, reps, fold_to in [(64, 16384, 36, 0.5, None, 16), (37, 9472, 70, 0.6, "96", 37), (64, 16384, 30, 1.0, None, 16)]:
+        if reps:
+            monkeypatch.setenv("RV_EARLY_REPS", reps)
+        else:
+            monkeypatch.delenv("RV_EARLY_REPS", raising=False)
+        prog, wit, wc, st = circuits.layered_gf2(n_in=n_in, width=width, layers=layers, p_and=p_and, fold_to=fold_to)
+        want = oracle.prove(prog, wit, [], wc, rule_seeds, threads=4)
+        c = rv.Circuit(prog, wc)
+        n0 = L.rv_hook_open_direct_proofs()
+        for _ in range(2):
+            assert bytes(rv.Proof.new(c, wit, [], seeds=rule_seeds)) == want, (direct, width, layers, st["and"] % 8)
+        assert L.rv_hook_open_direct_proofs() == n0 + (0 if direct == "0/1" else 2), "the direct openings were not (or should not have been) taken"
+        c.close()
+
+
 @pytest.mark.parametrize("reps", ["64", "128", "256"])
 def test_early_corrections_path_z64(rv, oracle, rule_seeds, monkeypatch, reps):
     """The Z64 form of the early-corrections path (a repetition's corrections vector is its preprocessing transcript: word
