@@ -1021,8 +1021,10 @@ __global__ __launch_bounds__(256) void k_b3_chunks_bits1(const uint8_t* __restri
 template <int LG>
 struct B_k_b3_reduce {
     __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in, uint64_t n_in, uint32_t R, uint32_t* __restrict__ out) const {
+    run((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, in, n_in, R, out);
+    }
+    static __device__ __forceinline__ void run(uint64_t tid, const uint32_t* __restrict__ in, uint64_t n_in, uint32_t R, uint32_t* __restrict__ out) {
     constexpr int G = 1 << LG;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t n_out = (n_in + G - 1) / G;
     const uint64_t g = tid / R;
     const uint32_t r = (uint32_t)(tid % R);
@@ -1221,6 +1223,96 @@ bool launch_b3_pair_small(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, 
     launch<B_k_b3_tree_tail_pair, 64>(k_b3_tree_tail_pair, st, dim3(2 * R), dim3(64), (const uint32_t*)d_cv_a, (uint32_t)c_pre, d_dig_pre,
                                       (const uint32_t*)d_cv_b, (uint32_t)c_on, d_dig_on, R);
     return true;
+}
+
+// The trees of BOTH transcripts of a large proof in shared launches (blockIdx.y = the stream): after the two chunk kernels a whole
+// proof of the 10^7-gate circuit ran two reduction launches and a tree top per stream, six dependent launches of ~20 us that each
+// occupy a fraction of the chip -- three of them now.  A stream that is already at the tree top's size sits a reduction out.
+// ... and their chunk kernels as ONE launch: the first workgroups hash the preprocessing stream (a bit per repetition), the others the online
+// stream (a byte), a chunk per wavefront in both (B_k_b3_chunks<4, true>) -- the ragged last generation of the first fills with
+// wavefronts of the second (on two streams that cost more in events than it gave: DESIGN.md section 4)
+struct B_k_b3_chunks_pair_uni {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
+                                               uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t blocks_pre) const {
+    const uint64_t c_pre = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, c_on = n_on == 0 ? 1 : (n_on + 1023) / 1024;
+    if (blockIdx.x < blocks_pre)
+        B_k_b3_chunks_bits<4, true>::run((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, pre, n_pre, 64, c_pre, cv_pre, 0, 1);
+    else
+        B_k_b3_chunks<4, true>::run((uint64_t)(blockIdx.x - blocks_pre) * blockDim.x + threadIdx.x, on, n_on, 64, c_on, cv_on, nullptr, 0, 0, 1);
+    }
+};
+__global__ __launch_bounds__(256) void k_b3_chunks_pair_uni(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
+                                                            uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t blocks_pre) {
+    B_k_b3_chunks_pair_uni{}(pre, n_pre, cv_pre, on, n_on, cv_on, blocks_pre);
+}
+struct B_k_b3_reduce_pair {
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in_a, uint64_t n_a, uint32_t* __restrict__ out_a, const uint32_t* __restrict__ in_b,
+                                               uint64_t n_b, uint32_t* __restrict__ out_b, uint32_t R) const {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y == 0) {
+        if (n_a > B3_TAIL) B_k_b3_reduce<2>::run(tid, in_a, n_a, R, out_a);
+    } else {
+        if (n_b > B3_TAIL) B_k_b3_reduce<2>::run(tid, in_b, n_b, R, out_b);
+    }
+    }
+};
+__global__ __launch_bounds__(256) void k_b3_reduce_pair(const uint32_t* __restrict__ in_a, uint64_t n_a, uint32_t* __restrict__ out_a, const uint32_t* __restrict__ in_b,
+                                                        uint64_t n_b, uint32_t* __restrict__ out_b, uint32_t R) {
+    B_k_b3_reduce_pair{}(in_a, n_a, out_a, in_b, n_b, out_b, R);
+}
+struct B_k_b3_tree_tail_pair_big {
+    __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in_a, uint32_t n_a, uint32_t* __restrict__ dig_a, const uint32_t* __restrict__ in_b, uint32_t n_b,
+                                               uint32_t* __restrict__ dig_b, uint32_t R) const {
+    if (blockIdx.x < R)
+        B_k_b3_tree_tail<(int)B3_TAIL>::run(blockIdx.x, in_a, n_a, R, dig_a);
+    else
+        B_k_b3_tree_tail<(int)B3_TAIL>::run(blockIdx.x - R, in_b, n_b, R, dig_b);
+    }
+};
+__global__ __launch_bounds__(256) void k_b3_tree_tail_pair_big(const uint32_t* __restrict__ in_a, uint32_t n_a, uint32_t* __restrict__ dig_a, const uint32_t* __restrict__ in_b,
+                                                               uint32_t n_b, uint32_t* __restrict__ dig_b, uint32_t R) {
+    B_k_b3_tree_tail_pair_big{}(in_a, n_a, dig_a, in_b, n_b, dig_b, R);
+}
+static uint64_t b3_rpl1_lanes();
+// does launch_b3_pair_big take these two transcripts?  (both trees must end in the 256-thread tree top: more than 64 nodes left)
+bool b3_pair_big_ok(uint64_t n_pre, uint64_t n_on, uint32_t NQ) {
+    if (NQ != 64 || g_recorder) return false;
+    for (uint64_t n_ev : {n_pre, n_on}) {
+        uint64_t n = n_ev == 0 ? 1 : (n_ev + 1023) / 1024;
+        if (n * NQ < b3_rpl1_lanes()) return false;  // (short transcripts: the separate launchers pick other chunk kernels)
+        while (n > B3_TAIL) n = (n + 3) / 4;
+        if (n <= 64) return false;
+    }
+    return true;
+}
+// cv_a0 / cv_a1 and cv_b0 / cv_b1: ping-pong buffers of the preprocessing and the online stream (b3_stream_scratch_words each);
+// -> launches
+uint32_t launch_b3_pair_big(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, const uint32_t* d_on, uint64_t n_on, uint32_t NQ, uint32_t* cv_a0,
+                            uint32_t* cv_a1, uint32_t* cv_b0, uint32_t* cv_b1, uint32_t* d_dig_pre, uint32_t* d_dig_on) {
+    const uint32_t R = NQ * 4;
+    uint64_t n_a = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, n_b = n_on == 0 ? 1 : (n_on + 1023) / 1024;
+    uint32_t launches;
+    if (RV_B3_RPL == 4) {
+        const uint32_t b_pre = (uint32_t)((n_a * 64 + 255) / 256), b_on = (uint32_t)((n_b * 64 + 255) / 256);  // (a chunk per wavefront)
+        launch<B_k_b3_chunks_pair_uni, 256>(k_b3_chunks_pair_uni, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, cv_a0, d_on, n_on, cv_b0, b_pre);
+        launches = 1;
+    } else {
+        launch_b3_stream_bits_chunks(st, d_pre, n_pre, NQ, cv_a0, 0, 1);
+        launch_b3_stream_chunks(st, d_on, n_on, NQ, cv_b0, nullptr, 0, 0, 1);
+        launches = 2;
+    }
+    while (n_a > B3_TAIL || n_b > B3_TAIL) {
+        const uint64_t out_a = (n_a + 3) / 4, out_b = (n_b + 3) / 4;
+        const uint64_t threads = std::max(n_a > B3_TAIL ? out_a : 0, n_b > B3_TAIL ? out_b : 0) * R;
+        launch<B_k_b3_reduce_pair, 256>(k_b3_reduce_pair, st, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), (const uint32_t*)cv_a0, n_a, cv_a1,
+                                        (const uint32_t*)cv_b0, n_b, cv_b1, R);
+        if (n_a > B3_TAIL) std::swap(cv_a0, cv_a1), n_a = out_a;
+        if (n_b > B3_TAIL) std::swap(cv_b0, cv_b1), n_b = out_b;
+        launches++;
+    }
+    launch<B_k_b3_tree_tail_pair_big, 256>(k_b3_tree_tail_pair_big, st, dim3(2 * R), dim3(256), (const uint32_t*)cv_a0, (uint32_t)n_a, d_dig_pre,
+                                           (const uint32_t*)cv_b0, (uint32_t)n_b, d_dig_on, R);
+    return launches + 1;
 }
 
 // tree reduction of n chunk chaining values per repetition; the roots land in d_digest ([R][8] words)
