@@ -183,9 +183,11 @@ void launch_interp_narrow(hipStream_t st, int mode, const Gate* d_gates, const L
 void launch_interp_batched(hipStream_t st, const Gate* d_gates, const LevelRange& r, const InterpParams* d_pp, uint32_t batch,
                            int mode = MODE_PROVE);
 // large proofs: the two transcripts' trees in shared launches (kernels.hip); four ping-pong buffers of b3_stream_scratch_words each
-bool b3_pair_big_ok(uint64_t n_pre, uint64_t n_on, uint32_t NQ);
+// (d_quads / n_quads as in launch_b3_stream: the verifier's online stream of the quad words with an opened repetition)
+bool b3_pair_big_ok(uint64_t n_pre, uint64_t n_on, uint32_t NQ, const uint32_t* d_quads = nullptr, uint32_t n_quads = 0);
 uint32_t launch_b3_pair_big(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, const uint32_t* d_on, uint64_t n_on, uint32_t NQ, uint32_t* cv_a0,
-                            uint32_t* cv_a1, uint32_t* cv_b0, uint32_t* cv_b1, uint32_t* d_dig_pre, uint32_t* d_dig_on);
+                            uint32_t* cv_a1, uint32_t* cv_b0, uint32_t* cv_b1, uint32_t* d_dig_pre, uint32_t* d_dig_on, const uint32_t* d_quads = nullptr,
+                            uint32_t n_quads = 0);
 bool launch_b3_pair_small(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, const uint32_t* d_on, uint64_t n_on, uint32_t NQ, uint32_t* d_cv_a,
                           uint32_t* d_cv_b, uint32_t* d_dig_pre, uint32_t* d_dig_on, const uint32_t* d_quads = nullptr, uint32_t n_quads = 0);
 void launch_store_word(hipStream_t st, const int* d_src, int* dst_mapped);

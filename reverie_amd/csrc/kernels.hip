@@ -1231,19 +1231,25 @@ bool launch_b3_pair_small(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, 
 // ... and their chunk kernels as ONE launch: the first workgroups hash the preprocessing stream (a bit per repetition), the others the online
 // stream (a byte), a chunk per wavefront in both (B_k_b3_chunks<4, true>) -- the ragged last generation of the first fills with
 // wavefronts of the second (on two streams that cost more in events than it gave: DESIGN.md section 4)
+// (QUADS: the verifier -- the online stream of the quad words with an opened repetition only, a lane per listed quad word)
+template <bool QUADS>
 struct B_k_b3_chunks_pair_uni {
     __device__ __forceinline__ void operator()(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
-                                               uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t blocks_pre) const {
+                                               uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t blocks_pre, const uint32_t* __restrict__ quads, uint32_t n_quads) const {
     const uint64_t c_pre = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, c_on = n_on == 0 ? 1 : (n_on + 1023) / 1024;
     if (blockIdx.x < blocks_pre)
         B_k_b3_chunks_bits<4, true>::run((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, pre, n_pre, 64, c_pre, cv_pre, 0, 1);
+    else if (QUADS)
+        B_k_b3_chunks<4, false>::run((uint64_t)(blockIdx.x - blocks_pre) * blockDim.x + threadIdx.x, on, n_on, 64, c_on, cv_on, quads, n_quads, 0, 1);
     else
         B_k_b3_chunks<4, true>::run((uint64_t)(blockIdx.x - blocks_pre) * blockDim.x + threadIdx.x, on, n_on, 64, c_on, cv_on, nullptr, 0, 0, 1);
     }
 };
+template <bool QUADS>
 __global__ __launch_bounds__(256) void k_b3_chunks_pair_uni(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
-                                                            uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t blocks_pre) {
-    B_k_b3_chunks_pair_uni{}(pre, n_pre, cv_pre, on, n_on, cv_on, blocks_pre);
+                                                            uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t blocks_pre, const uint32_t* __restrict__ quads,
+                                                            uint32_t n_quads) {
+    B_k_b3_chunks_pair_uni<QUADS>{}(pre, n_pre, cv_pre, on, n_on, cv_on, blocks_pre, quads, n_quads);
 }
 struct B_k_b3_reduce_pair {
     __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in_a, uint64_t n_a, uint32_t* __restrict__ out_a, const uint32_t* __restrict__ in_b,
@@ -1275,11 +1281,12 @@ __global__ __launch_bounds__(256) void k_b3_tree_tail_pair_big(const uint32_t* _
 }
 static uint64_t b3_rpl1_lanes();
 // does launch_b3_pair_big take these two transcripts?  (both trees must end in the 256-thread tree top: more than 64 nodes left)
-bool b3_pair_big_ok(uint64_t n_pre, uint64_t n_on, uint32_t NQ) {
-    if (NQ != 64 || g_recorder) return false;
+bool b3_pair_big_ok(uint64_t n_pre, uint64_t n_on, uint32_t NQ, const uint32_t* d_quads, uint32_t n_quads) {
+    if (NQ != 64 || g_recorder || RV_B3_RPL != 4) return false;
+    if (d_quads && n_quads * 4 <= NQ) return false;  // (few opened quad words: the separate launcher hashes a repetition per lane)
     for (uint64_t n_ev : {n_pre, n_on}) {
         uint64_t n = n_ev == 0 ? 1 : (n_ev + 1023) / 1024;
-        if (n * NQ < b3_rpl1_lanes()) return false;  // (short transcripts: the separate launchers pick other chunk kernels)
+        if (n * (d_quads ? std::min(n_quads, NQ) : NQ) < b3_rpl1_lanes()) return false;  // (short transcripts: the separate launchers pick other chunk kernels)
         while (n > B3_TAIL) n = (n + 3) / 4;
         if (n <= 64) return false;
     }
@@ -1288,18 +1295,22 @@ bool b3_pair_big_ok(uint64_t n_pre, uint64_t n_on, uint32_t NQ) {
 // cv_a0 / cv_a1 and cv_b0 / cv_b1: ping-pong buffers of the preprocessing and the online stream (b3_stream_scratch_words each);
 // -> launches
 uint32_t launch_b3_pair_big(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, const uint32_t* d_on, uint64_t n_on, uint32_t NQ, uint32_t* cv_a0,
-                            uint32_t* cv_a1, uint32_t* cv_b0, uint32_t* cv_b1, uint32_t* d_dig_pre, uint32_t* d_dig_on) {
+                            uint32_t* cv_a1, uint32_t* cv_b0, uint32_t* cv_b1, uint32_t* d_dig_pre, uint32_t* d_dig_on, const uint32_t* d_quads,
+                            uint32_t n_quads) {
     const uint32_t R = NQ * 4;
     uint64_t n_a = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, n_b = n_on == 0 ? 1 : (n_on + 1023) / 1024;
-    uint32_t launches;
-    if (RV_B3_RPL == 4) {
-        const uint32_t b_pre = (uint32_t)((n_a * 64 + 255) / 256), b_on = (uint32_t)((n_b * 64 + 255) / 256);  // (a chunk per wavefront)
-        launch<B_k_b3_chunks_pair_uni, 256>(k_b3_chunks_pair_uni, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, cv_a0, d_on, n_on, cv_b0, b_pre);
-        launches = 1;
+    uint32_t launches = 1;
+    const uint32_t b_pre = (uint32_t)((n_a * 64 + 255) / 256);  // (a chunk per wavefront)
+    if (d_quads) {
+        // (the chaining values of skipped quad words stay whatever the buffer held: the tree above them runs on garbage and the caller
+        // replaces those digests, as with launch_b3_stream)
+        const uint32_t b_on = (uint32_t)((n_b * n_quads + 255) / 256);
+        launch<B_k_b3_chunks_pair_uni<true>, 256>(k_b3_chunks_pair_uni<true>, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, cv_a0, d_on, n_on, cv_b0, b_pre,
+                                                 d_quads, n_quads);
     } else {
-        launch_b3_stream_bits_chunks(st, d_pre, n_pre, NQ, cv_a0, 0, 1);
-        launch_b3_stream_chunks(st, d_on, n_on, NQ, cv_b0, nullptr, 0, 0, 1);
-        launches = 2;
+        const uint32_t b_on = (uint32_t)((n_b * 64 + 255) / 256);
+        launch<B_k_b3_chunks_pair_uni<false>, 256>(k_b3_chunks_pair_uni<false>, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, cv_a0, d_on, n_on, cv_b0, b_pre,
+                                                  (const uint32_t*)nullptr, 0u);
     }
     while (n_a > B3_TAIL || n_b > B3_TAIL) {
         const uint64_t out_a = (n_a + 3) / 4, out_b = (n_b + 3) / 4;
