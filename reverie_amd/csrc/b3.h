@@ -165,6 +165,63 @@ RV_HD void hash64(const uint32_t m[16], uint32_t out[8]) {
     compress<false>(c, m, 0, 64, CHUNK_START | CHUNK_END | ROOT, out);
 }
 
+#if defined(__HIPCC__)
+// One compression on the FOUR lanes of a quad (lane & 3 = column c of the 4 x 4 state): a lone chain of compressions -- the 16 blocks of a
+// chunk, the levels of a small tree -- is bound by the ~690 instructions of a compression issued one after the other, whatever the
+// number of idle lanes beside it; a column per lane is ~200 per lane (the G function once per half round instead of four times,
+// three quad-permute moves to turn columns into diagonals and three back).  The message is read from memory the four lanes share
+// (LDS): word idx of block `msg` at msg[idx]; which words a lane needs depends on its column, so its 28 word indices are made once
+// (quad_schedule) and reused for every block.  cva / cvb: chaining-value words c and 4 + c, in and out.  FULL: hi_a / hi_b receive
+// output words 8 + c and 12 + c (XOF).
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_from(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
+struct QuadSchedule {
+    uint32_t idx[28];  // [round][column step x, y, diagonal step x, y]
+};
+__device__ __forceinline__ QuadSchedule quad_schedule(uint32_t c) {
+    // the message schedule of compress(): row r = the 16 word indices of round r
+    constexpr uint8_t S[7][16] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8},
+                                  {3, 4, 10, 12, 13, 2, 7, 14, 6, 5, 9, 0, 11, 15, 8, 1}, {10, 7, 12, 9, 14, 3, 13, 15, 4, 0, 11, 2, 5, 8, 1, 6},
+                                  {12, 13, 9, 11, 15, 10, 14, 8, 7, 2, 5, 3, 0, 1, 6, 4}, {9, 14, 11, 5, 8, 12, 15, 1, 13, 3, 0, 10, 2, 6, 4, 7},
+                                  {11, 15, 5, 0, 1, 9, 8, 6, 14, 10, 2, 12, 3, 4, 7, 13}};
+    QuadSchedule q;
+#pragma unroll
+    for (int r = 0; r < 7; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // column step: words 2c, 2c + 1 of the row; diagonal step: words 8 + 2c, 8 + 2c + 1
+            const int base = (j >> 1) * 8 + (j & 1);
+            const uint32_t k = (uint32_t)S[r][base] | ((uint32_t)S[r][base + 2] << 4) | ((uint32_t)S[r][base + 4] << 8) | ((uint32_t)S[r][base + 6] << 12);
+            q.idx[4 * r + j] = (k >> (4 * c)) & 15u;
+        }
+    return q;
+}
+template <bool FULL>
+__device__ __forceinline__ void compress_q(uint32_t& cva, uint32_t& cvb, const uint32_t* msg, const QuadSchedule& q, uint32_t c, uint64_t t, uint32_t blen,
+                                           uint32_t flags, uint32_t* hi_a = nullptr, uint32_t* hi_b = nullptr) {
+    uint32_t a = cva, b = cvb;
+    uint32_t cc = c == 0 ? B3_IV0 : c == 1 ? B3_IV1 : c == 2 ? B3_IV2 : B3_IV3;
+    uint32_t d = c == 0 ? (uint32_t)t : c == 1 ? (uint32_t)(t >> 32) : c == 2 ? blen : flags;
+    uint32_t m[28];
+#pragma unroll
+    for (int k = 0; k < 28; k++) m[k] = msg[q.idx[k]];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        B3_G(a, b, cc, d, m[4 * r], m[4 * r + 1])
+        // diagonals: lane c takes b of column c + 1, c of column c + 2, d of column c + 3
+        b = quad_from<0x39>(b), cc = quad_from<0x4E>(cc), d = quad_from<0x93>(d);
+        B3_G(a, b, cc, d, m[4 * r + 2], m[4 * r + 3])
+        b = quad_from<0x93>(b), cc = quad_from<0x4E>(cc), d = quad_from<0x39>(d);
+    }
+    if (FULL) {
+        *hi_a = cc ^ cva;
+        *hi_b = d ^ cvb;
+    }
+    cva = a ^ cc;
+    cvb = b ^ d;
+}
+#endif
+
 }  // namespace b3
 
 // ---- host-only incremental hasher (small inputs: commitment of 256 digests, random oracle) ----

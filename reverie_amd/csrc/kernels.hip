@@ -1831,28 +1831,47 @@ struct B_k_fs_challenge {
     __shared__ uint32_t s_count;
     const uint32_t lane = threadIdx.x;
     const uint32_t* hw = (const uint32_t*)h;
-    if (lane < 8) {
-        uint32_t cv[8], m[16], o[8];
-        b3::iv(cv);
-        for (uint32_t b = 0; b < 16; b++) {
+    // The commitment's 8 chunks x 16 chained blocks and its three tree levels are 19 compressions one after the other on the path
+    // between the hashes and the openings of EVERY proof: a quad of lanes per compression (b3.h: compress_q, the digests staged in
+    // LDS for the quads to share) instead of a lane -- 41 -> about 25 us for the kernel.
+    __shared__ uint32_t s_h[RV_TOTAL_REPS * 8];
 #pragma unroll
-            for (int k = 0; k < 16; k++) m[k] = hw[lane * 256 + b * 16 + k];
-            b3::compress<false>(cv, m, lane, 64, (b == 0 ? b3::CHUNK_START : 0u) | (b == 15 ? b3::CHUNK_END : 0u), o);
-#pragma unroll
-            for (int k = 0; k < 8; k++) cv[k] = o[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) s_cv[lane][k] = cv[k];
-    }
+    for (uint32_t i = 0; i < RV_TOTAL_REPS * 8 / 64; i++) s_h[i * 64 + lane] = hw[i * 64 + lane];
     for (uint32_t r = lane; r < RV_TOTAL_REPS; r += 64) s_omit[r] = RV_PLAYERS;
     if (lane == 0) s_count = 0;
     __syncthreads();
-    if (lane < 4) b3::parent(s_cv[2 * lane], s_cv[2 * lane + 1], 0, s_t1[lane]);
+    const uint32_t qc = lane & 3, qi = lane >> 2;  // column, quad
+    const b3::QuadSchedule qs = b3::quad_schedule(qc);
+    const uint32_t iv_a = qc == 0 ? B3_IV0 : qc == 1 ? B3_IV1 : qc == 2 ? B3_IV2 : B3_IV3;
+    const uint32_t iv_b = qc == 0 ? B3_IV4 : qc == 1 ? B3_IV5 : qc == 2 ? B3_IV6 : B3_IV7;
+    {
+        // (all 16 quads run -- quad_from moves data between the lanes of a quad, every lane must be active --, the first 8 count)
+        const uint32_t ch = qi & 7;
+        uint32_t cva = iv_a, cvb = iv_b;
+        for (uint32_t b = 0; b < 16; b++)
+            b3::compress_q<false>(cva, cvb, s_h + ch * 256 + b * 16, qs, qc, ch, 64, (b == 0 ? b3::CHUNK_START : 0u) | (b == 15 ? b3::CHUNK_END : 0u));
+        if (qi < 8) s_cv[qi][qc] = cva, s_cv[qi][4 + qc] = cvb;
+    }
     __syncthreads();
-    if (lane < 2) b3::parent(s_t1[2 * lane], s_t1[2 * lane + 1], 0, s_t2[lane]);
+    {
+        uint32_t cva = iv_a, cvb = iv_b;
+        b3::compress_q<false>(cva, cvb, &s_cv[2 * (qi & 3)][0], qs, qc, 0, 64, b3::PARENT);  // (s_cv[2p], s_cv[2p + 1]: 16 consecutive words)
+        if (qi < 4) s_t1[qi][qc] = cva, s_t1[qi][4 + qc] = cvb;
+    }
+    __syncthreads();
+    {
+        uint32_t cva = iv_a, cvb = iv_b;
+        b3::compress_q<false>(cva, cvb, &s_t1[2 * (qi & 1)][0], qs, qc, 0, 64, b3::PARENT);
+        if (qi < 2) s_t2[qi][qc] = cva, s_t2[qi][4 + qc] = cvb;
+    }
+    __syncthreads();
+    {
+        uint32_t cva = iv_a, cvb = iv_b;
+        b3::compress_q<false>(cva, cvb, &s_t2[0][0], qs, qc, 0, 64, b3::PARENT | b3::ROOT);
+        if (qi == 0) s_comm[qc] = cva, s_comm[4 + qc] = cvb;
+    }
     __syncthreads();
     if (lane == 0) {
-        b3::parent(s_t2[0], s_t2[1], b3::ROOT, s_comm);
         // the random oracle's one input block: context string, a zero byte, comm; 56 bytes, zero padded
         const char ctx[] = "random-oracle challenge";  // proof/mod.rs:18
         uint8_t blk[64];
