@@ -312,6 +312,12 @@ struct FsLayout {
 // not opened} repetition counts; d_comm[32]; d_omit_all[256] (nullable) = the whole opening map
 void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint32_t rep_begin, uint32_t R, uint8_t* d_comm,
                          uint8_t* d_omit, uint8_t* d_omit_all, uint64_t* d_offs, OnlineList* d_ol, uint32_t* d_res);
+// one small GF(2) proof's openings (heads + the three kinds of vectors [+ the error word]) in ONE launch (kernels.hip: k_open_small);
+// false: not taken (a recorded batch, long vectors) -- the caller launches the pieces
+bool launch_open_small(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys, const uint32_t* d_on2,
+                       const uint32_t* d_on64, const uint64_t* d_offs, uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i,
+                       const uint32_t* d_on, const uint32_t* d_rec_rows, uint64_t n_rec, const uint8_t* d_pre, uint64_t n_pre, const uint32_t* d_in_rows,
+                       uint64_t n_in, uint32_t NQ, const OnlineList* d_ol, uint32_t corr_rep_min, uint8_t* d_out, const int* d_err, int* err_dst_mapped);
 // kind 0: omitted player's bit of a share row; 1: smeared byte of a row
 // d_out2 / n_direct (kind 0, rv_prove's early path): the first n_direct tiles ALSO go to d_out2 (the proof buffer's device address), same offsets
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,

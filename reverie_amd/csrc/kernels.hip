@@ -1193,6 +1193,98 @@ __global__ __launch_bounds__(256) void k_b3_chunks_pair(const uint8_t* __restric
                                                         const uint32_t* __restrict__ quads, uint32_t n_quads) {
     B_k_b3_chunks_pair{}(pre, n_pre, cv_pre, on, n_on, cv_on, NQ, blocks_pre, quads, n_quads);
 }
+// ONE small proof (no batch to supply wavefronts): a chunk's 16 chained compressions are the whole duration of the chunk launch, so
+// each repetition's chain runs on a QUAD of lanes (b3.h: compress_q) -- lane = (chunk, repetition, column).  A lane assembles the four
+// message words of its column's share of the block (16 of the block's 64 rows), the quad exchanges them through LDS.  ~37 -> ~15 us.
+// BITS: the preprocessing stream (a bit per repetition and event); else the online stream (a byte).  quads / n_quads as in
+// B_k_b3_chunks; a quad of lanes never straddles two chunks, so its four lanes always run the same number of blocks.
+template <bool BITS>
+struct B_k_b3_chunks_q {
+    static __device__ __forceinline__ void run(uint64_t tid, const void* __restrict__ stream, uint64_t n_events, uint32_t NQ, uint64_t n_chunks, uint32_t* __restrict__ cvs,
+                                               const uint32_t* __restrict__ quads, uint32_t n_quads, uint32_t* s_msg /* [threads / 4][16] */) {
+    const uint32_t qc = (uint32_t)(tid & 3);
+    const uint32_t reps_per_chunk = (quads ? n_quads : NQ) * 4;
+    const uint64_t gi = tid >> 2;  // (chunk, repetition slot)
+    const uint64_t c = gi / reps_per_chunk;
+    const uint32_t rs = (uint32_t)(gi % reps_per_chunk);
+    if (c >= n_chunks) return;  // (whole quads leave together)
+    const uint32_t q = quads ? quads[rs >> 2] : rs >> 2, i4 = rs & 3;
+    uint32_t* const msg = s_msg + (threadIdx.x >> 2) * 16;
+    const b3::QuadSchedule qs = b3::quad_schedule(qc);
+    const uint64_t ev0 = c * 1024;
+    const uint64_t len = (n_events - ev0 < 1024) ? (n_events - ev0) : 1024;
+    const uint32_t nblk = len == 0 ? 1 : (uint32_t)((len + 63) / 64);
+    uint32_t cva = qc == 0 ? B3_IV0 : qc == 1 ? B3_IV1 : qc == 2 ? B3_IV2 : B3_IV3;
+    uint32_t cvb = qc == 0 ? B3_IV4 : qc == 1 ? B3_IV5 : qc == 2 ? B3_IV6 : B3_IV7;
+    // this lane's 16 rows of block b (message words 4 qc .. 4 qc + 3), one word each (a byte of the bit rows); the rows of block b + 1
+    // are requested before block b is compressed -- a memory round trip per block was most of the chain
+    const uint32_t h = NQ >> 1, o = q >> 1, sh = 4 * (q & 1);
+    auto load_rows = [&](uint32_t b, uint32_t (&w)[16]) {
+        const uint64_t e0 = ev0 + 64ull * b + 16ull * qc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            if (BITS)
+                w[e] = (e0 + e < n_events) ? (uint32_t)((const uint8_t*)stream)[(e0 + e) * h + o] : 0u;
+            else
+                w[e] = (e0 + e < n_events) ? ((const uint32_t*)stream)[(e0 + e) * NQ + q] : 0u;
+        }
+    };
+    uint32_t w[16];
+    load_rows(0, w);
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint32_t blen = (b + 1 < nblk) ? 64u : (uint32_t)(len - 64ull * b);
+        uint32_t flags = (b == 0 ? b3::CHUNK_START : 0u) | (b + 1 == nblk ? b3::CHUNK_END : 0u);
+        if (b + 1 == nblk && n_chunks == 1) flags |= b3::ROOT;
+        uint32_t m4[4];
+        if (BITS) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                uint32_t P = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) P |= ((w[4 * kk + j] >> sh) & 0xFu) << (8 * j);
+                const uint32_t t = (P >> (3 - i4)) & 0x01010101u;
+                m4[kk] = (t << 8) - t;
+            }
+        } else {
+            const uint32_t sel = 3 - i4;  // byte index for v_perm (0 = LSB): the repetition's byte counts from the MSB
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const uint32_t lo = __builtin_amdgcn_perm(w[4 * kk + 1], w[4 * kk], 0x0c0c0400u + sel * 0x0101u);
+                const uint32_t hi = __builtin_amdgcn_perm(w[4 * kk + 3], w[4 * kk + 2], 0x0c0c0400u + sel * 0x0101u);
+                m4[kk] = lo | (hi << 16);
+            }
+        }
+        if (b + 1 < nblk) load_rows(b + 1, w);
+        // (the quad's lanes sit in one wavefront, whose LDS accesses execute in order: the block's reads of the step before are done)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) msg[4 * qc + kk] = m4[kk];
+        __builtin_amdgcn_wave_barrier();
+        b3::compress_q<false>(cva, cvb, msg, qs, qc, c, blen, flags);
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t R = NQ * 4;
+    uint32_t* dst = cvs + ((size_t)c * R + 4 * q + i4) * 8;
+    dst[qc] = cva;
+    dst[4 + qc] = cvb;
+    }
+};
+struct B_k_b3_chunks_pair_q {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
+                                               uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t NQ, uint32_t blocks_pre, const uint32_t* __restrict__ quads,
+                                               uint32_t n_quads) const {
+    __shared__ uint32_t s_msg[64 * 16];
+    const uint64_t c_pre = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, c_on = n_on == 0 ? 1 : (n_on + 1023) / 1024;
+    if (blockIdx.x < blocks_pre)
+        B_k_b3_chunks_q<true>::run((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, pre, n_pre, NQ, c_pre, cv_pre, nullptr, 0, s_msg);
+    else
+        B_k_b3_chunks_q<false>::run((uint64_t)(blockIdx.x - blocks_pre) * blockDim.x + threadIdx.x, on, n_on, NQ, c_on, cv_on, quads, n_quads, s_msg);
+    }
+};
+__global__ __launch_bounds__(256) void k_b3_chunks_pair_q(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
+                                                          uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t NQ, uint32_t blocks_pre,
+                                                          const uint32_t* __restrict__ quads, uint32_t n_quads) {
+    B_k_b3_chunks_pair_q{}(pre, n_pre, cv_pre, on, n_on, cv_on, NQ, blocks_pre, quads, n_quads);
+}
 // tree tops of both: workgroups [0, R) the preprocessing stream, [R, 2R) the online one
 struct B_k_b3_tree_tail_pair {
     __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in_a, uint32_t n_a, uint32_t* __restrict__ dig_a, const uint32_t* __restrict__ in_b, uint32_t n_b,
@@ -1218,8 +1310,14 @@ bool launch_b3_pair_small(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, 
     // (the same "few chunks" rule as the separate launchers' one-repetition-per-lane choice, and trees the small tail kernel takes)
     if (c_pre > 64 || c_on > 64 || std::max(c_pre, c_on) * NQ * batch >= 64 * 1024) return false;
     const uint32_t R = NQ * 4;
+    if (!g_recorder) {
+        // (one proof: a quad of lanes per repetition's chain)
+        const uint32_t b_pre = (uint32_t)((c_pre * NQ * 16 + 255) / 256), b_on = (uint32_t)((c_on * (d_quads ? n_quads : NQ) * 16 + 255) / 256);
+        hipLaunchKernelGGL(k_b3_chunks_pair_q, dim3(b_pre + b_on), dim3(256), 0, st, d_pre, n_pre, d_cv_a, d_on, n_on, d_cv_b, NQ, b_pre, d_quads, n_quads);
+    } else {
     const uint32_t b_pre = (uint32_t)((c_pre * NQ * 4 + 255) / 256), b_on = (uint32_t)((c_on * (d_quads ? n_quads : NQ) * 4 + 255) / 256);
     launch<B_k_b3_chunks_pair, 256>(k_b3_chunks_pair, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, d_cv_a, d_on, n_on, d_cv_b, NQ, b_pre, d_quads, n_quads);
+    }
     launch<B_k_b3_tree_tail_pair, 64>(k_b3_tree_tail_pair, st, dim3(2 * R), dim3(64), (const uint32_t*)d_cv_a, (uint32_t)c_pre, d_dig_pre,
                                       (const uint32_t*)d_cv_b, (uint32_t)c_on, d_dig_on, R);
     return true;
@@ -1657,7 +1755,7 @@ struct B_k_extract_rows {
     __shared__ uint8_t s_aq[64];
     __shared__ uint32_t s_naq;
     const uint64_t n_bytes = n_items / 8 + 1;
-    const uint64_t t0 = (uint64_t)(blockIdx.x + block0) * tb;
+    const uint64_t t0 = (uint64_t)(uint32_t)(blockIdx.x + block0) * tb;  // (modulo 2^32: k_open_small passes minus its range's first block)
     const uint32_t nb = (uint32_t)((n_bytes - t0 < tb) ? n_bytes - t0 : tb);
     const bool direct = out2 && blockIdx.x + block0 < n_direct;
     const uint32_t nbx = direct ? (uint32_t)((n_bytes - t0 < nb + LA) ? n_bytes - t0 : nb + LA) : nb;  // bytes extracted
@@ -1736,7 +1834,8 @@ __global__ __launch_bounds__(256) void k_extract_rows(const uint32_t* __restrict
 // the workgroup's 8*tb rows are contiguous in HBM and are copied to LDS in one coalesced pass; thread =
 // (output byte, opened repetition) then picks its 8 bits out of LDS.
 struct B_k_extract_from_bits {
-    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const OnlineList* __restrict__ olp, uint8_t* __restrict__ out, uint32_t rep_min) const {
+    // (block0: added to blockIdx.x modulo 2^32 -- k_open_small runs this as one range of its grid)
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ bits, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EX_TB */, const OnlineList* __restrict__ olp, uint8_t* __restrict__ out, uint32_t rep_min, uint32_t block0 = 0) const {
     __shared__ uint8_t s_buf[RV_ONLINE_REPS * EX_TB];
     __shared__ uint64_t s_dst[RV_ONLINE_REPS];
     __shared__ uint32_t s_pos[RV_ONLINE_REPS];  // byte in the row << 3 | bit in the byte
@@ -1744,7 +1843,7 @@ struct B_k_extract_from_bits {
     const uint32_t n_ol = olp->n < RV_ONLINE_REPS ? olp->n : RV_ONLINE_REPS;
     if (!n_ol) return;
     const uint64_t n_bytes = n_items / 8 + 1;
-    const uint64_t t0 = (uint64_t)blockIdx.x * tb;
+    const uint64_t t0 = (uint64_t)(uint32_t)(blockIdx.x + block0) * tb;
     const uint32_t nb = (uint32_t)((n_bytes - t0 < tb) ? n_bytes - t0 : tb);
     const uint32_t h = NQ >> 1;  // bytes per row
     const uint64_t r0 = 8 * t0;
@@ -2157,7 +2256,10 @@ struct B_k_open_headers {
     // coalesce, also when the proof buffer is mapped host memory); a lane-per-repetition version that walked its ~300
     // bytes one by one took 14 us of a 0.5 ms AES-128 proof
     __device__ __forceinline__ void operator()(uint32_t R, const uint8_t* __restrict__ omit, const uint8_t* __restrict__ seeds, const uint8_t* __restrict__ keys, const uint32_t* __restrict__ on2, const uint32_t* __restrict__ on64, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ off64, uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i, uint8_t* __restrict__ out) const {
-    const uint32_t r = blockIdx.x >> 1, dom = blockIdx.x & 1u, i = threadIdx.x;
+    run(blockIdx.x, R, omit, seeds, keys, on2, on64, off2, off64, l2r, l2c, l2i, l64r, l64c, l64i, out);
+    }
+    static __device__ __forceinline__ void run(uint32_t bx, uint32_t R, const uint8_t* __restrict__ omit, const uint8_t* __restrict__ seeds, const uint8_t* __restrict__ keys, const uint32_t* __restrict__ on2, const uint32_t* __restrict__ on64, const uint64_t* __restrict__ off2, const uint64_t* __restrict__ off64, uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i, uint8_t* __restrict__ out) {
+    const uint32_t r = bx >> 1, dom = bx & 1u, i = threadIdx.x;
     if (r >= R) return;
     const uint32_t om = omit[r];
     uint8_t* o = out + (dom == 0 ? off2[r] : off64[r]);
@@ -2194,6 +2296,66 @@ void launch_open_headers(hipStream_t st, uint32_t R, const uint8_t* d_omit, cons
                          uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i, uint8_t* d_out) {
     launch<B_k_open_headers, 192>(k_open_headers, st, dim3(2 * R), dim3(192), R, d_omit, d_seeds, d_keys, d_on2, d_on64, d_off2,
                        d_off64, l2r, l2c, l2i, l64r, l64c, l64i, d_out);
+}
+
+// ONE small GF(2) proof's openings in one launch: the record heads, the broadcast vectors, the corrections vectors and the input vectors
+// are four independent pieces of work behind the challenge, each a kernel of 5 - 11 us that occupies a corner of the chip -- as ranges
+// of one grid they cost one launch (and the error word for the host rides along).  Large proofs keep the separate launches: the
+// pieces' LDS adds up here (58 KB per workgroup).
+struct OpenSmall {
+    // heads
+    uint32_t R;
+    const uint8_t *omit, *seeds, *keys;
+    const uint32_t *on2, *on64;
+    const uint64_t *off2, *off64;
+    uint64_t l2r, l2c, l2i, l64r, l64c, l64i;
+    // vectors
+    const uint32_t *on, *rec_rows, *in_rows;
+    const uint8_t* pre;
+    uint64_t n_rec, n_pre, n_in;
+    uint32_t NQ, tb_rec, tb_pre, tb_in;
+    const uint64_t *dst_rec, *dst_in;
+    const OnlineList* ol;
+    uint32_t corr_rep_min;
+    uint32_t g_hdr, g_rec, g_pre;  // workgroups of the first three ranges
+    uint8_t* out;
+    const int* err_src;
+    int* err_dst;  // (nullable) host-mapped
+};
+__global__ __launch_bounds__(256) void k_open_small(OpenSmall a) {
+    const uint32_t bx = blockIdx.x;
+    if (bx < a.g_hdr) {
+        if (threadIdx.x < 192) B_k_open_headers::run(bx, a.R, a.omit, a.seeds, a.keys, a.on2, a.on64, a.off2, a.off64, a.l2r, a.l2c, a.l2i, a.l64r, a.l64c, a.l64i, a.out);
+        if (bx == 0 && threadIdx.x == 255 && a.err_dst) *a.err_dst = *a.err_src;
+    } else if (bx < a.g_hdr + a.g_rec) {
+        B_k_extract_rows<0>{}(a.on, a.rec_rows, a.n_rec, a.NQ, a.tb_rec, a.omit, a.dst_rec, a.out, 0, 0u - a.g_hdr);
+    } else if (bx < a.g_hdr + a.g_rec + a.g_pre) {
+        B_k_extract_from_bits{}(a.pre, a.n_pre, a.NQ, a.tb_pre, a.ol, a.out, a.corr_rep_min, 0u - (a.g_hdr + a.g_rec));
+    } else {
+        B_k_extract_rows<1>{}(a.on, a.in_rows, a.n_in, a.NQ, a.tb_in, a.omit, a.dst_in, a.out, 0, 0u - (a.g_hdr + a.g_rec + a.g_pre));
+    }
+}
+// true (and the launch made) when the proof is small enough and nothing records launches; otherwise the caller launches the pieces
+bool launch_open_small(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys, const uint32_t* d_on2,
+                       const uint32_t* d_on64, const uint64_t* d_offs /* [8][R] as shard_open_impl lays them out */, uint64_t l2r, uint64_t l2c, uint64_t l2i,
+                       uint64_t l64r, uint64_t l64c, uint64_t l64i, const uint32_t* d_on, const uint32_t* d_rec_rows, uint64_t n_rec, const uint8_t* d_pre,
+                       uint64_t n_pre, const uint32_t* d_in_rows, uint64_t n_in, uint32_t NQ, const OnlineList* d_ol, uint32_t corr_rep_min, uint8_t* d_out,
+                       const int* d_err, int* err_dst_mapped) {
+    if (g_recorder) return false;
+    OpenSmall a{};
+    a.tb_rec = ex_tb_for(n_rec / 8 + 1, EXR_TB), a.tb_pre = ex_tb_for(n_pre / 8 + 1), a.tb_in = ex_tb_for(n_in / 8 + 1, EXR_TB);
+    a.g_hdr = 2 * R;
+    a.g_rec = (uint32_t)((n_rec / 8 + 1 + a.tb_rec - 1) / a.tb_rec);
+    a.g_pre = corr_rep_min < R ? (uint32_t)((n_pre / 8 + 1 + a.tb_pre - 1) / a.tb_pre) : 0u;
+    const uint32_t g_in = (uint32_t)((n_in / 8 + 1 + a.tb_in - 1) / a.tb_in);
+    if ((uint64_t)a.g_rec + a.g_pre + g_in > 16384) return false;  // (vectors of up to ~64 KB: the sizes at which a launch matters)
+    a.R = R, a.omit = d_omit, a.seeds = d_seeds, a.keys = d_keys, a.on2 = d_on2, a.on64 = d_on64, a.off2 = d_offs, a.off64 = d_offs + R;
+    a.l2r = l2r, a.l2c = l2c, a.l2i = l2i, a.l64r = l64r, a.l64c = l64c, a.l64i = l64i;
+    a.on = d_on, a.rec_rows = d_rec_rows, a.in_rows = d_in_rows, a.pre = d_pre, a.n_rec = n_rec, a.n_pre = n_pre, a.n_in = n_in, a.NQ = NQ;
+    a.dst_rec = d_offs + 2 * (size_t)R, a.dst_in = d_offs + 4 * (size_t)R, a.ol = d_ol, a.corr_rep_min = corr_rep_min;
+    a.out = d_out, a.err_src = d_err, a.err_dst = err_dst_mapped;
+    hipLaunchKernelGGL(k_open_small, dim3(a.g_hdr + a.g_rec + a.g_pre + g_in), dim3(256), 0, st, a);
+    return true;
 }
 
 // the device error word into a host-mapped word (small proofs leave without a copy engine: api.hip, rv_prove_impl)
