@@ -1642,20 +1642,29 @@ void launch_fill_digests(hipStream_t st, uint32_t* d_dst, uint32_t n_rows, const
 }
 
 // start of the interpreter phase: clear the invalid-witness flag and the all-zero row (mask words, corr-bit words)
+// (fill / n_fill_rows / d: also n_fill_rows copies of the digest d -- the Z64 transcripts' digests of a pure GF(2) circuit, BLAKE3(""),
+// which otherwise cost a launch of their own between the hashes and the commitment)
 struct B_k_shard_init {
-    __device__ __forceinline__ void operator()(int* __restrict__ err, uint32_t* __restrict__ zero_mask, uint32_t n_mask_words, uint8_t* __restrict__ zero_corr, uint32_t n_corr_bytes) const {
+    __device__ __forceinline__ void operator()(int* __restrict__ err, uint32_t* __restrict__ zero_mask, uint32_t n_mask_words, uint8_t* __restrict__ zero_corr, uint32_t n_corr_bytes,
+                                               uint32_t* __restrict__ fill, uint32_t n_fill_rows, Digest8 d) const {
     const uint32_t i = threadIdx.x;
     if (i == 0) *err = 0;
     if (i < n_mask_words) zero_mask[i] = 0;
     if (i < n_corr_bytes) zero_corr[i] = 0;
+    if (fill)
+        for (uint32_t j = i; j < n_fill_rows * 8; j += blockDim.x) fill[j] = d.w[j & 7];
 }
 };
-__global__ void k_shard_init(int* __restrict__ err, uint32_t* __restrict__ zero_mask, uint32_t n_mask_words, uint8_t* __restrict__ zero_corr, uint32_t n_corr_bytes) {
-    B_k_shard_init{}(err, zero_mask, n_mask_words, zero_corr, n_corr_bytes);
+__global__ void k_shard_init(int* __restrict__ err, uint32_t* __restrict__ zero_mask, uint32_t n_mask_words, uint8_t* __restrict__ zero_corr, uint32_t n_corr_bytes,
+                             uint32_t* __restrict__ fill, uint32_t n_fill_rows, Digest8 d) {
+    B_k_shard_init{}(err, zero_mask, n_mask_words, zero_corr, n_corr_bytes, fill, n_fill_rows, d);
 }
 void launch_shard_init(hipStream_t st, int* d_err, uint32_t* d_zero_mask, uint32_t n_mask_words, uint8_t* d_zero_corr,
-                       uint32_t n_corr_bytes) {
-    launch<B_k_shard_init, 64>(k_shard_init, st, dim3(1), dim3(64), d_err, d_zero_mask, n_mask_words, d_zero_corr, n_corr_bytes);
+                       uint32_t n_corr_bytes, uint32_t* d_fill, uint32_t n_fill_rows, const uint32_t* digest) {
+    Digest8 d{};
+    if (d_fill)
+        for (int k = 0; k < 8; k++) d.w[k] = digest[k];
+    launch<B_k_shard_init, 64>(k_shard_init, st, dim3(1), dim3(64), d_err, d_zero_mask, n_mask_words, d_zero_corr, n_corr_bytes, d_fill, n_fill_rows, d);
 }
 
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
