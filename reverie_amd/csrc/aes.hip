@@ -20,6 +20,7 @@
 
 #include "internal.h"
 #include "z64_dev.h"
+#include "aes_col4_dev.h"
 #include "launch.h"
 
 namespace rv {
@@ -83,6 +84,10 @@ struct B_k_expand_seeds {
     __device__ __forceinline__ void operator()(const uint8_t* __restrict__ seeds, uint32_t n_reps, uint8_t* __restrict__ keys) const {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_reps * 8) return;
+    slot_key(seeds, t, keys);
+    }
+    // slot t = 8 * repetition + player
+    static __device__ __forceinline__ void slot_key(const uint8_t* __restrict__ seeds, uint32_t t, uint8_t* __restrict__ keys) {
     uint32_t r = t >> 3, p = t & 7;
     uint8_t key[16], rk[176], in[16], out[16];
     for (int i = 0; i < 16; i++) key[i] = seeds[16 * r + i];
@@ -100,10 +105,13 @@ struct B_k_key_schedule {
     __device__ __forceinline__ void operator()(const uint8_t* __restrict__ keys, uint32_t n_slots, uint8_t* __restrict__ rkbytes) const {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_slots) return;
+    slot_schedule(keys, t, rkbytes + RK_BYTES * (size_t)t);
+    }
+    // slot t's RK_BYTES at dst (global or LDS)
+    static __device__ __forceinline__ void slot_schedule(const uint8_t* __restrict__ keys, uint32_t t, uint8_t* dst) {
     uint8_t key[16], rk[176];
     for (int i = 0; i < 16; i++) key[i] = keys[16 * t + i];
     key_expand(key, rk);
-    uint8_t* dst = rkbytes + RK_BYTES * (size_t)t;
     for (int i = 0; i < 176; i++) dst[i] = rk[i];
     // first-round constants (layout: internal.h).  Round 0 of a CTR block with j < 2^24: x = rk0 ^ (0,..,0,j2,j1,j0).
     uint8_t sb[16], k1[16];
@@ -165,6 +173,61 @@ struct B_k_bitslice_rk {
 };
 __global__ void k_bitslice_rk(const uint8_t* __restrict__ rkbytes, uint32_t NQ, uint32_t* __restrict__ rk) {
     B_k_bitslice_rk{}(rkbytes, NQ, rk);
+}
+
+// The whole key setup of a prover's shard in ONE launch, a workgroup per quad word (its 32 slots = 4 repetitions x 8 players):
+// seed -> player key (B_k_expand_seeds) -> round keys and first-round constants (B_k_key_schedule) by 32 threads into LDS, the quad
+// word's bit planes (B_k_bitslice_rk) out of LDS, and -- img != null -- its lanes of the lane-distributed generator's key image
+// (aes_col4.hip: k_rk_col4) out of the planes.  Four dependent launches of 4 - 8 us each otherwise, at the head of every proof.
+__global__ __launch_bounds__(256) void k_setup_keys(const uint8_t* __restrict__ seeds, uint32_t NQ, uint8_t* __restrict__ keys, uint8_t* __restrict__ rkbytes,
+                                                    uint32_t* __restrict__ rk, uint32_t* __restrict__ img) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_rkb[32][RK_BYTES];
+    __shared__ uint32_t s_pl[RK_BYTES * 8];  // plane 8 * byte + bit of this quad word
+    const uint32_t q = blockIdx.x, t = threadIdx.x;
+    if (t < 32) {
+        const uint32_t slot = q * 32 + t;
+        B_k_expand_seeds::slot_key(seeds, slot, keys);
+        B_k_key_schedule::slot_schedule(keys, slot, s_rkb[t]);
+        uint8_t* dst = rkbytes + RK_BYTES * (size_t)slot;
+        for (uint32_t i = 0; i < RK_BYTES; i += 4) *(uint32_t*)(dst + i) = *(const uint32_t*)(&s_rkb[t][i]);
+    }
+    __syncthreads();
+    if (t < RK_BYTES / 4) {
+        const uint32_t bg = t;
+        uint32_t v[32];
+#pragma unroll
+        for (uint32_t s = 0; s < 32; s++) v[s] = *(const uint32_t*)(&s_rkb[s][4 * bg]);
+        transpose32(v);
+#pragma unroll
+        for (uint32_t k = 0; k < 32; k++) {
+            rk[(size_t)(32 * bg + k) * NQ + q] = v[31 - k];
+            s_pl[32 * bg + k] = v[31 - k];
+        }
+    }
+    if (!img) return;
+    __syncthreads();
+    const uint32_t qg = q >> 4, ql = q & 15;
+    for (uint32_t e = t; e < C4_AREAS * 8 * 16; e += 256) {
+        const uint32_t row = e & 3, c = (e >> 2) & 3, k = (e >> 4) & 7, area = e >> 7;
+        const uint32_t lane = 4 * ql + c;
+        const size_t at = ((((size_t)qg * C4_AREAS + area) * 8 + k) * 64 + lane) * 4 + row;
+        // (the mapping of k_rk_col4)
+        uint32_t ga = area, byte = 4 * ((c + row) & 3) + row;
+        if (area == 10) byte = 4 * c + row;
+        if (area == 1) ga = 12;
+        uint32_t val;
+        if (area == 0) {
+            ga = 11;
+            byte = 15 - c;
+            val = (row != 0 || c == 3) ? 0u : s_pl[ga * 128 + 8 * byte + k];
+        } else {
+            val = s_pl[ga * 128 + 8 * byte + k];
+        }
+        img[at] = val;
+    }
+}
+void launch_setup_keys(hipStream_t st, const uint8_t* d_seeds, uint32_t NQ, uint8_t* d_keys, uint8_t* d_rkbytes, uint32_t* d_rk, uint32_t* d_img) {
+    hipLaunchKernelGGL(k_setup_keys, dim3(NQ), dim3(256), 0, st, d_seeds, NQ, d_keys, d_rkbytes, d_rk, d_img);
 }
 
 // test hook / Z64 path helper: plain CTR blocks, one thread per (key, block)
