@@ -40,7 +40,9 @@ constexpr uint32_t C4_LDS_BYTES = C4_IMG_U4 * 16;      // 88 KiB
 
 // one middle round on the shifted state: s = ShiftRows(MixColumns(SubBytes(s))) ^ srk.  MixColumns plane by plane:
 // out_r[k] = d_r[k-1] ^ all[k] ^ a_r[k] (^ d_r[7] for k = 1, 3, 4; d_r[-1] = d_r[7]) with d_r = a_r ^ a_(r+1), all = a_0^a_1^a_2^a_3:
-// beside the state only d[7], d[k-1], d[k] and the plane's four key words are live
+// beside the state only d[7], d[k-1], d[k] and the plane's four key words are live.  The d_r[7] of planes 1, 3, 4 rides in the
+// PREVIOUS plane's d (planes 0, 2, 3 make theirs with a 3-input XOR: d' = d ^ d_r[7]; their `all` takes d_0[7] ^ d_2[7] back out
+// in its own 3-input XOR) -- twelve XORs per round and lane less than adding it to the four outputs of three planes
 __device__ __forceinline__ void c4_round(uint32_t* s, const uint4* rk4 /* lds + area*8*64 + lane */) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -50,19 +52,19 @@ __device__ __forceinline__ void c4_round(uint32_t* s, const uint4* rk4 /* lds + 
     uint32_t d7[4], prev[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) prev[r] = d7[r] = s[8 * r + 7] ^ s[8 * ((r + 1) & 3) + 7];
+    const uint32_t dd = d7[0] ^ d7[2];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const uint4 kv = rk4[k * 64];
+        const bool fold = k == 0 || k == 2 || k == 3;  // the next plane (1, 3, 4) wants d_r[7] in its d_r[k - 1]
         uint32_t cur[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) cur[r] = k == 7 ? d7[r] : (s[8 * r + k] ^ s[8 * ((r + 1) & 3) + k]);
-        const uint32_t all = cur[0] ^ cur[2];
+        for (int r = 0; r < 4; r++)
+            cur[r] = k == 7 ? d7[r] : fold ? XOR3(s[8 * r + k], s[8 * ((r + 1) & 3) + k], d7[r]) : (s[8 * r + k] ^ s[8 * ((r + 1) & 3) + k]);
+        const uint32_t all = fold ? XOR3(cur[0], cur[2], dd) : cur[0] ^ cur[2];
         uint32_t t[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            t[r] = XOR3(prev[r], all, s[8 * r + k]);
-            if (k == 1 || k == 3 || k == 4) t[r] ^= d7[r];
-        }
+        for (int r = 0; r < 4; r++) t[r] = XOR3(prev[r], all, s[8 * r + k]);
         s[k] = t[0] ^ kv.x;
         s[8 + k] = c4_shift_xor<1>(t[1], kv.y);
         s[16 + k] = c4_shift_xor<2>(t[2], kv.z);
