@@ -1330,20 +1330,23 @@ bool launch_b3_pair_small(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre, 
 // stream (a byte), a chunk per wavefront in both (B_k_b3_chunks<4, true>) -- the ragged last generation of the first fills with
 // wavefronts of the second (on two streams that cost more in events than it gave: DESIGN.md section 4)
 // (QUADS: the verifier -- the online stream of the quad words with an opened repetition only, a lane per listed quad word)
-template <bool QUADS>
+// (QUADS = 2: few listed quad words -- a quarter of the row or less --: a lane per REPETITION of them, as launch_b3_stream_chunks chooses)
+template <int QUADS>
 struct B_k_b3_chunks_pair_uni {
     __device__ __forceinline__ void operator()(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
                                                uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t blocks_pre, const uint32_t* __restrict__ quads, uint32_t n_quads) const {
     const uint64_t c_pre = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, c_on = n_on == 0 ? 1 : (n_on + 1023) / 1024;
     if (blockIdx.x < blocks_pre)
         B_k_b3_chunks_bits<4, true>::run((uint64_t)blockIdx.x * blockDim.x + threadIdx.x, pre, n_pre, 64, c_pre, cv_pre, 0, 1);
+    else if (QUADS == 2)
+        B_k_b3_chunks<1, false>::run((uint64_t)(blockIdx.x - blocks_pre) * blockDim.x + threadIdx.x, on, n_on, 64, c_on, cv_on, quads, n_quads, 0, 1);
     else if (QUADS)
         B_k_b3_chunks<4, false>::run((uint64_t)(blockIdx.x - blocks_pre) * blockDim.x + threadIdx.x, on, n_on, 64, c_on, cv_on, quads, n_quads, 0, 1);
     else
         B_k_b3_chunks<4, true>::run((uint64_t)(blockIdx.x - blocks_pre) * blockDim.x + threadIdx.x, on, n_on, 64, c_on, cv_on, nullptr, 0, 0, 1);
     }
 };
-template <bool QUADS>
+template <int QUADS>
 __global__ __launch_bounds__(256) void k_b3_chunks_pair_uni(const uint8_t* __restrict__ pre, uint64_t n_pre, uint32_t* __restrict__ cv_pre, const uint32_t* __restrict__ on,
                                                             uint64_t n_on, uint32_t* __restrict__ cv_on, uint32_t blocks_pre, const uint32_t* __restrict__ quads,
                                                             uint32_t n_quads) {
@@ -1381,10 +1384,13 @@ static uint64_t b3_rpl1_lanes();
 // does launch_b3_pair_big take these two transcripts?  (both trees must end in the 256-thread tree top: more than 64 nodes left)
 bool b3_pair_big_ok(uint64_t n_pre, uint64_t n_on, uint32_t NQ, const uint32_t* d_quads, uint32_t n_quads) {
     if (NQ != 64 || g_recorder || RV_B3_RPL != 4) return false;
-    if (d_quads && n_quads * 4 <= NQ) return false;  // (few opened quad words: the separate launcher hashes a repetition per lane)
-    for (uint64_t n_ev : {n_pre, n_on}) {
+    if (d_quads && !n_quads) return false;
+    for (int i = 0; i < 2; i++) {
+        const uint64_t n_ev = i == 0 ? n_pre : n_on;
+        const bool listed = i == 1 && d_quads;  // (the online stream of the listed quad words only)
         uint64_t n = n_ev == 0 ? 1 : (n_ev + 1023) / 1024;
-        if (n * (d_quads ? std::min(n_quads, NQ) : NQ) < b3_rpl1_lanes()) return false;  // (short transcripts: the separate launchers pick other chunk kernels)
+        // (short transcripts: the separate launchers pick other chunk kernels; few listed quad words are hashed a repetition per lane anyway)
+        if (!(listed && n_quads * 4 <= NQ) && n * (listed ? std::min(n_quads, NQ) : NQ) < b3_rpl1_lanes()) return false;
         while (n > B3_TAIL) n = (n + 3) / 4;
         if (n <= 64) return false;
     }
@@ -1399,16 +1405,20 @@ uint32_t launch_b3_pair_big(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre
     uint64_t n_a = n_pre == 0 ? 1 : (n_pre + 1023) / 1024, n_b = n_on == 0 ? 1 : (n_on + 1023) / 1024;
     uint32_t launches = 1;
     const uint32_t b_pre = (uint32_t)((n_a * 64 + 255) / 256);  // (a chunk per wavefront)
-    if (d_quads) {
+    if (d_quads && n_quads * 4 <= NQ) {
         // (the chaining values of skipped quad words stay whatever the buffer held: the tree above them runs on garbage and the caller
         // replaces those digests, as with launch_b3_stream)
+        const uint32_t b_on = (uint32_t)((n_b * n_quads * 4 + 255) / 256);
+        launch<B_k_b3_chunks_pair_uni<2>, 256>(k_b3_chunks_pair_uni<2>, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, cv_a0, d_on, n_on, cv_b0, b_pre, d_quads,
+                                              n_quads);
+    } else if (d_quads) {
         const uint32_t b_on = (uint32_t)((n_b * n_quads + 255) / 256);
-        launch<B_k_b3_chunks_pair_uni<true>, 256>(k_b3_chunks_pair_uni<true>, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, cv_a0, d_on, n_on, cv_b0, b_pre,
-                                                 d_quads, n_quads);
+        launch<B_k_b3_chunks_pair_uni<1>, 256>(k_b3_chunks_pair_uni<1>, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, cv_a0, d_on, n_on, cv_b0, b_pre, d_quads,
+                                              n_quads);
     } else {
         const uint32_t b_on = (uint32_t)((n_b * 64 + 255) / 256);
-        launch<B_k_b3_chunks_pair_uni<false>, 256>(k_b3_chunks_pair_uni<false>, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, cv_a0, d_on, n_on, cv_b0, b_pre,
-                                                  (const uint32_t*)nullptr, 0u);
+        launch<B_k_b3_chunks_pair_uni<0>, 256>(k_b3_chunks_pair_uni<0>, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, cv_a0, d_on, n_on, cv_b0, b_pre,
+                                              (const uint32_t*)nullptr, 0u);
     }
     while (n_a > B3_TAIL || n_b > B3_TAIL) {
         const uint64_t out_a = (n_a + 3) / 4, out_b = (n_b + 3) / 4;
