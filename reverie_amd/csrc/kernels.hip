@@ -1759,9 +1759,9 @@ __device__ __forceinline__ void ex_flush_host(const uint8_t* s_buf, const uint64
 
 template <int KIND>
 struct B_k_extract_rows {
-    // stage_pitch / block0: a SLICE of the vectors (workgroups block0 .. block0 + gridDim.x of the whole launch) into a dense staging
-    // block [slot][stage_pitch] instead of the proof image (rv_prove's early path: the slices leave through the copy engine while
-    // the next ones are extracted)
+    // block0: added to blockIdx.x modulo 2^32 = this launch's workgroup 0 is workgroup block0 of the vectors (k_open_small runs the
+    // extraction as one range of its grid and passes minus the range's first workgroup).  stage_pitch != 0: into a dense staging block
+    // [slot][stage_pitch] instead of the proof image (unused since round 6's pruning; ex_slots keeps the form)
     __device__ __forceinline__ void operator()(const uint32_t* __restrict__ stream, const uint32_t* __restrict__ rows, uint64_t n_items, uint32_t NQ, uint32_t tb /* <= EXR_TB */, const uint8_t* __restrict__ omit /*[R]*/, const uint64_t* __restrict__ dst_off /*[R]*/, uint8_t* __restrict__ out, uint64_t stage_pitch, uint32_t block0, uint8_t* __restrict__ out2 = nullptr, uint32_t n_direct = 0) const {
     // (internal.h: OpenDirect) a workgroup that also writes to the proof buffer on the host sends every 16-byte aligned word that
     // STARTS in its tile, so it extracts up to LA bytes of the next tile as well: no word is left for two workgroups to share
