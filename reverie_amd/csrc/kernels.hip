@@ -2367,7 +2367,9 @@ bool launch_open_small(hipStream_t st, uint32_t R, const uint8_t* d_omit, const 
     a.g_rec = (uint32_t)((n_rec / 8 + 1 + a.tb_rec - 1) / a.tb_rec);
     a.g_pre = corr_rep_min < R ? (uint32_t)((n_pre / 8 + 1 + a.tb_pre - 1) / a.tb_pre) : 0u;
     const uint32_t g_in = (uint32_t)((n_in / 8 + 1 + a.tb_in - 1) / a.tb_in);
-    if ((uint64_t)a.g_rec + a.g_pre + g_in > 16384) return false;  // (vectors of up to ~64 KB: the sizes at which a launch matters)
+    // (the sizes at which a launch matters: vectors of a few KB.  Longer ones keep their own launches -- 58 KB of LDS per workgroup here
+    // against 20 there: the 10^7-gate circuit's openings took 470 us this way instead of 360)
+    if ((uint64_t)a.g_rec + a.g_pre + g_in > 2048) return false;
     a.R = R, a.omit = d_omit, a.seeds = d_seeds, a.keys = d_keys, a.on2 = d_on2, a.on64 = d_on64, a.off2 = d_offs, a.off64 = d_offs + R;
     a.l2r = l2r, a.l2c = l2c, a.l2i = l2i, a.l64r = l64r, a.l64c = l64c, a.l64i = l64i;
     a.on = d_on, a.rec_rows = d_rec_rows, a.in_rows = d_in_rows, a.pre = d_pre, a.n_rec = n_rec, a.n_pre = n_pre, a.n_in = n_in, a.NQ = NQ;
