@@ -204,7 +204,8 @@ struct OpenDirect {
     uint64_t rvec_at = 0, rvec_len = 0;
 };
 void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
-                      uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit /*[256]*/, uint32_t rep_limit, OpenDirect od = OpenDirect());
+                      uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit /*[256]*/, uint32_t rep_limit, OpenDirect od = OpenDirect(),
+                      const int* d_err = nullptr, int* err_dst_mapped = nullptr /* also: the error word into a host-mapped word */);
 uint32_t extract_tile_bytes(uint64_t n_items);  // the tile of launch_extract_bits for vectors of n_items bits
 void launch_publish(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, uint32_t* flag_mapped, uint32_t seq);
 void launch_store_words(hipStream_t st, const uint32_t* d_src, uint32_t n_words, uint32_t* dst_mapped, const int* d_err, int* dst_err_mapped);
@@ -319,7 +320,8 @@ void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, 
 bool launch_open_small(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys, const uint32_t* d_on2,
                        const uint32_t* d_on64, const uint64_t* d_offs, uint64_t l2r, uint64_t l2c, uint64_t l2i, uint64_t l64r, uint64_t l64c, uint64_t l64i,
                        const uint32_t* d_on, const uint32_t* d_rec_rows, uint64_t n_rec, const uint8_t* d_pre, uint64_t n_pre, const uint32_t* d_in_rows,
-                       uint64_t n_in, uint32_t NQ, const OnlineList* d_ol, uint32_t corr_rep_min, uint8_t* d_out, const int* d_err, int* err_dst_mapped);
+                       uint64_t n_in, uint32_t NQ, const OnlineList* d_ol, uint32_t corr_rep_min, uint8_t* d_out, const int* d_err, int* err_dst_mapped,
+                       bool heads_inputs_only = false);
 // kind 0: omitted player's bit of a share row; 1: smeared byte of a row
 // d_out2 / n_direct (kind 0, rv_prove's early path): the first n_direct tiles ALSO go to d_out2 (the proof buffer's device address), same offsets
 void launch_extract_bits(hipStream_t st, const void* d_stream, const uint32_t* d_rows /*nullable*/, uint64_t n_items,

@@ -2355,17 +2355,18 @@ __global__ __launch_bounds__(256) void k_open_small(OpenSmall a) {
     }
 }
 // true (and the launch made) when the proof is small enough and nothing records launches; otherwise the caller launches the pieces
+// heads_inputs_only: the record heads and the input vectors only (a large proof: its broadcast and corrections vectors keep their launches)
 bool launch_open_small(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys, const uint32_t* d_on2,
                        const uint32_t* d_on64, const uint64_t* d_offs /* [8][R] as shard_open_impl lays them out */, uint64_t l2r, uint64_t l2c, uint64_t l2i,
                        uint64_t l64r, uint64_t l64c, uint64_t l64i, const uint32_t* d_on, const uint32_t* d_rec_rows, uint64_t n_rec, const uint8_t* d_pre,
                        uint64_t n_pre, const uint32_t* d_in_rows, uint64_t n_in, uint32_t NQ, const OnlineList* d_ol, uint32_t corr_rep_min, uint8_t* d_out,
-                       const int* d_err, int* err_dst_mapped) {
+                       const int* d_err, int* err_dst_mapped, bool heads_inputs_only) {
     if (g_recorder) return false;
     OpenSmall a{};
     a.tb_rec = ex_tb_for(n_rec / 8 + 1, EXR_TB), a.tb_pre = ex_tb_for(n_pre / 8 + 1), a.tb_in = ex_tb_for(n_in / 8 + 1, EXR_TB);
     a.g_hdr = 2 * R;
-    a.g_rec = (uint32_t)((n_rec / 8 + 1 + a.tb_rec - 1) / a.tb_rec);
-    a.g_pre = corr_rep_min < R ? (uint32_t)((n_pre / 8 + 1 + a.tb_pre - 1) / a.tb_pre) : 0u;
+    a.g_rec = heads_inputs_only ? 0u : (uint32_t)((n_rec / 8 + 1 + a.tb_rec - 1) / a.tb_rec);
+    a.g_pre = !heads_inputs_only && corr_rep_min < R ? (uint32_t)((n_pre / 8 + 1 + a.tb_pre - 1) / a.tb_pre) : 0u;
     const uint32_t g_in = (uint32_t)((n_in / 8 + 1 + a.tb_in - 1) / a.tb_in);
     // (the sizes at which a launch matters: vectors of a few KB.  Longer ones keep their own launches -- 58 KB of LDS per workgroup here
     // against 20 there: the 10^7-gate circuit's openings took 470 us this way instead of 360)
@@ -2486,8 +2487,9 @@ void launch_pack_corr_all(hipStream_t st, const uint8_t* d_bits, uint64_t n_item
 // both bases 16-byte aligned.
 __global__ __launch_bounds__(256) void k_copy_gaps(const uint8_t* __restrict__ img, uint8_t* __restrict__ dst_mapped, uint64_t total, uint64_t first,
                                                    uint64_t rec, uint64_t corr_at, uint64_t corr_len, uint32_t n_rec, const uint8_t* __restrict__ omit,
-                                                   uint32_t rep_limit, OpenDirect od) {
+                                                   uint32_t rep_limit, OpenDirect od, const int* __restrict__ err_src, int* __restrict__ err_dst) {
     __shared__ uint32_t s_m;
+    if (err_dst && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 255) *err_dst = *err_src;  // (the error word for the host rides along)
     if (threadIdx.x < 64) {
         uint32_t cnt = 0;
         for (uint32_t r = threadIdx.x; r < rep_limit && r < RV_TOTAL_REPS; r += 64) cnt += omit[r] < 8 ? 1u : 0u;
@@ -2526,11 +2528,11 @@ __global__ __launch_bounds__(256) void k_copy_gaps(const uint8_t* __restrict__ i
     for (uint64_t i = b16 + tid; i < b; i += nth) dst_mapped[i] = img[i];
 }
 void launch_copy_gaps(hipStream_t st, const uint8_t* d_img, uint8_t* dst_mapped, uint64_t total, uint64_t first, uint64_t rec, uint64_t corr_at,
-                      uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit, uint32_t rep_limit, OpenDirect od) {
+                      uint64_t corr_len, uint32_t n_rec, const uint8_t* d_omit, uint32_t rep_limit, OpenDirect od, const int* d_err, int* err_dst_mapped) {
     if (!od.n_direct || od.tile < 16 || (od.tile & (od.tile - 1))) od = OpenDirect();
     // (the last piece may be most of the image -- Z64 with few staged repetitions --: enough workgroups per piece to fill PCIe alone)
     hipLaunchKernelGGL(k_copy_gaps, dim3(rep_limit < RV_TOTAL_REPS ? 64 : 8, n_rec + 1), dim3(256), 0, st, d_img, dst_mapped, total, first, rec, corr_at, corr_len,
-                       n_rec, d_omit, rep_limit, od);
+                       n_rec, d_omit, rep_limit, od, d_err, err_dst_mapped);
 }
 
 // n_words of device memory into host-mapped memory, then (ordered behind them at system scope) a sequence number the
