@@ -314,7 +314,9 @@ struct FsLayout {
 // d_h: all 256 digests.  Produces for the shard (rep_begin, R): d_omit[R], d_offs[8*R], *d_ol, and d_res = {opened,
 // not opened} repetition counts; d_comm[32]; d_omit_all[256] (nullable) = the whole opening map
 void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint32_t rep_begin, uint32_t R, uint8_t* d_comm,
-                         uint8_t* d_omit, uint8_t* d_omit_all, uint64_t* d_offs, OnlineList* d_ol, uint32_t* d_res);
+                         uint8_t* d_omit, uint8_t* d_omit_all, uint64_t* d_offs, OnlineList* d_ol, uint32_t* d_res,
+                         uint32_t* mbox = nullptr /* host-mapped: comm, the opening map, the counts for the host; then *mbox_flag = mbox_seq */,
+                         uint32_t* mbox_flag = nullptr, uint32_t mbox_seq = 0);
 // one small GF(2) proof's openings (heads + the three kinds of vectors [+ the error word]) in ONE launch (kernels.hip: k_open_small);
 // false: not taken (a recorded batch, long vectors) -- the caller launches the pieces
 bool launch_open_small(hipStream_t st, uint32_t R, const uint8_t* d_omit, const uint8_t* d_seeds, const uint8_t* d_keys, const uint32_t* d_on2,

@@ -1941,7 +1941,7 @@ void launch_extract_from_bits(hipStream_t st, const uint8_t* d_bits, uint64_t n_
 // per domain) are computed on the device from L.base[0] (= start of the output, 40 past it when framed) and returned
 // in res = {n_online_local, n_preprocessing_local}; omit_all (nullable) receives the full map for the host.
 struct B_k_fs_challenge {
-    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ h, FsLayout L, uint32_t rep_begin, uint32_t R, uint8_t* __restrict__ comm, uint8_t* __restrict__ omit, uint8_t* __restrict__ omit_all, uint64_t* __restrict__ offs, OnlineList* __restrict__ ol, uint32_t* __restrict__ res) const {
+    __device__ __forceinline__ void operator()(const uint8_t* __restrict__ h, FsLayout L, uint32_t rep_begin, uint32_t R, uint8_t* __restrict__ comm, uint8_t* __restrict__ omit, uint8_t* __restrict__ omit_all, uint64_t* __restrict__ offs, OnlineList* __restrict__ ol, uint32_t* __restrict__ res, uint32_t* __restrict__ mbox = nullptr, uint32_t* __restrict__ mbox_flag = nullptr, uint32_t mbox_seq = 0) const {
     __shared__ uint32_t s_cv[8][8], s_t1[4][8], s_t2[2][8], s_comm[8];
     __shared__ uint32_t s_msg[16];
     __shared__ uint8_t s_draw[128][2];
@@ -2099,15 +2099,27 @@ struct B_k_fs_challenge {
             res[1] = n_pre;
         }
     }
+    if (mbox) {
+        // rv_prove's early path: what k_publish used to copy for the host in a launch of its own -- comm, the opening map, the two
+        // counts (the bytes behind `comm` in device memory, in that order) -- into the host-mapped mailbox, then the stamp
+        if (lane < 8) mbox[lane] = s_comm[lane];
+        mbox[8 + lane] = (uint32_t)s_omit[4 * lane] | ((uint32_t)s_omit[4 * lane + 1] << 8) | ((uint32_t)s_omit[4 * lane + 2] << 16) | ((uint32_t)s_omit[4 * lane + 3] << 24);
+        if (lane == 0) mbox[8 + RV_TOTAL_REPS / 4] = n_on, mbox[9 + RV_TOTAL_REPS / 4] = n_pre;
+        __threadfence_system();
+        __syncthreads();
+        if (lane == 0) __hip_atomic_store(mbox_flag, mbox_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 };
-__global__ __launch_bounds__(64) void k_fs_challenge(const uint8_t* __restrict__ h, FsLayout L, uint32_t rep_begin, uint32_t R, uint8_t* __restrict__ comm, uint8_t* __restrict__ omit, uint8_t* __restrict__ omit_all, uint64_t* __restrict__ offs, OnlineList* __restrict__ ol, uint32_t* __restrict__ res) {
-    B_k_fs_challenge{}(h, L, rep_begin, R, comm, omit, omit_all, offs, ol, res);
+__global__ __launch_bounds__(64) void k_fs_challenge(const uint8_t* __restrict__ h, FsLayout L, uint32_t rep_begin, uint32_t R, uint8_t* __restrict__ comm, uint8_t* __restrict__ omit, uint8_t* __restrict__ omit_all, uint64_t* __restrict__ offs, OnlineList* __restrict__ ol, uint32_t* __restrict__ res, uint32_t* __restrict__ mbox, uint32_t* __restrict__ mbox_flag, uint32_t mbox_seq) {
+    B_k_fs_challenge{}(h, L, rep_begin, R, comm, omit, omit_all, offs, ol, res, mbox, mbox_flag, mbox_seq);
 }
 
 void launch_fs_challenge(hipStream_t st, const uint8_t* d_h, const FsLayout& L, uint32_t rep_begin, uint32_t R, uint8_t* d_comm,
-                         uint8_t* d_omit, uint8_t* d_omit_all, uint64_t* d_offs, OnlineList* d_ol, uint32_t* d_res) {
-    launch<B_k_fs_challenge, 64>(k_fs_challenge, st, dim3(1), dim3(64), d_h, L, rep_begin, R, d_comm, d_omit, d_omit_all, d_offs, d_ol, d_res);
+                         uint8_t* d_omit, uint8_t* d_omit_all, uint64_t* d_offs, OnlineList* d_ol, uint32_t* d_res, uint32_t* mbox, uint32_t* mbox_flag,
+                         uint32_t mbox_seq) {
+    launch<B_k_fs_challenge, 64>(k_fs_challenge, st, dim3(1), dim3(64), d_h, L, rep_begin, R, d_comm, d_omit, d_omit_all, d_offs, d_ol, d_res, mbox, mbox_flag,
+                                 mbox_seq);
 }
 
 uint32_t extract_tile_bytes(uint64_t n_items) { return ex_tb_for(n_items / 8 + 1, EXR_TB); }
