@@ -334,7 +334,7 @@ void launch_unpack_bits(hipStream_t st, const uint8_t* d_blob, const uint64_t* d
                         uint64_t first_item = 0 /* the vectors' item row 0 of the output is */);
 void launch_shard_init(hipStream_t st, int* d_err, uint32_t* d_zero_mask, uint32_t n_mask_words /* <= 64 */, uint8_t* d_zero_corr,
                        uint32_t n_corr_bytes /* <= 64 */, uint32_t* d_fill = nullptr /* also: n_fill_rows copies of digest[8] */, uint32_t n_fill_rows = 0,
-                       const uint32_t* digest = nullptr);
+                       const uint32_t* digest = nullptr, uint8_t* d_zero_byte = nullptr /* also: one byte cleared */);
 void launch_fill_digests(hipStream_t st, uint32_t* d_dst, uint32_t n_rows, const uint32_t digest[8]);
 void launch_overlay_rows(hipStream_t st, uint32_t* d_dst, const uint32_t* d_src, const uint8_t* d_omit, uint32_t R,
                          uint32_t row_words, int want_online);

@@ -1656,9 +1656,10 @@ void launch_fill_digests(hipStream_t st, uint32_t* d_dst, uint32_t n_rows, const
 // which otherwise cost a launch of their own between the hashes and the commitment)
 struct B_k_shard_init {
     __device__ __forceinline__ void operator()(int* __restrict__ err, uint32_t* __restrict__ zero_mask, uint32_t n_mask_words, uint8_t* __restrict__ zero_corr, uint32_t n_corr_bytes,
-                                               uint32_t* __restrict__ fill, uint32_t n_fill_rows, Digest8 d) const {
+                                               uint32_t* __restrict__ fill, uint32_t n_fill_rows, Digest8 d, uint8_t* __restrict__ zero_byte) const {
     const uint32_t i = threadIdx.x;
     if (i == 0) *err = 0;
+    if (i == 1 && zero_byte) *zero_byte = 0;  // (MODE_PROVE_V: the zero row's cleartext value -- a memset launch of its own before)
     if (i < n_mask_words) zero_mask[i] = 0;
     if (i < n_corr_bytes) zero_corr[i] = 0;
     if (fill)
@@ -1666,15 +1667,15 @@ struct B_k_shard_init {
 }
 };
 __global__ void k_shard_init(int* __restrict__ err, uint32_t* __restrict__ zero_mask, uint32_t n_mask_words, uint8_t* __restrict__ zero_corr, uint32_t n_corr_bytes,
-                             uint32_t* __restrict__ fill, uint32_t n_fill_rows, Digest8 d) {
-    B_k_shard_init{}(err, zero_mask, n_mask_words, zero_corr, n_corr_bytes, fill, n_fill_rows, d);
+                             uint32_t* __restrict__ fill, uint32_t n_fill_rows, Digest8 d, uint8_t* __restrict__ zero_byte) {
+    B_k_shard_init{}(err, zero_mask, n_mask_words, zero_corr, n_corr_bytes, fill, n_fill_rows, d, zero_byte);
 }
 void launch_shard_init(hipStream_t st, int* d_err, uint32_t* d_zero_mask, uint32_t n_mask_words, uint8_t* d_zero_corr,
-                       uint32_t n_corr_bytes, uint32_t* d_fill, uint32_t n_fill_rows, const uint32_t* digest) {
+                       uint32_t n_corr_bytes, uint32_t* d_fill, uint32_t n_fill_rows, const uint32_t* digest, uint8_t* d_zero_byte) {
     Digest8 d{};
     if (d_fill)
         for (int k = 0; k < 8; k++) d.w[k] = digest[k];
-    launch<B_k_shard_init, 64>(k_shard_init, st, dim3(1), dim3(64), d_err, d_zero_mask, n_mask_words, d_zero_corr, n_corr_bytes, d_fill, n_fill_rows, d);
+    launch<B_k_shard_init, 64>(k_shard_init, st, dim3(1), dim3(64), d_err, d_zero_mask, n_mask_words, d_zero_corr, n_corr_bytes, d_fill, n_fill_rows, d, d_zero_byte);
 }
 
 void launch_join(hipStream_t st, const uint32_t* d_pre2, const uint32_t* d_on2, const uint32_t* d_pre64, const uint32_t* d_on64,
