@@ -179,21 +179,11 @@ __global__ void k_bitslice_rk(const uint8_t* __restrict__ rkbytes, uint32_t NQ, 
 // seed -> player key (B_k_expand_seeds) -> round keys and first-round constants (B_k_key_schedule) by 32 threads into LDS, the quad
 // word's bit planes (B_k_bitslice_rk) out of LDS, and -- img != null -- its lanes of the lane-distributed generator's key image
 // (aes_col4.hip: k_rk_col4) out of the planes.  Four dependent launches of 4 - 8 us each otherwise, at the head of every proof.
-// in_host / in_bytes (in_host != null): the seeds -- and behind them the witness -- still sit in the caller's page-locked, device-visible
-// staging buffer: the workgroups read their seeds from there and copy all in_bytes to `seeds` (the device block that the later
-// kernels read) -- the proof's one input copy was a copy-engine transfer ahead of the first kernel, ~10 us of a 0.24 ms AES-128 proof.
-__global__ __launch_bounds__(256) void k_setup_keys(const uint8_t* __restrict__ seeds_in, uint32_t NQ, uint8_t* __restrict__ keys, uint8_t* __restrict__ rkbytes,
-                                                    uint32_t* __restrict__ rk, uint32_t* __restrict__ img, const uint8_t* __restrict__ in_host, uint32_t in_bytes,
-                                                    uint8_t* __restrict__ in_dev) {
+__global__ __launch_bounds__(256) void k_setup_keys(const uint8_t* __restrict__ seeds, uint32_t NQ, uint8_t* __restrict__ keys, uint8_t* __restrict__ rkbytes,
+                                                    uint32_t* __restrict__ rk, uint32_t* __restrict__ img) {
     __shared__ __attribute__((aligned(16))) uint8_t s_rkb[32][RK_BYTES];
     __shared__ uint32_t s_pl[RK_BYTES * 8];  // plane 8 * byte + bit of this quad word
     const uint32_t q = blockIdx.x, t = threadIdx.x;
-    const uint8_t* seeds = in_host ? in_host : seeds_in;
-    if (in_host) {
-        const uint32_t n4 = in_bytes / 4;
-        for (uint32_t i = q * 256 + t; i < n4; i += gridDim.x * 256) ((uint32_t*)in_dev)[i] = ((const uint32_t*)in_host)[i];
-        if (q == 0 && t < (in_bytes & 3u)) in_dev[4 * n4 + t] = in_host[4 * n4 + t];
-    }
     if (t < 32) {
         const uint32_t slot = q * 32 + t;
         B_k_expand_seeds::slot_key(seeds, slot, keys);
@@ -236,9 +226,8 @@ __global__ __launch_bounds__(256) void k_setup_keys(const uint8_t* __restrict__ 
         img[at] = val;
     }
 }
-void launch_setup_keys(hipStream_t st, const uint8_t* d_seeds, uint32_t NQ, uint8_t* d_keys, uint8_t* d_rkbytes, uint32_t* d_rk, uint32_t* d_img,
-                       const uint8_t* in_host_dev, uint32_t in_bytes) {
-    hipLaunchKernelGGL(k_setup_keys, dim3(NQ), dim3(256), 0, st, d_seeds, NQ, d_keys, d_rkbytes, d_rk, d_img, in_host_dev, in_bytes, const_cast<uint8_t*>(d_seeds));
+void launch_setup_keys(hipStream_t st, const uint8_t* d_seeds, uint32_t NQ, uint8_t* d_keys, uint8_t* d_rkbytes, uint32_t* d_rk, uint32_t* d_img) {
+    hipLaunchKernelGGL(k_setup_keys, dim3(NQ), dim3(256), 0, st, d_seeds, NQ, d_keys, d_rkbytes, d_rk, d_img);
 }
 
 // test hook / Z64 path helper: plain CTR blocks, one thread per (key, block)

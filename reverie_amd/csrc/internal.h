@@ -152,9 +152,7 @@ constexpr uint32_t RK_AREAS = 13;
 constexpr uint64_t RV_MAX_CTR_BLOCKS = 1ull << 24;
 void launch_key_schedule(hipStream_t st, const uint8_t* d_keys, uint32_t n_slots, uint8_t* d_rkbytes /*[n][RK_BYTES]*/);
 // expand_seeds + key_schedule + bitslice_rk (+ the lane-distributed generator's key image, d_img != null) of an NQ-quad-word shard in one launch
-// (in_host_dev != null: the in_bytes of seeds [+ witness] are still in the caller's device-visible staging buffer: read from there and copied to d_seeds)
-void launch_setup_keys(hipStream_t st, const uint8_t* d_seeds, uint32_t NQ, uint8_t* d_keys, uint8_t* d_rkbytes, uint32_t* d_rk, uint32_t* d_img,
-                       const uint8_t* in_host_dev = nullptr, uint32_t in_bytes = 0);
+void launch_setup_keys(hipStream_t st, const uint8_t* d_seeds, uint32_t NQ, uint8_t* d_keys, uint8_t* d_rkbytes, uint32_t* d_rk, uint32_t* d_img);
 void launch_bitslice_rk(hipStream_t st, const uint8_t* d_rkbytes, uint32_t NQ, uint32_t* d_rk /*[RK_AREAS][128][NQ]*/);
 void launch_aes_gf2_masks(hipStream_t st, const uint32_t* d_rk, const uint32_t* d_keep, uint32_t NQ, uint64_t first_block,
                           uint64_t n_blocks, uint32_t* d_masks);
