@@ -597,7 +597,8 @@ def main():
             peak_issue = 1024 * 0.5 * 2.4e9
             valu = {"peak": peak_issue, "unit": "wavefront VALU instructions/s", "kernels": {}}
             mask_pf, interp_pf = ("rv::k_aes_gf2_masks",), ("rv::k_interp_full<",)
-            hash_pf = ("rv::k_b3_chunks<", "rv::k_b3_chunks_uni", "rv::k_b3_chunks_bits", "rv::k_b3_chunks_pair", "rv::k_b3_reduce<", "rv::k_b3_reduce_pair", "rv::k_b3_tree_tail")
+            # (the prover's hash launches; k_b3_chunks_pair_uni<1> / <2> are the one verification of the profiled run)
+            hash_pf = ("rv::k_b3_chunks_uni", "rv::k_b3_chunks_bits_uni", "rv::k_b3_chunks_pair_uni<0>", "rv::k_b3_reduce_pair", "rv::k_b3_tree_tail_pair_big")
             # overlapped: the cipher and the level launches share the interpreter's phase (and the SIMDs): one entry for both
             for phase, prefixes, ms in ((("masks+interp", mask_pf + interp_pf, phases["interp"]),) if overlapped else (("masks", mask_pf, phases["masks"]),)) + (("hash", hash_pf, phases["hash"]),):
                 insts = sum(v.get("SQ_INSTS_VALU_per_proof", 0.0) for k, v in sk.items() if k.startswith(prefixes))
