@@ -122,8 +122,9 @@ typedef struct rv_profile {
     uint64_t launches[RV_PH_COUNT]; /* kernel launches per phase              */
     uint64_t calls;                 /* commit / verify_shard calls accumulated */
 } rv_profile;
-/* enable != 0 turns event timing on (adds a few stream events per call); reset != 0 zeroes
- * the accumulators; out (nullable) receives the current totals. */
+/* enable != 0 turns event timing on (a stream event per phase boundary: every one costs the call ~5 us of idle GPU; enable == 2: only
+ * the interpreter's phase, RV_PH_INTERP, is timed -- two events per call); reset != 0 zeroes the accumulators; out (nullable) receives
+ * the current totals. */
 int rv_ctx_profile(rv_ctx *ctx, int enable, int reset, rv_profile *out);
 
 /* ---- circuit: the `Arc<Vec<CombineOperation>>` + `wire_counts` arguments of

@@ -241,7 +241,7 @@ struct rv_ctx {
     std::map<void*, size_t> live;
     size_t cached_bytes = 0;
     // event timing (rv_ctx_profile)
-    bool profiling = false;
+    int profiling = 0;  // rv_ctx_profile: 0 off, 1 every phase, 2 the interpreter's phase only
     rv_profile prof{};
     std::vector<hipEvent_t> ev_pool;
     struct Mark {
@@ -272,6 +272,7 @@ struct rv_ctx {
         // (not while a batch is being recorded: the launches happen later, and a thousand event markers queued between
         // two phases of a batch kept the GPU idle for 7 ms)
         if (!profiling || g_recorder) return;
+        if (profiling == 2 && p != RV_PH_INTERP) p = -1;  // (only the dominant phase is marked: two markers per proof instead of seven)
         // ONE marker per boundary: the event that ends a phase also starts the next one on the same stream (every marker
         // in the queue costs the proof ~5 us of idle GPU, and the bench's timed region runs with the phases on)
         hipStream_t next = p >= 0 ? (st ? st : stream) : nullptr;
@@ -581,7 +582,7 @@ extern "C" int rv_ctx_profile(rv_ctx* ctx, int enable, int reset, rv_profile* ou
     ctx->collect();
     if (out) *out = ctx->prof;
     if (reset) ctx->prof = rv_profile{};
-    ctx->profiling = enable != 0;
+    ctx->profiling = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return RV_OK;
 }
 
