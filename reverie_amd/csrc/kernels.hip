@@ -1352,14 +1352,17 @@ __global__ __launch_bounds__(256) void k_b3_chunks_pair_uni(const uint8_t* __res
                                                             uint32_t n_quads) {
     B_k_b3_chunks_pair_uni<QUADS>{}(pre, n_pre, cv_pre, on, n_on, cv_on, blocks_pre, quads, n_quads);
 }
+// (B3_TAIL_PAIR: the shared tree top takes up to 1 024 nodes per repetition with 512 threads, and a shared reduction launch folds THREE
+// levels -- 4 900 chunks are 613 nodes after one launch, where two levels per launch and a 512-node top needed two launches)
+constexpr uint32_t B3_TAIL_PAIR = 1024;
 struct B_k_b3_reduce_pair {
     __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in_a, uint64_t n_a, uint32_t* __restrict__ out_a, const uint32_t* __restrict__ in_b,
                                                uint64_t n_b, uint32_t* __restrict__ out_b, uint32_t R) const {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.y == 0) {
-        if (n_a > B3_TAIL) B_k_b3_reduce<2>::run(tid, in_a, n_a, R, out_a);
+        if (n_a > B3_TAIL_PAIR) B_k_b3_reduce<3>::run(tid, in_a, n_a, R, out_a);
     } else {
-        if (n_b > B3_TAIL) B_k_b3_reduce<2>::run(tid, in_b, n_b, R, out_b);
+        if (n_b > B3_TAIL_PAIR) B_k_b3_reduce<3>::run(tid, in_b, n_b, R, out_b);
     }
     }
 };
@@ -1371,12 +1374,12 @@ struct B_k_b3_tree_tail_pair_big {
     __device__ __forceinline__ void operator()(const uint32_t* __restrict__ in_a, uint32_t n_a, uint32_t* __restrict__ dig_a, const uint32_t* __restrict__ in_b, uint32_t n_b,
                                                uint32_t* __restrict__ dig_b, uint32_t R) const {
     if (blockIdx.x < R)
-        B_k_b3_tree_tail<(int)B3_TAIL>::run(blockIdx.x, in_a, n_a, R, dig_a);
+        B_k_b3_tree_tail<(int)B3_TAIL_PAIR>::run(blockIdx.x, in_a, n_a, R, dig_a);
     else
-        B_k_b3_tree_tail<(int)B3_TAIL>::run(blockIdx.x - R, in_b, n_b, R, dig_b);
+        B_k_b3_tree_tail<(int)B3_TAIL_PAIR>::run(blockIdx.x - R, in_b, n_b, R, dig_b);
     }
 };
-__global__ __launch_bounds__(256) void k_b3_tree_tail_pair_big(const uint32_t* __restrict__ in_a, uint32_t n_a, uint32_t* __restrict__ dig_a, const uint32_t* __restrict__ in_b,
+__global__ __launch_bounds__(512) void k_b3_tree_tail_pair_big(const uint32_t* __restrict__ in_a, uint32_t n_a, uint32_t* __restrict__ dig_a, const uint32_t* __restrict__ in_b,
                                                                uint32_t n_b, uint32_t* __restrict__ dig_b, uint32_t R) {
     B_k_b3_tree_tail_pair_big{}(in_a, n_a, dig_a, in_b, n_b, dig_b, R);
 }
@@ -1391,7 +1394,7 @@ bool b3_pair_big_ok(uint64_t n_pre, uint64_t n_on, uint32_t NQ, const uint32_t* 
         uint64_t n = n_ev == 0 ? 1 : (n_ev + 1023) / 1024;
         // (short transcripts: the separate launchers pick other chunk kernels; few listed quad words are hashed a repetition per lane anyway)
         if (!(listed && n_quads * 4 <= NQ) && n * (listed ? std::min(n_quads, NQ) : NQ) < b3_rpl1_lanes()) return false;
-        while (n > B3_TAIL) n = (n + 3) / 4;
+        while (n > B3_TAIL_PAIR) n = (n + 7) / 8;
         if (n <= 64) return false;
     }
     return true;
@@ -1420,16 +1423,16 @@ uint32_t launch_b3_pair_big(hipStream_t st, const uint8_t* d_pre, uint64_t n_pre
         launch<B_k_b3_chunks_pair_uni<0>, 256>(k_b3_chunks_pair_uni<0>, st, dim3(b_pre + b_on), dim3(256), d_pre, n_pre, cv_a0, d_on, n_on, cv_b0, b_pre,
                                               (const uint32_t*)nullptr, 0u);
     }
-    while (n_a > B3_TAIL || n_b > B3_TAIL) {
-        const uint64_t out_a = (n_a + 3) / 4, out_b = (n_b + 3) / 4;
-        const uint64_t threads = std::max(n_a > B3_TAIL ? out_a : 0, n_b > B3_TAIL ? out_b : 0) * R;
+    while (n_a > B3_TAIL_PAIR || n_b > B3_TAIL_PAIR) {
+        const uint64_t out_a = (n_a + 7) / 8, out_b = (n_b + 7) / 8;
+        const uint64_t threads = std::max(n_a > B3_TAIL_PAIR ? out_a : 0, n_b > B3_TAIL_PAIR ? out_b : 0) * R;
         launch<B_k_b3_reduce_pair, 256>(k_b3_reduce_pair, st, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), (const uint32_t*)cv_a0, n_a, cv_a1,
                                         (const uint32_t*)cv_b0, n_b, cv_b1, R);
-        if (n_a > B3_TAIL) std::swap(cv_a0, cv_a1), n_a = out_a;
-        if (n_b > B3_TAIL) std::swap(cv_b0, cv_b1), n_b = out_b;
+        if (n_a > B3_TAIL_PAIR) std::swap(cv_a0, cv_a1), n_a = out_a;
+        if (n_b > B3_TAIL_PAIR) std::swap(cv_b0, cv_b1), n_b = out_b;
         launches++;
     }
-    launch<B_k_b3_tree_tail_pair_big, 256>(k_b3_tree_tail_pair_big, st, dim3(2 * R), dim3(256), (const uint32_t*)cv_a0, (uint32_t)n_a, d_dig_pre,
+    launch<B_k_b3_tree_tail_pair_big, 512>(k_b3_tree_tail_pair_big, st, dim3(2 * R), dim3(512), (const uint32_t*)cv_a0, (uint32_t)n_a, d_dig_pre,
                                            (const uint32_t*)cv_b0, (uint32_t)n_b, d_dig_on, R);
     return launches + 1;
 }
