@@ -461,7 +461,7 @@ def main():
     # HIP events around the dominant phase (the interpreter's: generator || levels) of every timed step; the other phases are timed on
     # PHASE_PASS proofs right behind the timed region -- every event in the stream costs a proof ~5 us of idle GPU, and seven of them
     # per step were 0.5 % of the headline spent on its own measurement
-    interp_only = world == 1 and not args.device_resident
+    interp_only = world == 1 and not args.device_resident and not args.profile_run  # (a profiled run makes exactly warmup + steps proofs: its summaries divide by that)
     L.rv_ctx_profile(ctx.handle, 2 if interp_only else 1, 1, None)
     sync_all()
     t0 = time.perf_counter()
