@@ -418,6 +418,23 @@ def test_full_size_all_and_bit_exact_vs_oracle(rv, oracle, rule_seeds):
     c.close()
 
 
+@pytest.mark.parametrize("layers,p_and", [(64, 0.5), (33, 1.0), (100, 0.5)])
+def test_mid_size_transcript_trees_bit_exact_vs_oracle(rv, oracle, rule_seeds, layers, p_and):
+    """Between the small cases and config 4 the two transcript hashes take other shapes (csrc/kernels.hip, launch_b3_pair_big: one shared
+    launch for the chunks of both streams, ONE shared reduction launch of three tree levels, a shared tree top of 257 ... 1 024 nodes per
+    repetition): 2.1 - 3.3 * 10^6 AND gates, the oracle's bytes for the first proof (plain openings) and the second (early corrections,
+    broadcast vectors written to the host by the extraction kernel), then verified."""
+    prog, wit, wc, st = circuits.layered_gf2(layers=layers, p_and=p_and)
+    assert 2048 <= (st["and"] + st["inputs"] + 1023) // 1024 <= 8192
+    want = oracle.prove(prog, wit, [], wc, rule_seeds, threads=min(32, os.cpu_count() or 1))
+    c = rv.Circuit(prog, wc, whole_prover=True)
+    for _ in range(2):
+        got = rv.Proof.new(c, wit, [], seeds=rule_seeds)
+        assert bytes(got) == want
+    assert got.verify(c)
+    c.close()
+
+
 def test_full_size_properties(rv, rule_seeds):
     """BASELINE config 4 at full size (10^7 gates): size-independent properties only —
     prove -> verify accepts, a flipped transcript bit is rejected, proof length is as derived."""
